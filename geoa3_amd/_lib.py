@@ -1,0 +1,98 @@
+"""ctypes binding of libgeoa3_hip.so (the C ABI declared in include/geoa3_hip.h).
+
+There is NO fallback: if the shared object is missing or a symbol is absent the import of the
+product path raises.  Build it with ``python -m geoa3_amd.build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgeoa3_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+
+class GeoArgs(C.Structure):
+    """struct geoa3_geo_args"""
+    _fields_ = [("adv", vp), ("ori", vp), ("normal_ori", vp), ("kappa_ori", vp), ("d_ao", vp), ("i_ao", vp),
+                ("d_oa", vp), ("i_oa", vp), ("knn_adv", vp), ("dkappa", vp),
+                ("B", C.c_int32), ("N", C.c_int32), ("k", C.c_int32), ("dis_type", C.c_int32),
+                ("single_side", C.c_int32), ("w_dis", C.c_float), ("w_hd", C.c_float), ("w_curv", C.c_float),
+                ("dis_loss", vp), ("hd_loss", vp), ("curv_loss", vp), ("constrain", vp), ("kappa_adv", vp),
+                ("grad", vp)]
+
+
+class TnetWeights(C.Structure):
+    """struct geoa3_tnet_weights"""
+    _fields_ = [("K", C.c_int32)] + [(n, vp) for n in (
+        "w1", "b1", "w2", "b2", "w3", "b3", "w3t", "w2t", "w1t", "f1", "fb1", "f2", "fb2", "f3", "fb3",
+        "f1t", "f2t", "f3t")]
+
+
+class PointNetWeights(C.Structure):
+    """struct geoa3_pointnet_weights"""
+    _fields_ = [("classes", C.c_int32), ("t3", TnetWeights), ("t64", TnetWeights)] + [(n, vp) for n in (
+        "w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "w5", "b5", "w5t", "w4t", "w3t", "w2t", "w1t",
+        "f1", "fb1", "f2", "fb2", "f3", "fb3", "f1t", "f2t", "f3t")]
+
+
+class AttackState(C.Structure):
+    """struct geoa3_attack_state"""
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("classes", C.c_int32), ("targeted", C.c_int32),
+                ("cls_loss_type", C.c_int32), ("confidence", C.c_float), ("inv_global_batch", C.c_float),
+                ("gt", vp), ("target", vp), ("scale_const", vp), ("lower_bound", vp), ("upper_bound", vp),
+                ("best_loss", vp), ("best_attack", vp), ("best_step", vp), ("best_bs", vp),
+                ("iter_best_loss", vp), ("iter_best_score", vp), ("prev_constrain", vp), ("label", vp),
+                ("cls_loss", vp), ("loss_n", vp), ("loss_hist", vp), ("last_label", vp)]
+
+
+# name -> (restype, argtypes); every symbol include/geoa3_hip.h declares
+SIGNATURES = {
+    "geoa3_version": (C.c_int, []),
+    "geoa3_strerror": (C.c_char_p, [C.c_int]),
+    "geoa3_nn1_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "geoa3_knn": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "geoa3_kappa": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "geoa3_geo_loss_grad": (C.c_int, [C.POINTER(GeoArgs), vp]),
+    "geoa3_pointnet_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "geoa3_pointnet_forward": (C.c_int, [C.POINTER(PointNetWeights), vp, C.c_int, C.c_int, vp, vp, vp]),
+    "geoa3_pointnet_backward": (C.c_int, [C.POINTER(PointNetWeights), vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "geoa3_attack_head": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "geoa3_attack_update": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float,
+                                      C.c_float, C.c_float, vp]),
+    "geoa3_attack_binary_update": (C.c_int, [C.POINTER(AttackState), vp]),
+    "geoa3_attack_begin_search_step": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class Geoa3Error(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built: there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Geoa3Error("%s is missing: build it with `python -m geoa3_amd.build` "
+                         "(the product path has no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().geoa3_strerror(code).decode()
+        raise Geoa3Error("%s failed: %s (%d)" % (what or "geoa3 call", msg, code))

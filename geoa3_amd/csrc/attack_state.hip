@@ -1,0 +1,244 @@
+// Device-resident state machine of attack() (Attacker/geoA3_attack.py:182-386): classification loss,
+// success bookkeeping, optimiser step and binary search, with no host synchronisation.
+#include "common.h"
+
+namespace {
+
+constexpr int HEAD_BLOCK = 256;
+
+// One workgroup per instance.  Wave 0 evaluates the classification loss and its gradient w.r.t. the
+// logits (geoA3_attack.py:105-127), lane 0 then runs the bookkeeping of geoA3_attack.py:297-310 and the
+// whole workgroup copies the iterate into best_attack when it improved.
+__global__ __launch_bounds__(HEAD_BLOCK) void attack_head_kernel(geoa3_attack_state st, const float* __restrict__ logits,
+                                                                 const float* __restrict__ constrain,
+                                                                 const float* __restrict__ x, int step,
+                                                                 int search_step, float* __restrict__ dlogits) {
+  __shared__ int s_copy;
+  const int b = blockIdx.x, tid = threadIdx.x, C = st.classes;
+  const float* lg = logits + (size_t)b * C;
+  if (tid < GEOA3_WAVE) {
+    const int lane = tid;
+    const int tgt = st.target[b];
+    // arg-max (first maximal index, as torch.argmax) and max over c != target
+    float mx = -__builtin_inff();
+    int am = 0x7fffffff;
+    float other = -__builtin_inff();
+    int oi = 0x7fffffff;
+    for (int c = lane; c < C; c += GEOA3_WAVE) {
+      const float v = lg[c];
+      if (v > mx) { mx = v; am = c; }
+      const float w = (c == tgt) ? -10000.0f : v;  // (1-onehot)*logits - onehot*1e4, geoA3_attack.py:110
+      if (w > other) { other = w; oi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(mx, o, 64);
+      const int i2 = __shfl_xor(am, o, 64);
+      if (v2 > mx || (v2 == mx && i2 < am)) { mx = v2; am = i2; }
+      const float w2 = __shfl_xor(other, o, 64);
+      const int j2 = __shfl_xor(oi, o, 64);
+      if (w2 > other || (w2 == other && j2 < oi)) { other = w2; oi = j2; }
+    }
+    float cls = 0.f;
+    const float invB = st.inv_global_batch;
+    if (st.cls_loss_type == 1) {  // CE (reduction none); untargeted: -CE
+      float se = 0.f;
+      for (int c = lane; c < C; c += GEOA3_WAVE) se += expf(lg[c] - mx);
+      se = wave_sum(se);
+      const float lse = logf(se) + mx;
+      const float ce = lse - lg[tgt];
+      const float sgn = st.targeted ? 1.f : -1.f;
+      cls = sgn * ce;
+      for (int c = lane; c < C; c += GEOA3_WAVE) {
+        const float p = expf(lg[c] - lse);
+        dlogits[(size_t)b * C + c] = sgn * invB * (p - (c == tgt ? 1.f : 0.f));
+      }
+    } else if (st.cls_loss_type == 2) {  // Margin
+      const float fake = lg[tgt];
+      const float raw = st.targeted ? (other - fake + st.confidence) : (fake - other + st.confidence);
+      cls = fmaxf(raw, 0.f);
+      const float gact = raw >= 0.f ? invB : 0.f;  // clamp(min=0) passes the gradient at equality
+      const float g_other = st.targeted ? gact : -gact;
+      for (int c = lane; c < C; c += GEOA3_WAVE) {
+        float g = 0.f;
+        if (c == oi) g += g_other;
+        if (c == tgt) g -= g_other;
+        dlogits[(size_t)b * C + c] = g;
+      }
+    } else {
+      for (int c = lane; c < C; c += GEOA3_WAVE) dlogits[(size_t)b * C + c] = 0.f;
+    }
+    if (lane == 0) {
+      const float con = constrain ? constrain[b] : 0.f;
+      const float ln = cls + st.scale_const[b] * con;
+      st.cls_loss[b] = cls;
+      st.loss_n[b] = ln;
+      if (st.loss_hist) st.loss_hist[(size_t)step * st.B + b] = ln;
+      st.label[b] = am;
+      if (b == st.B - 1) *st.last_label = am;
+      const bool ok = st.targeted ? (am == tgt) : (am != st.gt[b]);
+      const float metric = st.prev_constrain[b];  // constrain of the PREVIOUS step (1e10 at step 0)
+      int copy = 0;
+      if (ok && metric < st.best_loss[b]) {
+        st.best_loss[b] = metric;
+        st.best_step[b] = step;
+        st.best_bs[b] = search_step;
+        copy = 1;
+      }
+      if (ok && metric < st.iter_best_loss[b]) {
+        st.iter_best_loss[b] = metric;
+        st.iter_best_score[b] = am;
+      }
+      st.prev_constrain[b] = con;
+      s_copy = copy;
+    }
+  }
+  __syncthreads();
+  if (s_copy) {
+    const size_t n3 = (size_t)3 * st.N;
+    const float* src = x + (size_t)b * n3;
+    float* dst = st.best_attack + (size_t)b * n3;
+    for (size_t i = tid; i < n3; i += HEAD_BLOCK) dst[i] = src[i];
+  }
+}
+
+// One thread per point (all three coordinates, so lp_clip sees the whole offset vector).
+__global__ __launch_bounds__(256) void attack_update_kernel(int B, int N, const float* __restrict__ scale_const,
+                                                            float inv_global_batch, const float* __restrict__ g_cls,
+                                                            const float* __restrict__ g_geo,
+                                                            const float* __restrict__ ori, float* __restrict__ offset,
+                                                            float* __restrict__ am, float* __restrict__ av,
+                                                            float* __restrict__ x, int optim, float step_size,
+                                                            float sqrt_bc2, float cc_linf) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (size_t)B * N) return;
+  const int b = (int)(p / N);
+  const int n = (int)(p - (size_t)b * N);
+  const float cg = g_geo ? scale_const[b] * inv_global_batch : 0.f;
+  float o[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t e = ((size_t)b * 3 + c) * N + n;
+    float g = g_cls ? g_cls[e] : 0.f;
+    if (g_geo) g += cg * g_geo[e];
+    float w = offset[e];
+    if (optim == 0) {  // torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8
+      const float m = am[e] * 0.9f + g * (1.0f - 0.9f);
+      const float v = av[e] * 0.999f + (g * g) * (1.0f - 0.999f);
+      am[e] = m;
+      av[e] = v;
+      const float denom = sqrtf(v) / sqrt_bc2 + 1e-8f;
+      w = w - step_size * (m / denom);
+    } else {  // plain SGD (geoA3_attack.py:271-272)
+      w = w - step_size * g;
+    }
+    o[c] = w;
+  }
+  if (cc_linf != 0.f) {  // lp_clip, geoA3_attack.py:88-98
+    const float len = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    if (!(len < cc_linf)) {
+      const bool big = len > 1e-6f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = big ? o[c] / len * cc_linf : 0.f;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t e = ((size_t)b * 3 + c) * N + n;
+    offset[e] = o[c];
+    x[e] = ori[e] + o[c];
+  }
+}
+
+__global__ void binary_update_kernel(geoa3_attack_state st) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= st.B) return;
+  const int lab = *st.last_label;  // geoA3_attack.py:375 uses the last instance's label for every k
+  const bool cmp = st.targeted ? (lab == st.target[k]) : (lab != st.gt[k]);
+  float c = st.scale_const[k], lo = st.lower_bound[k], up = st.upper_bound[k];
+  if (cmp && st.iter_best_score[k] != -1) {
+    lo = fmaxf(lo, c);
+    if (up < 1e9f) c = (lo + up) * 0.5f;
+    else c = c * 2.0f;
+  } else {
+    up = fminf(up, c);
+    if (up < 1e9f) c = (lo + up) * 0.5f;
+  }
+  st.scale_const[k] = c;
+  st.lower_bound[k] = lo;
+  st.upper_bound[k] = up;
+}
+
+__global__ __launch_bounds__(256) void begin_search_step_kernel(geoa3_attack_state st, const float* __restrict__ ori,
+                                                                const float* __restrict__ init_offset,
+                                                                float* __restrict__ offset, float* __restrict__ am,
+                                                                float* __restrict__ av, float* __restrict__ x) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)st.B * 3 * st.N;
+  if (e < total) {
+    const float o = init_offset[e];
+    offset[e] = o;
+    if (am) am[e] = 0.f;
+    if (av) av[e] = 0.f;
+    x[e] = ori[e] + o;
+  }
+  if (e < (size_t)st.B) {
+    st.iter_best_loss[e] = 1e10f;
+    st.iter_best_score[e] = -1;
+    st.prev_constrain[e] = 1e10f;
+  }
+}
+
+}  // namespace
+
+extern "C" int geoa3_attack_head(const geoa3_attack_state* st, const float* logits, const float* constrain,
+                                 const float* x, int step, int search_step, float* dlogits, void* stream) {
+  if (!st || !logits || !x || !dlogits || st->B <= 0 || st->classes <= 0) return GEOA3_EINVAL;
+  hipLaunchKernelGGL(attack_head_kernel, dim3(st->B), dim3(HEAD_BLOCK), 0, geoa3_stream(stream), *st, logits,
+                     constrain, x, step, search_step, dlogits);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_attack_update(const geoa3_attack_state* st, const float* g_cls, const float* g_geo,
+                                   const float* ori, float* offset, float* adam_m, float* adam_v, float* x,
+                                   int optim, float step_size, float sqrt_bc2, float cc_linf, void* stream) {
+  if (!st || !ori || !offset || !x) return GEOA3_EINVAL;
+  if (optim == 0 && (!adam_m || !adam_v)) return GEOA3_EINVAL;
+  const size_t pts = (size_t)st->B * st->N;
+  hipLaunchKernelGGL(attack_update_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, geoa3_stream(stream),
+                     st->B, st->N, st->scale_const, st->inv_global_batch, g_cls, g_geo, ori, offset, adam_m, adam_v,
+                     x, optim, step_size, sqrt_bc2, cc_linf);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_attack_binary_update(const geoa3_attack_state* st, void* stream) {
+  if (!st || st->B <= 0) return GEOA3_EINVAL;
+  hipLaunchKernelGGL(binary_update_kernel, dim3((st->B + 255) / 256), dim3(256), 0, geoa3_stream(stream), *st);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_attack_begin_search_step(const geoa3_attack_state* st, const float* ori,
+                                              const float* init_offset, float* offset, float* adam_m, float* adam_v,
+                                              float* x, void* stream) {
+  if (!st || !ori || !init_offset || !offset || !x) return GEOA3_EINVAL;
+  const size_t total = (size_t)st->B * 3 * st->N;
+  hipLaunchKernelGGL(begin_search_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     geoa3_stream(stream), *st, ori, init_offset, offset, adam_m, adam_v, x);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_version(void) { return 100; }
+
+extern "C" const char* geoa3_strerror(int code) {
+  switch (code) {
+    case GEOA3_OK: return "ok";
+    case GEOA3_EINVAL: return "invalid argument";
+    case GEOA3_ELAUNCH: return "HIP kernel launch failed";
+    case GEOA3_ENOSUPPORT: return "size outside the supported range";
+    default: return "unknown error";
+  }
+}

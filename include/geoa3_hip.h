@@ -1,0 +1,206 @@
+/*
+ * geoa3_hip.h -- C ABI of libgeoa3_hip.so: the MI355X (gfx950) implementation of the GeoA3
+ * inner attack loop (Gorilla-Lab-SCUT/GeoA3: Attacker/geoA3_attack.py + Lib/loss_utils.py +
+ * Model/PointNet.py).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - point tensors are planar fp32 [B,3,N] (the reference's logical layout): plane c of
+ *     instance b starts at base + (b*3 + c)*N, so a wavefront reads 64 consecutive floats;
+ *   - indices are int32; distances are squared L2, evaluated un-fused as
+ *       d = fl(fl(fl(dx*dx)+fl(dy*dy))+fl(dz*dz))   (bit-identical to the CPU oracle);
+ *     exact distance ties go to the LOWER index;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every entry
+ *     point only enqueues work: no allocation, no host synchronisation, no global state;
+ *   - return value: 0 on success, a negative GEOA3_E* code otherwise (geoa3_strerror()).
+ *     The reference prints and exit(-1)s on a launch failure
+ *     (Model/pointnet2_ops_lib/pointnet2_ops/_ext-src/include/cuda_utils.h:30-39); callers of
+ *     this library are expected to raise instead.
+ *
+ * Each declaration cites the reference interface it replaces (file:line under the reference
+ * repository).  INTEGRATION.md shows the ctypes binding a maintainer of the reference adds.
+ */
+#ifndef GEOA3_HIP_H
+#define GEOA3_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOA3_OK 0
+#define GEOA3_EINVAL (-1)   /* bad argument (null pointer, size out of the supported range) */
+#define GEOA3_ELAUNCH (-2)  /* hipLaunchKernel / hipGetLastError reported a failure */
+#define GEOA3_ENOSUPPORT (-3)
+
+int geoa3_version(void);
+const char* geoa3_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator level: pytorch3d.ops.knn_points as called from
+ * Lib/loss_utils.py:32,33,41,48,57,70,77,92 and Attacker/geoA3_attack.py:65,80.
+ * ------------------------------------------------------------------------------------------ */
+
+/* K = 1, both directions in ONE launch ("CD kernel"): for every point of `a` its nearest
+ * point of `r` (d_ar, i_ar: [B,Na]) and for every point of `r` its nearest point of `a`
+ * (d_ra, i_ra: [B,Nr]).  Replaces the knn_points(K=1) pairs at Lib/loss_utils.py:32-33 (and the
+ * repeated adv->ori queries at :48,:70,:92).  d_ra/i_ra may be NULL (one direction only,
+ * pseudo_chamfer_loss, Lib/loss_utils.py:41). */
+int geoa3_nn1_pair(const float* a, const float* r, int B, int Na, int Nr,
+                   float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, void* stream);
+
+/* General K (1..GEOA3_KNN_MAX_K): dists/idx [B,Nq,K] ascending by (distance, index).
+ * `prior` (optional, [B,Nq,K], int32, K DISTINCT valid indices per query, e.g. the previous
+ * iteration's result) only seeds the pruning radius; the result is exact for any prior.
+ * Replaces knn_points(K=k+1) at Lib/loss_utils.py:57,77. */
+#define GEOA3_KNN_MAX_K 64
+int geoa3_knn(const float* q, const float* r, int B, int Nq, int Nr, int K,
+              const int32_t* prior, float* dists, int32_t* idx, void* stream);
+
+/* _get_kappa_ori (Lib/loss_utils.py:52-62) given the self K-NN table knn_idx [B,N,k+1]
+ * (column 0, the nearest hit, is dropped exactly as the reference's [:, :, :, 1:] slice):
+ *   kappa[b,i] = mean_m | < normalize(p[knn_idx[b,i,m]] - p_i), n_i > |,  m = 1..k.
+ * nn_idx (optional, [B,N]): normals are taken from normal[:, nn_idx[b,i]] -- the
+ * _get_kappa_adv form (Lib/loss_utils.py:64-82); NULL = normal[:, i]. */
+int geoa3_kappa(const float* pc, const float* normal, const int32_t* knn_idx, const int32_t* nn_idx,
+                int B, int N, int k, float* kappa, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Objective level: the geometric part of _forward_step (Attacker/geoA3_attack.py:131-166) and its
+ * gradient, fused.  Consumes the tables produced by geoa3_nn1_pair / geoa3_knn.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct geoa3_geo_args {
+  /* inputs */
+  const float* adv;        /* [B,3,N] current iterate                                  */
+  const float* ori;        /* [B,3,N] clean cloud                                      */
+  const float* normal_ori; /* [B,3,N]          (may be NULL when w_curv == 0)          */
+  const float* kappa_ori;  /* [B,N]            (may be NULL when w_curv == 0)          */
+  const float* d_ao;       /* [B,N] adv->ori squared distance                          */
+  const int32_t* i_ao;     /* [B,N] adv->ori index                                     */
+  const float* d_oa;       /* [B,N] ori->adv       (NULL when single_side or dis_type != CD) */
+  const int32_t* i_oa;     /* [B,N]                                                    */
+  const int32_t* knn_adv;  /* [B,N,k+1] self K-NN of adv (NULL when w_curv == 0)       */
+  const float* dkappa;     /* [B,N] optional upstream d L / d kappa_adv: when given, the curvature part of
+                              `grad` is the vector-Jacobian product of _get_kappa_adv with it (operator-level
+                              autograd) instead of the curvature_loss gradient                */
+  int32_t B, N, k;
+  int32_t dis_type;        /* 0 = none, 1 = CD (chamfer_loss / pseudo_chamfer_loss), 2 = L2 (norm_l2_loss) */
+  int32_t single_side;     /* --is_cd_single_side                                      */
+  float w_dis, w_hd, w_curv; /* dis_loss_weight, hd_loss_weight, curv_loss_weight     */
+  /* outputs (each may be NULL) */
+  float* dis_loss;         /* [B] chamfer_loss / pseudo_chamfer_loss / norm_l2_loss, Lib/loss_utils.py:25-43 */
+  float* hd_loss;          /* [B] hausdorff_loss, Lib/loss_utils.py:45-50              */
+  float* curv_loss;        /* [B] curvature_loss, Lib/loss_utils.py:84-97              */
+  float* constrain;        /* [B] w_dis*dis + w_hd*hd + w_curv*curv (geoA3_attack.py:137,153,162) */
+  float* kappa_adv;        /* [B,N] _get_kappa_adv, Lib/loss_utils.py:64-82            */
+  float* grad;             /* [B,3,N] d constrain[b] / d adv[b]                        */
+} geoa3_geo_args;
+int geoa3_geo_loss_grad(const geoa3_geo_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Victim model: PointNet eval forward and input-gradient (Model/PointNet.py:56-160).
+ * Weights: BatchNorm folded and repacked by the host (geoa3_amd/pointnet.py) into the arrays
+ * below; all fp32, row-major [C_out, K] with K contiguous unless noted.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 */
+  int32_t K;                /* 3 or 64 */
+  const float *w1, *b1;     /* conv1+bn1 folded  [64,K]           */
+  const float *w2, *b2;     /* conv2+bn2         [128,64]         */
+  const float *w3, *b3;     /* conv3+bn3         [1024,128]       */
+  const float *w3t;         /*                   [128,1024] = w3^T (backward) */
+  const float *w2t;         /* [64,128]  */
+  const float *w1t;         /* [K,64]    */
+  const float *f1, *fb1;    /* fc1+bn4 [512,1024] */
+  const float *f2, *fb2;    /* fc2+bn5 [256,512]  */
+  const float *f3, *fb3;    /* fc3     [K*K,256]  */
+  const float *f1t, *f2t, *f3t; /* transposes: [1024,512], [512,256], [256,K*K] */
+} geoa3_tnet_weights;
+
+typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 */
+  int32_t classes;
+  geoa3_tnet_weights t3, t64;
+  const float *w1, *b1;     /* conv1+bn1 [64,3]    */
+  const float *w2, *b2;     /* conv2+bn2 [64,64]   */
+  const float *w3, *b3;     /* conv3+bn3 [64,64]   */
+  const float *w4, *b4;     /* conv4+bn4 [128,64]  */
+  const float *w5, *b5;     /* conv5+bn5 [1024, 3*128]: k = tap*128 + ci (kernel 3, pad 1, PointNet.py:110) */
+  const float *w5t;         /* [1024, 3, 128] rows for the sparse backward: same memory order as w5 */
+  const float *w4t, *w3t, *w2t, *w1t;  /* [64,128] [64,64] [64,64] [3,64] */
+  const float *f1, *fb1;    /* fc1+bn6 [512,1024] */
+  const float *f2, *fb2;    /* fc2+bn7 [256,512]  */
+  const float *f3, *fb3;    /* fc3     [classes,256] */
+  const float *f1t, *f2t, *f3t; /* [1024,512] [512,256] [256,classes] */
+} geoa3_pointnet_weights;
+
+/* bytes of scratch the forward+backward pair needs for a batch of B clouds of N points */
+int64_t geoa3_pointnet_workspace_bytes(int B, int N, int classes);
+
+/* logits[B,classes] = net(x[B,3,N]); keeps the activations backward needs in `workspace`.
+ * Replaces `net(input_curr_iter)` at Attacker/geoA3_attack.py:103 (and the b batch-1 calls at :297). */
+int geoa3_pointnet_forward(const geoa3_pointnet_weights* w, const float* x, int B, int N,
+                           float* logits, void* workspace, void* stream);
+
+/* dx[B,3,N] = d( sum_b <dlogits[b], logits[b]> ) / d x, for the forward that last filled
+ * `workspace`.  Replaces the autograd walk of loss.backward() through the network
+ * (Attacker/geoA3_attack.py:326); weight gradients are never formed. */
+int geoa3_pointnet_backward(const geoa3_pointnet_weights* w, const float* x, const float* dlogits,
+                            int B, int N, float* dx, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Driver level: device-resident state of attack() (Attacker/geoA3_attack.py:182-386).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct geoa3_attack_state {
+  int32_t B, N, classes;
+  int32_t targeted;          /* cfg.attack_label != 'Untarget' (geoA3_attack.py:189-192) */
+  int32_t cls_loss_type;     /* 0 = None, 1 = CE, 2 = Margin (geoA3_attack.py:105-127)   */
+  float confidence;          /* cfg.confidence                                          */
+  float inv_global_batch;    /* 1 / b of `loss_n.mean()` (geoA3_attack.py:178); the GLOBAL b when sharded */
+  const int32_t* gt;         /* [B] ground-truth labels                                 */
+  const int32_t* target;     /* [B] attack targets (== gt when untargeted, geoA3_attack.py:211-214) */
+  float* scale_const;        /* [B] */
+  float* lower_bound;        /* [B] */
+  float* upper_bound;        /* [B] */
+  float* best_loss;          /* [B] init 1e10 */
+  float* best_attack;        /* [B,3,N] init 1.0 (geoA3_attack.py:226) */
+  int32_t* best_step;        /* [B] init -1 */
+  int32_t* best_bs;          /* [B] init -1 */
+  float* iter_best_loss;     /* [B] reset to 1e10 per binary step */
+  int32_t* iter_best_score;  /* [B] reset to -1 per binary step   */
+  float* prev_constrain;     /* [B] reset to 1e10 per binary step (geoA3_attack.py:233,301) */
+  int32_t* label;            /* [B] arg-max label of the current iterate */
+  float* cls_loss;           /* [B] */
+  float* loss_n;             /* [B] */
+  float* loss_hist;          /* [iter_max_steps, B] (all_loss_list, geoA3_attack.py:229,321) or NULL */
+  int32_t* last_label;       /* [1] label of the LAST instance at the LAST step (the `output_label`
+                                reused for every k at geoA3_attack.py:375) */
+} geoa3_attack_state;
+
+/* Per step, after the forward: classification loss + d loss/d logits, arg-max label, the success
+ * bookkeeping of geoA3_attack.py:288-310 for the CURRENT iterate x with the PREVIOUS step's
+ * constrain loss, loss_n = cls + scale_const*constrain, and prev_constrain <- constrain.
+ * dlogits[B,classes] already carries inv_global_batch. */
+int geoa3_attack_head(const geoa3_attack_state* st, const float* logits, const float* constrain,
+                      const float* x, int step, int search_step, float* dlogits, void* stream);
+
+/* Per step, after both backward passes: g = g_cls + scale_const[b]*inv_global_batch*g_geo, then the
+ * optimiser update of `offset` (torch.optim.Adam defaults or plain SGD, geoA3_attack.py:269-272,
+ * 323-331), optional lp_clip (geoA3_attack.py:88-98,349-352), and x = ori + offset for the next step.
+ * step_size = lr/(1-beta1^t) and sqrt_bc2 = sqrt(1-beta2^t) are formed on the host in double
+ * exactly as torch.optim.Adam does.  optim: 0 = adam, 1 = sgd (step_size = lr). */
+int geoa3_attack_update(const geoa3_attack_state* st, const float* g_cls, const float* g_geo,
+                        const float* ori, float* offset, float* adam_m, float* adam_v, float* x,
+                        int optim, float step_size, float sqrt_bc2, float cc_linf, void* stream);
+
+/* End of a binary step: the scale_const / bound update of geoA3_attack.py:374-384, bug-compatible
+ * (uses *last_label for every instance).  Also re-arms the per-binary-step state. */
+int geoa3_attack_binary_update(const geoa3_attack_state* st, void* stream);
+
+/* Start of a binary step: offset <- init_offset, adam state <- 0, x = ori + offset, per-step state reset. */
+int geoa3_attack_begin_search_step(const geoa3_attack_state* st, const float* ori, const float* init_offset,
+                                   float* offset, float* adam_m, float* adam_v, float* x, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOA3_HIP_H */

@@ -1,0 +1,166 @@
+"""HIP geometry kernels (through the C ABI) against the CPU oracle and the golden fixtures.
+Runs on the GPU box: python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geoa3_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+CASES = ["n64k2", "n64k16", "n256k16", "n128k32", "dup", "zero"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from geoa3_amd import ops as _ops
+    assert torch.cuda.is_available(), "needs the MI355X"
+    return _ops
+
+
+def dev(x):
+    return x.contiguous().cuda()
+
+
+def _rand_clouds(B, Na, Nr, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(B, 3, Na, generator=g)
+    r = torch.randn(B, 3, Nr, generator=g)
+    return a, r
+
+
+@pytest.mark.parametrize("B,Na,Nr", [(3, 64, 64), (2, 1000, 1000), (2, 1024, 1024), (2, 300, 777), (1, 2500, 2049),
+                                     (1, 5, 3)])
+def test_nn1_pair_bit_exact(ops, B, Na, Nr):
+    a, r = _rand_clouds(B, Na, Nr, 7)
+    a[:, :, 0] = r[:, :, min(2, Nr - 1)]          # an exact zero distance
+    if Nr > 4:
+        r[:, :, 4] = r[:, :, 1]                   # duplicate reference points: tie -> lower index
+    d_ar, i_ar, d_ra, i_ra = ops.nn1_pair(dev(a), dev(r))
+    od, oi = O.knn_points(a.permute(0, 2, 1), r.permute(0, 2, 1), 1)
+    assert torch.equal(i_ar.cpu().long(), oi.squeeze(-1))
+    assert torch.equal(d_ar.cpu(), od.squeeze(-1))     # bit-exact: same un-fused arithmetic
+    od, oi = O.knn_points(r.permute(0, 2, 1), a.permute(0, 2, 1), 1)
+    assert torch.equal(i_ra.cpu().long(), oi.squeeze(-1))
+    assert torch.equal(d_ra.cpu(), od.squeeze(-1))
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_nn1_on_golden_clouds(ops, golden, tag):
+    pre = "ops/%s/" % tag
+    adv, ori = T(golden[pre + "adv"]), T(golden[pre + "ori"])
+    d_ar, i_ar, d_ra, i_ra = ops.nn1_pair(dev(adv), dev(ori))
+    od, oi = O.knn_points(adv.permute(0, 2, 1), ori.permute(0, 2, 1), 1)
+    assert torch.equal(i_ar.cpu().long(), oi.squeeze(-1)) and torch.equal(d_ar.cpu(), od.squeeze(-1))
+
+
+@pytest.mark.parametrize("B,Nq,Nr,K", [(2, 64, 64, 3), (2, 1024, 1024, 17), (1, 1024, 1024, 33), (2, 500, 300, 5),
+                                       (1, 2100, 2100, 17), (1, 10, 6, 8), (1, 700, 700, 64)])
+@pytest.mark.parametrize("prior_kind", ["none", "good", "stale", "duplicate"])
+def test_knn_bit_exact(ops, B, Nq, Nr, K, prior_kind):
+    q, r = _rand_clouds(B, Nq, Nr, 11)
+    if Nq == Nr:
+        q = r + 0.01 * q                         # self-like query (the curvature use case)
+        q[:, :, 3] = q[:, :, 2]                   # duplicates inside the cloud
+    od, oi = O.knn_points(q.permute(0, 2, 1), r.permute(0, 2, 1), min(K, Nr))
+    prior = None
+    if prior_kind != "none":
+        if K > Nr:
+            pytest.skip("prior needs K <= Nr")
+        if prior_kind == "good":
+            prior = oi.int()
+        elif prior_kind == "stale":               # neighbours of a perturbed cloud
+            _, pi = O.knn_points((q + 0.05 * torch.randn_like(q)).permute(0, 2, 1), r.permute(0, 2, 1), K)
+            prior = pi.int()
+        else:                                     # invalid prior: all the same index
+            prior = torch.zeros(B, Nq, K, dtype=torch.int32)
+        prior = dev(prior)
+    d, i = ops.knn_planar(dev(q), dev(r), K, prior)
+    kk = min(K, Nr)
+    assert torch.equal(i.cpu().long()[:, :, :kk], oi)
+    assert torch.equal(d.cpu()[:, :, :kk], od)
+    if K > Nr:
+        assert (i.cpu()[:, :, kk:] == -1).all() and torch.isinf(d.cpu()[:, :, kk:]).all()
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_kappa_ori_golden(ops, golden, tag):
+    pre = "ops/%s/" % tag
+    ori, nrm, k = T(golden[pre + "ori"]), T(golden[pre + "nrm"]), int(golden[pre + "k"])
+    _, idx = ops.knn_planar(dev(ori), dev(ori), k + 1)
+    kap = ops.kappa(dev(ori), dev(nrm), idx)
+    np.testing.assert_allclose(kap.cpu().numpy(), golden[pre + "kappa_ori"], rtol=2e-5, atol=2e-6)
+
+
+def _geo(ops, golden, tag, **kw):
+    pre = "ops/%s/" % tag
+    adv, ori, nrm = (dev(T(golden[pre + n])) for n in ("adv", "ori", "nrm"))
+    k = int(golden[pre + "k"])
+    d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(adv, ori)
+    _, knn_ori = ops.knn_planar(ori, ori, k + 1)
+    kap_ori = ops.kappa(ori, nrm, knn_ori)
+    _, knn_adv = ops.knn_planar(adv, adv, k + 1, knn_ori)
+    return ops.geo_loss_grad(adv, ori, normal_ori=nrm, kappa_ori=kap_ori, d_ao=d_ao, i_ao=i_ao, d_oa=d_oa, i_oa=i_oa,
+                             knn_adv=knn_adv, k=k, want_kappa=True, **kw), pre
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_geo_losses_and_grads_golden(ops, golden, tag):
+    # fp32 tolerance: 2e-5 relative on values, 1e-4 relative (+1e-7 abs) on gradients
+    def close(a, b, rtol, atol):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=rtol, atol=atol)
+
+    o, pre = _geo(ops, golden, tag, dis_type=1, w_dis=1.0)
+    close(o["dis_loss"], golden[pre + "cd"], 2e-5, 1e-7)
+    close(o["grad"], golden[pre + "g_cd"], 1e-4, 1e-7)
+    o, _ = _geo(ops, golden, tag, dis_type=1, single_side=True, w_dis=1.0)
+    close(o["dis_loss"], golden[pre + "pcd"], 2e-5, 1e-7)
+    close(o["grad"], golden[pre + "g_pcd"], 1e-4, 1e-7)
+    o, _ = _geo(ops, golden, tag, dis_type=2, w_dis=1.0)
+    close(o["dis_loss"], golden[pre + "l2"], 2e-5, 1e-7)
+    close(o["grad"], golden[pre + "g_l2"], 1e-4, 1e-7)
+    o, _ = _geo(ops, golden, tag, dis_type=0, w_hd=1.0)
+    close(o["hd_loss"], golden[pre + "hd"], 2e-5, 1e-7)
+    if tag != "zero":   # all distances are 0: the arg-max point is a tie and its gradient is 0 anyway
+        close(o["grad"], golden[pre + "g_hd"], 1e-4, 1e-7)
+    o, _ = _geo(ops, golden, tag, dis_type=0, w_curv=1.0)
+    close(o["kappa_adv"], golden[pre + "kappa_adv"], 2e-5, 2e-6)
+    close(o["curv_loss"], golden[pre + "curv"], 1e-4, 1e-8)
+    close(o["grad"], golden[pre + "g_curv"], 2e-3, 2e-6)
+    # the combined objective: constrain and its gradient
+    o, _ = _geo(ops, golden, tag, dis_type=1, w_dis=1.0, w_hd=0.1, w_curv=1.0)
+    con = golden[pre + "cd"] + 0.1 * golden[pre + "hd"] + golden[pre + "curv"]
+    close(o["constrain"], con, 5e-5, 1e-7)
+    g = golden[pre + "g_cd"] + 0.1 * golden[pre + "g_hd"] + golden[pre + "g_curv"]
+    if tag != "zero":
+        close(o["grad"], g, 2e-3, 2e-6)
+
+
+def test_knn_points_operator_autograd(ops, golden):
+    """pytorch3d-shaped operator: values, indices and gradients through dists."""
+    pre = "ops/n64k16/"
+    adv = T(golden[pre + "adv"]).permute(0, 2, 1).contiguous()
+    ori = T(golden[pre + "ori"]).permute(0, 2, 1).contiguous()
+    for K in (1, 5):
+        a_c = adv.clone().requires_grad_()
+        o_c = ori.clone().requires_grad_()
+        od, oi = O.knn_points(a_c, o_c, K)
+        w = torch.rand(od.shape, generator=torch.Generator().manual_seed(K))
+        (od * w).sum().backward()
+        a_g = adv.cuda().requires_grad_()
+        o_g = ori.cuda().requires_grad_()
+        r = ops.knn_points(a_g, o_g, K)
+        assert r.idx.dtype == torch.int64 and torch.equal(r.idx.cpu(), oi)
+        assert torch.equal(r.dists.detach().cpu(), od.detach())
+        (r.dists * w.cuda()).sum().backward()
+        np.testing.assert_allclose(a_g.grad.cpu().numpy(), a_c.grad.numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(o_g.grad.cpu().numpy(), o_c.grad.numpy(), rtol=1e-5, atol=1e-7)
+        g = ops.knn_gather(o_g.detach(), r.idx)
+        assert torch.equal(g.cpu(), O.knn_gather(ori, oi))
+
+
+def test_cpu_tensors_are_rejected(ops):
+    from geoa3_amd._lib import Geoa3Error
+    a, r = _rand_clouds(1, 8, 8, 0)
+    with pytest.raises(Geoa3Error):
+        ops.nn1_pair(a, r)
