@@ -1,11 +1,225 @@
-// PointNet forward / input-gradient (placeholder translation unit: kernels land in pointnet_*.hip).
-#include "common.h"
+// PointNet eval forward and input-gradient: launch sequence over the kernels of pointnet_*.hip.
+// Reference: Model/PointNet.py:56-94 (transform_net) and :96-160 (PointNet.forward); the backward is the
+// hand-derived input-gradient of that graph (weights never receive gradients; the reference's autograd
+// also forms the unused weight gradients, Attacker/geoA3_attack.py:326).
+#include "pointnet_kernels.h"
 
-extern "C" int64_t geoa3_pointnet_workspace_bytes(int B, int N, int classes) { return -1; }
-extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights*, const float*, int, int, float*, void*, void*) {
-  return GEOA3_ENOSUPPORT;
+namespace {
+
+struct Ws {  // workspace carve-up; every buffer starts on a 256-byte boundary
+  // T-Net 3 (input transform)
+  float *a1, *a2, *p3, *tf4, *tf5, *T3;
+  int* i3;
+  // trunk + T-Net 64 (feature transform)
+  float *h1, *h2, *c1, *c2, *q3, *qf4, *qf5, *T64;
+  int* iq3;
+  float *h2p, *h3, *h4, *p5, *f6, *f7;
+  int* i5;
+  // backward temporaries
+  float *G128, *G64a, *G64b, *dh2, *g1024, *g512, *g256, *gT64, *gT3;
+  size_t total;
+};
+
+Ws carve(void* base, int B, int N, int classes) {
+  Ws w{};
+  size_t off = 0;
+  char* p = static_cast<char*>(base);
+  auto take = [&](size_t nfloats) {
+    void* r = p ? p + off : nullptr;
+    off += ((nfloats * 4 + 255) / 256) * 256;
+    return r;
+  };
+  const size_t s64 = (size_t)B * 64 * N, s128 = (size_t)B * 128 * N, b = (size_t)B;
+  w.a1 = (float*)take(s64);
+  w.a2 = (float*)take(s128);
+  w.p3 = (float*)take(b * 1024);
+  w.i3 = (int*)take(b * 1024);
+  w.tf4 = (float*)take(b * 512);
+  w.tf5 = (float*)take(b * 256);
+  w.T3 = (float*)take(b * 9);
+  w.h1 = (float*)take(s64);
+  w.h2 = (float*)take(s64);
+  w.c1 = (float*)take(s64);
+  w.c2 = (float*)take(s128);
+  w.q3 = (float*)take(b * 1024);
+  w.iq3 = (int*)take(b * 1024);
+  w.qf4 = (float*)take(b * 512);
+  w.qf5 = (float*)take(b * 256);
+  w.T64 = (float*)take(b * 4096);
+  w.h2p = (float*)take(s64);
+  w.h3 = (float*)take(s64);
+  w.h4 = (float*)take(s128);
+  w.p5 = (float*)take(b * 1024);
+  w.i5 = (int*)take(b * 1024);
+  w.f6 = (float*)take(b * 512);
+  w.f7 = (float*)take(b * 256);
+  w.G128 = (float*)take(s128);
+  w.G64a = (float*)take(s64);
+  w.G64b = (float*)take(s64);
+  w.dh2 = (float*)take(s64);
+  w.g1024 = (float*)take(b * 1024);
+  w.g512 = (float*)take(b * 512);
+  w.g256 = (float*)take(b * 256);
+  w.gT64 = (float*)take(b * 4096);
+  w.gT3 = (float*)take(b * 16);
+  w.total = off;
+  (void)classes;
+  return w;
 }
-extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights*, const float*, const float*, int, int, float*,
-                                       void*, void*) {
-  return GEOA3_ENOSUPPORT;
+
+#define TRY(expr)             \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+// Y = act(W X + bias) over [B][K][N] -> [B][Co][N]; shared weights [Co][K]
+int conv(const float* X, int K, const float* W, const float* bias, float* Y, int Co, int B, int N, bool relu,
+         const float* Z, bool accumulate, hipStream_t s) {
+  ConvArgs a{};
+  a.X = X; a.sXb = (long)K * N; a.ldX = N;
+  a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
+  a.bias = bias;
+  a.Z = Z; a.sZb = (long)Co * N; a.ldZ = N;
+  a.Y = Y; a.sYb = (long)Co * N; a.ldY = N;
+  a.Co = Co; a.K = K; a.N = N; a.B = B;
+  a.relu = relu; a.accumulate = accumulate;
+  return launch_conv_cm(a, s);
+}
+
+// per-instance 64x64 transform: transposed=true: Y[j][n] = sum_i T[i][j] X[i][n]; false: Y[i][n] = sum_j T[i][j] X[j][n]
+int transform64(const float* X, const float* T, float* Y, bool transposed, int B, int N, hipStream_t s) {
+  ConvArgs a{};
+  a.X = X; a.sXb = (long)64 * N; a.ldX = N;
+  a.W = T; a.sWb = 4096;
+  if (transposed) { a.sWco = 1; a.sWk = 64; } else { a.sWco = 64; a.sWk = 1; }
+  a.Y = Y; a.sYb = (long)64 * N; a.ldY = N;
+  a.Co = 64; a.K = 64; a.N = N; a.B = B;
+  return launch_conv_cm(a, s);
+}
+
+int fc(const float* X, int K, const float* W, const float* bias, float* Y, int Nout, int M, bool relu, const float* Z,
+       hipStream_t s) {
+  FcArgs a{};
+  a.X = X; a.ldX = K;
+  a.W = W; a.ldW = K;
+  a.bias = bias;
+  a.Z = Z; a.ldZ = Nout;
+  a.Y = Y; a.ldY = Nout;
+  a.M = M; a.Nout = Nout; a.K = K; a.relu = relu;
+  return launch_fc(a, s);
+}
+
+int wide(const float* X, const float* W, const float* bias, float* out, int* arg, int taps, int B, int N,
+         hipStream_t s) {
+  WideArgs a{};
+  a.X = X; a.sXb = (long)128 * N; a.ldX = N;
+  a.W = W; a.bias = bias; a.out = out; a.arg = arg;
+  a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
+  return launch_wide_max(a, s);
+}
+
+int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, float* dX, int taps, int B, int N,
+             hipStream_t s) {
+  WideBwdArgs a{};
+  a.g = g; a.arg = arg; a.W = W;
+  a.Z = Z; a.sZb = (long)128 * N; a.ldZ = N;
+  a.dX = dX; a.sXb = (long)128 * N; a.ldX = N;
+  a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
+  return launch_wide_max_bwd(a, s);
+}
+
+// transform_net.forward (Model/PointNet.py:78-87) after its first layer
+int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, float* act128, float* pooled, int* arg, float* f4,
+                  float* f5, float* T, int B, int N, hipStream_t s) {
+  TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s));
+  TRY(wide(act128, t.w3, t.b3, pooled, arg, 1, B, N, s));
+  TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
+  TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
+  TRY(fc(f5, 256, t.f3, t.fb3, T, t.K * t.K, B, false, nullptr, s));
+  return 0;
+}
+
+// d/d(transform) [B][K*K] -> gradient w.r.t. the pre-activation of the T-Net's first layer (G64 out)
+int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, const float* act128,
+             const float* pooled, const int* arg, const float* f4, const float* f5, Ws& w, float* G64out, int B, int N,
+             hipStream_t s) {
+  TRY(fc(gT, t.K * t.K, t.f3t, nullptr, w.g256, 256, B, false, f5, s));
+  TRY(fc(w.g256, 256, t.f2t, nullptr, w.g512, 512, B, false, f4, s));
+  TRY(fc(w.g512, 512, t.f1t, nullptr, w.g1024, 1024, B, false, pooled, s));
+  TRY(wide_bwd(w.g1024, arg, t.w3, act128, w.G128, 1, B, N, s));
+  TRY(conv(w.G128, 128, t.w2t, nullptr, G64out, 64, B, N, false, act64, false, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t geoa3_pointnet_workspace_bytes(int B, int N, int classes) {
+  if (B <= 0 || N <= 0 || classes <= 0) return -1;
+  return (int64_t)carve(nullptr, B, N, classes).total;
+}
+
+extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const float* x, int B, int N, float* logits,
+                                      void* workspace, void* stream) {
+  if (!pw || !x || !logits || !workspace || B <= 0 || N <= 0) return GEOA3_EINVAL;
+  if (pw->t3.K != 3 || pw->t64.K != 64 || pw->classes <= 0) return GEOA3_EINVAL;
+  if (((uintptr_t)workspace & 255) != 0) return GEOA3_EINVAL;
+  hipStream_t s = geoa3_stream(stream);
+  Ws w = carve(workspace, B, N, pw->classes);
+  const geoa3_pointnet_weights& p = *pw;
+  // input transform (Model/PointNet.py:137-138)
+  TRY(launch_conv_in3(x, nullptr, p.t3.w1, p.t3.b1, w.a1, B, N, s));
+  TRY(tnet_tail_fwd(p.t3, w.a1, w.a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, B, N, s));
+  // trunk conv1, conv2 (:139-140)
+  TRY(launch_conv_in3(x, w.T3, p.w1, p.b1, w.h1, B, N, s));
+  TRY(conv(w.h1, 64, p.w2, p.b2, w.h2, 64, B, N, true, nullptr, false, s));
+  // feature transform (:142-143)
+  TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s));
+  TRY(tnet_tail_fwd(p.t64, w.c1, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, B, N, s));
+  TRY(transform64(w.h2, w.T64, w.h2p, true, B, N, s));
+  // conv3, conv4, conv5 + max (:144-147)
+  TRY(conv(w.h2p, 64, p.w3, p.b3, w.h3, 64, B, N, true, nullptr, false, s));
+  TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s));
+  TRY(wide(w.h4, p.w5, p.b5, w.p5, w.i5, 3, B, N, s));
+  // classifier head (:150-152), dropout is the identity in eval mode
+  TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));
+  TRY(fc(w.f6, 512, p.f2, p.fb2, w.f7, 256, B, true, nullptr, s));
+  TRY(fc(w.f7, 256, p.f3, p.fb3, logits, p.classes, B, false, nullptr, s));
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const float* x, const float* dlogits, int B,
+                                       int N, float* dx, void* workspace, void* stream) {
+  if (!pw || !x || !dlogits || !dx || !workspace || B <= 0 || N <= 0) return GEOA3_EINVAL;
+  hipStream_t s = geoa3_stream(stream);
+  Ws w = carve(workspace, B, N, pw->classes);
+  const geoa3_pointnet_weights& p = *pw;
+  // classifier head
+  TRY(fc(dlogits, p.classes, p.f3t, nullptr, w.g256, 256, B, false, w.f7, s));
+  TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.f6, s));
+  TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, 1024, B, false, w.p5, s));
+  // max + conv5 (sparse), conv4, conv3
+  TRY(wide_bwd(w.g1024, w.i5, p.w5, w.h4, w.G128, 3, B, N, s));
+  TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, w.h3, false, s));
+  TRY(conv(w.G64a, 64, p.w3t, nullptr, w.G64b, 64, B, N, false, nullptr, false, s));   // d/d(h2')
+  // feature transform: h2' = T64^T h2
+  TRY(launch_gram64(w.h2, w.G64b, w.gT64, B, N, s));
+  TRY(transform64(w.G64b, w.T64, w.dh2, false, B, N, s));
+  TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
+  // dh2 += W_t64.conv1^T G64a, then the relu gate of h2
+  {
+    ConvArgs a{};
+    a.X = w.G64a; a.sXb = (long)64 * N; a.ldX = N;
+    a.W = p.t64.w1; a.sWb = 0; a.sWco = 1; a.sWk = 64;  // W^T through the strided loader
+    a.Z = w.h2; a.sZb = (long)64 * N; a.ldZ = N;
+    a.Y = w.dh2; a.sYb = (long)64 * N; a.ldY = N;
+    a.Co = 64; a.K = 64; a.N = N; a.B = B; a.accumulate = 1;
+    TRY(launch_conv_cm(a, s));
+  }
+  TRY(conv(w.dh2, 64, p.w2t, nullptr, w.G64b, 64, B, N, false, w.h1, false, s));
+  // trunk conv1 + input transform: dx, dT3
+  TRY(launch_conv_in3_bwd(w.G64b, p.w1, w.T3, x, dx, w.gT3, 0, B, N, s));
+  TRY(tnet_bwd(p.t3, w.gT3, w.a1, w.a2, w.p3, w.i3, w.tf4, w.tf5, w, w.G64a, B, N, s));
+  TRY(launch_conv_in3_bwd(w.G64a, p.t3.w1, nullptr, x, dx, nullptr, 1, B, N, s));
+  return GEOA3_OK;
 }

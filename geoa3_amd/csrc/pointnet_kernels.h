@@ -1,0 +1,71 @@
+// Internal launch interface between pointnet.hip (orchestration) and the kernel translation units.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// exact-fp32 matrix core op: D(32x32) += A(32x2) * B(2x32).  Lane l supplies A[l&31][l>>5] and
+// B[l>>5][l&31]; D[i][j]: j = l&31, i = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// Y[b][co][n] = epi( sum_k W[b][co][k] * X[b][k][n] ),  n contiguous ("channel-major" 1x1 convolution,
+// per-instance transforms, and their transposed/backward forms).
+struct ConvArgs {
+  const float* X; long sXb; int ldX;
+  const float* W; long sWb; int sWco, sWk;   // element (co,k) at W + b*sWb + co*sWco + k*sWk
+  const float* bias;                          // [Co] or null
+  const float* Z; long sZb; int ldZ;          // relu mask source (keep where Z > 0) or null
+  float* Y; long sYb; int ldY;
+  int Co, K, N, B;
+  int relu, accumulate;
+};
+int launch_conv_cm(const ConvArgs& a, hipStream_t s);
+
+// Y[m][o] = epi( sum_k X[m][k] * W[o][k] + bias[o] )   (fully connected layers, both directions)
+struct FcArgs {
+  const float* X; int ldX;
+  const float* W; int ldW;
+  const float* bias;
+  const float* Z; int ldZ;                    // relu mask source or null
+  float* Y; int ldY;
+  int M, Nout, K;
+  int relu;
+};
+int launch_fc(const FcArgs& a, hipStream_t s);
+
+// out[b][co] = relu( max_n ( sum_{tap,ci} W[co][tap*Ci+ci] * X[b][ci][n+tap-(TAPS/2)] ) + bias[co] ),
+// arg[b][co] = the maximising n.  Ci = 128; TAPS = 1 (T-Net conv3) or 3 (conv5, zero padded).
+struct WideArgs {
+  const float* X; long sXb; int ldX;          // [B][128][N]
+  const float* W;                             // [Co][TAPS*128]
+  const float* bias;                          // [Co]
+  float* out; int* arg;                       // [B][Co]
+  int Co, N, B, taps;
+};
+int launch_wide_max(const WideArgs& a, hipStream_t s);
+
+// dX[b][ci][m] = relu'(Z) * sum_{co,tap : arg[b][co]+tap-(TAPS/2) == m} W[co][tap*128+ci] * g[b][co]
+struct WideBwdArgs {
+  const float* g; const int* arg;             // [B][Co]
+  const float* W;                             // [Co][TAPS*128]
+  const float* Z; long sZb; int ldZ;          // activation whose relu gates the result ([B][128][N])
+  float* dX; long sXb; int ldX;               // [B][128][N]
+  int Co, N, B, taps;
+};
+int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s);
+
+// First layers: Y[b][co][n] = relu( sum_c W[co][c] * (sum_d T[b][d][c] * x[b][d][n]) + bias[co] ), co < 64
+int launch_conv_in3(const float* x, const float* T /*[B][9] or null*/, const float* W /*[64][3]*/,
+                    const float* bias, float* Y /*[B][64][N]*/, int B, int N, hipStream_t s);
+
+// Backward of the first layers.  g [B][64][N] is d/d(pre-activation).  Computes
+//   dxp[c][n] = sum_co W[co][c] g[co][n];  dx[d][n] (+)= sum_c T[d][c] dxp[c][n] (T null: identity);
+//   dT[b][d][c] = sum_n x[d][n] dxp[c][n]  (when dT != null)
+int launch_conv_in3_bwd(const float* g, const float* W /*[64][3]*/, const float* T, const float* x, float* dx,
+                        float* dT, int accumulate, int B, int N, hipStream_t s);
+
+// dT[b][i][j] = sum_n F[b][i][n] * G[b][j][n]   (i, j < 64)
+int launch_gram64(const float* F, const float* G, float* dT, int B, int N, hipStream_t s);

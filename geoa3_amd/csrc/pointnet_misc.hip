@@ -1,0 +1,154 @@
+// Small PointNet pieces that are not MFMA-shaped (gfx950): the 3-channel input layers with the 3x3 input
+// transform (Model/PointNet.py:79,137-139), their backward, and the 64x64 transform-gradient Gram product.
+#include "pointnet_kernels.h"
+
+namespace {
+
+// Y[b][co][n] = relu( W[co][:] . (T[b]^T x[b][:,n]) + bias[co] );  one thread per point, weights in LDS.
+__global__ __launch_bounds__(256) void conv_in3_kernel(const float* __restrict__ x, const float* __restrict__ T,
+                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ Y, int N) {
+  __shared__ float s_w[64 * 3], s_b[64], s_t[9];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 192) s_w[tid] = W[tid];
+  if (tid < 64) s_b[tid] = bias[tid];
+  if (tid < 9) s_t[tid] = T ? T[(size_t)b * 9 + tid] : ((tid % 4 == 0) ? 1.f : 0.f);
+  __syncthreads();
+  const int n = blockIdx.x * 256 + tid;
+  if (n >= N) return;
+  const float* xb = x + (size_t)b * 3 * N;
+  const float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+  float p0 = x0, p1 = x1, p2 = x2;
+  if (T) {  // bmm(pc^T, T)^T : x'[c] = sum_d x[d] T[d][c]
+    p0 = x0 * s_t[0] + x1 * s_t[3] + x2 * s_t[6];
+    p1 = x0 * s_t[1] + x1 * s_t[4] + x2 * s_t[7];
+    p2 = x0 * s_t[2] + x1 * s_t[5] + x2 * s_t[8];
+  }
+  float* yb = Y + (size_t)b * 64 * N + n;
+#pragma unroll 8
+  for (int co = 0; co < 64; ++co) {
+    const float v = s_w[co * 3] * p0 + s_w[co * 3 + 1] * p1 + s_w[co * 3 + 2] * p2 + s_b[co];
+    yb[(size_t)co * N] = fmaxf(v, 0.f);
+  }
+}
+
+// One workgroup per instance (deterministic dT reduction).
+__global__ __launch_bounds__(256) void conv_in3_bwd_kernel(const float* __restrict__ g, const float* __restrict__ W,
+                                                           const float* __restrict__ T, const float* __restrict__ x,
+                                                           float* __restrict__ dx, float* __restrict__ dT,
+                                                           int accumulate, int N) {
+  __shared__ float s_w[64 * 3], s_t[9], s_red[4][9];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 192) s_w[tid] = W[tid];
+  if (tid < 9) s_t[tid] = T ? T[(size_t)b * 9 + tid] : ((tid % 4 == 0) ? 1.f : 0.f);
+  __syncthreads();
+  const float* gb = g + (size_t)b * 64 * N;
+  const float* xb = x + (size_t)b * 3 * N;
+  float* dxb = dx + (size_t)b * 3 * N;
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t[i] = 0.f;
+  for (int n = tid; n < N; n += 256) {
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;  // d/d x' (the transformed input)
+#pragma unroll 8
+    for (int co = 0; co < 64; ++co) {
+      const float gv = gb[(size_t)co * N + n];
+      q0 += s_w[co * 3] * gv;
+      q1 += s_w[co * 3 + 1] * gv;
+      q2 += s_w[co * 3 + 2] * gv;
+    }
+    // x' = T^T x  =>  dx[d] = sum_c T[d][c] q[c]
+    float d0 = s_t[0] * q0 + s_t[1] * q1 + s_t[2] * q2;
+    float d1 = s_t[3] * q0 + s_t[4] * q1 + s_t[5] * q2;
+    float d2 = s_t[6] * q0 + s_t[7] * q1 + s_t[8] * q2;
+    if (accumulate) {
+      d0 += dxb[n];
+      d1 += dxb[N + n];
+      d2 += dxb[2 * N + n];
+    }
+    dxb[n] = d0;
+    dxb[N + n] = d1;
+    dxb[2 * N + n] = d2;
+    if (dT) {
+      const float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+      t[0] += x0 * q0; t[1] += x0 * q1; t[2] += x0 * q2;
+      t[3] += x1 * q0; t[4] += x1 * q1; t[5] += x1 * q2;
+      t[6] += x2 * q0; t[7] += x2 * q1; t[8] += x2 * q2;
+    }
+  }
+  if (dT) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float v = wave_sum(t[i]);
+      if (lane == 0) s_red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < 9) dT[(size_t)b * 9 + tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+  }
+}
+
+// dT[b][i][j] = sum_n F[b][i][n] G[b][j][n].  One workgroup per instance; thread (ti,tj) owns a 4x4 block.
+constexpr int GR_TN = 32;
+__global__ __launch_bounds__(256) void gram64_kernel(const float* __restrict__ F, const float* __restrict__ G,
+                                                     float* __restrict__ dT, int N) {
+  __shared__ float s_f[64][GR_TN + 1], s_g[64][GR_TN + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+  const float* Fb = F + (size_t)b * 64 * N;
+  const float* Gb = G + (size_t)b * 64 * N;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int n0 = 0; n0 < N; n0 += GR_TN) {
+    __syncthreads();
+    for (int e = tid; e < 64 * GR_TN; e += 256) {
+      const int r = e / GR_TN, c = e - r * GR_TN;
+      const bool ok = n0 + c < N;
+      s_f[r][c] = ok ? Fb[(size_t)r * N + n0 + c] : 0.f;
+      s_g[r][c] = ok ? Gb[(size_t)r * N + n0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < GR_TN; ++c) {
+      float fv[4], gv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fv[i] = s_f[ti + i][c];
+        gv[i] = s_g[tj + i][c];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += fv[i] * gv[j];
+    }
+  }
+  float* o = dT + (size_t)b * 4096;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[(ti + i) * 64 + tj + j] = acc[i][j];
+}
+
+}  // namespace
+
+int launch_conv_in3(const float* x, const float* T, const float* W, const float* bias, float* Y, int B, int N,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(conv_in3_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, x, T, W, bias, Y, N);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+int launch_conv_in3_bwd(const float* g, const float* W, const float* T, const float* x, float* dx, float* dT,
+                        int accumulate, int B, int N, hipStream_t s) {
+  hipLaunchKernelGGL(conv_in3_bwd_kernel, dim3(B), dim3(256), 0, s, g, W, T, x, dx, dT, accumulate, N);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+int launch_gram64(const float* F, const float* G, float* dT, int B, int N, hipStream_t s) {
+  hipLaunchKernelGGL(gram64_kernel, dim3(B), dim3(256), 0, s, F, G, dT, N);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}

@@ -1,0 +1,191 @@
+"""Module-level boundary: a PointNet nn.Module with the reference's constructor signature
+and state_dict layout (Model/PointNet.py:56-179: 110 entries), whose eval-mode forward and input
+gradient run in the HIP library (geoa3_pointnet_forward / geoa3_pointnet_backward).
+
+BatchNorm (eval: an affine map from the running statistics) is folded into the preceding conv / linear
+layer on the host, in float64, once per weight version; the packed buffers are what the C ABI consumes.
+There is no CPU forward: a CPU input raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import PointNetWeights, TnetWeights, check
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------------
+# host-side weight folding / packing (pure tensor algebra, runs on any device)
+# --------------------------------------------------------------------------------------------
+def _fold(w: Tensor, b: Tensor, sd: Dict[str, Tensor], bn: Optional[str], eps: float):
+    """(W, bias) of `bn(conv(x))` as one affine map.  w: [Co, ...]."""
+    w64, b64 = w.double(), b.double()
+    if bn is None:
+        return w64, b64
+    g, beta = sd[bn + ".weight"].double(), sd[bn + ".bias"].double()
+    mean, var = sd[bn + ".running_mean"].double(), sd[bn + ".running_var"].double()
+    s = g / torch.sqrt(var + eps)
+    return w64 * s.view(-1, *([1] * (w64.dim() - 1))), (b64 - mean) * s + beta
+
+
+def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
+    eps = 1e-3  # transform_net.eps, Model/PointNet.py:59
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    out: Dict[str, Tensor] = {}
+    w1, out["b1"] = _fold(sub["conv1.weight"], sub["conv1.bias"], sub, "bn1", eps)
+    w2, out["b2"] = _fold(sub["conv2.weight"], sub["conv2.bias"], sub, "bn2", eps)
+    w3, out["b3"] = _fold(sub["conv3.weight"], sub["conv3.bias"], sub, "bn3", eps)
+    out["w1"], out["w2"], out["w3"] = w1.squeeze(-1), w2.squeeze(-1), w3.squeeze(-1)
+    out["w2t"] = out["w2"].t()
+    out["f1"], out["fb1"] = _fold(sub["fc1.weight"], sub["fc1.bias"], sub, "bn4", eps)
+    out["f2"], out["fb2"] = _fold(sub["fc2.weight"], sub["fc2.bias"], sub, "bn5", eps)
+    out["f3"], out["fb3"] = _fold(sub["fc3.weight"], sub["fc3.bias"], sub, None, eps)
+    for n in ("f1", "f2", "f3"):
+        out[n + "t"] = out[n].t()
+    return {k: v.float().contiguous() for k, v in out.items()}
+
+
+def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
+    """state_dict (reference layout) -> {'t3': {...}, 't64': {...}, 'w1': ..., ...} fp32 contiguous."""
+    eps = 1e-3  # PointNet.eps for bn1..bn5 (Model/PointNet.py:100); bn6/bn7 use the default 1e-5 (:119,122)
+    out: Dict[str, object] = {"t3": pack_tnet(sd, "input_transform.", 3),
+                              "t64": pack_tnet(sd, "feature_transform.", 64)}
+    t: Dict[str, Tensor] = {}
+    for i, name in enumerate(["conv1", "conv2", "conv3", "conv4"], 1):
+        w, t["b%d" % i] = _fold(sd[name + ".weight"], sd[name + ".bias"], sd, "bn%d" % i, eps)
+        t["w%d" % i] = w.squeeze(-1)
+    w5, t["b5"] = _fold(sd["conv5.weight"], sd["conv5.bias"], sd, "bn5", eps)   # [1024,128,3]
+    t["w5"] = w5.permute(0, 2, 1).reshape(w5.shape[0], -1)                         # k = tap*128 + ci
+    t["w4t"], t["w3t"], t["w2t"] = t["w4"].t(), t["w3"].t(), t["w2"].t()
+    t["f1"], t["fb1"] = _fold(sd["fc1.weight"], sd["fc1.bias"], sd, "bn6", 1e-5)
+    t["f2"], t["fb2"] = _fold(sd["fc2.weight"], sd["fc2.bias"], sd, "bn7", 1e-5)
+    t["f3"], t["fb3"] = _fold(sd["fc3.weight"], sd["fc3.bias"], sd, None, eps)
+    for n in ("f1", "f2", "f3"):
+        t[n + "t"] = t[n].t()
+    out.update({k: v.float().contiguous() for k, v in t.items()})
+    return out
+
+
+class PackedPointNet:
+    """Device copies of the packed weights + the ctypes struct handed to the library."""
+
+    def __init__(self, sd: Dict[str, Tensor], device: torch.device):
+        packed = pack_pointnet({k: v.detach().cpu() for k, v in sd.items()})
+        self.classes = int(packed["f3"].shape[0])
+        self._keep = []
+
+        def dev(t: Tensor) -> int:
+            d = t.to(device).contiguous()
+            self._keep.append(d)
+            return d.data_ptr()
+
+        def tnet(p: Dict[str, Tensor], K: int) -> TnetWeights:
+            return TnetWeights(K=K, **{f[0]: dev(p[f[0]]) for f in TnetWeights._fields_ if f[0] != "K"})
+
+        fields = {f[0]: dev(packed[f[0]]) for f in PointNetWeights._fields_ if f[0] not in ("classes", "t3", "t64")}
+        self.struct = PointNetWeights(classes=self.classes, t3=tnet(packed["t3"], 3), t64=tnet(packed["t64"], 64),
+                                      **fields)
+
+
+class _PointNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, packed: PackedPointNet, ws_cache: dict):
+        if not x.is_cuda:
+            raise _lib.Geoa3Error("geoa3_amd.PointNet runs on the GPU only (no CPU path)")
+        x = x.contiguous().float()
+        B, _, N = x.shape
+        lib = _lib.load()
+        nbytes = lib.geoa3_pointnet_workspace_bytes(B, N, packed.classes)
+        ws = ws_cache.get("ws")
+        if ws is None or ws.numel() < nbytes or ws.device != x.device:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            ws_cache["ws"] = ws
+        logits = torch.empty(B, packed.classes, device=x.device, dtype=torch.float32)
+        s = torch.cuda.current_stream().cuda_stream
+        check(lib.geoa3_pointnet_forward(C.byref(packed.struct), x.data_ptr(), B, N, logits.data_ptr(),
+                                         ws.data_ptr(), s), "geoa3_pointnet_forward")
+        ctx.packed, ctx.ws = packed, ws
+        ctx.ws_version = ws_cache["version"] = ws_cache.get("version", 0) + 1
+        ctx.ws_cache = ws_cache
+        ctx.save_for_backward(x)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (x,) = ctx.saved_tensors
+        if ctx.ws_cache.get("version") != ctx.ws_version:
+            raise _lib.Geoa3Error("PointNet workspace was overwritten by a later forward before backward ran")
+        B, _, N = x.shape
+        dx = torch.empty_like(x)
+        s = torch.cuda.current_stream().cuda_stream
+        check(_lib.load().geoa3_pointnet_backward(C.byref(ctx.packed.struct), x.data_ptr(),
+                                                  g.contiguous().float().data_ptr(), B, N, dx.data_ptr(),
+                                                  ctx.ws.data_ptr(), s), "geoa3_pointnet_backward")
+        return dx, None, None
+
+
+class _TransformNet(nn.Module):
+    """Parameter container with the layout of transform_net (Model/PointNet.py:56-94)."""
+
+    def __init__(self, K: int = 3):
+        super().__init__()
+        self.K = K
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(K, 64, 1), nn.Conv1d(64, 128, 1), nn.Conv1d(128, 1024, 1)
+        self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, K * K)
+        self.bn1, self.bn2, self.bn3 = (nn.BatchNorm1d(c, eps=1e-3) for c in (64, 128, 1024))
+        self.bn4, self.bn5 = nn.BatchNorm1d(512, eps=1e-3), nn.BatchNorm1d(256, eps=1e-3)
+        with torch.no_grad():  # Model/PointNet.py:89-94
+            for m in (self.conv1, self.conv2, self.conv3, self.fc1, self.fc2):
+                nn.init.xavier_uniform_(m.weight)
+                m.bias.zero_()
+            self.fc3.weight.zero_()
+            self.fc3.bias.copy_(torch.eye(K).view(-1))
+
+
+class PointNet(nn.Module):
+    """Drop-in for Model.PointNet.PointNet(classes, return_idx=False, npoint=1024) in EVAL mode.
+    `net.load_state_dict(torch.load(path)['state_dict'])` works unchanged (main_attack.py:144-145)."""
+
+    def __init__(self, classes: int, return_idx: bool = False, npoint: int = 1024):
+        super().__init__()
+        if return_idx:
+            raise NotImplementedError("return_idx is not on the attack path")
+        self.num_class = classes
+        self.input_transform = _TransformNet(3)
+        self.feature_transform = _TransformNet(64)
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(3, 64, 1), nn.Conv1d(64, 64, 1), nn.Conv1d(64, 64, 1)
+        self.conv4, self.conv5 = nn.Conv1d(64, 128, 1), nn.Conv1d(128, 1024, 3, 1, 1)
+        self.bn1, self.bn2, self.bn3 = (nn.BatchNorm1d(64, eps=1e-3) for _ in range(3))
+        self.bn4, self.bn5 = nn.BatchNorm1d(128, eps=1e-3), nn.BatchNorm1d(1024, eps=1e-3)
+        self.fc1, self.bn6 = nn.Linear(1024, 512), nn.BatchNorm1d(512)
+        self.fc2, self.bn7 = nn.Linear(512, 256), nn.BatchNorm1d(256)
+        self.fc3 = nn.Linear(256, classes)
+        with torch.no_grad():  # Model/PointNet.py:162-164
+            for m in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.fc1, self.fc2, self.fc3):
+                nn.init.xavier_uniform_(m.weight)
+                m.bias.zero_()
+        self._packed: Optional[PackedPointNet] = None
+        self._packed_key = None
+        self._ws_cache: dict = {}
+
+    def _weights_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def packed(self, device) -> PackedPointNet:
+        key = self._weights_key(device)
+        if self._packed is None or key != self._packed_key:
+            self._packed = PackedPointNet(self.state_dict(), device)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, pc: Tensor) -> Tensor:
+        assert pc.size(1) == 3
+        if self.training:
+            raise NotImplementedError("only the eval-mode forward (the attack's victim) is implemented")
+        return _PointNetFn.apply(pc, self.packed(pc.device), self._ws_cache)
