@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the GeoA3 inner attack loop on MI355X (BASELINE.json metric: attack-iterations/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE inner iteration of the attack (Attacker/geoA3_attack.py:238-352) applied to the whole batch of
+victim instances that lives on a GPU: success check + PointNet forward + CE/CD/HD/curvature objective + input
+gradient + Adam step.  Workload = BASELINE.json configs[1]: PointNet, N=1024 points, 250 instances per GPU, full
+GeoA3 (CD 1.0 + HD 0.1 + curvature 1.0 with k=16), untargeted CE.  Instances are independent, so N GPUs hold N
+independent 250-instance shards (weak scaling, no data-path collective; the global-batch loss divisor and the
+one-int last-label broadcast per binary step are what the sharded attack() adds, geoa3_amd/distributed.py).
+
+value = (instances advanced per second over all ranks) / 250 = iterations/sec of a 250-instance batch.
+Inputs are synthetic (seeded ellipsoid clouds, calibrated random-init PointNet), resident in HBM before timing.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+INSTANCES = 250
+NPOINT = 1024
+KNN = 16
+CLASSES = 40
+PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: dense fp32 matrix peak (spec)
+PEAK_HBM = 8.0e12
+
+
+def cfg_config2(steps):
+    from oracle.geoa3_oracle import AttackCfg  # plain namespace of the reference flags (no compute)
+    return AttackCfg(attack_label="Untarget", binary_max_steps=1, iter_max_steps=steps, lr=0.01, initial_const=10.0,
+                     cls_loss_type="CE", dis_loss_type="CD", dis_loss_weight=1.0, hd_loss_weight=0.1,
+                     curv_loss_weight=1.0, curv_loss_knn=KNN, classes=CLASSES)
+
+
+def cpu_baseline(sample_b=16, iters=3):
+    """The CPU port (oracle, reference semantics incl. the b batch-1 success-check forwards and the six dense
+    K-NN queries per iteration) timed on a bounded sample of the same workload."""
+    import torch
+    from oracle import geoa3_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = O.make_pointnet_state_dict(CLASSES, seed=0)
+    net = lambda x: O.pointnet_forward(sd, x)
+    ori, nrm = O.make_synthetic_clouds(sample_b, NPOINT, seed=0)
+    with torch.no_grad():
+        gt = net(ori).argmax(1)
+    g = torch.Generator().manual_seed(1)
+    init = [torch.randn(sample_b, 3, NPOINT, generator=g) * 1e-3]
+    O.attack(net, ori, nrm, gt, None, cfg_config2(1), init, faithful_success_check=True)  # warm-up
+    t0 = time.perf_counter()
+    O.attack(net, ori, nrm, gt, None, cfg_config2(iters), init, faithful_success_check=True)
+    dt = time.perf_counter() - t0
+    inst_it_per_s = sample_b * iters / dt
+    return {"value": inst_it_per_s / INSTANCES, "unit": "attack-iterations/sec (250-instance batch)",
+            "cores": threads, "kind": "port",
+            "sample": "oracle attack(), %d instances x %d iterations of config 2 (N=1024, CE+CD+HD+curv k=16), "
+                      "%.1f s, rate scaled to 250 instances" % (sample_b, iters, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--instances", type=int, default=INSTANCES, help="instances per GPU (default 250)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__
+    if not os.path.exists(os.path.join(REPO, "geoa3_amd", "lib", "libgeoa3_hip.so")):
+        __graft_entry__.build()
+    from geoa3_amd import _lib
+    from geoa3_amd.attack import AttackRunner
+    from geoa3_amd.pointnet import PointNet
+    from oracle.geoa3_oracle import make_pointnet_state_dict, make_synthetic_clouds  # input generators only
+
+    B = a.instances
+    total = a.warmup + a.steps
+    cfg = cfg_config2(total)
+    net = PointNet(CLASSES)
+    net.load_state_dict(make_pointnet_state_dict(CLASSES, seed=0))
+    net = net.to(dev).eval()
+    ori, nrm = make_synthetic_clouds(B, NPOINT, seed=100 + rank)
+    ori, nrm = ori.to(dev), nrm.to(dev)
+    with torch.no_grad():
+        gt = net(ori).argmax(1)
+    runner = AttackRunner(net, B, NPOINT, cfg, dev, global_batch=B * world)
+    runner.setup(ori, nrm, gt, gt)
+    g = torch.Generator(device="cpu").manual_seed(7 + rank)
+    init = (torch.randn(B, 3, NPOINT, generator=g) * 1e-3).to(dev)
+    runner.begin_search_step(init)
+    lib = _lib.load()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(a.warmup):
+        runner.step(s, 0)
+    barrier()
+    lib.geoa3_profile_enable(a.steps)
+    t0 = time.perf_counter()
+    for s in range(a.warmup, total):
+        runner.step(s, 0)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    def kernel_ms(tag):
+        buf = (C.c_float * a.steps)()
+        n = lib.geoa3_profile_read(tag, buf, a.steps)
+        return (sum(buf[:n]) / n) if n > 0 else None
+
+    conv5_ms, nn1_ms, knn_ms, tnet_ms = (kernel_ms(t) for t in range(4))
+    lib.geoa3_profile_enable(0)
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = (B * world * a.steps / dt) / INSTANCES
+        conv5_flops = 2.0 * B * NPOINT * 1024 * 384          # algorithmic: 1024 outputs x (3 taps x 128) MACs / point
+        achieved = conv5_flops / (conv5_ms * 1e-3) / 1e12 if conv5_ms else None
+        out = {
+            "metric": "attack-iterations/sec (B=250, N=1024)", "value": round(value, 3),
+            "unit": "iterations/s of a 250-instance batch", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: PointNet 1024-pt, %d instances per GPU, full GeoA3 "
+                                   "(CE + CD 1.0 + HD 0.1 + curvature 1.0 k=16), untargeted" % B,
+                       "instances_per_gpu": B, "npoint": NPOINT, "knn": KNN, "classes": CLASSES,
+                       "parallelism": "instance-sharded x%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "wide_max_kernel<3> (conv5+bn5+relu+max, fp32 MFMA)",
+                         "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_F32_MFMA / 1e12,
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_F32_MFMA, 4) if achieved else None,
+                         "avg_launch_ms": round(conv5_ms, 4) if conv5_ms else None,
+                         "algorithmic_flops_per_launch": conv5_flops, "traffic": None},
+        }
+        if nn1_ms:
+            cd_bytes = 40.0 * B * NPOINT
+            out["cd_kernel"] = {"kernel": "nn1_pair_kernel (1-NN both directions)", "avg_launch_us": round(nn1_ms * 1e3, 2),
+                                "hbm_GBps_algorithmic": round(cd_bytes / (nn1_ms * 1e-3) / 1e9, 2),
+                                "hbm_frac": round(cd_bytes / (nn1_ms * 1e-3) / PEAK_HBM, 5),
+                                "valu_frac": round(8.0 * B * NPOINT * NPOINT / (nn1_ms * 1e-3) / 157.3e12, 4)}
+        out["kernels_ms"] = {"conv5_wide_max": conv5_ms, "tnet_wide_max(x2)": tnet_ms, "nn1_pair": nn1_ms, "knn": knn_ms}
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline never blocks the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,8 @@ SIGNATURES = {
                                       C.c_float, C.c_float, vp]),
     "geoa3_attack_binary_update": (C.c_int, [C.POINTER(AttackState), vp]),
     "geoa3_attack_begin_search_step": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, vp, vp, vp, vp]),
+    "geoa3_profile_enable": (C.c_int, [C.c_int]),
+    "geoa3_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_int]),
 }
 
 _lib = None

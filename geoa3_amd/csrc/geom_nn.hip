@@ -6,6 +6,7 @@
 // as three planes (x|y|z), every lane reads the same LDS address (broadcast, conflict free) while
 // holding its own query point(s) in registers.  The N x N distance matrix is never materialised.
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -239,8 +240,10 @@ extern "C" int geoa3_nn1_pair(const float* a, const float* r, int B, int Na, int
   const int nmax = ndir == 2 ? (Na > Nr ? Na : Nr) : Na;
   constexpr int QPT = 2;
   dim3 grid((nmax + NN_BLOCK * QPT - 1) / (NN_BLOCK * QPT), B, ndir);
+  geoa3_prof_begin(GEOA3_PROF_NN1, geoa3_stream(stream));
   hipLaunchKernelGGL(nn1_pair_kernel<QPT>, grid, dim3(NN_BLOCK), 0, geoa3_stream(stream), a, r, Na, Nr, d_ar, i_ar,
                      d_ra, i_ra);
+  geoa3_prof_end(GEOA3_PROF_NN1, geoa3_stream(stream));
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
@@ -251,6 +254,7 @@ extern "C" int geoa3_knn(const float* q, const float* r, int B, int Nq, int Nr, 
     return GEOA3_EINVAL;
   if (Nr > 65535) return GEOA3_ENOSUPPORT;  // candidate indices are stored as uint16 in LDS
   dim3 grid((Nq + KNN_BLOCK - 1) / KNN_BLOCK, B);
+  geoa3_prof_begin(GEOA3_PROF_KNN, geoa3_stream(stream));
   if (K <= 20) {
     constexpr int CAP = 40;
     size_t lds = 3 * KNN_CHUNK * 4 + (size_t)CAP * KNN_BLOCK * 6;
@@ -271,6 +275,7 @@ extern "C" int geoa3_knn(const float* q, const float* r, int B, int Nq, int Nr, 
     hipLaunchKernelGGL(knn_kernel<CAP>, grid, dim3(KNN_BLOCK), lds, geoa3_stream(stream), q, r, Nq, Nr, K, prior,
                        dists, idx);
   }
+  geoa3_prof_end(GEOA3_PROF_KNN, geoa3_stream(stream));
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

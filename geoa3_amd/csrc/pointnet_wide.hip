@@ -7,6 +7,7 @@
 // The backward is sparse -- only the arg-max column of every channel carries gradient -- and is a
 // deterministic gather-by-owner accumulation in LDS (no atomics).
 #include "pointnet_kernels.h"
+#include "profile.h"
 
 namespace {
 
@@ -207,6 +208,8 @@ __global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
 int launch_wide_max(const WideArgs& a, hipStream_t s) {
   if (a.Co % WM_CO != 0 || (a.taps != 1 && a.taps != 3)) return GEOA3_ENOSUPPORT;
   dim3 grid(a.Co / WM_CO, a.B);
+  const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
+  geoa3_prof_begin(tag, s);
   if (a.taps == 1) {
     const size_t lds = WideCfg<1>::LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(wide_max_kernel<1>, grid, dim3(WM_THREADS), lds, s, a);
@@ -214,6 +217,7 @@ int launch_wide_max(const WideArgs& a, hipStream_t s) {
     const size_t lds = WideCfg<3>::LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(wide_max_kernel<3>, grid, dim3(WM_THREADS), lds, s, a);
   }
+  geoa3_prof_end(tag, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -1,0 +1,10 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#define GEOA3_PROF_TAGS 4
+#define GEOA3_PROF_CONV5 0   // wide_max_kernel<3>: conv5 + bn5 + relu + max
+#define GEOA3_PROF_NN1 1     // nn1_pair_kernel: the "CD kernel"
+#define GEOA3_PROF_KNN 2     // knn_kernel
+#define GEOA3_PROF_TNETWIDE 3 // wide_max_kernel<1>
+bool geoa3_prof_on();
+void geoa3_prof_begin(int tag, hipStream_t s);
+void geoa3_prof_end(int tag, hipStream_t s);

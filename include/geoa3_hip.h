@@ -197,6 +197,15 @@ int geoa3_attack_binary_update(const geoa3_attack_state* st, void* stream);
 int geoa3_attack_begin_search_step(const geoa3_attack_state* st, const float* ori, const float* init_offset,
                                    float* offset, float* adam_m, float* adam_v, float* x, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Diagnostics (bench.py): per-launch durations of selected kernels, taken with HIP events recorded on the
+ * launch stream.  Off by default; the only process-global state in the library; never changes results.
+ * tag: 0 = conv5+max (wide_max_kernel<3>), 1 = geoa3_nn1_pair ("CD kernel"), 2 = geoa3_knn,
+ *      3 = T-Net conv3+max (wide_max_kernel<1>).
+ * ------------------------------------------------------------------------------------------ */
+int geoa3_profile_enable(int capacity);                 /* events for `capacity` launches per tag; 0 = off */
+int geoa3_profile_read(int tag, float* ms_host, int cap); /* waits for the recorded launches; returns count */
+
 #ifdef __cplusplus
 }
 #endif
