@@ -41,12 +41,13 @@ def cfg_config2(steps):
                      curv_loss_weight=1.0, curv_loss_knn=KNN, classes=CLASSES)
 
 
-def cpu_baseline(sample_b=16, iters=3):
+def cpu_baseline(sample_b=8, budget_s=20.0):
     """The CPU port (oracle, reference semantics incl. the b batch-1 success-check forwards and the six dense
-    K-NN queries per iteration) timed on a bounded sample of the same workload."""
+    K-NN queries per iteration) timed on a bounded sample of the same workload: one warm-up iteration sizes
+    the timed run so that it stays within ~budget_s."""
     import torch
     from oracle import geoa3_oracle as O
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)   # more intra-op threads than this only adds contention on this path
     torch.set_num_threads(threads)
     sd = O.make_pointnet_state_dict(CLASSES, seed=0)
     net = lambda x: O.pointnet_forward(sd, x)
@@ -55,7 +56,10 @@ def cpu_baseline(sample_b=16, iters=3):
         gt = net(ori).argmax(1)
     g = torch.Generator().manual_seed(1)
     init = [torch.randn(sample_b, 3, NPOINT, generator=g) * 1e-3]
-    O.attack(net, ori, nrm, gt, None, cfg_config2(1), init, faithful_success_check=True)  # warm-up
+    t0 = time.perf_counter()
+    O.attack(net, ori, nrm, gt, None, cfg_config2(1), init, faithful_success_check=True)  # warm-up, sizes the run
+    warm = time.perf_counter() - t0
+    iters = max(1, min(10, int(budget_s / max(warm, 1e-3))))
     t0 = time.perf_counter()
     O.attack(net, ori, nrm, gt, None, cfg_config2(iters), init, faithful_success_check=True)
     dt = time.perf_counter() - t0

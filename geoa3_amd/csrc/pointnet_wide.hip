@@ -156,37 +156,69 @@ __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Sparse backward.  One workgroup per (instance, 128-point tile); thread (ci, half) owns row ci of
-// the tile's gradient for 64 columns and walks the 1024 (arg, g) pairs in channel order.
+// Sparse backward.  One workgroup per (instance, 128-point tile), split in two 64-column halves of 128
+// threads; thread (ci, half) owns row ci of its half, so no two threads ever touch the same accumulator
+// and the summation order is fixed (deterministic, no atomics).
+// Per block of WB_BLOCK output channels: the first wave of each half compacts the (channel, tap) pairs
+// whose arg-max column falls into its half into an LDS hit list (ballot + popcount, in (co, tap) order);
+// then the 128 threads of the half walk ONLY the hits, 16 independent weight-row loads in flight.
 // ------------------------------------------------------------------------------------------
 constexpr int WB_COLS = 128;
+constexpr int WB_BLOCK = 512;   // output channels per compaction round
+constexpr int WB_BATCH = 16;
 
 template <int TAPS>
 __global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_acc = smem;                                  // [128 ci][WB_COLS + 1]
-  float* s_g = smem + WM_CI * (WB_COLS + 1);            // [Co]
-  int* s_arg = reinterpret_cast<int*>(s_g + a.Co);      // [Co]
+  float* s_acc = smem;                                                        // [128 ci][WB_COLS + 1]
+  int* s_hit = reinterpret_cast<int*>(smem + WM_CI * (WB_COLS + 1));          // [2][WB_BLOCK*TAPS]
+  int* s_cnt = s_hit + 2 * WB_BLOCK * TAPS;                                   // [2]
   const int tid = threadIdx.x, b = blockIdx.y, m0 = blockIdx.x * WB_COLS;
-  const int ci = tid & 127, half = tid >> 7;
-  const int KTOT = TAPS * WM_CI;
-  for (int c = tid; c < a.Co; c += 256) {
-    s_g[c] = a.g[(size_t)b * a.Co + c];
-    s_arg[c] = a.arg[(size_t)b * a.Co + c];
-  }
+  const int ci = tid & 127, half = tid >> 7, lane = tid & 63;
+  const bool builder = (tid & 127) < 64;                                      // first wave of each half
+  const float* gb = a.g + (size_t)b * a.Co;
+  const int* argb = a.arg + (size_t)b * a.Co;
+  int* hits = s_hit + half * WB_BLOCK * TAPS;
   float* row = s_acc + ci * (WB_COLS + 1);
   for (int j = half * 64; j < half * 64 + 64; ++j) row[j] = 0.f;
-  __syncthreads();
   const int lo = m0 + half * 64, hi = lo + 64;
-  for (int co = 0; co < a.Co; ++co) {
-    const float g = s_g[co];
-    if (g == 0.f) continue;
-    const int base = s_arg[co] - TAPS / 2;
-    if (base + TAPS <= lo || base >= hi) continue;      // wave-uniform: all lanes share (co, half)
+
+  for (int cb = 0; cb < a.Co; cb += WB_BLOCK) {
+    __syncthreads();  // the previous round's list has been consumed
+    if (builder) {
+      int cnt = 0;
+      for (int c0 = cb; c0 < min(cb + WB_BLOCK, a.Co); c0 += 64) {
+        const int co = c0 + lane;
+        const bool in = co < a.Co;
+        const float g = in ? gb[co] : 0.f;
+        const int base = (in ? argb[co] : 0) - TAPS / 2;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int m = base + tap;
-      if (m >= lo && m < hi) row[m - m0] += a.W[(size_t)co * KTOT + tap * WM_CI + ci] * g;
+        for (int tap = 0; tap < TAPS; ++tap) {
+          const int m = base + tap;
+          const bool hit = g != 0.f && m >= lo && m < hi;
+          const unsigned long long mask = __ballot(hit);
+          if (hit) hits[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (co * TAPS + tap) | ((m - m0) << 16);
+          cnt += __popcll(mask);
+        }
+      }
+      if (lane == 0) s_cnt[half] = cnt;
+    }
+    __syncthreads();
+    const int cnt = s_cnt[half];
+    for (int h0 = 0; h0 < cnt; h0 += WB_BATCH) {
+      float w[WB_BATCH], gg[WB_BATCH];
+      int mm[WB_BATCH];
+#pragma unroll
+      for (int u = 0; u < WB_BATCH; ++u) {
+        const bool ok = h0 + u < cnt;
+        const int e = hits[ok ? h0 + u : cnt - 1];
+        const int kt = e & 0xffff;                      // co*TAPS + tap: row of the [Co*TAPS][128] weight view
+        w[u] = a.W[(size_t)kt * WM_CI + ci];
+        gg[u] = ok ? gb[kt / TAPS] : 0.f;
+        mm[u] = e >> 16;
+      }
+#pragma unroll
+      for (int u = 0; u < WB_BATCH; ++u) row[mm[u]] += w[u] * gg[u];
     }
   }
   __syncthreads();
@@ -225,7 +257,7 @@ int launch_wide_max(const WideArgs& a, hipStream_t s) {
 int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s) {
   if (a.taps != 1 && a.taps != 3) return GEOA3_ENOSUPPORT;
   dim3 grid((a.N + WB_COLS - 1) / WB_COLS, a.B);
-  const size_t lds = ((size_t)WM_CI * (WB_COLS + 1) + 2 * (size_t)a.Co) * sizeof(float);
+  const size_t lds = ((size_t)WM_CI * (WB_COLS + 1) + 2 * (size_t)WB_BLOCK * a.taps + 4) * sizeof(float);
   if (a.taps == 1) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_max_bwd_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
