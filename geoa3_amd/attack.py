@@ -267,3 +267,36 @@ def attack(net, input_data, cfg, i, loader_len, saved_dir=None, *, init_offsets=
     runner.setup(pc_ori, normal_ori, gt, target)
     runner.run(init_offsets, i, loader_len, verbose, sync_last_label)
     return runner.results()
+
+
+def attack_sharded(net, input_data, cfg, i, loader_len, saved_dir=None, *, init_offsets=None, verbose=False,
+                   group=None):
+    """attack() with the batch sharded by instance over the ranks of an initialised process group (one process
+    per GPU, RCCL).  Every rank passes the SAME full batch and receives the full 5-tuple; a rank computes only
+    its own block of instances (geoa3_amd.distributed)."""
+    import torch.distributed as dist
+    from .distributed import sharded_attack
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return attack(net, input_data, cfg, i, loader_len, saved_dir, init_offsets=init_offsets, verbose=verbose)
+    targeted = cfg.attack_label != "Untarget"
+    pc_ori, normal_ori, gt, target = unpack_input(input_data, targeted)
+    b, _, n = pc_ori.shape
+    device = next(net.parameters()).device
+    if init_offsets is None:   # one shared draw so every rank sees the same global initial offsets
+        g = torch.Generator(device="cpu").manual_seed(int(getattr(cfg, "id", 0)) * 1000003 + int(i))
+        init_offsets = [torch.randn(b, 3, n, generator=g) * 1e-3 for _ in range(int(cfg.binary_max_steps))]
+
+    def run_shard(pc, normal, g_, t_, inits, global_batch, sync):
+        bl = pc.shape[0]
+        if bl == 0:   # more ranks than instances: still take part in the per-binary-step broadcasts
+            dummy = torch.zeros(1, dtype=torch.int32, device=device)
+            for _ in range(int(cfg.binary_max_steps)):
+                sync(dummy)
+            return (torch.zeros(0, 3, n, device=device), t_.to(device).long(), np.zeros(0, bool), [],
+                    [[] for _ in range(int(cfg.iter_max_steps))])
+        runner = AttackRunner(net, bl, n, cfg, device, global_batch)
+        runner.setup(pc, normal, g_, t_)
+        runner.run([o.to(device) for o in inits], i, loader_len, verbose and dist.get_rank(group) == 0, sync)
+        return runner.results()
+
+    return sharded_attack(run_shard, pc_ori, normal_ori, gt, target, init_offsets, group)

@@ -1,0 +1,85 @@
+"""Instance sharding of one attack batch over the GPUs of a node: one process per GPU,
+`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
+
+Every quantity of the loop is per instance, so there is NO collective in the per-iteration data path.
+Two couplings of the reference are kept exact:
+  1. `loss = loss_n.mean()` (Attacker/geoA3_attack.py:178): each shard divides by the GLOBAL batch size;
+  2. the binary-search `output_label` quirk (geoA3_attack.py:298,375): the rank that owns the global last
+     instance broadcasts ONE int32 per binary step.
+Results are all-gathered once per batch (best_attack shards, success, best step, loss history).
+
+The per-shard computation is injected (`run_shard`) so that this host logic is testable on CPU with gloo.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(b: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous blocks of ceil/floor(b/world) instances; the remainder goes to the first ranks."""
+    base, rem = divmod(b, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def owner_of_last_instance(b: int, world: int) -> int:
+    bounds = shard_bounds(b, world)
+    return max(r for r, (lo, hi) in enumerate(bounds) if hi > lo and hi == b)
+
+
+def make_last_label_sync(b_global: int, group=None) -> Callable[[torch.Tensor], None]:
+    """-> sync(t): t is the local [1] int32 `last_label`; after the call every rank holds the label of the
+    GLOBAL last instance (a 4-byte broadcast, once per binary step)."""
+    world = dist.get_world_size(group)
+    src = owner_of_last_instance(b_global, world)
+
+    def sync(t: torch.Tensor) -> None:
+        dist.broadcast(t, src=src, group=group)
+
+    return sync
+
+
+def _gather_rows(x: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+    """all_gather of row blocks with different row counts (pads to the largest block)."""
+    world = len(counts)
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)], dim=0)
+
+
+def sharded_attack(run_shard: Callable, pc: torch.Tensor, normal: torch.Tensor, gt: torch.Tensor,
+                   target: torch.Tensor, init_offsets: Sequence[torch.Tensor], group=None):
+    """Run one batch of b attacks sharded over the process group.
+
+    run_shard(pc, normal, gt, target, init_offsets, global_batch, sync_last_label)
+        -> (best_attack [bl,3,n], target [bl], success bool[bl], best_step list[bl], all_loss [iters][bl])
+    is the single-device attack (geoa3_amd.attack.attack on a GPU; the oracle in the CPU tests).
+    Returns the reference 5-tuple for the WHOLE batch on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b = pc.shape[0]
+    bounds = shard_bounds(b, world)
+    lo, hi = bounds[rank]
+    counts = [h - l for l, h in bounds]
+    sync = make_last_label_sync(b, group)
+    sl = slice(lo, hi)
+    best, tgt, succ, step, loss = run_shard(pc[sl], normal[sl], gt[sl], target[sl],
+                                            [o[sl] for o in init_offsets], b, sync)
+    dev = best.device
+    best_all = _gather_rows(best.contiguous(), counts, group)
+    tgt_all = _gather_rows(tgt.contiguous(), counts, group)
+    succ_all = _gather_rows(torch.as_tensor(np.asarray(succ), device=dev).to(torch.uint8), counts, group)
+    step_all = _gather_rows(torch.as_tensor(step, device=dev, dtype=torch.int64), counts, group)
+    loss_t = torch.as_tensor(np.asarray(loss, dtype=np.float32), device=dev).t().contiguous()   # [bl, iters]
+    loss_all = _gather_rows(loss_t, counts, group).t()
+    return (best_all, tgt_all, succ_all.cpu().numpy().astype(bool), step_all.cpu().tolist(), loss_all.cpu().tolist())

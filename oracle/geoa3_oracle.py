@@ -380,7 +380,7 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, t: int, lr: float,
 
 def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional[Tensor], cfg,
            init_offsets: Sequence[Tensor], loss_divisor: Optional[int] = None,
-           last_label_override: Optional[Sequence[int]] = None,
+           last_label_override: Optional[Sequence[int]] = None, last_label_hook=None,
            faithful_success_check: bool = False, trace: Optional[dict] = None):
     """attack() (geoA3_attack.py:182-386) on already-unpacked [b,3,N] inputs.
 
@@ -465,6 +465,8 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
                     offset.copy_(lp_clip(offset, cfg.cc_linf))
         if last_label_override is not None:
             output_label = int(last_label_override[s])
+        if last_label_hook is not None:  # sharded runs: local label in, the GLOBAL last instance's label out
+            output_label = int(last_label_hook(output_label))
         for k in range(b):
             if bool(_compare(output_label, int(tgt[k]), int(gt[k]), targeted)) and iter_best_score[k] != -1:
                 lower[k] = max(lower[k], scale_const[k])
