@@ -133,7 +133,7 @@ int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, flo
 int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, float* act128, float* pooled, int* arg, float* f4,
                   float* f5, float* T, int B, int N, hipStream_t s) {
   TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s));
-  TRY(wide(act128, t.w3, t.b3, pooled, arg, 1, B, N, s));
+  TRY(wide(act128, t.w3p, t.b3, pooled, arg, 1, B, N, s));
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
   TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
   TRY(fc(f5, 256, t.f3, t.fb3, T, t.K * t.K, B, false, nullptr, s));
@@ -180,7 +180,7 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   // conv3, conv4, conv5 + max (:144-147)
   TRY(conv(w.h2p, 64, p.w3, p.b3, w.h3, 64, B, N, true, nullptr, false, s));
   TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s));
-  TRY(wide(w.h4, p.w5, p.b5, w.p5, w.i5, 3, B, N, s));
+  TRY(wide(w.h4, p.w5p, p.b5, w.p5, w.i5, 3, B, N, s));
   // classifier head (:150-152), dropout is the identity in eval mode
   TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));
   TRY(fc(w.f6, 512, p.f2, p.fb2, w.f7, 256, B, true, nullptr, s));

@@ -40,7 +40,7 @@ int launch_fc(const FcArgs& a, hipStream_t s);
 // arg[b][co] = the maximising n.  Ci = 128; TAPS = 1 (T-Net conv3) or 3 (conv5, zero padded).
 struct WideArgs {
   const float* X; long sXb; int ldX;          // [B][128][N]
-  const float* W;                             // [Co][TAPS*128]
+  const float* W;                             // MFMA A-fragment order of [Co][TAPS*128] (pointnet_wide.hip)
   const float* bias;                          // [Co]
   float* out; int* arg;                       // [B][Co]
   int Co, N, B, taps;

@@ -8,37 +8,85 @@
 // deterministic gather-by-owner accumulation in LDS (no atomics).
 #include "pointnet_kernels.h"
 #include "profile.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int WM_CO = 128;     // output channels per workgroup
-constexpr int WM_COLS = 128;   // points per tile
-constexpr int WM_THREADS = 512;
+constexpr int WM_CO = 128;     // output channels per workgroup (4 waves x 32)
+constexpr int WM_COLS = 64;    // points per tile
+constexpr int WM_THREADS = 256;
 constexpr int WM_CI = 128;     // input channels of every wide layer
-constexpr int WM_HALO = 4;     // left halo (float4 aligned); right halo is 4 as well
+constexpr int WM_HALO = 4;     // halo on both sides of a staged activation row (float4 aligned)
+constexpr int WM_XP = WM_COLS + 2 * WM_HALO;   // LDS pitch of an activation row
 
-template <int TAPS>
-struct WideCfg {
-  static constexpr int CI_CHUNK = TAPS == 1 ? 32 : 16;     // input channels staged per pass
-  static constexpr int KC = CI_CHUNK * TAPS;               // k extent of one pass
-  static constexpr int WPITCH = KC + 1;                    // LDS pitch of the weight chunk
-  static constexpr int XPITCH = WM_COLS + 2 * WM_HALO;     // LDS pitch of the activation chunk
-  static constexpr int LDS_FLOATS = WM_CO * WPITCH + CI_CHUNK * XPITCH;
-};
-
-template <int TAPS>
+// Weights arrive in MFMA A-fragment order (host: geoa3_amd/pointnet.py pack_wide_fragments):
+//   Wp[((T*TAPS + tap)*16 + j)*64 + lane][i] = W[32*T + (lane&31)][tap*128 + 8*j + 4*(lane>>5) + i]
+// so that one 16-byte load per lane (1 KiB per wave, fully coalesced, served by L2) yields the A operands
+// of four k-steps; k is consumed in the order 8j + 4*(lane>>5) + i, and the B operand is read from the
+// LDS activation tile with the same k.  The weights never touch LDS.
+//
+// Activations: chunk of CHUNK input channels x (64 + halo) points, double buffered in LDS, staged through
+// registers one pass ahead (global loads of pass p+1 fly under the MFMAs of pass p); ONE barrier per pass.
+template <int TAPS, int CHUNK>
 __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
-  using Cfg = WideCfg<TAPS>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_w = smem;                              // [128 co][KC+1]
-  float* s_x = smem + WM_CO * Cfg::WPITCH;        // [CI_CHUNK][XPITCH]
+  constexpr int NXTOT = CHUNK * (WM_XP / 4);                    // float4 slots of one activation chunk
+  constexpr int NX = (NXTOT + WM_THREADS - 1) / WM_THREADS;
+  constexpr int NG = TAPS * CHUNK / 8;                          // weight fragment groups per pass (8 k each)
+  constexpr int PASSES = WM_CI / CHUNK;
+  constexpr int PF = 3;                                         // weight groups in flight
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][CHUNK][WM_XP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y, co0 = blockIdx.x * WM_CO;
-  const int wco = (wave & 3) * 32;                // this wave's 32 channels inside the tile
-  const int wcol = (wave >> 2) * 64;              // and its 64 columns
+  // XCD-aware mapping: workgroup ids are dealt round-robin over the 8 XCDs, so the 8 channel tiles of one
+  // instance get ids that are equal mod 8 -> one XCD, one L2 copy of the instance's activations.
+  const int L = blockIdx.x, grp = L >> 6, rem = L & 63;
+  const int b = grp * 8 + (rem & 7);
+  if (b >= a.B) return;
+  const int co0 = (rem >> 3) * WM_CO + wave * 32;               // this wave's 32 output channels
   const int N = a.N, kh = lane >> 5, l31 = lane & 31;
   const float* X = a.X + (size_t)b * a.sXb;
-  const int KTOT = TAPS * WM_CI;
+  const bool xvec = (a.ldX & 3) == 0;
+  const float4* Wp = reinterpret_cast<const float4*>(a.W) + (size_t)(co0 / 32) * TAPS * 16 * 64 + lane;
+
+  float4 xreg[NX];
+  auto load_x = [&](int n0, int ci0) {
+    const bool interior = xvec && n0 >= WM_HALO && n0 + WM_COLS + WM_HALO <= N;   // workgroup-uniform
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * WM_THREADS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < NXTOT) {
+        const int q = e % (WM_XP / 4), c = e / (WM_XP / 4);
+        const int n = n0 - WM_HALO + q * 4;
+        const float* src = X + (size_t)(ci0 + c) * a.ldX;
+        if (interior) {
+          v = *reinterpret_cast<const float4*>(src + n);
+        } else if (n >= 0 && n + 3 < N && xvec) {
+          v = *reinterpret_cast<const float4*>(src + n);
+        } else {
+          v.x = (n >= 0 && n < N) ? src[n] : 0.f;
+          v.y = (n + 1 >= 0 && n + 1 < N) ? src[n + 1] : 0.f;
+          v.z = (n + 2 >= 0 && n + 2 < N) ? src[n + 2] : 0.f;
+          v.w = (n + 3 >= 0 && n + 3 < N) ? src[n + 3] : 0.f;
+        }
+      }
+      xreg[i] = v;
+    }
+  };
+  auto store_x = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * WM_THREADS;
+      if (e < NXTOT) {
+        const int q = e % (WM_XP / 4), c = e / (WM_XP / 4);
+        *reinterpret_cast<float4*>(buf + c * WM_XP + q * 4) = xreg[i];
+      }
+    }
+  };
+  // fragment group g of the pass starting at input channel ci0: (tap, jj) = (g / (CHUNK/8), g % (CHUNK/8))
+  auto load_w = [&](int ci0, int g) -> float4 {
+    const int tap = g / (CHUNK / 8), jj = g - tap * (CHUNK / 8);
+    return Wp[(size_t)((tap * 16) + (ci0 >> 3) + jj) * 64];
+  };
 
   float rmax[16];
   int rarg[16];
@@ -48,6 +96,10 @@ __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
     rarg[r] = 0;
   }
 
+  load_x(0, 0);
+  store_x(smem);
+  __syncthreads();
+  int pass = 0;
   for (int n0 = 0; n0 < N; n0 += WM_COLS) {
     f32x16 acc[2];
 #pragma unroll
@@ -55,52 +107,55 @@ __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int ci0 = 0; ci0 < WM_CI; ci0 += Cfg::CI_CHUNK) {
-      __syncthreads();  // previous pass has finished reading LDS
-      // weight chunk: s_w[co][tap*CI_CHUNK + c] = W[co0+co][tap*128 + ci0 + c]
-      for (int e = tid; e < WM_CO * Cfg::KC / 4; e += WM_THREADS) {
-        const int q = e % (Cfg::KC / 4), co = e / (Cfg::KC / 4);
-        const int kk = q * 4, tap = kk / Cfg::CI_CHUNK, c = kk - tap * Cfg::CI_CHUNK;
-        const float4 w = *reinterpret_cast<const float4*>(a.W + (size_t)(co0 + co) * KTOT + tap * WM_CI + ci0 + c);
-        float* d = s_w + co * Cfg::WPITCH + kk;
-        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-      }
-      // activation chunk with halo: s_x[c][j] = X[ci0+c][n0 - HALO + j], zero outside [0,N)
-      for (int e = tid; e < Cfg::CI_CHUNK * (Cfg::XPITCH / 4); e += WM_THREADS) {
-        const int q = e % (Cfg::XPITCH / 4), c = e / (Cfg::XPITCH / 4);
-        const int n = n0 - WM_HALO + q * 4;
-        const float* src = X + (size_t)(ci0 + c) * a.ldX;
-        float4 v;
-        if (n >= 0 && n + 3 < N && (a.ldX & 3) == 0) {
-          v = *reinterpret_cast<const float4*>(src + n);
-        } else {
-          v.x = (n >= 0 && n < N) ? src[n] : 0.f;
-          v.y = (n + 1 >= 0 && n + 1 < N) ? src[n + 1] : 0.f;
-          v.z = (n + 2 >= 0 && n + 2 < N) ? src[n + 2] : 0.f;
-          v.w = (n + 3 >= 0 && n + 3 < N) ? src[n + 3] : 0.f;
-        }
-        *reinterpret_cast<float4*>(s_x + c * Cfg::XPITCH + q * 4) = v;
-      }
-      __syncthreads();
-      const float* wp = s_w + (wco + l31) * Cfg::WPITCH + kh;
+#pragma unroll 1
+    for (int p = 0; p < PASSES; ++p, ++pass) {
+      const int ci0 = p * CHUNK;
+      const bool last = p + 1 == PASSES;
+      const int nn0 = last ? n0 + WM_COLS : n0, nci0 = last ? 0 : ci0 + CHUNK;
+      const bool more = nn0 < N;
+      float4 wf[PF];
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        // column of the B operand inside the haloed row: HALO + col + tap - TAPS/2
-        const float* xp = s_x + kh * Cfg::XPITCH + WM_HALO + wcol + l31 + tap - TAPS / 2;
-#pragma unroll 8
-        for (int c = 0; c < Cfg::CI_CHUNK; c += 2) {
-          const float av = wp[tap * Cfg::CI_CHUNK + c];
-          const float b0 = xp[c * Cfg::XPITCH];
-          const float b1 = xp[c * Cfg::XPITCH + 32];
-          acc[0] = mfma32(av, b0, acc[0]);
-          acc[1] = mfma32(av, b1, acc[1]);
+      for (int g = 0; g < PF; ++g) wf[g] = load_w(ci0, g);
+      if (more) load_x(nn0, nci0);
+      const float* xb = smem + (pass & 1) * (CHUNK * WM_XP) + kh * 4 * WM_XP + WM_HALO + l31 - TAPS / 2;
+      // B operands of one fragment group: rows 8jj + 4*kh + i, columns col+tap-TAPS/2 and +32
+      float bq[8], bn[8];
+      auto read_b = [&](int g, float* d) {
+        const int tap = g / (CHUNK / 8), jj = g - tap * (CHUNK / 8);
+        const float* xp = xb + jj * 8 * WM_XP + tap;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[2 * i] = xp[i * WM_XP];
+          d[2 * i + 1] = xp[i * WM_XP + 32];
         }
+      };
+      read_b(0, bq);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float4 w = wf[g % PF];
+        // issue the memory traffic of later groups BEFORE this group's MFMAs and pin it there: the matrix
+        // pipe then covers the L2 / LDS latency instead of the compiler sinking the loads next to their use
+        if (g + PF < NG) wf[g % PF] = load_w(ci0, g + PF);
+        if (g + 1 < NG) read_b(g + 1, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[0] = mfma32(wv[i], bq[2 * i], acc[0]);
+          acc[1] = mfma32(wv[i], bq[2 * i + 1], acc[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bq[i] = bn[i];
       }
+      if (more) store_x(smem + ((pass + 1) & 1) * (CHUNK * WM_XP));
+      __syncthreads();
     }
     // fold this tile into the running maximum (strict >: the lowest point index wins a tie)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int col = n0 + wcol + t * 32 + l31;
+      const int col = n0 + t * 32 + l31;
       const bool ok = col < N;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -111,7 +166,7 @@ __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
     }
   }
 
-  // reduce over the 32 lanes that share (reg, lane>>5), i.e. over this wave's columns
+  // reduce over the 32 lanes that share (reg, lane>>5), i.e. over the columns; then bias + relu
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -123,34 +178,13 @@ __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
       rarg[r] = take ? i2 : rarg[r];
     }
   }
-  // combine the two column-halves (waves w and w+4) through LDS, then bias + relu
-  __syncthreads();
-  float* s_v = smem;
-  int* s_i = reinterpret_cast<int*>(smem + WM_CO);
-  if (wave >= 4 && l31 == 0) {
+  if (l31 == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = wco + mfma_row(r, lane);
-      s_v[co] = rmax[r];
-      s_i[co] = rarg[r];
-    }
-  }
-  __syncthreads();
-  if (wave < 4 && l31 == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = wco + mfma_row(r, lane);
-      float v = rmax[r];
-      int i = rarg[r];
-      const float v2 = s_v[co];
-      const int i2 = s_i[co];
-      if (v2 > v || (v2 == v && i2 < i)) {
-        v = v2;
-        i = i2;
-      }
-      const size_t o = (size_t)b * a.Co + co0 + co;
-      a.out[o] = fmaxf(v + a.bias[co0 + co], 0.f);
-      a.arg[o] = i;
+      const int co = co0 + mfma_row(r, lane);
+      const size_t o = (size_t)b * a.Co + co;
+      a.out[o] = fmaxf(rmax[r] + a.bias[co], 0.f);
+      a.arg[o] = rarg[r];
     }
   }
 }
@@ -237,18 +271,19 @@ __global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
 
 }  // namespace
 
+template <int TAPS, int CHUNK>
+static void launch_wide_variant(const WideArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)2 * CHUNK * WM_XP * sizeof(float);
+  const int groups = (a.B + 7) / 8;   // 8 instances x 8 channel tiles per group of 64 workgroups
+  hipLaunchKernelGGL((wide_max_kernel<TAPS, CHUNK>), dim3(groups * 64), dim3(WM_THREADS), lds, s, a);
+}
+
 int launch_wide_max(const WideArgs& a, hipStream_t s) {
-  if (a.Co % WM_CO != 0 || (a.taps != 1 && a.taps != 3)) return GEOA3_ENOSUPPORT;
-  dim3 grid(a.Co / WM_CO, a.B);
+  if (a.Co != 8 * WM_CO || (a.taps != 1 && a.taps != 3)) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
   geoa3_prof_begin(tag, s);
-  if (a.taps == 1) {
-    const size_t lds = WideCfg<1>::LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL(wide_max_kernel<1>, grid, dim3(WM_THREADS), lds, s, a);
-  } else {
-    const size_t lds = WideCfg<3>::LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL(wide_max_kernel<3>, grid, dim3(WM_THREADS), lds, s, a);
-  }
+  if (a.taps == 1) launch_wide_variant<1, 64>(a, s);
+  else launch_wide_variant<3, 32>(a, s);
   geoa3_prof_end(tag, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;

@@ -34,6 +34,14 @@ def _fold(w: Tensor, b: Tensor, sd: Dict[str, Tensor], bn: Optional[str], eps: f
     return w64 * s.view(-1, *([1] * (w64.dim() - 1))), (b64 - mean) * s + beta
 
 
+def pack_wide_fragments(w: Tensor, taps: int) -> Tensor:
+    """[Co, taps*128] (k = tap*128 + ci) -> MFMA A-fragment order consumed by wide_max_kernel:
+    out[((T*taps + tap)*16 + j)*64 + lane, i] = w[32T + (lane & 31), tap*128 + 8j + 4(lane >> 5) + i]."""
+    co = w.shape[0]
+    v = w.reshape(co // 32, 32, taps, 16, 2, 4)          # T, r, tap, j, h, i
+    return v.permute(0, 2, 3, 4, 1, 5).reshape(-1, 4).contiguous()   # T, tap, j, (h, r) = lane, i
+
+
 def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     eps = 1e-3  # transform_net.eps, Model/PointNet.py:59
     sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
@@ -43,6 +51,7 @@ def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     w3, out["b3"] = _fold(sub["conv3.weight"], sub["conv3.bias"], sub, "bn3", eps)
     out["w1"], out["w2"], out["w3"] = w1.squeeze(-1), w2.squeeze(-1), w3.squeeze(-1)
     out["w2t"] = out["w2"].t()
+    out["w3p"] = pack_wide_fragments(out["w3"], 1)
     out["f1"], out["fb1"] = _fold(sub["fc1.weight"], sub["fc1.bias"], sub, "bn4", eps)
     out["f2"], out["fb2"] = _fold(sub["fc2.weight"], sub["fc2.bias"], sub, "bn5", eps)
     out["f3"], out["fb3"] = _fold(sub["fc3.weight"], sub["fc3.bias"], sub, None, eps)
@@ -62,6 +71,7 @@ def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
         t["w%d" % i] = w.squeeze(-1)
     w5, t["b5"] = _fold(sd["conv5.weight"], sd["conv5.bias"], sd, "bn5", eps)   # [1024,128,3]
     t["w5"] = w5.permute(0, 2, 1).reshape(w5.shape[0], -1)                         # k = tap*128 + ci
+    t["w5p"] = pack_wide_fragments(t["w5"], 3)
     t["w4t"], t["w3t"], t["w2t"] = t["w4"].t(), t["w3"].t(), t["w2"].t()
     t["f1"], t["fb1"] = _fold(sd["fc1.weight"], sd["fc1.bias"], sd, "bn6", 1e-5)
     t["f2"], t["fb2"] = _fold(sd["fc2.weight"], sd["fc2.bias"], sd, "bn7", 1e-5)

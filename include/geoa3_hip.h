@@ -108,6 +108,7 @@ typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 
   const float *w1, *b1;     /* conv1+bn1 folded  [64,K]           */
   const float *w2, *b2;     /* conv2+bn2         [128,64]         */
   const float *w3, *b3;     /* conv3+bn3         [1024,128]       */
+  const float *w3p;         /* w3 in MFMA A-fragment order (see w5p) */
   const float *w2t;         /* [64,128] = w2^T (input-gradient; conv3's is sparse and reads w3) */
   const float *f1, *fb1;    /* fc1+bn4 [512,1024] */
   const float *f2, *fb2;    /* fc2+bn5 [256,512]  */
@@ -123,6 +124,8 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
   const float *w3, *b3;     /* conv3+bn3 [64,64]   */
   const float *w4, *b4;     /* conv4+bn4 [128,64]  */
   const float *w5, *b5;     /* conv5+bn5 [1024, 3*128]: k = tap*128 + ci (kernel 3, pad 1, PointNet.py:110) */
+  const float *w5p;         /* w5 in MFMA A-fragment order: [(T*3+tap)*16+j][lane 0..63][i 0..3] =
+                               w5[32T + (lane&31)][tap*128 + 8j + 4(lane>>5) + i] -- one coalesced 16-byte load per lane */
   const float *w4t, *w3t, *w2t;  /* [64,128] [64,64] [64,64] (transposes for the input-gradient) */
   const float *f1, *fb1;    /* fc1+bn6 [512,1024] */
   const float *f2, *fb2;    /* fc2+bn7 [256,512]  */
