@@ -3,22 +3,34 @@
 // (:82-84,150-152), forward and input-gradient.  v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf
 // chain, so results differ from the CPU reference only by summation order.
 #include "pointnet_kernels.h"
+#include <cstdlib>
 
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// conv_cm: one wavefront owns 32 columns (points) and ALL Co output channels; the weight matrix
-// of the instance sits in LDS (pitch K+1: bank-conflict-free column reads), the activations stream
-// straight from HBM into the B operand (each element is read once and reused Co/32 times from the
-// register).  A 256-thread workgroup covers 128 points.
+// conv_cm: one wavefront owns 32 columns (points) and ALL Co output channels; the weight matrix of the
+// instance sits in LDS (pitch K+1: bank-conflict-free column reads) and is staged ONCE per workgroup for
+// CONV_TILES x 128 points; the activations stream straight from HBM into the B operand (each element
+// is read once and reused Co/32 times from the register), 16 k-steps of loads in flight per wave.
+// (Measured: 8- and 16-byte-per-lane column vectorisation is slower here -- it quadruples the
+// accumulator registers and the kernel is latency-, not instruction-bound.)
 // ------------------------------------------------------------------------------------------
+constexpr int CONV_TILES = 1;   // 128-point tiles per workgroup (more, longer workgroups measured slower)
+
 template <int CT>  // Co = 32*CT
 __global__ __launch_bounds__(256) void conv_cm_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [Co][K+1]
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K, Co = 32 * CT, pitch = K + 1;
   const float* W = a.W + (size_t)b * a.sWb;
-  if (a.sWk == 1) {
+  if (a.sWk == 1 && (a.sWco & 3) == 0 && (a.sWb & 3) == 0) {   // rows are k-contiguous: 16-byte loads
+    for (int e = tid; e < Co * K / 4; e += 256) {
+      const int co = e / (K / 4), k = (e - co * (K / 4)) * 4;
+      const float4 w = *reinterpret_cast<const float4*>(W + (size_t)co * a.sWco + k);
+      float* d = s_w + co * pitch + k;
+      d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+    }
+  } else if (a.sWk == 1) {
     for (int e = tid; e < Co * K; e += 256) {
       const int co = e / K, k = e - co * K;
       s_w[co * pitch + k] = W[(size_t)co * a.sWco + k];
@@ -30,47 +42,50 @@ __global__ __launch_bounds__(256) void conv_cm_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
-
-  const int col = blockIdx.x * 128 + wave * 32 + (lane & 31);
-  const bool live = col < a.N;
-  const int colc = live ? col : a.N - 1;
   const int kh = lane >> 5;
-  const float* X = a.X + (size_t)b * a.sXb + colc;
   const float* wrow = s_w + (lane & 31) * pitch + kh;
 
-  f32x16 acc[CT];
-#pragma unroll
-  for (int t = 0; t < CT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int tile = 0; tile < CONV_TILES; ++tile) {
+    const int col = (blockIdx.x * CONV_TILES + tile) * 128 + wave * 32 + (lane & 31);
+    if ((blockIdx.x * CONV_TILES + tile) * 128 >= a.N) break;   // workgroup-uniform
+    const bool live = col < a.N;
+    const int colc = live ? col : a.N - 1;
+    const float* X = a.X + (size_t)b * a.sXb + colc;
 
-  constexpr int U = 8;  // k-steps whose loads are in flight together
-  for (int s0 = 0; s0 < K / 2; s0 += U) {
-    float xr[U];
+    f32x16 acc[CT];
 #pragma unroll
-    for (int u = 0; u < U; ++u) xr[u] = X[(size_t)(2 * (s0 + u) + kh) * a.ldX];
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = 2 * (s0 + u);
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    constexpr int U = 32;  // k-steps whose loads are in flight together (all of K = 64)
+    for (int s0 = 0; s0 < K / 2; s0 += U) {
+      float xr[U];
 #pragma unroll
-      for (int t = 0; t < CT; ++t) acc[t] = mfma32(wrow[t * 32 * pitch + k], xr[u], acc[t]);
+      for (int u = 0; u < U; ++u) xr[u] = X[(size_t)(2 * (s0 + u) + kh) * a.ldX];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = 2 * (s0 + u);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[t] = mfma32(wrow[t * 32 * pitch + k], xr[u], acc[t]);
+      }
     }
-  }
 
-  if (!live) return;
-  float* Y = a.Y + (size_t)b * a.sYb + col;
-  const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
+    if (!live) continue;
+    float* Y = a.Y + (size_t)b * a.sYb + col;
+    const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
 #pragma unroll
-  for (int t = 0; t < CT; ++t) {
+    for (int t = 0; t < CT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = t * 32 + mfma_row(r, lane);
-      float v = acc[t][r];
-      if (a.bias) v += a.bias[co];
-      if (a.relu) v = fmaxf(v, 0.f);
-      if (a.accumulate) v += Y[(size_t)co * a.ldY];
-      if (Z) v = Z[(size_t)co * a.ldZ] > 0.f ? v : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
-      Y[(size_t)co * a.ldY] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int co = t * 32 + mfma_row(r, lane);
+        float v = acc[t][r];
+        if (a.bias) v += a.bias[co];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.accumulate) v += Y[(size_t)co * a.ldY];
+        if (Z) v = Z[(size_t)co * a.ldZ] > 0.f ? v : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
+        Y[(size_t)co * a.ldY] = v;
+      }
     }
   }
 }
@@ -154,9 +169,9 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
 }  // namespace
 
 int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
-  if (a.K % 16 != 0 || (a.Co != 64 && a.Co != 128)) return GEOA3_ENOSUPPORT;
-  dim3 grid((a.N + 127) / 128, a.B);
+  if (a.K % 32 != 0 || (a.Co != 64 && a.Co != 128)) return GEOA3_ENOSUPPORT;
   const size_t lds = (size_t)a.Co * (a.K + 1) * sizeof(float);
+  dim3 grid((a.N + 128 * CONV_TILES - 1) / (128 * CONV_TILES), a.B);
   if (a.Co == 64)
     hipLaunchKernelGGL(conv_cm_kernel<2>, grid, dim3(256), lds, s, a);
   else

@@ -256,15 +256,26 @@ __global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
     }
   }
   __syncthreads();
-  // write out with the relu gate of the layer input; consecutive threads -> consecutive points
+  // write out with the relu gate of the layer input: 4 consecutive points per thread (16-byte loads / stores)
   float* dX = a.dX + (size_t)b * a.sXb;
   const float* Z = a.Z + (size_t)b * a.sZb;
-  for (int e = tid; e < WM_CI * WB_COLS; e += 256) {
-    const int c = e / WB_COLS, j = e - c * WB_COLS;
+  const bool vec = ((a.ldX | a.ldZ) & 3) == 0;
+#pragma unroll 4
+  for (int e = tid; e < WM_CI * (WB_COLS / 4); e += 256) {
+    const int c = e / (WB_COLS / 4), j = (e - c * (WB_COLS / 4)) * 4;
     const int m = m0 + j;
-    if (m < a.N) {
-      const float v = s_acc[c * (WB_COLS + 1) + j];
-      dX[(size_t)c * a.ldX + m] = Z[(size_t)c * a.ldZ + m] > 0.f ? v : 0.f;
+    const float* sa = s_acc + c * (WB_COLS + 1) + j;
+    if (vec && m + 3 < a.N) {
+      const float4 z = *reinterpret_cast<const float4*>(Z + (size_t)c * a.ldZ + m);
+      float4 v;
+      v.x = z.x > 0.f ? sa[0] : 0.f;
+      v.y = z.y > 0.f ? sa[1] : 0.f;
+      v.z = z.z > 0.f ? sa[2] : 0.f;
+      v.w = z.w > 0.f ? sa[3] : 0.f;
+      *reinterpret_cast<float4*>(dX + (size_t)c * a.ldX + m) = v;
+    } else {
+      for (int i = 0; i < 4; ++i)
+        if (m + i < a.N) dX[(size_t)c * a.ldX + m + i] = Z[(size_t)c * a.ldZ + m + i] > 0.f ? sa[i] : 0.f;
     }
   }
 }
