@@ -203,7 +203,14 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, w.h3, false, s));
   TRY(conv(w.G64a, 64, p.w3t, nullptr, w.G64b, 64, B, N, false, nullptr, false, s));   // d/d(h2')
   // feature transform: h2' = T64^T h2
-  TRY(launch_gram64(w.h2, w.G64b, w.gT64, B, N, s));
+  {  // dT64[b][i][j] = sum_n h2[b][i][n] dh2'[b][j][n]: the batched NT product of the FC kernel (K = N)
+    FcArgs g{};
+    g.X = w.h2; g.ldX = N; g.sXb = (long)64 * N;
+    g.W = w.G64b; g.ldW = N; g.sWb = (long)64 * N;
+    g.Y = w.gT64; g.ldY = 64; g.sYb = 4096;
+    g.M = 64; g.Nout = 64; g.K = N; g.batch = B;
+    TRY(launch_fc(g, s));
+  }
   TRY(transform64(w.G64b, w.T64, w.dh2, false, B, N, s));
   TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
   // dh2 += W_t64.conv1^T G64a, then the relu gate of h2

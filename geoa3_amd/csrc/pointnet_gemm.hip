@@ -113,10 +113,11 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
   const int o0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int r = lane & 31, h = lane >> 5;
   const int m = min(m0 + r, a.M - 1), o = min(o0 + r, a.Nout - 1);
-  const float* xp = a.X + (size_t)m * a.ldX;
-  const float* wp = a.W + (size_t)o * a.ldW;
-  const bool xvec = (a.ldX & 3) == 0 && ((uintptr_t)a.X & 15) == 0;
-  const bool wvec = (a.ldW & 3) == 0 && ((uintptr_t)a.W & 15) == 0;
+  const int bz = blockIdx.z;
+  const float* xp = a.X + (size_t)bz * a.sXb + (size_t)m * a.ldX;
+  const float* wp = a.W + (size_t)bz * a.sWb + (size_t)o * a.ldW;
+  const bool xvec = ((a.ldX | a.sXb) & 3) == 0 && ((uintptr_t)a.X & 15) == 0;
+  const bool wvec = ((a.ldW | a.sWb) & 3) == 0 && ((uintptr_t)a.W & 15) == 0;
   // this wave's K range, in units of 8
   const int k8 = (a.K + 7) / 8;
   const int per = (k8 + S - 1) / S;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
       float v = acc[i] + bias;
       if (a.relu) v = fmaxf(v, 0.f);
       if (a.Z) v = a.Z[(size_t)mr * a.ldZ + oc] > 0.f ? v : 0.f;
-      a.Y[(size_t)mr * a.ldY + oc] = v;
+      a.Y[(size_t)bz * a.sYb + (size_t)mr * a.ldY + oc] = v;
     }
   }
 }
@@ -181,8 +182,8 @@ int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_fc(const FcArgs& a, hipStream_t s) {
-  dim3 grid((a.Nout + 31) / 32, (a.M + 31) / 32);
-  if (a.K >= 2048)
+  dim3 grid((a.Nout + 31) / 32, (a.M + 31) / 32, a.batch > 1 ? a.batch : 1);
+  if (a.K >= 2048 || (a.batch > 1 && a.K >= 512))
     hipLaunchKernelGGL(fc_kernel<8>, grid, dim3(512), 0, s, a);
   else if (a.K >= 256)
     hipLaunchKernelGGL(fc_kernel<4>, grid, dim3(256), 0, s, a);

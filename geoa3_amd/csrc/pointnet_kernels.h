@@ -28,6 +28,7 @@ int launch_conv_cm(const ConvArgs& a, hipStream_t s);
 struct FcArgs {
   const float* X; int ldX;
   const float* W; int ldW;
+  long sXb, sWb, sYb; int batch;              // optional batch (blockIdx.z): per-instance X, W, Y (0 / 1 = none)
   const float* bias;
   const float* Z; int ldZ;                    // relu mask source or null
   float* Y; int ldY;
@@ -67,5 +68,3 @@ int launch_conv_in3(const float* x, const float* T /*[B][9] or null*/, const flo
 int launch_conv_in3_bwd(const float* g, const float* W /*[64][3]*/, const float* T, const float* x, float* dx,
                         float* dT, int accumulate, int B, int N, hipStream_t s);
 
-// dT[b][i][j] = sum_n F[b][i][n] * G[b][j][n]   (i, j < 64)
-int launch_gram64(const float* F, const float* G, float* dT, int B, int N, hipStream_t s);

@@ -87,50 +87,6 @@ __global__ __launch_bounds__(256) void conv_in3_bwd_kernel(const float* __restri
   }
 }
 
-// dT[b][i][j] = sum_n F[b][i][n] G[b][j][n].  One workgroup per instance; thread (ti,tj) owns a 4x4 block.
-constexpr int GR_TN = 32;
-__global__ __launch_bounds__(256) void gram64_kernel(const float* __restrict__ F, const float* __restrict__ G,
-                                                     float* __restrict__ dT, int N) {
-  __shared__ float s_f[64][GR_TN + 1], s_g[64][GR_TN + 1];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
-  const float* Fb = F + (size_t)b * 64 * N;
-  const float* Gb = G + (size_t)b * 64 * N;
-  float acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (int n0 = 0; n0 < N; n0 += GR_TN) {
-    __syncthreads();
-    for (int e = tid; e < 64 * GR_TN; e += 256) {
-      const int r = e / GR_TN, c = e - r * GR_TN;
-      const bool ok = n0 + c < N;
-      s_f[r][c] = ok ? Fb[(size_t)r * N + n0 + c] : 0.f;
-      s_g[r][c] = ok ? Gb[(size_t)r * N + n0 + c] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int c = 0; c < GR_TN; ++c) {
-      float fv[4], gv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fv[i] = s_f[ti + i][c];
-        gv[i] = s_g[tj + i][c];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += fv[i] * gv[j];
-    }
-  }
-  float* o = dT + (size_t)b * 4096;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[(ti + i) * 64 + tj + j] = acc[i][j];
-}
-
 }  // namespace
 
 int launch_conv_in3(const float* x, const float* T, const float* W, const float* bias, float* Y, int B, int N,
@@ -143,12 +99,6 @@ int launch_conv_in3(const float* x, const float* T, const float* W, const float*
 int launch_conv_in3_bwd(const float* g, const float* W, const float* T, const float* x, float* dx, float* dT,
                         int accumulate, int B, int N, hipStream_t s) {
   hipLaunchKernelGGL(conv_in3_bwd_kernel, dim3(B), dim3(256), 0, s, g, W, T, x, dx, dT, accumulate, N);
-  GEOA3_CHECK_LAUNCH();
-  return GEOA3_OK;
-}
-
-int launch_gram64(const float* F, const float* G, float* dT, int B, int N, hipStream_t s) {
-  hipLaunchKernelGGL(gram64_kernel, dim3(B), dim3(256), 0, s, F, G, dT, N);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -8,16 +8,13 @@
 // deterministic gather-by-owner accumulation in LDS (no atomics).
 #include "pointnet_kernels.h"
 #include "profile.h"
-#include <cstdlib>
 
 namespace {
 
 constexpr int WM_CO = 128;     // output channels per workgroup (4 waves x 32)
-constexpr int WM_COLS = 64;    // points per tile
 constexpr int WM_THREADS = 256;
 constexpr int WM_CI = 128;     // input channels of every wide layer
 constexpr int WM_HALO = 4;     // halo on both sides of a staged activation row (float4 aligned)
-constexpr int WM_XP = WM_COLS + 2 * WM_HALO;   // LDS pitch of an activation row
 
 // Weights arrive in MFMA A-fragment order (host: geoa3_amd/pointnet.py pack_wide_fragments):
 //   Wp[((T*TAPS + tap)*16 + j)*64 + lane][i] = W[32*T + (lane&31)][tap*128 + 8*j + 4*(lane>>5) + i]
@@ -27,8 +24,10 @@ constexpr int WM_XP = WM_COLS + 2 * WM_HALO;   // LDS pitch of an activation row
 //
 // Activations: chunk of CHUNK input channels x (64 + halo) points, double buffered in LDS, staged through
 // registers one pass ahead (global loads of pass p+1 fly under the MFMAs of pass p); ONE barrier per pass.
-template <int TAPS, int CHUNK>
-__global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
+template <int TAPS, int CHUNK, int CT, int OCC>   // CT = 32-column sub-tiles per wave: the tile is 32*CT points wide
+__global__ __launch_bounds__(WM_THREADS, OCC) void wide_max_kernel(WideArgs a) {
+  constexpr int WM_COLS = 32 * CT;
+  constexpr int WM_XP = WM_COLS + 2 * WM_HALO;                  // LDS pitch of an activation row
   constexpr int NXTOT = CHUNK * (WM_XP / 4);                    // float4 slots of one activation chunk
   constexpr int NX = (NXTOT + WM_THREADS - 1) / WM_THREADS;
   constexpr int NG = TAPS * CHUNK / 8;                          // weight fragment groups per pass (8 k each)
@@ -101,9 +100,9 @@ __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
   __syncthreads();
   int pass = 0;
   for (int n0 = 0; n0 < N; n0 += WM_COLS) {
-    f32x16 acc[2];
+    f32x16 acc[CT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -119,15 +118,14 @@ __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
       if (more) load_x(nn0, nci0);
       const float* xb = smem + (pass & 1) * (CHUNK * WM_XP) + kh * 4 * WM_XP + WM_HALO + l31 - TAPS / 2;
       // B operands of one fragment group: rows 8jj + 4*kh + i, columns col+tap-TAPS/2 and +32
-      float bq[8], bn[8];
+      float bq[4 * CT], bn[4 * CT];
       auto read_b = [&](int g, float* d) {
         const int tap = g / (CHUNK / 8), jj = g - tap * (CHUNK / 8);
         const float* xp = xb + jj * 8 * WM_XP + tap;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          d[2 * i] = xp[i * WM_XP];
-          d[2 * i + 1] = xp[i * WM_XP + 32];
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) d[CT * i + t] = xp[i * WM_XP + 32 * t];
       };
       read_b(0, bq);
       __builtin_amdgcn_sched_barrier(0);
@@ -141,20 +139,19 @@ __global__ __launch_bounds__(WM_THREADS) void wide_max_kernel(WideArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[0] = mfma32(wv[i], bq[2 * i], acc[0]);
-          acc[1] = mfma32(wv[i], bq[2 * i + 1], acc[1]);
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[t] = mfma32(wv[i], bq[CT * i + t], acc[t]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bq[i] = bn[i];
+        for (int i = 0; i < 4 * CT; ++i) bq[i] = bn[i];
       }
       if (more) store_x(smem + ((pass + 1) & 1) * (CHUNK * WM_XP));
       __syncthreads();
     }
     // fold this tile into the running maximum (strict >: the lowest point index wins a tie)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < CT; ++t) {
       const int col = n0 + t * 32 + l31;
       const bool ok = col < N;
 #pragma unroll
@@ -282,19 +279,24 @@ __global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
 
 }  // namespace
 
-template <int TAPS, int CHUNK>
+template <int TAPS, int CHUNK, int CT, int OCC>
 static void launch_wide_variant(const WideArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)2 * CHUNK * WM_XP * sizeof(float);
+  const size_t lds = (size_t)2 * CHUNK * (32 * CT + 2 * WM_HALO) * sizeof(float);
   const int groups = (a.B + 7) / 8;   // 8 instances x 8 channel tiles per group of 64 workgroups
-  hipLaunchKernelGGL((wide_max_kernel<TAPS, CHUNK>), dim3(groups * 64), dim3(WM_THREADS), lds, s, a);
+  auto kern = wide_max_kernel<TAPS, CHUNK, CT, OCC>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  hipLaunchKernelGGL(kern, dim3(groups * 64), dim3(WM_THREADS), lds, s, a);
 }
 
 int launch_wide_max(const WideArgs& a, hipStream_t s) {
   if (a.Co != 8 * WM_CO || (a.taps != 1 && a.taps != 3)) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
   geoa3_prof_begin(tag, s);
-  if (a.taps == 1) launch_wide_variant<1, 64>(a, s);
-  else launch_wide_variant<3, 32>(a, s);
+  // chunk sizes / occupancy picked on hardware (profiles/): 3 workgroups of 4 waves per CU
+  if (a.taps == 1) launch_wide_variant<1, 32, 2, 3>(a, s);
+  else launch_wide_variant<3, 16, 2, 3>(a, s);
   geoa3_prof_end(tag, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
