@@ -35,10 +35,12 @@ PEAK_HBM = 8.0e12
 
 
 def cfg_config2(steps):
-    from oracle.geoa3_oracle import AttackCfg  # plain namespace of the reference flags (no compute)
-    return AttackCfg(attack_label="Untarget", binary_max_steps=1, iter_max_steps=steps, lr=0.01, initial_const=10.0,
-                     cls_loss_type="CE", dis_loss_type="CD", dis_loss_weight=1.0, hd_loss_weight=0.1,
-                     curv_loss_weight=1.0, curv_loss_knn=KNN, classes=CLASSES)
+    """The reference flags of BASELINE.json configs[1] (main_attack.py:317-384 defaults + Untarget)."""
+    return argparse.Namespace(attack_label="Untarget", binary_max_steps=1, iter_max_steps=steps, lr=0.01,
+                              initial_const=10.0, optim="adam", cls_loss_type="CE", confidence=0.0,
+                              dis_loss_type="CD", dis_loss_weight=1.0, is_cd_single_side=False, hd_loss_weight=0.1,
+                              curv_loss_weight=1.0, curv_loss_knn=KNN, uniform_loss_weight=0.0,
+                              is_use_lr_scheduler=False, cc_linf=0.0, npoint=NPOINT, classes=CLASSES)
 
 
 def cpu_baseline(sample_b=8, budget_s=20.0):
@@ -97,15 +99,15 @@ def main():
     from geoa3_amd import _lib
     from geoa3_amd.attack import AttackRunner
     from geoa3_amd.pointnet import PointNet
-    from oracle.geoa3_oracle import make_pointnet_state_dict, make_synthetic_clouds  # input generators only
+    from geoa3_amd.data import synthetic_clouds, synthetic_state_dict
 
     B = a.instances
     total = a.warmup + a.steps
     cfg = cfg_config2(total)
     net = PointNet(CLASSES)
-    net.load_state_dict(make_pointnet_state_dict(CLASSES, seed=0))
+    net.load_state_dict(synthetic_state_dict(CLASSES, seed=0, device=dev))
     net = net.to(dev).eval()
-    ori, nrm = make_synthetic_clouds(B, NPOINT, seed=100 + rank)
+    ori, nrm = synthetic_clouds(B, NPOINT, seed=100 + rank)
     ori, nrm = ori.to(dev), nrm.to(dev)
     with torch.no_grad():
         gt = net(ori).argmax(1)

@@ -287,6 +287,31 @@ def main():
         ps.append(t2n(p).copy())
     out["adam/grads"], out["adam/params"] = np.stack(grads), np.stack(ps)
 
+    # ---------------------------------------------------------------- CLI flags + dataset expansion
+    import json
+    import re
+    import tempfile
+    src = open(os.path.join(REF, "main_attack.py")).read()
+    flags = []
+    for m in re.finditer(r"parser\.add_argument\((.*?)\)\s*$", src, re.M):
+        body = m.group(1)
+        names = re.findall(r"'(-{1,2}[A-Za-z_0-9]+)'", body.split("default")[0] if "default" in body else body)
+        d = re.search(r"default=([^,\)]+)", body)
+        flags.append([names, d.group(1).strip() if d else None, "store_true" in body])
+    out["cli/flags_json"] = np.array(json.dumps(flags))
+    from Provider.modelnet10_instance250 import ModelNet40 as RefDataset
+    from geoa3_amd.data import TEN_LABEL_INDEXES, write_synthetic_mat
+    with tempfile.TemporaryDirectory() as td:
+        mat = write_synthetic_mat(os.path.join(td, "d.mat"), [TEN_LABEL_INDEXES[i // 25] for i in range(250)], 32, 9)
+        for lab in ("All", "Untarget", "chair"):
+            ds = RefDataset(data_mat_file=mat, attack_label=lab)
+            out["ds/%s/len" % lab] = np.int64(len(ds))
+            out["ds/%s/start" % lab] = np.int64(ds.start_index)
+            for idx in (0, 7):
+                item = ds[idx]
+                for j, t in enumerate(item):
+                    out["ds/%s/%d/%d" % (lab, idx, j)] = t2n(t)
+
     path = os.path.join(HERE, "geoa3_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), len(out), "arrays")
