@@ -26,7 +26,7 @@ from .pointnet import PointNet
 
 Tensor = torch.Tensor
 
-_UNSUPPORTED = ("is_partial_var", "is_subsample_opt", "is_pre_jitter_input", "is_pro_grad")
+_UNSUPPORTED = ("is_partial_var", "is_subsample_opt", "is_pre_jitter_input")
 
 
 def _cfg(cfg, name, default):
@@ -165,6 +165,7 @@ class AttackRunner:
                                               self.b, self.n, t["g_cls"].data_ptr(), self.ws.data_ptr(), s),
                   "pointnet_backward")
             g_cls = t["g_cls"]
+        pro_grad = bool(_cfg(cfg, "is_pro_grad", False))
         # optimiser scalars in double, as torch.optim.Adam forms them
         lr = cfg.lr * (0.9990 ** step if _cfg(cfg, "is_use_lr_scheduler", False) else 1.0)
         if cfg.optim == "adam":
@@ -175,7 +176,19 @@ class AttackRunner:
         check(lib.geoa3_attack_update(st, self._p(g_cls), self._p(t["g_geo"]) if constrain is not None else None,
                                       self.ori.data_ptr(), t["offset"].data_ptr(), t["m"].data_ptr(),
                                       t["v"].data_ptr(), x.data_ptr(), optim, step_size, sqrt_bc2,
-                                      float(_cfg(cfg, "cc_linf", 0.0)), s), "attack_update")
+                                      0.0 if pro_grad else float(_cfg(cfg, "cc_linf", 0.0)), s), "attack_update")
+        if pro_grad:   # geoA3_attack.py:341-352: (real offset,) projection onto the normal, then lp_clip
+            if _cfg(cfg, "is_real_offset", False):
+                check(lib.geoa3_nn1_pair(x.data_ptr(), self.ori.data_ptr(), self.b, self.n, self.n,
+                                         t["d_ao"].data_ptr(), t["i_ao"].data_ptr(), None, None, s), "nn1_pair")
+                check(lib.geoa3_attack_project(0, self.ori.data_ptr(), None, t["i_ao"].data_ptr(),
+                                               t["offset"].data_ptr(), x.data_ptr(), self.b, self.n, 0.0, s),
+                      "attack_project")
+            check(lib.geoa3_nn1_pair(t["offset"].data_ptr(), self.ori.data_ptr(), self.b, self.n, self.n,
+                                     t["d_ao"].data_ptr(), t["i_ao"].data_ptr(), None, None, s), "nn1_pair")
+            check(lib.geoa3_attack_project(1, self.ori.data_ptr(), self.nrm.data_ptr(), t["i_ao"].data_ptr(),
+                                           t["offset"].data_ptr(), x.data_ptr(), self.b, self.n,
+                                           float(_cfg(cfg, "cc_linf", 0.0)), s), "attack_project")
 
     def end_search_step(self, sync_last_label: Optional[Callable[[Tensor], None]] = None):
         if sync_last_label is not None:

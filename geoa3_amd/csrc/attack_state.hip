@@ -150,6 +150,54 @@ __global__ __launch_bounds__(256) void attack_update_kernel(int B, int N, const 
   }
 }
 
+__global__ __launch_bounds__(256) void attack_project_kernel(int mode, int B, int N, const float* __restrict__ ori,
+                                                             const float* __restrict__ normal,
+                                                             const int32_t* __restrict__ nn, float* __restrict__ offset,
+                                                             float* __restrict__ x, float cc_linf) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (size_t)B * N) return;
+  const int b = (int)(p / N);
+  const int n = (int)(p - (size_t)b * N);
+  const size_t base = (size_t)b * 3 * N;
+  const int j = nn[p];
+  if (mode == 0) {  // find_offset: measured from the nearest original point
+#pragma unroll
+    for (int c = 0; c < 3; ++c) offset[base + (size_t)c * N + n] = x[base + (size_t)c * N + n] - ori[base + (size_t)c * N + j];
+    return;
+  }
+  float o[3], u[3];
+  float n2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o[c] = offset[base + (size_t)c * N + n];
+    u[c] = normal[base + (size_t)c * N + j];
+    n2 += u[c] * u[c];
+  }
+  const float den = sqrtf(n2) + 1e-6f;
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    u[c] = u[c] / den;
+    dot += o[c] * u[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = dot * u[c];
+  if (cc_linf != 0.f) {
+    const float len = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    if (!(len < cc_linf)) {
+      const bool big = len > 1e-6f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = big ? o[c] / len * cc_linf : 0.f;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t e = base + (size_t)c * N + n;
+    offset[e] = o[c];
+    x[e] = ori[e] + o[c];
+  }
+}
+
 __global__ void binary_update_kernel(geoa3_attack_state st) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= st.B) return;
@@ -209,6 +257,17 @@ extern "C" int geoa3_attack_update(const geoa3_attack_state* st, const float* g_
   hipLaunchKernelGGL(attack_update_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, geoa3_stream(stream),
                      st->B, st->N, st->scale_const, st->inv_global_batch, g_cls, g_geo, ori, offset, adam_m, adam_v,
                      x, optim, step_size, sqrt_bc2, cc_linf);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_attack_project(int mode, const float* ori, const float* normal_ori, const int32_t* nn,
+                                    float* offset, float* x, int B, int N, float cc_linf, void* stream) {
+  if (!ori || !nn || !offset || !x || B <= 0 || N <= 0 || (mode != 0 && mode != 1)) return GEOA3_EINVAL;
+  if (mode == 1 && !normal_ori) return GEOA3_EINVAL;
+  const size_t pts = (size_t)B * N;
+  hipLaunchKernelGGL(attack_project_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, geoa3_stream(stream),
+                     mode, B, N, ori, normal_ori, nn, offset, x, cc_linf);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -192,6 +192,16 @@ int geoa3_attack_update(const geoa3_attack_state* st, const float* g_cls, const 
                         const float* ori, float* offset, float* adam_m, float* adam_v, float* x,
                         int optim, float step_size, float sqrt_bc2, float cc_linf, void* stream);
 
+/* The flag-gated projections that follow the optimiser step (--is_pro_grad / --is_real_offset,
+ * geoA3_attack.py:59-85,341-347), one point per thread.
+ *   mode 0 (find_offset, :79-85):  offset = x - ori[:, nn[b,i]]            (nn = nearest original of x)
+ *   mode 1 (offset_proj, :59-77):  n = normal_ori[:, nn[b,i]] with nn = nearest original point OF THE OFFSET
+ *          VECTOR (the reference queries knn_points with `offset` as the cloud, :65);
+ *          offset = <offset, n/(|n|+1e-6)> n/(|n|+1e-6); then lp_clip (cc_linf != 0, :88-98,349-352) and
+ *          x = ori + offset. */
+int geoa3_attack_project(int mode, const float* ori, const float* normal_ori, const int32_t* nn, float* offset,
+                         float* x, int B, int N, float cc_linf, void* stream);
+
 /* End of a binary step: the scale_const / bound update of geoA3_attack.py:374-384, bug-compatible
  * (uses *last_label for every instance).  Also re-arms the per-binary-step state. */
 int geoa3_attack_binary_update(const geoa3_attack_state* st, void* stream);

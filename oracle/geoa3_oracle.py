@@ -24,6 +24,7 @@ reference hot path, function by function:
     Lib/loss_utils.py:84-97  curvature_loss                curvature_loss
     Model/PointNet.py:56-94  transform_net                 _tnet_forward
     Model/PointNet.py:96-160 PointNet.forward (eval)       pointnet_forward
+    Attacker/geoA3_attack.py:59-85   offset_proj/find_offset  offset_proj, find_offset
     Attacker/geoA3_attack.py:88-98   lp_clip               lp_clip
     Attacker/geoA3_attack.py:100-180 _forward_step         forward_step
     Attacker/geoA3_attack.py:182-386 attack                attack
@@ -281,6 +282,22 @@ def lp_clip(offset: Tensor, cc_linf: float) -> Tensor:
     return torch.where(lengths < cc_linf, offset, offset_scaled)
 
 
+def offset_proj(offset: Tensor, ori_pc: Tensor, ori_normal: Tensor) -> Tensor:
+    """offset_proj (geoA3_attack.py:59-77): project every offset vector onto the normal of the original point that
+    is nearest TO THE OFFSET VECTOR ITSELF (the reference queries the K-NN with `offset` as the cloud, :65)."""
+    _, idx = knn_points(offset.permute(0, 2, 1), ori_pc.permute(0, 2, 1), 1)
+    normal = knn_gather(ori_normal.permute(0, 2, 1), idx).permute(0, 3, 1, 2).squeeze(3).contiguous()
+    nl = (normal ** 2).sum(1, keepdim=True).sqrt().expand_as(offset)
+    return (offset * normal / (nl + 1e-6)).sum(1, keepdim=True) * normal / (nl + 1e-6)
+
+
+def find_offset(ori_pc: Tensor, adv_pc: Tensor) -> Tensor:
+    """find_offset (geoA3_attack.py:79-85): offset measured from the NEAREST original point."""
+    _, idx = knn_points(adv_pc.permute(0, 2, 1), ori_pc.permute(0, 2, 1), 1)
+    knn_pc = knn_gather(ori_pc.permute(0, 2, 1), idx).permute(0, 3, 1, 2).squeeze(3).contiguous()
+    return adv_pc - knn_pc
+
+
 class AttackCfg:
     """The subset of main_attack.py's argparse namespace (main_attack.py:317-384) the hot path
     reads, with the reference defaults."""
@@ -304,6 +321,8 @@ class AttackCfg:
         self.uniform_loss_weight = 0.0
         self.is_use_lr_scheduler = False
         self.cc_linf = 0.0
+        self.is_pro_grad = False
+        self.is_real_offset = False
         self.npoint = 1024
         for k, v in kw.items():
             setattr(self, k, v)
@@ -461,6 +480,10 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
                     raise AssertionError("Not support such optimizer.")
                 if cfg.is_use_lr_scheduler:
                     lr = lr * 0.9990
+                if cfg.is_pro_grad:     # geoA3_attack.py:341-347
+                    if cfg.is_real_offset:
+                        offset.copy_(find_offset(pc_ori, pc_ori + offset))
+                    offset.copy_(offset_proj(offset, pc_ori, normal_ori))
                 if cfg.cc_linf != 0:
                     offset.copy_(lp_clip(offset, cfg.cc_linf))
         if last_label_override is not None:

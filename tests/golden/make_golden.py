@@ -72,6 +72,12 @@ def install_shims():
         return real_popen(cmd, *a, **k)
 
     os.popen = popen
+    real_where = torch.where
+
+    def where(cond, *a, **k):   # the reference passes uint8 masks (geoA3_attack.py:63,75); torch >= 2 wants bool
+        return real_where(cond.bool() if torch.is_tensor(cond) and cond.dtype == torch.uint8 else cond, *a, **k)
+
+    torch.where = where
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
     sys.path.insert(0, REF)
@@ -106,6 +112,10 @@ ATK_CASES = {
                             initial_const=2000.0), False, 6, 35),
     "untarget_lowlr": (dict(curv_loss_knn=4, binary_max_steps=4, iter_max_steps=8, lr=0.001,
                             initial_const=2.0), False, 6, 35),
+    "pro_grad": (dict(curv_loss_knn=4, binary_max_steps=2, iter_max_steps=6, lr=0.002, is_pro_grad=True,
+                      hd_loss_weight=0.0), False, 4, 37),
+    "pro_grad_real_clip": (dict(curv_loss_knn=4, binary_max_steps=2, iter_max_steps=6, lr=0.002, is_pro_grad=True,
+                                is_real_offset=True, cc_linf=0.01, hd_loss_weight=0.0), False, 4, 38),
     "margin_sgd": (dict(cls_loss_type="Margin", optim="sgd", lr=0.05, curv_loss_knn=4, binary_max_steps=2,
                         iter_max_steps=5), False, 3, 36),
 }
