@@ -73,13 +73,17 @@ def cpu_baseline(sample_b=8, budget_s=20.0):
 
 
 def main():
+    global NPOINT, KNN
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--instances", type=int, default=INSTANCES, help="instances per GPU (default 250)")
+    ap.add_argument("--npoint", type=int, default=NPOINT, help="points per cloud (configs[4]: 4096)")
+    ap.add_argument("--knn", type=int, default=KNN, help="curv_loss_knn (configs[4]: 32)")
     a = ap.parse_args()
+    NPOINT, KNN = a.npoint, a.knn
 
     import torch
     import torch.distributed as dist
@@ -152,12 +156,12 @@ def main():
         conv5_flops = 2.0 * B * NPOINT * 1024 * 384          # algorithmic: 1024 outputs x (3 taps x 128) MACs / point
         achieved = conv5_flops / (conv5_ms * 1e-3) / 1e12 if conv5_ms else None
         out = {
-            "metric": "attack-iterations/sec (B=250, N=1024)", "value": round(value, 3),
+            "metric": "attack-iterations/sec (B=250, N=%d)" % NPOINT, "value": round(value, 3),
             "unit": "iterations/s of a 250-instance batch", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: PointNet 1024-pt, %d instances per GPU, full GeoA3 "
-                                   "(CE + CD 1.0 + HD 0.1 + curvature 1.0 k=16), untargeted" % B,
+            "config": {"workload": "configs[%d]: PointNet %d-pt, %d instances per GPU, full GeoA3 (CE + CD 1.0 + HD 0.1 + "
+                                   "curvature 1.0 k=%d), untargeted" % (1 if NPOINT == 1024 else 4, NPOINT, B, KNN),
                        "instances_per_gpu": B, "npoint": NPOINT, "knn": KNN, "classes": CLASSES,
                        "parallelism": "instance-sharded x%d" % world},
             "roofline": {"bound": "mfma", "kernel": "wide_max_kernel<3> (conv5+bn5+relu+max, fp32 MFMA)",

@@ -134,3 +134,21 @@ def test_shard_invariance_on_device(net, golden):
                              [i[lo:hi] for i in inits], global_batch=6, sync_last_label=sync)
         assert torch.equal(part[0].cpu(), full[0][lo:hi].cpu())          # bit-identical shards
         assert (part[2] == full[2][lo:hi]).all() and list(part[3]) == list(full[3][lo:hi])
+
+
+def test_config5_shape_n4096_k32(net):
+    """BASELINE configs[4]: N = 4096 points, curv_loss_knn = 32 (K-NN K = 33, 114 KB LDS objective kernel)."""
+    from geoa3_amd.attack import attack
+    cfg = O.AttackCfg(binary_max_steps=1, iter_max_steps=3, lr=0.002, curv_loss_knn=32)
+    sd = O.make_pointnet_state_dict(40, seed=0)
+    onet = lambda x: O.pointnet_forward(sd, x)
+    ori, nrm = O.make_synthetic_clouds(2, 4096, seed=91)
+    with torch.no_grad():
+        gt = onet(ori).argmax(1)
+    inits = [torch.randn(2, 3, 4096, generator=torch.Generator().manual_seed(92)) * 1e-3]
+    tr = {}
+    _, _, osucc, _, oloss = O.attack(onet, ori, nrm, gt, None, cfg, inits, trace=tr)
+    best, target, succ, best_step, all_loss = attack(net, _loader_batch(ori, nrm, gt, None, False), cfg, 0, 1,
+                                                     init_offsets=[i.cuda() for i in inits], verbose=False)
+    np.testing.assert_allclose(np.asarray(all_loss, dtype=np.float32), np.asarray(oloss, dtype=np.float32),
+                               rtol=2e-3, atol=2e-4)
