@@ -67,6 +67,12 @@ SIGNATURES = {
     "geoa3_attack_project": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "geoa3_attack_binary_update": (C.c_int, [C.POINTER(AttackState), vp]),
     "geoa3_attack_begin_search_step": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, vp, vp, vp, vp]),
+    "geoa3_pn2_furthest_point_sampling": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "geoa3_pn2_gather_points": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "geoa3_pn2_gather_points_grad": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "geoa3_pn2_ball_query": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp]),
+    "geoa3_pn2_group_points": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "geoa3_pn2_group_points_grad": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_profile_enable": (C.c_int, [C.c_int]),
     "geoa3_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_int]),
 }

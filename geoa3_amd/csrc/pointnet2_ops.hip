@@ -1,0 +1,237 @@
+// PointNet++ set-abstraction operators (gfx950): the six functions the reference's vendored CUDA extension
+// `pointnet2_ops._ext` exports to the SSG classifier (Model/pointnet2_ops_lib/pointnet2_ops/_ext-src/src/
+// bindings.cpp:6-19): furthest_point_sampling, gather_points(+grad), ball_query, group_points(+grad).
+// Same argument layouts ([B,N,3] point-major xyz, [B,C,N] channel-major features, int32 indices) so that the
+// Python autograd Functions of pointnet2_utils.py:34-101,194-276 bind to them unchanged.
+//
+// Semantics kept from the .cu sources:
+//   * FPS (sampling_gpu.cu:69-173): starts at index 0; points with |p|^2 <= 1e-3 are skipped (never selected,
+//     their running distance is not updated); arg-max ties go to the lowest (k mod T), then the lowest k, where
+//     T = opt_n_threads(N) = largest power of two <= min(N, 512) (cuda_utils.h:13-19) is the reference's block.
+//   * ball query (ball_query_gpu.cu:9-44): first `nsample` points IN INDEX ORDER with d^2 < r^2; the first hit
+//     pre-fills every slot; no hit leaves zeros.
+//   * gradients of gather / group are scatter-adds (atomicAdd, sampling_gpu.cu:42, group_points_gpu.cu:60).
+// Distances are evaluated un-fused, fl(fl(dx*dx + dy*dy) + dz*dz) with each product rounded (the CPU oracle's
+// order); nvcc's contraction choice for the reference is not specified by its sources.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sq3(float dx, float dy, float dz) {
+#pragma clang fp contract(off)
+  const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  const float s = xx + yy;
+  return s + zz;
+}
+
+// ------------------------------------------------------------------------------------------
+// FPS: one workgroup per cloud, every thread keeps PPT points and their running distances in registers;
+// a round is: distance update -> wave arg-max (shuffles) -> cross-wave arg-max through LDS (2 barriers).
+// ------------------------------------------------------------------------------------------
+constexpr int FPS_BLOCK = 1024;
+constexpr int FPS_PPT = 8;  // up to 8192 points per cloud
+
+struct Best {
+  float v;
+  int t, k;  // t = k mod T (the reference thread that owns k)
+};
+__device__ __forceinline__ Best fps_better(Best a, Best b) {
+  const bool take = b.v > a.v || (b.v == a.v && (b.t < a.t || (b.t == a.t && b.k < a.k)));
+  return take ? b : a;
+}
+
+__global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict__ xyz, int N, int m, int T,
+                                                        float* __restrict__ temp, int32_t* __restrict__ idxs) {
+  __shared__ float s_v[FPS_BLOCK / 64];
+  __shared__ int s_t[FPS_BLOCK / 64], s_k[FPS_BLOCK / 64];
+  __shared__ float s_sel[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* P = xyz + (size_t)b * N * 3;
+  float px[FPS_PPT], py[FPS_PPT], pz[FPS_PPT], td[FPS_PPT];
+  bool use[FPS_PPT];
+#pragma unroll
+  for (int i = 0; i < FPS_PPT; ++i) {
+    const int k = tid + i * FPS_BLOCK;
+    const bool in = k < N;
+    px[i] = in ? P[k * 3] : 0.f;
+    py[i] = in ? P[k * 3 + 1] : 0.f;
+    pz[i] = in ? P[k * 3 + 2] : 0.f;
+    td[i] = 1e10f;  // sampling.cpp:74-76
+    const float mag = sq3(px[i], py[i], pz[i]);
+    use[i] = in && !(mag <= 1e-3f);
+  }
+  int old = 0;
+  if (tid == 0) idxs[(size_t)b * m] = 0;
+  for (int j = 1; j < m; ++j) {
+    if (tid == 0) {
+      s_sel[0] = P[old * 3];
+      s_sel[1] = P[old * 3 + 1];
+      s_sel[2] = P[old * 3 + 2];
+    }
+    __syncthreads();
+    const float x1 = s_sel[0], y1 = s_sel[1], z1 = s_sel[2];
+    Best best{-1.f, 0x7fffffff, 0x7fffffff};
+#pragma unroll
+    for (int i = 0; i < FPS_PPT; ++i) {
+      if (use[i]) {
+        const int k = tid + i * FPS_BLOCK;
+        const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
+        const float d2 = fminf(d, td[i]);
+        td[i] = d2;
+        best = fps_better(best, Best{d2, k & (T - 1), k});
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      Best other{__shfl_xor(best.v, o, 64), __shfl_xor(best.t, o, 64), __shfl_xor(best.k, o, 64)};
+      best = fps_better(best, other);
+    }
+    if (lane == 0) {
+      s_v[wave] = best.v;
+      s_t[wave] = best.t;
+      s_k[wave] = best.k;
+    }
+    __syncthreads();
+    Best r{s_v[0], s_t[0], s_k[0]};
+#pragma unroll
+    for (int w = 1; w < FPS_BLOCK / 64; ++w) r = fps_better(r, Best{s_v[w], s_t[w], s_k[w]});
+    old = r.v < 0.f ? 0 : r.k;  // every point skipped: the reference's reduction returns its initial index 0
+    if (tid == 0) idxs[(size_t)b * m + j] = old;
+  }
+  if (temp) {
+#pragma unroll
+    for (int i = 0; i < FPS_PPT; ++i) {
+      const int k = tid + i * FPS_BLOCK;
+      if (k < N) temp[(size_t)b * N + k] = td[i];
+    }
+  }
+}
+
+// out[b][c][j] = points[b][c][idx[b][j]]
+__global__ __launch_bounds__(256) void gather_points_kernel(const float* __restrict__ points,
+                                                            const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                            int C, int N, int M) {
+  const int b = blockIdx.z, c = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  out[((size_t)b * C + c) * M + j] = points[((size_t)b * C + c) * N + idx[(size_t)b * M + j]];
+}
+__global__ __launch_bounds__(256) void gather_points_grad_kernel(const float* __restrict__ grad_out,
+                                                                 const int32_t* __restrict__ idx,
+                                                                 float* __restrict__ grad_points, int C, int N, int M) {
+  const int b = blockIdx.z, c = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  atomicAdd(grad_points + ((size_t)b * C + c) * N + idx[(size_t)b * M + j], grad_out[((size_t)b * C + c) * M + j]);
+}
+
+// ball query: one thread per centre, the cloud of the instance staged in LDS in chunks; all lanes read the
+// same point (broadcast) and stop individually once their ball is full.
+constexpr int BQ_CHUNK = 1024;
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ new_xyz,
+                                                         const float* __restrict__ xyz, int N, int M, float radius2,
+                                                         int nsample, int32_t* __restrict__ idx) {
+  __shared__ float s_p[BQ_CHUNK * 3];
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  const bool live = j < M;
+  const float* C = new_xyz + ((size_t)b * M + (live ? j : 0)) * 3;
+  const float cx = C[0], cy = C[1], cz = C[2];
+  int32_t* out = idx + ((size_t)b * M + (live ? j : 0)) * nsample;
+  int cnt = live ? 0 : nsample;
+  for (int k0 = 0; k0 < N; k0 += BQ_CHUNK) {
+    const int kn = min(BQ_CHUNK, N - k0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < kn * 3; e += 256) s_p[e] = xyz[((size_t)b * N + k0) * 3 + e];
+    __syncthreads();
+    if (__syncthreads_and(cnt >= nsample)) break;
+    for (int k = 0; k < kn && !__all(cnt >= nsample); ++k) {
+      const float d2 = sq3(cx - s_p[k * 3], cy - s_p[k * 3 + 1], cz - s_p[k * 3 + 2]);
+      if (cnt < nsample && d2 < radius2) {
+        if (cnt == 0)
+          for (int l = 0; l < nsample; ++l) out[l] = k0 + k;
+        out[cnt] = k0 + k;
+        ++cnt;
+      }
+    }
+  }
+}
+
+// out[b][c][j][k] = points[b][c][idx[b][j][k]]
+__global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ points,
+                                                           const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                           int C, int N, int MS) {
+  const int b = blockIdx.z, c = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  out[((size_t)b * C + c) * MS + e] = points[((size_t)b * C + c) * N + idx[(size_t)b * MS + e]];
+}
+__global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __restrict__ grad_out,
+                                                                const int32_t* __restrict__ idx,
+                                                                float* __restrict__ grad_points, int C, int N, int MS) {
+  const int b = blockIdx.z, c = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  atomicAdd(grad_points + ((size_t)b * C + c) * N + idx[(size_t)b * MS + e], grad_out[((size_t)b * C + c) * MS + e]);
+}
+
+}  // namespace
+
+extern "C" int geoa3_pn2_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int32_t* idx,
+                                                 void* stream) {
+  if (!xyz || !idx || B <= 0 || N <= 0 || m <= 0) return GEOA3_EINVAL;
+  if (N > FPS_BLOCK * FPS_PPT) return GEOA3_ENOSUPPORT;
+  int T = 1;
+  while (T * 2 <= N && T * 2 <= 512) T *= 2;  // opt_n_threads(N), cuda_utils.h:13-19
+  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(FPS_BLOCK), 0, geoa3_stream(stream), xyz, N, m, T, temp, idx);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_gather_points(const float* points, const int32_t* idx, int B, int C, int N, int M, float* out,
+                                       void* stream) {
+  if (!points || !idx || !out || B <= 0 || C <= 0 || N <= 0 || M <= 0) return GEOA3_EINVAL;
+  hipLaunchKernelGGL(gather_points_kernel, dim3((M + 255) / 256, C, B), dim3(256), 0, geoa3_stream(stream), points, idx,
+                     out, C, N, M);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_gather_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                                            float* grad_points, void* stream) {
+  if (!grad_out || !idx || !grad_points || B <= 0 || C <= 0 || N <= 0 || M <= 0) return GEOA3_EINVAL;
+  if (hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), geoa3_stream(stream)) != hipSuccess)
+    return GEOA3_ELAUNCH;
+  hipLaunchKernelGGL(gather_points_grad_kernel, dim3((M + 255) / 256, C, B), dim3(256), 0, geoa3_stream(stream),
+                     grad_out, idx, grad_points, C, N, M);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
+                                    int nsample, int32_t* idx, void* stream) {
+  if (!new_xyz || !xyz || !idx || B <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
+  if (hipMemsetAsync(idx, 0, (size_t)B * M * nsample * sizeof(int32_t), geoa3_stream(stream)) != hipSuccess)
+    return GEOA3_ELAUNCH;
+  hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, geoa3_stream(stream), new_xyz, xyz, N, M,
+                     radius * radius, nsample, idx);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_group_points(const float* points, const int32_t* idx, int B, int C, int N, int M, int nsample,
+                                      float* out, void* stream) {
+  if (!points || !idx || !out || B <= 0 || C <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
+  const int MS = M * nsample;
+  hipLaunchKernelGGL(group_points_kernel, dim3((MS + 255) / 256, C, B), dim3(256), 0, geoa3_stream(stream), points, idx,
+                     out, C, N, MS);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_group_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                                           int nsample, float* grad_points, void* stream) {
+  if (!grad_out || !idx || !grad_points || B <= 0 || C <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
+  if (hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), geoa3_stream(stream)) != hipSuccess)
+    return GEOA3_ELAUNCH;
+  const int MS = M * nsample;
+  hipLaunchKernelGGL(group_points_grad_kernel, dim3((MS + 255) / 256, C, B), dim3(256), 0, geoa3_stream(stream),
+                     grad_out, idx, grad_points, C, N, MS);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}

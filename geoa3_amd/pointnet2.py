@@ -1,0 +1,265 @@
+"""PointNet++ SSG victim (BASELINE configs[3]) on the HIP set-abstraction operators.
+
+Mirrors, for the classifier path only, the three layers of the reference's vendored package
+`Model/pointnet2_ops_lib/pointnet2_ops`:
+  * `ext`  -- the attribute surface of the native module `_ext` (_ext-src/src/bindings.cpp:6-19), each function a
+    thin call into libgeoa3_hip.so (geoa3_pn2_*), same argument order, dtypes and fresh-output convention;
+  * the autograd Functions / groupers of pointnet2_utils.py:34-101,194-379;
+  * the set-abstraction modules of pointnet2_modules.py:9-146 and `PointNet2ClassificationSSG`
+    (Model/PointNetPP_ssg.py:51-124) with the reference's state_dict keys (SA_modules.{0,1,2}.mlps.0.{0..8}.*,
+    fc_layer.{0,1,3,4,7}.*), so `load_state_dict(torch.load(...)['state_dict'])` works (main_attack.py:139-145).
+
+As in the reference, the shared MLPs (1x1 Conv2d + BatchNorm2d + ReLU), the max-pool and the FC head are torch.nn
+modules (MIOpen / hipBLASLt on ROCm); the native part -- FPS, ball query, grouping, gathering and their
+scatter-add gradients -- is this library's HIP code.  GPU tensors only.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check
+
+Tensor = torch.Tensor
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: Tensor, dtype) -> Tensor:
+    if not t.is_cuda:
+        raise _lib.Geoa3Error("CPU not supported")          # the reference asserts the same (ball_query.cpp:27-29)
+    if t.dtype != dtype:
+        raise _lib.Geoa3Error("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.Geoa3Error("tensor must be contiguous")  # utils.h:5-25 CHECK_CONTIGUOUS
+    return t
+
+
+class _Ext:
+    """`pointnet2_ops._ext` replacement: same six entry points, backed by the C ABI."""
+
+    @staticmethod
+    def furthest_point_sampling(xyz: Tensor, nsamples: int) -> Tensor:
+        _chk(xyz, torch.float32)
+        B, N, _ = xyz.shape
+        out = torch.zeros(B, nsamples, device=xyz.device, dtype=torch.int32)
+        check(_lib.load().geoa3_pn2_furthest_point_sampling(xyz.data_ptr(), B, N, nsamples, None, out.data_ptr(), _s()),
+              "furthest_point_sampling")
+        return out
+
+    @staticmethod
+    def gather_points(points: Tensor, idx: Tensor) -> Tensor:
+        _chk(points, torch.float32), _chk(idx, torch.int32)
+        B, C, N = points.shape
+        M = idx.shape[1]
+        out = torch.empty(B, C, M, device=points.device, dtype=torch.float32)
+        check(_lib.load().geoa3_pn2_gather_points(points.data_ptr(), idx.data_ptr(), B, C, N, M, out.data_ptr(), _s()),
+              "gather_points")
+        return out
+
+    @staticmethod
+    def gather_points_grad(grad_out: Tensor, idx: Tensor, n: int) -> Tensor:
+        _chk(grad_out, torch.float32), _chk(idx, torch.int32)
+        B, C, M = grad_out.shape
+        out = torch.empty(B, C, n, device=grad_out.device, dtype=torch.float32)
+        check(_lib.load().geoa3_pn2_gather_points_grad(grad_out.data_ptr(), idx.data_ptr(), B, C, n, M,
+                                                       out.data_ptr(), _s()), "gather_points_grad")
+        return out
+
+    @staticmethod
+    def ball_query(new_xyz: Tensor, xyz: Tensor, radius: float, nsample: int) -> Tensor:
+        _chk(new_xyz, torch.float32), _chk(xyz, torch.float32)
+        B, M, _ = new_xyz.shape
+        N = xyz.shape[1]
+        out = torch.empty(B, M, nsample, device=xyz.device, dtype=torch.int32)
+        check(_lib.load().geoa3_pn2_ball_query(new_xyz.data_ptr(), xyz.data_ptr(), B, N, M, float(radius), nsample,
+                                               out.data_ptr(), _s()), "ball_query")
+        return out
+
+    @staticmethod
+    def group_points(points: Tensor, idx: Tensor) -> Tensor:
+        _chk(points, torch.float32), _chk(idx, torch.int32)
+        B, C, N = points.shape
+        _, M, S = idx.shape
+        out = torch.empty(B, C, M, S, device=points.device, dtype=torch.float32)
+        check(_lib.load().geoa3_pn2_group_points(points.data_ptr(), idx.data_ptr(), B, C, N, M, S, out.data_ptr(),
+                                                 _s()), "group_points")
+        return out
+
+    @staticmethod
+    def group_points_grad(grad_out: Tensor, idx: Tensor, n: int) -> Tensor:
+        _chk(grad_out, torch.float32), _chk(idx, torch.int32)
+        B, C, M, S = grad_out.shape
+        out = torch.empty(B, C, n, device=grad_out.device, dtype=torch.float32)
+        check(_lib.load().geoa3_pn2_group_points_grad(grad_out.data_ptr(), idx.data_ptr(), B, C, n, M, S,
+                                                      out.data_ptr(), _s()), "group_points_grad")
+        return out
+
+
+ext = _Ext()
+
+
+# ------------------------------------------------------------------ pointnet2_utils.py:34-101,194-276
+class _FPS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        out = ext.furthest_point_sampling(xyz, npoint)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = features.size(2)
+        return ext.gather_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return ext.gather_points_grad(g.contiguous(), idx, ctx.n), None
+
+
+class _Group(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = features.size(2)
+        return ext.group_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return ext.group_points_grad(g.contiguous(), idx, ctx.n), None
+
+
+class _BallQuery(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        out = ext.ball_query(new_xyz, xyz, radius, nsample)   # note the argument order of the native call
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None, None, None
+
+
+furthest_point_sample = _FPS.apply
+gather_operation = _Gather.apply
+grouping_operation = _Group.apply
+ball_query = _BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """pointnet2_utils.py:279-333: ball query, group xyz (re-centred on the ball centre) and features."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: Tensor, new_xyz: Tensor, features: Optional[Tensor] = None) -> Tensor:
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped = grouping_operation(features, idx)
+        return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped
+
+
+class GroupAll(nn.Module):
+    """pointnet2_utils.py:336-379: one group holding every point."""
+
+    def __init__(self, use_xyz: bool = True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: Tensor, new_xyz: Optional[Tensor], features: Optional[Tensor] = None) -> Tensor:
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return grouped_xyz
+        grouped = features.unsqueeze(2)
+        return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped
+
+
+# ------------------------------------------------------------------ pointnet2_modules.py:9-146
+def build_shared_mlp(mlp_spec: List[int], bn: bool = True) -> nn.Sequential:
+    layers: List[nn.Module] = []
+    for cin, cout in zip(mlp_spec[:-1], mlp_spec[1:]):
+        layers.append(nn.Conv2d(cin, cout, kernel_size=1, bias=not bn))
+        if bn:
+            layers.append(nn.BatchNorm2d(cout))
+        layers.append(nn.ReLU(True))
+    return nn.Sequential(*layers)
+
+
+class PointnetSAModuleMSG(nn.Module):
+    def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(QueryAndGroup(radius, nsample, use_xyz=use_xyz) if npoint is not None
+                                 else GroupAll(use_xyz))
+            spec = list(spec)
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(build_shared_mlp(spec, bn))
+
+    def forward(self, xyz: Tensor, features: Optional[Tensor]):
+        new_xyz = None
+        if self.npoint is not None:
+            centres = furthest_point_sample(xyz, self.npoint)
+            new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            f = mlp(grouper(xyz, new_xyz, features))               # [B, C, npoint, nsample]
+            outs.append(F.max_pool2d(f, kernel_size=[1, f.size(3)]).squeeze(-1))
+        return new_xyz, torch.cat(outs, dim=1)
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    def __init__(self, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz)
+
+
+class PointNet2ClassificationSSG(nn.Module):
+    """Model/PointNetPP_ssg.py:51-124 (40 output classes hard-coded as in the reference, main_attack.py:140)."""
+
+    def __init__(self, use_xyz: bool = True, use_normal: bool = False):
+        super().__init__()
+        self.use_xyz, self.use_normal = use_xyz, use_normal
+        c0 = 3 if use_normal else 0
+        self.SA_modules = nn.ModuleList([
+            PointnetSAModule(npoint=512, radius=0.2, nsample=64, mlp=[c0, 64, 64, 128], use_xyz=use_xyz),
+            PointnetSAModule(npoint=128, radius=0.4, nsample=64, mlp=[128, 128, 128, 256], use_xyz=use_xyz),
+            PointnetSAModule(mlp=[256, 256, 512, 1024], use_xyz=use_xyz),
+        ])
+        self.fc_layer = nn.Sequential(
+            nn.Linear(1024, 512, bias=False), nn.BatchNorm1d(512), nn.ReLU(True),
+            nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(True),
+            nn.Dropout(0.5), nn.Linear(256, 40))
+
+    def forward(self, pointcloud: Tensor) -> Tensor:
+        """pointcloud [B, 3(+C), N] (the attack's layout) -> logits [B, 40]"""
+        pc = pointcloud.transpose(2, 1)
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        for module in self.SA_modules:
+            xyz, features = module(xyz, features)
+        return self.fc_layer(features.squeeze(-1))

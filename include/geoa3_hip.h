@@ -211,6 +211,31 @@ int geoa3_attack_begin_search_step(const geoa3_attack_state* st, const float* or
                                    float* offset, float* adam_m, float* adam_v, float* x, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * PointNet++ set-abstraction operators: the functions of the reference's vendored CUDA extension
+ * `pointnet2_ops._ext` that the SSG classifier uses (Model/pointnet2_ops_lib/pointnet2_ops/_ext-src/src/
+ * bindings.cpp:6-19; three_nn / three_interpolate serve only the segmentation FP module and are out of scope).
+ * Layouts as in the extension: xyz [B,N,3] point-major, features [B,C,N], indices int32.
+ * ------------------------------------------------------------------------------------------ */
+/* sampling.cpp:66-87 / sampling_gpu.cu:69-229.  temp: optional [B,N] scratch that receives the final running
+ * distances (the extension's `tmp` tensor); idx [B,m]. */
+int geoa3_pn2_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int32_t* idx, void* stream);
+/* sampling.cpp:25-43 / sampling_gpu.cu:8-30: out[b,c,j] = points[b,c,idx[b,j]] */
+int geoa3_pn2_gather_points(const float* points, const int32_t* idx, int B, int C, int N, int M, float* out,
+                            void* stream);
+/* sampling.cpp:45-64 / sampling_gpu.cu:34-57: scatter-add into grad_points [B,C,N] (zeroed here) */
+int geoa3_pn2_gather_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                                 float* grad_points, void* stream);
+/* ball_query.cpp:10-32 / ball_query_gpu.cu:9-54: idx [B,M,nsample] (zeroed here) */
+int geoa3_pn2_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius, int nsample,
+                         int32_t* idx, void* stream);
+/* group_points.cpp:13-34 / group_points_gpu.cu:8-39: out[b,c,j,k] = points[b,c,idx[b,j,k]] */
+int geoa3_pn2_group_points(const float* points, const int32_t* idx, int B, int C, int N, int M, int nsample,
+                           float* out, void* stream);
+/* group_points.cpp:36-58 / group_points_gpu.cu:43-75: scatter-add into grad_points [B,C,N] (zeroed here) */
+int geoa3_pn2_group_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int nsample,
+                                float* grad_points, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Diagnostics (bench.py): per-launch durations of selected kernels, taken with HIP events recorded on the
  * launch stream.  Off by default; the only process-global state in the library; never changes results.
  * tag: 0 = conv5+max (wide_max_kernel<3>), 1 = geoa3_nn1_pair ("CD kernel"), 2 = geoa3_knn,

@@ -1,0 +1,158 @@
+"""CPU oracle for the PointNet++ SSG path (config 4)  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Restates, in numpy / torch-CPU, the six native functions of the reference's vendored CUDA extension that the SSG
+classifier uses, following the .cu sources line by line (all under
+Model/pointnet2_ops_lib/pointnet2_ops/_ext-src/src/):
+
+    furthest_point_sampling   sampling_gpu.cu:69-173 (+ sampling.cpp:66-87, cuda_utils.h:13-19)
+    gather_points / _grad     sampling_gpu.cu:8-57
+    ball_query                ball_query_gpu.cu:9-44
+    group_points / _grad      group_points_gpu.cu:8-75
+
+The extension is CUDA-only (every host wrapper asserts "CPU not supported", e.g. ball_query.cpp:27-29) and cannot be
+built in this image (no nvcc, no CUDA runtime): there is no oracle/_ref for it.  These restatements are what
+tests/golden/make_golden.py registers as `pointnet2_ops._ext` BEFORE importing the reference's Python
+(pointnet2_utils.py / pointnet2_modules.py / PointNetPP_ssg.py run unchanged on top of them), so the golden fixtures
+pin the reference's Python composition; the native arithmetic itself is pinned to the .cu semantics only
+("parity unpinned" for the nvcc contraction choice in the distance expressions: evaluated un-fused here).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+
+
+def _sq3(dx, dy, dz):
+    f = np.float32
+    return f(f(f(dx * dx) + f(dy * dy)) + f(dz * dz))
+
+
+def opt_n_threads(work_size: int) -> int:
+    """cuda_utils.h:13-19: clamp(2^floor(log2(work_size)), 1, 512)."""
+    p = 1
+    while p * 2 <= work_size:
+        p *= 2
+    return max(min(p, 512), 1)
+
+
+def furthest_point_sampling(xyz: Tensor, npoint: int) -> Tensor:
+    """xyz [B,N,3] f32 -> idx [B,npoint] int32."""
+    P = xyz.detach().cpu().numpy().astype(np.float32)
+    B, N, _ = P.shape
+    T = opt_n_threads(N)
+    out = np.zeros((B, npoint), dtype=np.int32)
+    kk = np.arange(N)
+    tt = kk % T
+    for b in range(B):
+        p = P[b]
+        mag = ((p[:, 0] * p[:, 0]).astype(np.float32) + (p[:, 1] * p[:, 1]).astype(np.float32)).astype(np.float32)
+        mag = (mag + (p[:, 2] * p[:, 2]).astype(np.float32)).astype(np.float32)
+        use = ~(mag <= np.float32(1e-3))
+        temp = np.full(N, 1e10, dtype=np.float32)
+        old = 0
+        for j in range(1, npoint):
+            d = p - p[old]
+            dd = ((d[:, 0] * d[:, 0]).astype(np.float32) + (d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
+            dd = (dd + (d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+            temp = np.where(use, np.minimum(dd, temp), temp)
+            if not use.any():
+                old = 0
+            else:
+                v = np.where(use, temp, np.float32(-2))
+                best = v.max()
+                cand = np.nonzero(v == best)[0]
+                # tie rule of the block reduction: lowest owning thread (k mod T), then lowest k
+                order = np.lexsort((kk[cand], tt[cand]))
+                old = int(cand[order[0]])
+            out[b, j] = old
+    return torch.from_numpy(out)
+
+
+def gather_points(points: Tensor, idx: Tensor) -> Tensor:
+    """points [B,C,N], idx [B,M] -> [B,C,M]"""
+    B, C, N = points.shape
+    return torch.gather(points, 2, idx.long().unsqueeze(1).expand(B, C, idx.shape[1])).contiguous()
+
+
+def gather_points_grad(grad_out: Tensor, idx: Tensor, n: int) -> Tensor:
+    B, C, M = grad_out.shape
+    g = torch.zeros(B, C, n, dtype=grad_out.dtype)
+    g.scatter_add_(2, idx.long().unsqueeze(1).expand(B, C, M), grad_out)
+    return g
+
+
+def ball_query(new_xyz: Tensor, xyz: Tensor, radius: float, nsample: int) -> Tensor:
+    """new_xyz [B,M,3], xyz [B,N,3] -> idx [B,M,nsample] int32 (note the extension's argument order)."""
+    C, P = new_xyz.detach().cpu().numpy().astype(np.float32), xyz.detach().cpu().numpy().astype(np.float32)
+    B, M, _ = C.shape
+    r2 = np.float32(np.float32(radius) * np.float32(radius))
+    out = np.zeros((B, M, nsample), dtype=np.int32)
+    for b in range(B):
+        d = C[b][:, None, :] - P[b][None, :, :]                                   # [M,N,3] f32
+        d2 = ((d[..., 0] * d[..., 0]).astype(np.float32) + (d[..., 1] * d[..., 1]).astype(np.float32)).astype(np.float32)
+        d2 = (d2 + (d[..., 2] * d[..., 2]).astype(np.float32)).astype(np.float32)
+        inside = d2 < r2
+        for j in range(M):
+            hits = np.nonzero(inside[j])[0][:nsample]
+            if len(hits):
+                out[b, j, :] = hits[0]
+                out[b, j, :len(hits)] = hits
+    return torch.from_numpy(out)
+
+
+def group_points(points: Tensor, idx: Tensor) -> Tensor:
+    """points [B,C,N], idx [B,M,S] -> [B,C,M,S]"""
+    B, C, N = points.shape
+    _, M, S = idx.shape
+    flat = idx.long().reshape(B, 1, M * S).expand(B, C, M * S)
+    return torch.gather(points, 2, flat).reshape(B, C, M, S).clone()   # a fresh tensor, as the extension returns
+
+
+def group_points_grad(grad_out: Tensor, idx: Tensor, n: int) -> Tensor:
+    B, C, M, S = grad_out.shape
+    g = torch.zeros(B, C, n, dtype=grad_out.dtype)
+    g.scatter_add_(2, idx.long().reshape(B, 1, M * S).expand(B, C, M * S), grad_out.reshape(B, C, M * S))
+    return g
+
+
+class ExtModule:
+    """Object with the attribute surface of `pointnet2_ops._ext` (bindings.cpp:6-19)."""
+    furthest_point_sampling = staticmethod(furthest_point_sampling)
+    gather_points = staticmethod(gather_points)
+    gather_points_grad = staticmethod(gather_points_grad)
+    ball_query = staticmethod(ball_query)
+    group_points = staticmethod(group_points)
+    group_points_grad = staticmethod(group_points_grad)
+
+
+def make_pn2_state_dict(seed: int = 0):
+    """Seeded synthetic weights in the state_dict layout of PointNet2ClassificationSSG(use_xyz=True,
+    use_normal=False) (68 entries), with randomised BatchNorm statistics."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"] = torch.rand(c, generator=g) + 0.5
+        sd[prefix + ".bias"] = torch.randn(c, generator=g) * 0.1
+        sd[prefix + ".running_mean"] = torch.randn(c, generator=g) * 0.1
+        sd[prefix + ".running_var"] = torch.rand(c, generator=g) + 0.5
+        sd[prefix + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    def w(shape):
+        fan_in = shape[1]
+        return (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(6.0 / fan_in)   # he-uniform: keeps activations O(1)
+
+    for i, spec in enumerate([[3, 64, 64, 128], [131, 128, 128, 256], [259, 256, 512, 1024]]):
+        for j, (ci, co) in enumerate(zip(spec[:-1], spec[1:])):
+            sd["SA_modules.%d.mlps.0.%d.weight" % (i, 3 * j)] = w((co, ci, 1, 1))
+            bn("SA_modules.%d.mlps.0.%d" % (i, 3 * j + 1), co)
+    sd["fc_layer.0.weight"] = w((512, 1024))
+    bn("fc_layer.1", 512)
+    sd["fc_layer.3.weight"] = w((256, 512))
+    bn("fc_layer.4", 256)
+    sd["fc_layer.7.weight"] = w((40, 256))
+    sd["fc_layer.7.bias"] = torch.randn(40, generator=g) * 0.05
+    return sd

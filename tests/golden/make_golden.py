@@ -80,6 +80,20 @@ def install_shims():
     torch.where = where
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
+    # the CUDA-only native module of PointNet++: registered BEFORE the package is imported so that
+    # pointnet2_utils.py:7-31 neither JIT-compiles nor hipifies anything inside /root/reference
+    from oracle import pointnet2_oracle as P2
+    ext = stub("pointnet2_ops._ext")
+    for name in ("furthest_point_sampling", "gather_points", "gather_points_grad", "ball_query", "group_points",
+                 "group_points_grad"):
+        setattr(ext, name, getattr(P2, name))
+    import torch.utils.cpp_extension as cpp_ext
+
+    def no_jit(*a, **k):
+        raise RuntimeError("JIT build of the reference extension is blocked in the golden generator")
+
+    cpp_ext.load = no_jit
+    sys.path.insert(0, os.path.join(REF, "Model", "pointnet2_ops_lib"))
     sys.path.insert(0, REF)
     sys.path.insert(0, os.path.join(REF, "Lib"))
     sys.path.insert(0, os.path.join(REF, "Model"))
@@ -296,6 +310,27 @@ def main():
         grads.append(t2n(gr))
         ps.append(t2n(p).copy())
     out["adam/grads"], out["adam/params"] = np.stack(grads), np.stack(ps)
+
+    # ---------------------------------------------------------------- PointNet++ SSG (config 4)
+    from oracle import pointnet2_oracle as P2
+    from PointNetPP_ssg import PointNet2ClassificationSSG as RefSSG      # reference Model/PointNetPP_ssg.py
+    sd2 = P2.make_pn2_state_dict(0)
+    net2 = RefSSG(use_xyz=True, use_normal=False)
+    net2.load_state_dict(sd2)
+    net2.eval()
+    out["pn2/sd_checksum"] = np.float64(sum(float(v.double().abs().sum()) for v in sd2.values()))
+    for tag, b, N, seed in [("n1024", 2, 1024, 41), ("n700", 1, 700, 42)]:
+        pc, _ = O.make_synthetic_clouds(b, N, seed)
+        pc = pc.clone()
+        pc[:, :, 5] = 0.001            # a point FPS must skip (|p|^2 <= 1e-3)
+        pc[:, :, 9] = pc[:, :, 8]      # a duplicate point (FPS / ball-query ties)
+        pc.requires_grad_()
+        logits = net2(pc)
+        wgt = torch.randn(b, 40, generator=torch.Generator().manual_seed(seed))
+        (gpc,) = torch.autograd.grad((logits * wgt).sum(), pc)
+        pre = "pn2/%s/" % tag
+        out[pre + "pc"], out[pre + "logits"], out[pre + "w"], out[pre + "g_pc"] = map(t2n, (pc, logits, wgt, gpc))
+    out["pn2/cases"] = np.array(["n1024", "n700"])
 
     # ---------------------------------------------------------------- CLI flags + dataset expansion
     import json
