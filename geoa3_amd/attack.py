@@ -48,8 +48,16 @@ class AttackRunner:
             raise AssertionError("Not support such optimizer.")
         self.net, self.cfg, self.b, self.n, self.dev = net, cfg, b, n, device
         self.lib = _lib.load()
-        self.packed = net.packed(device)
-        self.classes = self.packed.classes
+        # Native victim: the PointNet whose forward / input-gradient live in the HIP library.  Any other eval-mode
+        # nn.Module (PointNet++ SSG on the HIP set-abstraction operators, geoa3_amd/pointnet2.py) is driven through
+        # torch autograd: logits = net(x); logits.backward(dlogits) -- still no host synchronisation.
+        self.native = isinstance(net, PointNet)
+        if self.native:
+            self.packed = net.packed(device)
+            self.classes = self.packed.classes
+        else:
+            self.packed = None
+            self.classes = int(_cfg(cfg, "classes", 40))
         self.global_batch = global_batch or b
         self.targeted = cfg.attack_label != "Untarget"
         self.k = int(cfg.curv_loss_knn)
@@ -79,8 +87,9 @@ class AttackRunner:
         if self.use_curv:
             t["knn"] = [torch.zeros(b, n, self.k + 1, **i32) for _ in range(2)]
             t["knn_d"] = z(b, n, self.k + 1)
-        nbytes = self.lib.geoa3_pointnet_workspace_bytes(b, n, self.classes)
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if self.native:
+            nbytes = self.lib.geoa3_pointnet_workspace_bytes(b, n, self.classes)
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.state: Optional[AttackState] = None
 
     # ------------------------------------------------------------------------------------
@@ -132,8 +141,18 @@ class AttackRunner:
         s = torch.cuda.current_stream().cuda_stream
         st = C.byref(self.state)
         x = t["x"]
-        check(lib.geoa3_pointnet_forward(C.byref(self.packed.struct), x.data_ptr(), self.b, self.n,
-                                         t["logits"].data_ptr(), self.ws.data_ptr(), s), "pointnet_forward")
+        logits_ag = x_leaf = None
+        if self.native:
+            check(lib.geoa3_pointnet_forward(C.byref(self.packed.struct), x.data_ptr(), self.b, self.n,
+                                             t["logits"].data_ptr(), self.ws.data_ptr(), s), "pointnet_forward")
+        else:
+            x_leaf = x.detach().clone().requires_grad_()
+            with torch.enable_grad():
+                logits_ag = self.net(x_leaf)
+            if logits_ag.shape != t["logits"].shape:
+                raise _lib.Geoa3Error("the victim returned logits of shape %s, expected %s (set cfg.classes)"
+                                      % (tuple(logits_ag.shape), tuple(t["logits"].shape)))
+            t["logits"].copy_(logits_ag.detach())
         constrain = None
         if self.need_nn:
             both = self.dis_type == 1 and not cfg.is_cd_single_side
@@ -161,9 +180,13 @@ class AttackRunner:
                                     t["dlogits"].data_ptr(), s), "attack_head")
         g_cls = None
         if cfg.cls_loss_type != "None":
-            check(lib.geoa3_pointnet_backward(C.byref(self.packed.struct), x.data_ptr(), t["dlogits"].data_ptr(),
-                                              self.b, self.n, t["g_cls"].data_ptr(), self.ws.data_ptr(), s),
-                  "pointnet_backward")
+            if self.native:
+                check(lib.geoa3_pointnet_backward(C.byref(self.packed.struct), x.data_ptr(), t["dlogits"].data_ptr(),
+                                                  self.b, self.n, t["g_cls"].data_ptr(), self.ws.data_ptr(), s),
+                      "pointnet_backward")
+            else:
+                logits_ag.backward(t["dlogits"])
+                t["g_cls"].copy_(x_leaf.grad)
             g_cls = t["g_cls"]
         pro_grad = bool(_cfg(cfg, "is_pro_grad", False))
         # optimiser scalars in double, as torch.optim.Adam forms them

@@ -135,8 +135,8 @@ def main(cfg):
 
     if cfg.attack == "GeoA3_mesh":
         raise AssertionError("Not uploaded yet.")          # as the reference (main_attack.py:27-28)
-    if cfg.arch != "PointNet":
-        raise NotImplementedError("only --arch PointNet is accelerated in this round (SURVEY 8a-17: next)")
+    if cfg.arch not in ("PointNet", "PointNetPP"):
+        raise AssertionError("Not support such arch.")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -171,10 +171,21 @@ def main(cfg):
 
     say("=>Loading model")
     model_path = os.path.join("Pretrained", cfg.arch, str(cfg.npoint), "model_best.pth.tar")
-    net = PointNet(cfg.classes, npoint=cfg.npoint)
+    if cfg.arch == "PointNet":
+        net = PointNet(cfg.classes, npoint=cfg.npoint)
+    else:   # main_attack.py:139-140: the SSG classifier, 40 classes
+        from geoa3_amd.pointnet2 import PointNet2ClassificationSSG
+        net = PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     if os.path.isfile(model_path):
         net.load_state_dict(torch.load(model_path, map_location="cpu")["state_dict"])
         say("==>Successfully load pretrained-model from {}".format(model_path))
+    elif cfg.synthetic and cfg.arch == "PointNetPP":
+        with torch.no_grad():   # default-initialised modules (seeded above) with non-trivial BatchNorm statistics
+            for mod in net.modules():
+                if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    mod.running_mean.normal_(0, 0.1)
+                    mod.running_var.uniform_(0.5, 1.5)
+        say("==>No checkpoint at {}: seeded random-init weights (--synthetic)".format(model_path))
     elif cfg.synthetic:
         net.load_state_dict(synthetic_state_dict(cfg.classes, seed=0, device=device))
         say("==>No checkpoint at {}: calibrated random-init weights (--synthetic)".format(model_path))

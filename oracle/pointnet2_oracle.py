@@ -156,3 +156,40 @@ def make_pn2_state_dict(seed: int = 0):
     sd["fc_layer.7.weight"] = w((40, 256))
     sd["fc_layer.7.bias"] = torch.randn(40, generator=g) * 0.05
     return sd
+
+
+def pointnet2_ssg_forward(sd, pc: Tensor) -> Tensor:
+    """Eval-mode PointNet2ClassificationSSG.forward (Model/PointNetPP_ssg.py:106-124 over
+    pointnet2_modules.py:29-74 and pointnet2_utils.py:296-333,349-379), functional over a state_dict.
+    pc [b,3,N] -> logits [b,40].  Differentiable w.r.t. pc (torch.gather carries the scatter-add backward)."""
+    import torch.nn.functional as F
+
+    def bn(x, prefix):
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                            sd[prefix + ".bias"], False, 0.0, 1e-5)
+
+    def mlp(x, i):
+        for j in range(3):
+            x = F.relu(bn(F.conv2d(x, sd["SA_modules.%d.mlps.0.%d.weight" % (i, 3 * j)]),
+                          "SA_modules.%d.mlps.0.%d" % (i, 3 * j + 1)))
+        return x
+
+    xyz = pc.transpose(2, 1).contiguous()                    # [b,N,3]
+    features = None
+    for i, (npoint, radius, nsample) in enumerate([(512, 0.2, 64), (128, 0.4, 64), (None, None, None)]):
+        if npoint is not None:
+            centres = furthest_point_sampling(xyz.detach(), npoint)
+            new_xyz = gather_points(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
+            idx = ball_query(new_xyz.detach(), xyz.detach(), radius, nsample)
+            grouped_xyz = group_points(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+            new = grouped_xyz if features is None else torch.cat([grouped_xyz, group_points(features, idx)], dim=1)
+        else:
+            new_xyz = None
+            new = torch.cat([xyz.transpose(1, 2).unsqueeze(2), features.unsqueeze(2)], dim=1)
+        new = mlp(new, i)
+        features = F.max_pool2d(new, kernel_size=[1, new.size(3)]).squeeze(-1)
+        xyz = new_xyz
+    f = features.squeeze(-1)
+    f = F.relu(bn(F.linear(f, sd["fc_layer.0.weight"]), "fc_layer.1"))
+    f = F.relu(bn(F.linear(f, sd["fc_layer.3.weight"]), "fc_layer.4"))
+    return F.linear(f, sd["fc_layer.7.weight"], sd["fc_layer.7.bias"])

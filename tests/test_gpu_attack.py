@@ -152,3 +152,27 @@ def test_config5_shape_n4096_k32(net):
                                                      init_offsets=[i.cuda() for i in inits], verbose=False)
     np.testing.assert_allclose(np.asarray(all_loss, dtype=np.float32), np.asarray(oloss, dtype=np.float32),
                                rtol=2e-3, atol=2e-4)
+
+
+def test_pointnetpp_attack_matches_oracle():
+    """BASELINE configs[3] shape: PointNet++ SSG victim (HIP FPS / ball query / grouping, torch MLPs) driven through
+    the same device-resident loop; compared with the oracle loop over the oracle SSG forward."""
+    from geoa3_amd.attack import attack
+    from geoa3_amd.pointnet2 import PointNet2ClassificationSSG
+    from oracle import pointnet2_oracle as P2
+    sd = P2.make_pn2_state_dict(0)
+    net2 = PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net2.load_state_dict(sd)
+    net2 = net2.cuda().eval()
+    onet = lambda x: P2.pointnet2_ssg_forward(sd, x)
+    ori, nrm = O.make_synthetic_clouds(3, 640, seed=55)
+    with torch.no_grad():
+        gt = onet(ori).argmax(1)
+    cfg = O.AttackCfg(binary_max_steps=2, iter_max_steps=4, lr=0.002, curv_loss_knn=8, initial_const=20.0)
+    inits = [torch.randn(3, 3, 640, generator=torch.Generator().manual_seed(56 + i)) * 1e-3 for i in range(2)]
+    ob, ot, osucc, ostep, oloss = O.attack(onet, ori, nrm, gt, None, cfg, inits)
+    best, target, succ, best_step, all_loss = attack(net2, _loader_batch(ori, nrm, gt, None, False), cfg, 0, 1,
+                                                     init_offsets=[i.cuda() for i in inits], verbose=False)
+    np.testing.assert_allclose(np.asarray(all_loss, dtype=np.float32), np.asarray(oloss, dtype=np.float32),
+                               rtol=5e-3, atol=2e-3)
+    assert (np.asarray(succ) == osucc).mean() >= 0.66
