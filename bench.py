@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--instances", type=int, default=INSTANCES, help="instances per GPU (default 250)")
     ap.add_argument("--npoint", type=int, default=NPOINT, help="points per cloud (configs[4]: 4096)")
     ap.add_argument("--knn", type=int, default=KNN, help="curv_loss_knn (configs[4]: 32)")
+    ap.add_argument("--arch", default="PointNet", choices=["PointNet", "PointNetPP"],
+                    help="victim (PointNetPP = configs[3]: SSG classifier on the HIP set-abstraction operators)")
     a = ap.parse_args()
     NPOINT, KNN = a.npoint, a.knn
 
@@ -108,8 +110,13 @@ def main():
     B = a.instances
     total = a.warmup + a.steps
     cfg = cfg_config2(total)
-    net = PointNet(CLASSES)
-    net.load_state_dict(synthetic_state_dict(CLASSES, seed=0, device=dev))
+    if a.arch == "PointNet":
+        net = PointNet(CLASSES)
+        net.load_state_dict(synthetic_state_dict(CLASSES, seed=0, device=dev))
+    else:
+        from geoa3_amd.pointnet2 import PointNet2ClassificationSSG
+        torch.manual_seed(0)
+        net = PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     net = net.to(dev).eval()
     ori, nrm = synthetic_clouds(B, NPOINT, seed=100 + rank)
     ori, nrm = ori.to(dev), nrm.to(dev)
@@ -170,6 +177,10 @@ def main():
                          "avg_launch_ms": round(conv5_ms, 4) if conv5_ms else None,
                          "algorithmic_flops_per_launch": conv5_flops, "traffic": None},
         }
+        if a.arch != "PointNet":   # configs[3]: the MLPs are MIOpen/hipBLASLt kernels, no single hand-written dominant kernel
+            out["config"]["workload"] = out["config"]["workload"].replace("PointNet ", "PointNet++ SSG ").replace(
+                "configs[1]", "configs[3]")
+            out["roofline"] = None
         if nn1_ms:
             cd_bytes = 40.0 * B * NPOINT
             out["cd_kernel"] = {"kernel": "nn1_pair_kernel (1-NN both directions)", "avg_launch_us": round(nn1_ms * 1e3, 2),

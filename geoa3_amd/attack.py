@@ -58,6 +58,8 @@ class AttackRunner:
         else:
             self.packed = None
             self.classes = int(_cfg(cfg, "classes", 40))
+            for prm in net.parameters():   # only d/d input is needed; the reference also forms the unused weight
+                prm.requires_grad_(False)  # gradients (its parameters keep requires_grad=True)
         self.global_batch = global_batch or b
         self.targeted = cfg.attack_label != "Untarget"
         self.k = int(cfg.curv_loss_knn)

@@ -37,18 +37,31 @@ struct Best {
 };
 __device__ __forceinline__ Best fps_better(Best a, Best b) {
   const bool take = b.v > a.v || (b.v == a.v && (b.t < a.t || (b.t == a.t && b.k < a.k)));
-  return take ? b : a;
+  // member-wise selects: `take ? b : a` on the struct is lowered through a scratch (stack) copy by hipcc
+  return Best{take ? b.v : a.v, take ? b.t : a.t, take ? b.k : a.k};
+}
+__device__ __forceinline__ Best wave_best(Best best) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Best other{__shfl_xor(best.v, o, 64), __shfl_xor(best.t, o, 64), __shfl_xor(best.k, o, 64)};
+    best = fps_better(best, other);
+  }
+  return best;
 }
 
+// One workgroup per cloud; the cloud also sits in LDS so that the coordinates of the point selected in the previous
+// round are an LDS read, not a dependent global load.  A round = distance update (registers) -> wave arg-max
+// (shuffles) -> 16 partial results through LDS -> every wave reduces them redundantly: 2 barriers, no global traffic.
 __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict__ xyz, int N, int m, int T,
                                                         float* __restrict__ temp, int32_t* __restrict__ idxs) {
-  __shared__ float s_v[FPS_BLOCK / 64];
-  __shared__ int s_t[FPS_BLOCK / 64], s_k[FPS_BLOCK / 64];
-  __shared__ float s_sel[4];
+  extern __shared__ __attribute__((aligned(16))) float s_p[];   // [N][3]
+  __shared__ float s_v[2][FPS_BLOCK / 64];
+  __shared__ int s_t[2][FPS_BLOCK / 64], s_k[2][FPS_BLOCK / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* P = xyz + (size_t)b * N * 3;
+  for (int e = tid; e < N * 3; e += FPS_BLOCK) s_p[e] = P[e];
   float px[FPS_PPT], py[FPS_PPT], pz[FPS_PPT], td[FPS_PPT];
-  bool use[FPS_PPT];
+  unsigned use = 0u;   // bit i: point tid + i*FPS_BLOCK exists and is not skipped
 #pragma unroll
   for (int i = 0; i < FPS_PPT; ++i) {
     const int k = tid + i * FPS_BLOCK;
@@ -58,43 +71,37 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict_
     pz[i] = in ? P[k * 3 + 2] : 0.f;
     td[i] = 1e10f;  // sampling.cpp:74-76
     const float mag = sq3(px[i], py[i], pz[i]);
-    use[i] = in && !(mag <= 1e-3f);
+    if (in && !(mag <= 1e-3f)) use |= 1u << i;
   }
   int old = 0;
   if (tid == 0) idxs[(size_t)b * m] = 0;
+  __syncthreads();
   for (int j = 1; j < m; ++j) {
-    if (tid == 0) {
-      s_sel[0] = P[old * 3];
-      s_sel[1] = P[old * 3 + 1];
-      s_sel[2] = P[old * 3 + 2];
-    }
-    __syncthreads();
-    const float x1 = s_sel[0], y1 = s_sel[1], z1 = s_sel[2];
+    const float x1 = s_p[old * 3], y1 = s_p[old * 3 + 1], z1 = s_p[old * 3 + 2];
     Best best{-1.f, 0x7fffffff, 0x7fffffff};
 #pragma unroll
     for (int i = 0; i < FPS_PPT; ++i) {
-      if (use[i]) {
+      if (i * FPS_BLOCK < N) {   // uniform: skips the register slots this cloud does not use
         const int k = tid + i * FPS_BLOCK;
+        const bool u = (use >> i) & 1u;
         const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
-        const float d2 = fminf(d, td[i]);
+        const float d2 = u ? fminf(d, td[i]) : td[i];
         td[i] = d2;
-        best = fps_better(best, Best{d2, k & (T - 1), k});
+        const Best cand{u ? d2 : -2.f, k & (T - 1), k};
+        best = fps_better(best, cand);
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      Best other{__shfl_xor(best.v, o, 64), __shfl_xor(best.t, o, 64), __shfl_xor(best.k, o, 64)};
-      best = fps_better(best, other);
-    }
+    best = wave_best(best);
+    const int buf = j & 1;   // double buffered: the next round's writes cannot race this round's reads
     if (lane == 0) {
-      s_v[wave] = best.v;
-      s_t[wave] = best.t;
-      s_k[wave] = best.k;
+      s_v[buf][wave] = best.v;
+      s_t[buf][wave] = best.t;
+      s_k[buf][wave] = best.k;
     }
     __syncthreads();
-    Best r{s_v[0], s_t[0], s_k[0]};
-#pragma unroll
-    for (int w = 1; w < FPS_BLOCK / 64; ++w) r = fps_better(r, Best{s_v[w], s_t[w], s_k[w]});
+    Best r{-1.f, 0x7fffffff, 0x7fffffff};
+    if (lane < FPS_BLOCK / 64) r = Best{s_v[buf][lane], s_t[buf][lane], s_k[buf][lane]};
+    r = wave_best(r);
     old = r.v < 0.f ? 0 : r.k;  // every point skipped: the reference's reduction returns its initial index 0
     if (tid == 0) idxs[(size_t)b * m + j] = old;
   }
@@ -170,6 +177,26 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __r
   atomicAdd(grad_points + ((size_t)b * C + c) * N + idx[(size_t)b * MS + e], grad_out[((size_t)b * C + c) * MS + e]);
 }
 
+// nsample == 64: one wavefront per (channel, centre) row.  The ball query pads a short ball by repeating its FIRST
+// index, so up to 63 lanes of a row would hammer one address; entries equal to idx[row][0] are summed with wave
+// shuffles first and leave as ONE atomic.  (Valid for any index table: only entries equal to the row's first one
+// are merged.)
+__global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* __restrict__ grad_out,
+                                                                  const int32_t* __restrict__ idx,
+                                                                  float* __restrict__ grad_points, int C, int N, int M) {
+  const int b = blockIdx.z, c = blockIdx.y, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= M) return;
+  const int i = idx[((size_t)b * M + j) * 64 + lane];
+  const float v = grad_out[(((size_t)b * C + c) * M + j) * 64 + lane];
+  const int i0 = __shfl(i, 0, 64);
+  const bool dup = lane > 0 && i == i0;
+  const float s = wave_sum(dup ? v : 0.f);
+  float* dst = grad_points + ((size_t)b * C + c) * N;
+  if (lane == 0) atomicAdd(dst + i, v + s);
+  else if (!dup) atomicAdd(dst + i, v);
+}
+
 }  // namespace
 
 extern "C" int geoa3_pn2_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int32_t* idx,
@@ -178,7 +205,11 @@ extern "C" int geoa3_pn2_furthest_point_sampling(const float* xyz, int B, int N,
   if (N > FPS_BLOCK * FPS_PPT) return GEOA3_ENOSUPPORT;
   int T = 1;
   while (T * 2 <= N && T * 2 <= 512) T *= 2;  // opt_n_threads(N), cuda_utils.h:13-19
-  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(FPS_BLOCK), 0, geoa3_stream(stream), xyz, N, m, T, temp, idx);
+  const size_t lds = (size_t)N * 3 * sizeof(float);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(FPS_BLOCK), lds, geoa3_stream(stream), xyz, N, m, T, temp, idx);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
@@ -230,8 +261,12 @@ extern "C" int geoa3_pn2_group_points_grad(const float* grad_out, const int32_t*
   if (hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), geoa3_stream(stream)) != hipSuccess)
     return GEOA3_ELAUNCH;
   const int MS = M * nsample;
-  hipLaunchKernelGGL(group_points_grad_kernel, dim3((MS + 255) / 256, C, B), dim3(256), 0, geoa3_stream(stream),
-                     grad_out, idx, grad_points, C, N, MS);
+  if (nsample == 64)
+    hipLaunchKernelGGL(group_points_grad64_kernel, dim3((M + 3) / 4, C, B), dim3(256), 0, geoa3_stream(stream),
+                       grad_out, idx, grad_points, C, N, M);
+  else
+    hipLaunchKernelGGL(group_points_grad_kernel, dim3((MS + 255) / 256, C, B), dim3(256), 0, geoa3_stream(stream),
+                       grad_out, idx, grad_points, C, N, MS);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -206,6 +206,22 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+def run_shared_mlp(mlp: nn.Sequential, x: Tensor) -> Tensor:
+    """Apply a build_shared_mlp() stack to [B,C,M,S].  The 1x1 Conv2d layers are evaluated as batched GEMMs over the
+    channel dimension (W[Co,Ci] @ X[B,Ci,M*S]): identical arithmetic, but it reaches hipBLASLt's MFMA kernels
+    instead of MIOpen's generic (naive, for these fp32 shapes) convolution path."""
+    B, _, M, S = x.shape
+    for layer in mlp:
+        if isinstance(layer, nn.Conv2d) and layer.kernel_size == (1, 1):
+            w = layer.weight.view(layer.out_channels, layer.in_channels)
+            x = torch.matmul(w, x.reshape(B, layer.in_channels, M * S)).view(B, layer.out_channels, M, S)
+            if layer.bias is not None:
+                x = x + layer.bias.view(1, -1, 1, 1)
+        else:
+            x = layer(x)
+    return x
+
+
 class PointnetSAModuleMSG(nn.Module):
     def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True):
         super().__init__()
@@ -228,8 +244,8 @@ class PointnetSAModuleMSG(nn.Module):
             new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            f = mlp(grouper(xyz, new_xyz, features))               # [B, C, npoint, nsample]
-            outs.append(F.max_pool2d(f, kernel_size=[1, f.size(3)]).squeeze(-1))
+            f = run_shared_mlp(mlp, grouper(xyz, new_xyz, features))   # [B, C, npoint, nsample]
+            outs.append(f.max(dim=3)[0])   # == F.max_pool2d(f, [1, nsample]).squeeze(-1): one winner per (channel, centre)
         return new_xyz, torch.cat(outs, dim=1)
 
 

@@ -67,6 +67,12 @@ def test_gather_group_and_grads(pn2):
                                P2.gather_points_grad(go1, idx1, N).numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pn2.ext.group_points_grad(go2.cuda(), idx2.cuda(), N).cpu().numpy(),
                                P2.group_points_grad(go2, idx2, N).numpy(), rtol=1e-5, atol=1e-5)
+    # nsample == 64 takes the wave-per-row path that merges the ball query's padding before the atomics
+    idx3 = torch.randint(0, N, (B, M, 64), generator=g, dtype=torch.int32)
+    idx3[:, ::2, 20:] = idx3[:, ::2, :1]                      # padded balls: the first index repeated
+    go3 = torch.randn(B, C, M, 64, generator=g)
+    np.testing.assert_allclose(pn2.ext.group_points_grad(go3.cuda(), idx3.cuda(), N).cpu().numpy(),
+                               P2.group_points_grad(go3, idx3, N).numpy(), rtol=1e-5, atol=2e-5)
     # through autograd, as pointnet2_utils uses them
     f = feats.cuda().requires_grad_()
     out = pn2.grouping_operation(f, idx2.cuda())
