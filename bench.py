@@ -40,7 +40,8 @@ def cfg_config2(steps):
                               initial_const=10.0, optim="adam", cls_loss_type="CE", confidence=0.0,
                               dis_loss_type="CD", dis_loss_weight=1.0, is_cd_single_side=False, hd_loss_weight=0.1,
                               curv_loss_weight=1.0, curv_loss_knn=KNN, uniform_loss_weight=0.0,
-                              is_use_lr_scheduler=False, cc_linf=0.0, npoint=NPOINT, classes=CLASSES)
+                              is_use_lr_scheduler=False, cc_linf=0.0, is_pro_grad=False, is_real_offset=False,
+                              npoint=NPOINT, classes=CLASSES)
 
 
 def cpu_baseline(sample_b=8, budget_s=20.0):
@@ -70,6 +71,21 @@ def cpu_baseline(sample_b=8, budget_s=20.0):
             "cores": threads, "kind": "port",
             "sample": "oracle attack(), %d instances x %d iterations of config 2 (N=1024, CE+CD+HD+curv k=16), "
                       "%.1f s, rate scaled to 250 instances" % (sample_b, iters, dt)}
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc.csv:
+    separate FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  None when no summary is present."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.csv")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    for r in csv.DictReader(open(files[-1])):
+        if kernel_substr in r["Kernel"]:
+            return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, os.path.basename(files[-1])
+    return None, None
 
 
 def main():
@@ -175,8 +191,12 @@ def main():
                          "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_F32_MFMA / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_F32_MFMA, 4) if achieved else None,
                          "avg_launch_ms": round(conv5_ms, 4) if conv5_ms else None,
-                         "algorithmic_flops_per_launch": conv5_flops, "traffic": None},
+                         "algorithmic_flops_per_launch": conv5_flops, "traffic": None},   # traffic filled below
         }
+        tr, src = pmc_traffic("wide_max_kernel<3")
+        if tr is not None and NPOINT == 1024 and B == INSTANCES:
+            out["roofline"]["traffic"] = tr
+            out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % src
         if a.arch != "PointNet":   # configs[3]: the MLPs are MIOpen/hipBLASLt kernels, no single hand-written dominant kernel
             out["config"]["workload"] = out["config"]["workload"].replace("PointNet ", "PointNet++ SSG ").replace(
                 "configs[1]", "configs[3]")
