@@ -208,7 +208,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     g.X = w.h2; g.ldX = N; g.sXb = (long)64 * N;
     g.W = w.G64b; g.ldW = N; g.sWb = (long)64 * N;
     g.Y = w.gT64; g.ldY = 64; g.sYb = 4096;
-    g.M = 64; g.Nout = 64; g.K = N; g.batch = B;
+    g.M = 64; g.Nout = 64; g.K = N; g.batch = B; g.ksplit = 8;
     TRY(launch_fc(g, s));
   }
   TRY(transform64(w.G64b, w.T64, w.dh2, false, B, N, s));

@@ -183,7 +183,7 @@ int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
 
 int launch_fc(const FcArgs& a, hipStream_t s) {
   dim3 grid((a.Nout + 31) / 32, (a.M + 31) / 32, a.batch > 1 ? a.batch : 1);
-  if (a.K >= 2048 || (a.batch > 1 && a.K >= 512))
+  if (a.ksplit == 8 || (a.ksplit == 0 && a.K >= 2048))
     hipLaunchKernelGGL(fc_kernel<8>, grid, dim3(512), 0, s, a);
   else if (a.K >= 256)
     hipLaunchKernelGGL(fc_kernel<4>, grid, dim3(256), 0, s, a);

@@ -29,6 +29,8 @@ struct FcArgs {
   const float* X; int ldX;
   const float* W; int ldW;
   long sXb, sWb, sYb; int batch;              // optional batch (blockIdx.z): per-instance X, W, Y (0 / 1 = none)
+  int ksplit;                                 // waves splitting K (0 = by K); fixed per call site so that the
+                                              // summation order never depends on the batch size
   const float* bias;
   const float* Z; int ldZ;                    // relu mask source or null
   float* Y; int ldY;
