@@ -73,6 +73,10 @@ SIGNATURES = {
     "geoa3_pn2_ball_query": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp]),
     "geoa3_pn2_group_points": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_pn2_group_points_grad": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "geoa3_pn2_bias_relu": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, vp]),
+    "geoa3_pn2_relu_grad": (C.c_int, [vp, vp, vp, C.c_long, vp]),
+    "geoa3_pn2_bias_relu_max": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, C.c_int, vp, vp, vp]),
+    "geoa3_pn2_bias_relu_max_grad": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_long, C.c_int, vp, vp]),
     "geoa3_profile_enable": (C.c_int, [C.c_int]),
     "geoa3_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_int]),
 }

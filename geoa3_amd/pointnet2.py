@@ -206,20 +206,77 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
-def run_shared_mlp(mlp: nn.Sequential, x: Tensor) -> Tensor:
-    """Apply a build_shared_mlp() stack to [B,C,M,S].  The 1x1 Conv2d layers are evaluated as batched GEMMs over the
-    channel dimension (W[Co,Ci] @ X[B,Ci,M*S]): identical arithmetic, but it reaches hipBLASLt's MFMA kernels
-    instead of MIOpen's generic (naive, for these fp32 shapes) convolution path."""
+class _BiasRelu(torch.autograd.Function):
+    """y = relu(z + shift[c]) in place on the GEMM output (one pass over the [B,C,M*S] tensor)."""
+
+    @staticmethod
+    def forward(ctx, z, shift):
+        B, C, L = z.shape
+        check(_lib.load().geoa3_pn2_bias_relu(z.data_ptr(), shift.data_ptr(), B, C, L, _s()), "bias_relu")
+        ctx.mark_dirty(z)
+        ctx.save_for_backward(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        check(_lib.load().geoa3_pn2_relu_grad(y.data_ptr(), g.data_ptr(), g.data_ptr(), g.numel(), _s()), "relu_grad")
+        return g, None
+
+
+class _BiasReluMax(torch.autograd.Function):
+    """out[b,c,m] = max_s relu(z[b,c,m,s] + shift[c]) without writing the activated tensor."""
+
+    @staticmethod
+    def forward(ctx, z, shift, M, S):
+        B, C, _ = z.shape
+        out = torch.empty(B, C, M, device=z.device, dtype=torch.float32)
+        arg = torch.empty(B, C, M, device=z.device, dtype=torch.int32)
+        check(_lib.load().geoa3_pn2_bias_relu_max(z.data_ptr(), shift.data_ptr(), B, C, M, S, out.data_ptr(),
+                                                  arg.data_ptr(), _s()), "bias_relu_max")
+        ctx.save_for_backward(out, arg)
+        ctx.S = S
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, arg = ctx.saved_tensors
+        B, C, M = out.shape
+        dz = torch.empty(B, C, M * ctx.S, device=out.device, dtype=torch.float32)
+        check(_lib.load().geoa3_pn2_bias_relu_max_grad(g.contiguous().data_ptr(), out.data_ptr(), arg.data_ptr(), B, C, M,
+                                                       ctx.S, dz.data_ptr(), _s()), "bias_relu_max_grad")
+        return dz, None, None, None
+
+
+def run_shared_mlp(mlp: nn.Sequential, x: Tensor, fuse_max: bool = False) -> Tensor:
+    """Apply a build_shared_mlp() stack to x [B,C,M,S] (eval mode).  Each Conv2d 1x1 + BatchNorm2d + ReLU triple is
+    ONE channel GEMM (hipBLASLt; BatchNorm's running-statistics scale folded into the weights) followed by ONE
+    in-place HIP pass relu(z + shift); with fuse_max the last triple's tail also takes the max over the S samples
+    (== F.max_pool2d over nsample, pointnet2_modules.py:66-70) and returns [B,C,M] without materialising its
+    activation.  Falls back to the plain module stack in training mode."""
+    layers = list(mlp)
+    triples = []
+    ok = len(layers) % 3 == 0
+    for i in range(0, len(layers) - 2, 3):
+        conv, bn, act = layers[i], layers[i + 1], layers[i + 2]
+        ok = ok and isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.bias is None and \
+            isinstance(bn, nn.BatchNorm2d) and not bn.training and isinstance(act, nn.ReLU)
+        triples.append((conv, bn))
+    if not ok or not x.is_cuda:
+        y = mlp(x)
+        return F.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1) if fuse_max else y
     B, _, M, S = x.shape
-    for layer in mlp:
-        if isinstance(layer, nn.Conv2d) and layer.kernel_size == (1, 1):
-            w = layer.weight.view(layer.out_channels, layer.in_channels)
-            x = torch.matmul(w, x.reshape(B, layer.in_channels, M * S)).view(B, layer.out_channels, M, S)
-            if layer.bias is not None:
-                x = x + layer.bias.view(1, -1, 1, 1)
-        else:
-            x = layer(x)
-    return x
+    h = x.reshape(B, x.shape[1], M * S)
+    for n, (conv, bn) in enumerate(triples):
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = (bn.bias - bn.running_mean * scale).contiguous()
+        w = conv.weight.view(conv.out_channels, conv.in_channels) * scale.view(-1, 1)
+        z = torch.matmul(w, h)                                   # [B,Co,M*S]
+        if fuse_max and n == len(triples) - 1:
+            return _BiasReluMax.apply(z, shift, M, S)
+        h = _BiasRelu.apply(z, shift)
+    return h.view(B, -1, M, S)
 
 
 class PointnetSAModuleMSG(nn.Module):
@@ -244,8 +301,7 @@ class PointnetSAModuleMSG(nn.Module):
             new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            f = run_shared_mlp(mlp, grouper(xyz, new_xyz, features))   # [B, C, npoint, nsample]
-            outs.append(f.max(dim=3)[0])   # == F.max_pool2d(f, [1, nsample]).squeeze(-1): one winner per (channel, centre)
+            outs.append(run_shared_mlp(mlp, grouper(xyz, new_xyz, features), fuse_max=True))   # [B, C, npoint]
         return new_xyz, torch.cat(outs, dim=1)
 
 

@@ -235,6 +235,19 @@ int geoa3_pn2_group_points(const float* points, const int32_t* idx, int B, int C
 int geoa3_pn2_group_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int nsample,
                                 float* grad_points, void* stream);
 
+/* Tails of the shared MLPs (pointnet2_modules.py:9-19: Conv2d 1x1 + BatchNorm2d + ReLU; :62-70: max over nsample)
+ * around the channel GEMMs, eval mode, BatchNorm scale already folded into the GEMM weights:
+ *   bias_relu:           z [B,C,L] <- relu(z + shift[c])                         (in place)
+ *   relu_grad:           dz = (y > 0) ? g : 0                                     (dz may alias g)
+ *   bias_relu_max:       out [B,C,M] = relu(max_s z[B,C,M,S] + shift[c]), arg = first maximising s (F.max_pool2d)
+ *   bias_relu_max_grad:  dz [B,C,M,S] = (s == arg && out > 0) ? g : 0 */
+int geoa3_pn2_bias_relu(float* z, const float* shift, int B, int C, long L, void* stream);
+int geoa3_pn2_relu_grad(const float* y, const float* g, float* dz, long total, void* stream);
+int geoa3_pn2_bias_relu_max(const float* z, const float* shift, int B, int C, long M, int S, float* out, int32_t* arg,
+                            void* stream);
+int geoa3_pn2_bias_relu_max_grad(const float* g, const float* out, const int32_t* arg, int B, int C, long M, int S,
+                                 float* dz, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Diagnostics (bench.py): per-launch durations of selected kernels, taken with HIP events recorded on the
  * launch stream.  Off by default; the only process-global state in the library; never changes results.
