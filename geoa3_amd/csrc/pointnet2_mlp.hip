@@ -44,7 +44,46 @@ __global__ __launch_bounds__(256) void relu_grad_kernel(const float* __restrict_
   }
 }
 
-// out[row] = relu(max_s z[row][s] + shift[c]), arg[row] = first maximising s; one wavefront per row of S samples
+// out[row] = relu(max_s z[row][s] + shift[c]), arg[row] = first maximising s.
+// S == 64 (every SSG ball): 16 lanes x 16-byte loads cover one row, a wavefront streams 4 rows per load and 16 rows
+// in total (4 independent 1-KiB loads in flight); the max / arg-max of a row is a 4-step shuffle inside its 16 lanes.
+__global__ __launch_bounds__(256) void bias_relu_max64_kernel(const float* __restrict__ z,
+                                                              const float* __restrict__ shift, float* __restrict__ out,
+                                                              int32_t* __restrict__ arg, int C, long M, long rows) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, rsel = lane >> 4;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long row = row0 + i * 4 + rsel;
+    v[i] = row < rows ? *reinterpret_cast<const float4*>(z + row * 64 + sub * 4)
+                      : make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long row = row0 + i * 4 + rsel;
+    float m = v[i].x;
+    int a = sub * 4;
+    if (v[i].y > m) { m = v[i].y; a = sub * 4 + 1; }
+    if (v[i].z > m) { m = v[i].z; a = sub * 4 + 2; }
+    if (v[i].w > m) { m = v[i].w; a = sub * 4 + 3; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const float m2 = __shfl_xor(m, o, 64);
+      const int a2 = __shfl_xor(a, o, 64);
+      const bool take = m2 > m || (m2 == m && a2 < a);
+      m = take ? m2 : m;
+      a = take ? a2 : a;
+    }
+    if (sub == 0 && row < rows) {
+      const int c = (int)((row / M) % C);
+      out[row] = fmaxf(m + shift[c], 0.f);
+      arg[row] = a;
+    }
+  }
+}
+
+// general S: one wavefront per row
 __global__ __launch_bounds__(256) void bias_relu_max_kernel(const float* __restrict__ z,
                                                             const float* __restrict__ shift, float* __restrict__ out,
                                                             int32_t* __restrict__ arg, int C, long M, int S, long rows) {
@@ -73,18 +112,23 @@ __global__ __launch_bounds__(256) void bias_relu_max_kernel(const float* __restr
   }
 }
 
-// dz[row][s] = (s == arg[row] && out[row] > 0) ? g[row] : 0
+// dz[row][s] = (s == arg[row] && out[row] > 0) ? g[row] : 0 ; 16-byte stores, 4 elements per thread
 __global__ __launch_bounds__(256) void bias_relu_max_grad_kernel(const float* __restrict__ g,
                                                                  const float* __restrict__ out,
                                                                  const int32_t* __restrict__ arg, float* __restrict__ dz,
-                                                                 int S, long rows) {
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
+                                                                 int S, long total) {
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= total) return;
+  const long row = e / S;
+  const int s0 = (int)(e - row * S);
   const float gv = out[row] > 0.f ? g[row] : 0.f;
   const int a = arg[row];
-  float* p = dz + row * S;
-  for (int s = lane; s < S; s += 64) p[s] = s == a ? gv : 0.f;
+  float4 v;
+  v.x = s0 == a ? gv : 0.f;
+  v.y = s0 + 1 == a ? gv : 0.f;
+  v.z = s0 + 2 == a ? gv : 0.f;
+  v.w = s0 + 3 == a ? gv : 0.f;
+  *reinterpret_cast<float4*>(dz + e) = v;
 }
 
 }  // namespace
@@ -111,8 +155,12 @@ extern "C" int geoa3_pn2_bias_relu_max(const float* z, const float* shift, int B
                                        int32_t* arg, void* stream) {
   if (!z || !shift || !out || !arg || B <= 0 || C <= 0 || M <= 0 || S <= 0) return GEOA3_EINVAL;
   const long rows = (long)B * C * M;
-  hipLaunchKernelGGL(bias_relu_max_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, geoa3_stream(stream), z, shift,
-                     out, arg, C, M, S, rows);
+  if (S == 64)
+    hipLaunchKernelGGL(bias_relu_max64_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, geoa3_stream(stream), z,
+                       shift, out, arg, C, M, rows);
+  else
+    hipLaunchKernelGGL(bias_relu_max_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, geoa3_stream(stream), z,
+                       shift, out, arg, C, M, S, rows);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
@@ -120,9 +168,10 @@ extern "C" int geoa3_pn2_bias_relu_max(const float* z, const float* shift, int B
 extern "C" int geoa3_pn2_bias_relu_max_grad(const float* g, const float* out, const int32_t* arg, int B, int C, long M,
                                             int S, float* dz, void* stream) {
   if (!g || !out || !arg || !dz || B <= 0 || C <= 0 || M <= 0 || S <= 0) return GEOA3_EINVAL;
-  const long rows = (long)B * C * M;
-  hipLaunchKernelGGL(bias_relu_max_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, geoa3_stream(stream), g,
-                     out, arg, dz, S, rows);
+  if (S % 4 != 0) return GEOA3_ENOSUPPORT;
+  const long total = (long)B * C * M * S;
+  hipLaunchKernelGGL(bias_relu_max_grad_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0,
+                     geoa3_stream(stream), g, out, arg, dz, S, total);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
