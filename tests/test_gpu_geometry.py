@@ -164,3 +164,30 @@ def test_cpu_tensors_are_rejected(ops):
     a, r = _rand_clouds(1, 8, 8, 0)
     with pytest.raises(Geoa3Error):
         ops.nn1_pair(a, r)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_loss_utils_mirror_golden(golden, tag):
+    """The reference's function names / signatures (Lib/loss_utils.py:25-97) through autograd."""
+    from geoa3_amd import loss_utils as LU
+    pre = "ops/%s/" % tag
+    ori, nrm = dev(T(golden[pre + "ori"])), dev(T(golden[pre + "nrm"]))
+    k = int(golden[pre + "k"])
+    kap_ori = LU._get_kappa_ori(ori, nrm, k)
+    np.testing.assert_allclose(kap_ori.cpu().numpy(), golden[pre + "kappa_ori"], rtol=2e-5, atol=2e-6)
+    for name, fn in [("cd", LU.chamfer_loss), ("pcd", LU.pseudo_chamfer_loss), ("hd", LU.hausdorff_loss),
+                     ("l2", LU.norm_l2_loss)]:
+        adv = dev(T(golden[pre + "adv"])).requires_grad_()
+        v = fn(adv, ori)
+        np.testing.assert_allclose(v.detach().cpu().numpy(), golden[pre + name], rtol=2e-5, atol=1e-7)
+        v.sum().backward()
+        if not (tag == "zero" and name == "hd"):
+            np.testing.assert_allclose(adv.grad.cpu().numpy(), golden[pre + "g_" + name], rtol=1e-4, atol=1e-7)
+    adv = dev(T(golden[pre + "adv"])).requires_grad_()
+    kap_adv, normal = LU._get_kappa_adv(adv, ori, nrm, k)
+    np.testing.assert_allclose(kap_adv.detach().cpu().numpy(), golden[pre + "kappa_adv"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(normal.cpu().numpy(), golden[pre + "normal_adv"], rtol=0, atol=0)
+    curv = LU.curvature_loss(adv, ori, kap_adv, kap_ori)
+    np.testing.assert_allclose(curv.detach().cpu().numpy(), golden[pre + "curv"], rtol=1e-4, atol=1e-8)
+    curv.sum().backward()
+    np.testing.assert_allclose(adv.grad.cpu().numpy(), golden[pre + "g_curv"], rtol=2e-3, atol=2e-6)
