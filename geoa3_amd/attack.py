@@ -66,6 +66,10 @@ class AttackRunner:
         self.use_curv = cfg.curv_loss_weight != 0
         self.dis_type = {"CD": 1, "L2": 2, "None": 0}[cfg.dis_loss_type]
         self.need_nn = self.dis_type == 1 or cfg.hd_loss_weight != 0 or self.use_curv
+        # cfg.graph_search (opt-in, results bit-identical): answer the per-iteration searches from the clean cloud's
+        # neighbour table (geom_graph.hip).  It wins while offsets stay below the point spacing; measured on the
+        # synthetic workload (offsets of several spacings) it is 2 % SLOWER than brute force, hence off by default.
+        self.graph_search = bool(_cfg(cfg, "graph_search", False)) and self.need_nn
         self.iters = int(cfg.iter_max_steps)
         f32 = dict(device=device, dtype=torch.float32)
         i32 = dict(device=device, dtype=torch.int32)
@@ -112,8 +116,14 @@ class AttackRunner:
         t["best_step"].fill_(-1)
         t["best_bs"].fill_(-1)
         self.kappa_ori = None
+        self.graph = None
+        if self.graph_search:
+            self.graph = ops.OriGraph(self.ori, 32 if (self.k + 1 if self.use_curv else 1) <= 24 else 64)
         if self.use_curv:  # _get_kappa_ori once per batch (geoA3_attack.py:216-217)
-            _, knn_ori = ops.knn_planar(self.ori, self.ori, self.k + 1)
+            if self.graph is not None:
+                knn_ori = self.graph.idx[:, : self.k + 1].permute(0, 2, 1).contiguous()
+            else:
+                _, knn_ori = ops.knn_planar(self.ori, self.ori, self.k + 1)
             self.kappa_ori = ops.kappa(self.ori, self.nrm, knn_ori)
             t["knn"][0].copy_(knn_ori)
             self.knn_cur = 0
@@ -158,14 +168,22 @@ class AttackRunner:
         constrain = None
         if self.need_nn:
             both = self.dis_type == 1 and not cfg.is_cd_single_side
-            check(lib.geoa3_nn1_pair(x.data_ptr(), self.ori.data_ptr(), self.b, self.n, self.n, t["d_ao"].data_ptr(),
-                                     t["i_ao"].data_ptr(), t["d_oa"].data_ptr() if both else None,
-                                     t["i_oa"].data_ptr() if both else None, s), "nn1_pair")
+            if self.graph is not None:
+                self.graph.nn1_pair(x, both, out=(t["d_ao"], t["i_ao"], t["d_oa"] if both else None,
+                                                  t["i_oa"] if both else None))
+            else:
+                check(lib.geoa3_nn1_pair(x.data_ptr(), self.ori.data_ptr(), self.b, self.n, self.n,
+                                         t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
+                                         t["d_oa"].data_ptr() if both else None,
+                                         t["i_oa"].data_ptr() if both else None, s), "nn1_pair")
         knn_adv = None
         if self.use_curv:
             prior, out = t["knn"][self.knn_cur], t["knn"][1 - self.knn_cur]
-            check(lib.geoa3_knn(x.data_ptr(), x.data_ptr(), self.b, self.n, self.n, self.k + 1, prior.data_ptr(),
-                                t["knn_d"].data_ptr(), out.data_ptr(), s), "knn")
+            if self.graph is not None:
+                self.graph.knn_self(x, self.k + 1, out=(t["knn_d"], out), prior=prior)
+            else:
+                check(lib.geoa3_knn(x.data_ptr(), x.data_ptr(), self.b, self.n, self.n, self.k + 1, prior.data_ptr(),
+                                    t["knn_d"].data_ptr(), out.data_ptr(), s), "knn")
             self.knn_cur = 1 - self.knn_cur
             knn_adv = out
         if self.dis_type != 0 or cfg.hd_loss_weight != 0 or self.use_curv:

@@ -7,6 +7,7 @@
 // holding its own query point(s) in registers.  The N x N distance matrix is never materialised.
 #include "common.h"
 #include "profile.h"
+#include "geom_internal.h"
 
 namespace {
 
@@ -21,7 +22,10 @@ template <int QPT>
 __global__ __launch_bounds__(NN_BLOCK) void nn1_pair_kernel(const float* __restrict__ A, const float* __restrict__ R,
                                                             int Na, int Nr, float* __restrict__ d_ar,
                                                             int32_t* __restrict__ i_ar, float* __restrict__ d_ra,
-                                                            int32_t* __restrict__ i_ra) {
+                                                            int32_t* __restrict__ i_ra,
+                                                            const uint8_t* __restrict__ only) {
+  // `only` (optional, [2][B][max(Na,Nr)] bytes, direction-major): restrict the search to the flagged queries --
+  // the exact fallback of the graph-pruned search (geom_graph.hip); a block without a flagged query exits at once.
   __shared__ __attribute__((aligned(16))) float s_ref[3 * NN_CHUNK];
   const int b = blockIdx.y;
   const bool swap = blockIdx.z != 0;
@@ -33,6 +37,17 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_pair_kernel(const float* __restr
   int32_t* iout = swap ? i_ra : i_ar;
   const int q0 = blockIdx.x * (NN_BLOCK * QPT) + threadIdx.x;
   if (blockIdx.x * (NN_BLOCK * QPT) >= Nq) return;  // whole block out of range (uniform)
+  const int nmax = Na > Nr ? Na : Nr;
+  const uint8_t* sel = only ? only + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nmax : nullptr;
+  if (sel) {
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < QPT; ++t) {
+      const int q = q0 + t * NN_BLOCK;
+      any = any || (q < Nq && sel[q] != 0);
+    }
+    if (!__syncthreads_or(any)) return;
+  }
 
   const float* Qb = Q + (size_t)b * 3 * Nq;
   const float* Pb = P + (size_t)b * 3 * Np;
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_pair_kernel(const float* __restr
 #pragma unroll
   for (int t = 0; t < QPT; ++t) {
     int q = q0 + t * NN_BLOCK;
-    if (q < Nq) {
+    if (q < Nq && (!sel || sel[q] != 0)) {
       dout[(size_t)b * Nq + q] = best[t];
       iout[(size_t)b * Nq + q] = bi[t];
     }
@@ -139,7 +154,8 @@ __device__ __forceinline__ float knn_compact(uint16_t* cand /*[CAP][KNN_BLOCK]*/
 template <int CAP>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict__ Q, const float* __restrict__ R,
                                                         int Nq, int Nr, int K, const int32_t* __restrict__ prior,
-                                                        float* __restrict__ dists, int32_t* __restrict__ idx) {
+                                                        float* __restrict__ dists, int32_t* __restrict__ idx,
+                                                        const uint8_t* __restrict__ only) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_ref = reinterpret_cast<float*>(smem);                                    // 3*KNN_CHUNK floats
   float* s_cd = s_ref + 3 * KNN_CHUNK;                                              // [CAP][KNN_BLOCK]
@@ -148,8 +164,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int q = blockIdx.x * KNN_BLOCK + tid;
-  const bool live = q < Nq;
-  const int qc = live ? q : Nq - 1;
+  bool live = q < Nq;
+  if (only) {  // exact fallback of the graph-pruned search: only the flagged queries, whole block skipped if none
+    live = live && only[(size_t)b * Nq + q] != 0;
+    if (!__syncthreads_or(live)) return;
+  }
+  const int qc = q < Nq ? q : Nq - 1;
   const float* Qb = Q + (size_t)b * 3 * Nq;
   const float* Rb = R + (size_t)b * 3 * Nr;
   const float qx = Qb[qc], qy = Qb[Nq + qc], qz = Qb[2 * Nq + qc];
@@ -232,20 +252,45 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int geoa3_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, float* d_ar, int32_t* i_ar,
-                              float* d_ra, int32_t* i_ra, void* stream) {
-  if (!a || !r || !d_ar || !i_ar || B <= 0 || Na <= 0 || Nr <= 0) return GEOA3_EINVAL;
-  if ((d_ra == nullptr) != (i_ra == nullptr)) return GEOA3_EINVAL;
+int geoa3_launch_nn1(const float* a, const float* r, int B, int Na, int Nr, float* d_ar, int32_t* i_ar, float* d_ra,
+                     int32_t* i_ra, const uint8_t* only, hipStream_t s) {
   const int ndir = d_ra ? 2 : 1;
   const int nmax = ndir == 2 ? (Na > Nr ? Na : Nr) : Na;
   constexpr int QPT = 2;
   dim3 grid((nmax + NN_BLOCK * QPT - 1) / (NN_BLOCK * QPT), B, ndir);
-  geoa3_prof_begin(GEOA3_PROF_NN1, geoa3_stream(stream));
-  hipLaunchKernelGGL(nn1_pair_kernel<QPT>, grid, dim3(NN_BLOCK), 0, geoa3_stream(stream), a, r, Na, Nr, d_ar, i_ar,
-                     d_ra, i_ra);
-  geoa3_prof_end(GEOA3_PROF_NN1, geoa3_stream(stream));
+  hipLaunchKernelGGL(nn1_pair_kernel<QPT>, grid, dim3(NN_BLOCK), 0, s, a, r, Na, Nr, d_ar, i_ar, d_ra, i_ra, only);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
+}
+
+int geoa3_launch_knn(const float* q, const float* r, int B, int Nq, int Nr, int K, const int32_t* prior, float* dists,
+                     int32_t* idx, const uint8_t* only, hipStream_t s) {
+  dim3 grid((Nq + KNN_BLOCK - 1) / KNN_BLOCK, B);
+#define KNN_LAUNCH(CAPV)                                                                                         \
+  do {                                                                                                           \
+    constexpr int CAP = CAPV;                                                                                    \
+    const size_t lds = 3 * KNN_CHUNK * 4 + (size_t)CAP * KNN_BLOCK * 6;                                          \
+    if (lds > 64 * 1024)                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<CAP>),                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+    hipLaunchKernelGGL(knn_kernel<CAP>, grid, dim3(KNN_BLOCK), lds, s, q, r, Nq, Nr, K, prior, dists, idx, only); \
+  } while (0)
+  if (K <= 20) KNN_LAUNCH(40);
+  else if (K <= 40) KNN_LAUNCH(72);
+  else KNN_LAUNCH(96);
+#undef KNN_LAUNCH
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, float* d_ar, int32_t* i_ar,
+                              float* d_ra, int32_t* i_ra, void* stream) {
+  if (!a || !r || !d_ar || !i_ar || B <= 0 || Na <= 0 || Nr <= 0) return GEOA3_EINVAL;
+  if ((d_ra == nullptr) != (i_ra == nullptr)) return GEOA3_EINVAL;
+  geoa3_prof_begin(GEOA3_PROF_NN1, geoa3_stream(stream));
+  const int rc = geoa3_launch_nn1(a, r, B, Na, Nr, d_ar, i_ar, d_ra, i_ra, nullptr, geoa3_stream(stream));
+  geoa3_prof_end(GEOA3_PROF_NN1, geoa3_stream(stream));
+  return rc;
 }
 
 extern "C" int geoa3_knn(const float* q, const float* r, int B, int Nq, int Nr, int K, const int32_t* prior,
@@ -253,29 +298,8 @@ extern "C" int geoa3_knn(const float* q, const float* r, int B, int Nq, int Nr, 
   if (!q || !r || !dists || !idx || B <= 0 || Nq <= 0 || Nr <= 0 || K <= 0 || K > GEOA3_KNN_MAX_K)
     return GEOA3_EINVAL;
   if (Nr > 65535) return GEOA3_ENOSUPPORT;  // candidate indices are stored as uint16 in LDS
-  dim3 grid((Nq + KNN_BLOCK - 1) / KNN_BLOCK, B);
   geoa3_prof_begin(GEOA3_PROF_KNN, geoa3_stream(stream));
-  if (K <= 20) {
-    constexpr int CAP = 40;
-    size_t lds = 3 * KNN_CHUNK * 4 + (size_t)CAP * KNN_BLOCK * 6;
-    hipLaunchKernelGGL(knn_kernel<CAP>, grid, dim3(KNN_BLOCK), lds, geoa3_stream(stream), q, r, Nq, Nr, K, prior,
-                       dists, idx);
-  } else if (K <= 40) {
-    constexpr int CAP = 72;
-    size_t lds = 3 * KNN_CHUNK * 4 + (size_t)CAP * KNN_BLOCK * 6;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    hipLaunchKernelGGL(knn_kernel<CAP>, grid, dim3(KNN_BLOCK), lds, geoa3_stream(stream), q, r, Nq, Nr, K, prior,
-                       dists, idx);
-  } else {
-    constexpr int CAP = 96;
-    size_t lds = 3 * KNN_CHUNK * 4 + (size_t)CAP * KNN_BLOCK * 6;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    hipLaunchKernelGGL(knn_kernel<CAP>, grid, dim3(KNN_BLOCK), lds, geoa3_stream(stream), q, r, Nq, Nr, K, prior,
-                       dists, idx);
-  }
+  const int rc = geoa3_launch_knn(q, r, B, Nq, Nr, K, prior, dists, idx, nullptr, geoa3_stream(stream));
   geoa3_prof_end(GEOA3_PROF_KNN, geoa3_stream(stream));
-  GEOA3_CHECK_LAUNCH();
-  return GEOA3_OK;
+  return rc;
 }

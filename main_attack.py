@@ -81,6 +81,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="fall back to seeded synthetic data / weights when the files are missing")
     p.add_argument("--out_root", default="Exps", type=str, help="root of the output tree (reference: Exps)")
     p.add_argument("--quiet", action="store_true", default=False)
+    p.add_argument("--graph_search", action="store_true", default=False,
+                   help="answer the per-iteration NN searches from the clean cloud's neighbour table (same results)")
     return p
 
 
@@ -245,7 +247,7 @@ def main(cfg):
             f.write(line)
         say("saved_dir: {0}".format(saved_dir))
         iters = cfg.binary_max_steps * cfg.iter_max_steps * len(loader)
-        say("attack time: {:.2f} s, {:.1f} inner iterations/s".format(t_attack, iters / max(t_attack, 1e-9)))
+        print("attack time: {:.2f} s, {:.1f} inner iterations/s".format(t_attack, iters / max(t_attack, 1e-9)))
     say("Finish!")
     if world > 1:
         dist.destroy_process_group()
