@@ -324,6 +324,13 @@ class AttackCfg:
         self.is_pro_grad = False
         self.is_real_offset = False
         self.npoint = 1024
+        self.is_subsample_opt = False
+        self.eval_num = 1
+        self.is_pre_jitter_input = False
+        self.calculate_project_jitter_noise_iter = 50
+        self.jitter_k = 16
+        self.jitter_sigma = 0.01
+        self.jitter_clip = 0.05
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -400,7 +407,8 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, t: int, lr: float,
 def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional[Tensor], cfg,
            init_offsets: Sequence[Tensor], loss_divisor: Optional[int] = None,
            last_label_override: Optional[Sequence[int]] = None, last_label_hook=None,
-           faithful_success_check: bool = False, trace: Optional[dict] = None):
+           faithful_success_check: bool = False, trace: Optional[dict] = None,
+           sub_starts=None, vote_starts=None, jitter_noise=None):
     """attack() (geoA3_attack.py:182-386) on already-unpacked [b,3,N] inputs.
 
     init_offsets[s] is the step-0 offset of binary step s (the reference draws it with
@@ -412,7 +420,15 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
     step of binary step s (the `output_label` quirk, geoA3_attack.py:298,375).
     faithful_success_check: run the b separate batch-1 forwards as the reference does
     (geoA3_attack.py:297); otherwise take the arg-max of one batched forward (identical in
-    eval mode up to 1e-7)."""
+    eval mode up to 1e-7).
+
+    Dense-cloud path (--is_subsample_opt with N > cfg.npoint, geoA3_attack.py:283-296): the objective is
+    evaluated on farthest_points_sample(x, npoint) and the success check is a majority vote over eval_num
+    resamplings; the reference's torch.randint start indices are inputs: sub_starts(s, step) -> int64 [b],
+    vote_starts(s, step) -> int64 [b, eval_num].  --is_pre_jitter_input (geoA3_attack.py:312-317):
+    jitter_noise(s, step, x_cur) -> [b,3,m] is called every calculate_project_jitter_noise_iter steps (the
+    reference's estimate_perpendicular with its randn draws) and the objective is evaluated at x_cur + noise."""
+    from . import aux_oracle as A
     targeted = cfg.attack_label != "Untarget"
     b, _, n = pc_ori.shape
     tgt = gt if not targeted else target
@@ -442,14 +458,31 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
             trace["scale_const"].append(scale_const.clone())
         for step in range(cfg.iter_max_steps):
             x = pc_ori + offset
+            sub = bool(getattr(cfg, "is_subsample_opt", False)) and n > cfg.npoint
+            if sub:   # geoA3_attack.py:283-284; the gather is differentiable, the selection is not
+                _, sel = A.farthest_points_sample(x.detach(), cfg.npoint, sub_starts(s, step))
+                x_cur = torch.gather(x, 2, sel.unsqueeze(1).expand(b, 3, cfg.npoint))
+            else:
+                x_cur = x
             with torch.no_grad():
-                if faithful_success_check:
+                votes_ok = None
+                if sub:   # geoA3_attack.py:289-295
+                    vs = vote_starts(s, step)
+                    labels, votes_ok = [], []
+                    for k in range(b):
+                        pts, _ = A.farthest_points_sample(x[k:k + 1].detach().expand(cfg.eval_num, 3, n),
+                                                          cfg.npoint, vs[k])
+                        ok_k, lab_k = A.vote(net(pts).argmax(1), int(tgt[k]), int(gt[k]), targeted, cfg.eval_num)
+                        labels.append(lab_k)
+                        votes_ok.append(ok_k)
+                elif faithful_success_check:
                     labels = [int(torch.argmax(net(x[k:k + 1])).item()) for k in range(b)]
                 else:
                     labels = net(x).argmax(1).tolist()
                 for k in range(b):
                     output_label = labels[k]
-                    ok = bool(_compare(output_label, int(tgt[k]), int(gt[k]), targeted))
+                    ok = bool(_compare(output_label, int(tgt[k]), int(gt[k]), targeted)) if votes_ok is None \
+                        else votes_ok[k]
                     metric = float(constrain[k])
                     if ok and metric < best_loss[k]:
                         best_loss[k] = metric
@@ -459,7 +492,11 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
                     if ok and metric < iter_best_loss[k]:
                         iter_best_loss[k] = metric
                         iter_best_score[k] = output_label
-            out = forward_step(net, pc_ori, x, normal_ori, kappa_ori, tgt, scale_const, cfg, targeted,
+            if getattr(cfg, "is_pre_jitter_input", False):   # geoA3_attack.py:312-317
+                if step % cfg.calculate_project_jitter_noise_iter == 0:
+                    noise = jitter_noise(s, step, x_cur.detach()).detach()
+                x_cur = x_cur + noise
+            out = forward_step(net, pc_ori, x_cur, normal_ori, kappa_ori, tgt, scale_const, cfg, targeted,
                                loss_divisor)
             loss, loss_n, constrain = out[2], out[3], out[8]
             constrain = constrain.detach() if torch.is_tensor(constrain) else torch.zeros(b)
