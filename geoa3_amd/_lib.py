@@ -80,6 +80,13 @@ SIGNATURES = {
     "geoa3_pn2_relu_grad": (C.c_int, [vp, vp, vp, C.c_long, vp]),
     "geoa3_pn2_bias_relu_max": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, C.c_int, vp, vp, vp]),
     "geoa3_pn2_bias_relu_max_grad": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_long, C.c_int, vp, vp]),
+    "geoa3_fps_sample": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "geoa3_knn_normal": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "geoa3_local_frames": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "geoa3_perp_jitter": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]),
+    "geoa3_smoothness": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "geoa3_sor_statistic": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "geoa3_sor_select": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]),
     "geoa3_profile_enable": (C.c_int, [C.c_int]),
     "geoa3_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_int]),
 }

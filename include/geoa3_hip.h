@@ -262,6 +262,42 @@ int geoa3_pn2_bias_relu_max_grad(const float* g, const float* out, const int32_t
                                  float* dz, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dense-cloud attack path, point-removal defence and smoothness measurement.
+ * ------------------------------------------------------------------------------------------ */
+/* farthest_points_sample, Lib/utility.py:175-187: m-1 rounds of dists = min(dists, |p - p_last|), next = first
+ * arg-max.  start [B]: the index the reference draws with torch.randint (:179).  idx [B,m]; pts [B,3,m] (optional)
+ * = pc gathered at idx.  N <= 16384. */
+int geoa3_fps_sample(const float* pc, int B, int N, int m, const int32_t* start, int32_t* idx, float* pts,
+                     void* stream);
+/* estimate_normal_via_ori_normal, Lib/utility.py:91-108, from (knn_d, knn_i) = geoa3_knn(adv, ori, K) [B,Nq,K]:
+ * out [B,3,Nq] = normal of the nearest original point when knn_d[..,0] < 1e-6, else the normalised mean of the K
+ * gathered normals (evaluated per instance, as main_attack.py:244-246 calls it). */
+int geoa3_knn_normal(const float* knn_d, const int32_t* knn_i, const float* normal_ori, int B, int Nq, int Nr, int K,
+                     float* out, void* stream);
+/* Local frames: eigen-decomposition of the covariance (factor 1/(k-1)) of the k = K1-1 nearest neighbours listed in
+ * knn_idx [B,N,K1] (column 0, the point itself, dropped) -- Lib/utility.py:122-133,
+ * Measurement/compute_data_smoothness.py:52-61.  evals [B,3,N] ascending; evecs [B,3(e),3(xyz),N], unit length,
+ * largest-magnitude component positive. */
+int geoa3_local_frames(const float* pc, const int32_t* knn_idx, int B, int N, int K1, float* evals, float* evecs,
+                       void* stream);
+/* estimate_perpendicular's tail, Lib/utility.py:146-149: out [B,3,N] = clamp(v_max*aux1, +-clip) +
+ * clamp(v_mid*aux2, +-clip); aux1/aux2 [B,N] = sigma * N(0,1) drawn by the caller. */
+int geoa3_perp_jitter(const float* evecs, const float* aux1, const float* aux2, int B, int N, float clip, float* out,
+                      void* stream);
+/* compute_data_smoothness.py:63-67: out[b] = max_i mean_{m=1..K1-1} |<p[knn_idx[b,i,m]] - p_i, n_i>| with n_i the
+ * smallest-eigenvalue eigenvector from geoa3_local_frames; per_point [B,N] optional. */
+int geoa3_smoothness(const float* pc, const int32_t* knn_idx, const float* evecs, int B, int N, int K1,
+                     float* per_point, float* out, void* stream);
+/* defense.py:27-28: dis [B,N] = mean distance to the K nearest neighbours, distances evaluated as
+ * sqrt(sum_c (p_j - p_i + 1e-10)^2) like the reference. */
+int geoa3_sor_statistic(const float* pc, int B, int N, int K, float* dis, void* stream);
+/* defense.py:31-45: the kept indices of every cloud, ascending, idx [B,N] padded with -1, count [B].
+ * mode 0 = outliers_fixNum (keep the N-drop_num smallest dis), 1 = outliers_variance (dis < mean + alpha*std);
+ * stats [B,2] (optional) = (mean, std). */
+int geoa3_sor_select(const float* dis, int B, int N, int mode, int drop_num, float alpha, int32_t* idx,
+                     int32_t* count, float* stats, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Diagnostics (bench.py): per-launch durations of selected kernels, taken with HIP events recorded on the
  * launch stream.  Off by default; the only process-global state in the library; never changes results.
  * tag: 0 = conv5+max (wide_max_kernel<3>), 1 = geoa3_nn1_pair ("CD kernel"), 2 = geoa3_knn,
