@@ -20,7 +20,7 @@ class GeoArgs(C.Structure):
     """struct geoa3_geo_args"""
     _fields_ = [("adv", vp), ("ori", vp), ("normal_ori", vp), ("kappa_ori", vp), ("d_ao", vp), ("i_ao", vp),
                 ("d_oa", vp), ("i_oa", vp), ("knn_adv", vp), ("dkappa", vp),
-                ("B", C.c_int32), ("N", C.c_int32), ("k", C.c_int32), ("dis_type", C.c_int32),
+                ("B", C.c_int32), ("N", C.c_int32), ("k", C.c_int32), ("Nr", C.c_int32), ("dis_type", C.c_int32),
                 ("single_side", C.c_int32), ("w_dis", C.c_float), ("w_hd", C.c_float), ("w_curv", C.c_float),
                 ("dis_loss", vp), ("hd_loss", vp), ("curv_loss", vp), ("constrain", vp), ("kappa_adv", vp),
                 ("grad", vp)]
@@ -59,12 +59,13 @@ SIGNATURES = {
     "geoa3_graph_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "geoa3_graph_nn1_pair": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "geoa3_graph_knn": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
-    "geoa3_kappa": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "geoa3_kappa": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_geo_loss_grad": (C.c_int, [C.POINTER(GeoArgs), vp]),
     "geoa3_pointnet_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "geoa3_pointnet_forward": (C.c_int, [C.POINTER(PointNetWeights), vp, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_pointnet_backward": (C.c_int, [C.POINTER(PointNetWeights), vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_attack_head": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "geoa3_attack_head_vote": (C.c_int, [C.POINTER(AttackState), vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]),
     "geoa3_attack_update": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float,
                                       C.c_float, C.c_float, vp]),
     "geoa3_attack_project": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),

@@ -26,7 +26,7 @@ from .pointnet import PointNet
 
 Tensor = torch.Tensor
 
-_UNSUPPORTED = ("is_partial_var", "is_subsample_opt", "is_pre_jitter_input")
+_UNSUPPORTED = ("is_partial_var",)
 
 
 def _cfg(cfg, name, default):
@@ -71,12 +71,38 @@ class AttackRunner:
         # synthetic workload (offsets of several spacings) it is 2 % SLOWER than brute force, hence off by default.
         self.graph_search = bool(_cfg(cfg, "graph_search", False)) and self.need_nn
         self.iters = int(cfg.iter_max_steps)
+        # Dense-cloud path (geoA3_attack.py:283-296): the offset lives on all n points, the objective sees the
+        # farthest-point sample of cfg.npoint of them, success is a vote over eval_num resamplings.
+        self.npoint = int(_cfg(cfg, "npoint", n))
+        self.sub = bool(_cfg(cfg, "is_subsample_opt", False)) and n > self.npoint
+        self.ne = self.npoint if self.sub else n          # points the objective is evaluated on
+        self.eval_num = int(_cfg(cfg, "eval_num", 1))
+        if self.sub and not 1 <= self.eval_num <= 64:
+            raise ValueError("eval_num must be in 1..64")
+        # --is_pre_jitter_input (geoA3_attack.py:312-317): the objective is evaluated at x + tangent-plane noise
+        self.jitter = bool(_cfg(cfg, "is_pre_jitter_input", False))
+        if self.sub:
+            self.graph_search = False
+        self.hooks = {}
+        ne = self.ne
         f32 = dict(device=device, dtype=torch.float32)
         i32 = dict(device=device, dtype=torch.int32)
         z = lambda *s: torch.zeros(*s, **f32)
         self.t = t = {}
-        for name in ("offset", "m", "v", "x", "g_cls", "g_geo"):
+        for name in ("offset", "m", "v", "x"):
             t[name] = z(b, 3, n)
+        for name in ("g_cls", "g_geo"):
+            t[name] = z(b, 3, ne)
+        if self.sub:
+            E = self.eval_num
+            t["g_cls_full"], t["g_geo_full"], t["x_cur"] = z(b, 3, n), z(b, 3, n), z(b, 3, ne)
+            t["sub_idx"] = torch.zeros(b, ne, **i32)
+            t["vote_idx"], t["vote_pts"] = torch.zeros(b * E, ne, **i32), z(b * E, 3, ne)
+            t["vote_logits"] = z(b * E, self.classes)
+        if self.jitter:
+            t["noise"], t["x_eval"] = z(b, 3, ne), z(b, 3, ne)
+            if not self.sub:
+                t["check_logits"] = z(b, self.classes)
         t["best_attack"] = torch.ones(b, 3, n, **f32)
         for name in ("scale_const", "lower", "upper", "best_loss", "iter_best_loss", "prev_constrain", "cls_loss",
                      "loss_n"):
@@ -86,15 +112,19 @@ class AttackRunner:
         t["last_label"] = torch.zeros(1, **i32)
         t["loss_hist"] = z(self.iters, b)
         t["logits"], t["dlogits"] = z(b, self.classes), z(b, self.classes)
-        t["d_ao"], t["d_oa"] = z(b, n), z(b, n)
-        t["i_ao"], t["i_oa"] = torch.zeros(b, n, **i32), torch.zeros(b, n, **i32)
+        t["d_ao"], t["d_oa"] = z(b, ne), z(b, n)
+        t["i_ao"], t["i_oa"] = torch.zeros(b, ne, **i32), torch.zeros(b, n, **i32)
+        if self.sub and _cfg(cfg, "is_pro_grad", False):   # the projections search with all n points
+            t["proj_d"], t["proj_i"] = z(b, n), torch.zeros(b, n, **i32)
+        else:
+            t["proj_d"], t["proj_i"] = t["d_ao"], t["i_ao"]
         self.geo_out = {name: z(b) for name in ("dis_loss", "hd_loss", "curv_loss", "constrain")}
         self.geo_out["grad"] = t["g_geo"]
         if self.use_curv:
-            t["knn"] = [torch.zeros(b, n, self.k + 1, **i32) for _ in range(2)]
-            t["knn_d"] = z(b, n, self.k + 1)
+            t["knn"] = [torch.zeros(b, ne, self.k + 1, **i32) for _ in range(2)]
+            t["knn_d"] = z(b, ne, self.k + 1)
         if self.native:
-            nbytes = self.lib.geoa3_pointnet_workspace_bytes(b, n, self.classes)
+            nbytes = self.lib.geoa3_pointnet_workspace_bytes(b * self.eval_num if self.sub else b, ne, self.classes)
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.state: Optional[AttackState] = None
 
@@ -125,8 +155,10 @@ class AttackRunner:
             else:
                 _, knn_ori = ops.knn_planar(self.ori, self.ori, self.k + 1)
             self.kappa_ori = ops.kappa(self.ori, self.nrm, knn_ori)
-            t["knn"][0].copy_(knn_ori)
             self.knn_cur = 0
+            self.knn_seeded = not self.sub
+            if self.knn_seeded:
+                t["knn"][0].copy_(knn_ori)
         cls_type = {"None": 0, "CE": 1, "Margin": 2}[cfg.cls_loss_type]
         self.state = AttackState(
             B=self.b, N=self.n, classes=self.classes, targeted=int(self.targeted), cls_loss_type=cls_type,
@@ -147,18 +179,63 @@ class AttackRunner:
                                                       self._p(t["offset"]), self._p(t["m"]), self._p(t["v"]),
                                                       self._p(t["x"]), s), "begin_search_step")
 
+    def _victim_labels_logits(self, pts: Tensor, out: Tensor):
+        """logits of the victim on pts [B',3,m] (no gradient kept) -> out [B',classes]."""
+        if self.native:
+            check(self.lib.geoa3_pointnet_forward(C.byref(self.packed.struct), pts.data_ptr(), pts.shape[0],
+                                                  pts.shape[2], out.data_ptr(), self.ws.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "pointnet_forward")
+        else:
+            with torch.no_grad():
+                out.copy_(self.net(pts))
+
     def step(self, step: int, search_step: int):
         """One inner iteration (geoA3_attack.py:238-352) for all b instances; only enqueues."""
+        from . import utility as U
         cfg, t, lib = self.cfg, self.t, self.lib
         s = torch.cuda.current_stream().cuda_stream
         st = C.byref(self.state)
-        x = t["x"]
+        x = t["x"]                      # the full iterate pc_ori + offset, [b,3,n]
+        xe, ne = x, self.ne             # what the objective is evaluated on, [b,3,ne]
+        vote_logits = None
+        if self.sub:
+            # geoA3_attack.py:283-284: the objective's sample; :289-295: eval_num resamplings per instance for the
+            # success vote.  The reference draws the start indices with torch.randint on its device.
+            hook = self.hooks.get("sub_starts")
+            start = hook(search_step, step) if hook else torch.randint(self.n, (self.b,), device=self.dev)
+            start = start.to(self.dev, torch.int32).contiguous()
+            check(lib.geoa3_fps_sample(x.data_ptr(), self.b, self.n, ne, start.data_ptr(), t["sub_idx"].data_ptr(),
+                                       t["x_cur"].data_ptr(), s), "fps_sample")
+            xe = t["x_cur"]
+            E = self.eval_num
+            hook = self.hooks.get("vote_starts")
+            vstart = hook(search_step, step) if hook else torch.randint(self.n, (self.b, E), device=self.dev)
+            vstart = vstart.to(self.dev, torch.int32).reshape(-1).contiguous()
+            xrep = x if E == 1 else x.unsqueeze(1).expand(self.b, E, 3, self.n).reshape(self.b * E, 3, self.n)
+            check(lib.geoa3_fps_sample(xrep.data_ptr(), self.b * E, self.n, ne, vstart.data_ptr(),
+                                       t["vote_idx"].data_ptr(), t["vote_pts"].data_ptr(), s), "fps_sample")
+            self._victim_labels_logits(t["vote_pts"], t["vote_logits"])
+            vote_logits = t["vote_logits"]
+        if self.jitter:
+            if not self.sub:   # the success check sees the iterate WITHOUT the jitter (geoA3_attack.py:297 vs :317)
+                self._victim_labels_logits(x, t["check_logits"])
+                vote_logits = t["check_logits"]
+            if step % int(cfg.calculate_project_jitter_noise_iter) == 0:
+                hook = self.hooks.get("jitter_noise")
+                if hook:
+                    t["noise"].copy_(hook(search_step, step, xe))
+                else:
+                    aux = self.hooks["jitter_aux"](search_step, step) if "jitter_aux" in self.hooks else None
+                    t["noise"].copy_(U.estimate_perpendicular(xe, int(cfg.jitter_k), float(cfg.jitter_sigma),
+                                                              float(cfg.jitter_clip), aux=aux))
+            torch.add(xe, t["noise"], out=t["x_eval"])
+            xe = t["x_eval"]
         logits_ag = x_leaf = None
         if self.native:
-            check(lib.geoa3_pointnet_forward(C.byref(self.packed.struct), x.data_ptr(), self.b, self.n,
+            check(lib.geoa3_pointnet_forward(C.byref(self.packed.struct), xe.data_ptr(), self.b, ne,
                                              t["logits"].data_ptr(), self.ws.data_ptr(), s), "pointnet_forward")
         else:
-            x_leaf = x.detach().clone().requires_grad_()
+            x_leaf = xe.detach().clone().requires_grad_()
             with torch.enable_grad():
                 logits_ag = self.net(x_leaf)
             if logits_ag.shape != t["logits"].shape:
@@ -169,10 +246,10 @@ class AttackRunner:
         if self.need_nn:
             both = self.dis_type == 1 and not cfg.is_cd_single_side
             if self.graph is not None:
-                self.graph.nn1_pair(x, both, out=(t["d_ao"], t["i_ao"], t["d_oa"] if both else None,
-                                                  t["i_oa"] if both else None))
+                self.graph.nn1_pair(xe, both, out=(t["d_ao"], t["i_ao"], t["d_oa"] if both else None,
+                                                   t["i_oa"] if both else None))
             else:
-                check(lib.geoa3_nn1_pair(x.data_ptr(), self.ori.data_ptr(), self.b, self.n, self.n,
+                check(lib.geoa3_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n,
                                          t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
                                          t["d_oa"].data_ptr() if both else None,
                                          t["i_oa"].data_ptr() if both else None, s), "nn1_pair")
@@ -180,14 +257,16 @@ class AttackRunner:
         if self.use_curv:
             prior, out = t["knn"][self.knn_cur], t["knn"][1 - self.knn_cur]
             if self.graph is not None:
-                self.graph.knn_self(x, self.k + 1, out=(t["knn_d"], out), prior=prior)
+                self.graph.knn_self(xe, self.k + 1, out=(t["knn_d"], out), prior=prior)
             else:
-                check(lib.geoa3_knn(x.data_ptr(), x.data_ptr(), self.b, self.n, self.n, self.k + 1, prior.data_ptr(),
-                                    t["knn_d"].data_ptr(), out.data_ptr(), s), "knn")
+                check(lib.geoa3_knn(xe.data_ptr(), xe.data_ptr(), self.b, ne, ne, self.k + 1,
+                                    prior.data_ptr() if self.knn_seeded else None, t["knn_d"].data_ptr(),
+                                    out.data_ptr(), s), "knn")
+            self.knn_seeded = True
             self.knn_cur = 1 - self.knn_cur
             knn_adv = out
         if self.dis_type != 0 or cfg.hd_loss_weight != 0 or self.use_curv:
-            ops.geo_loss_grad(x, self.ori, normal_ori=self.nrm if self.use_curv else None,
+            ops.geo_loss_grad(xe, self.ori, normal_ori=self.nrm if self.use_curv else None,
                               kappa_ori=self.kappa_ori, d_ao=t["d_ao"] if self.need_nn else None,
                               i_ao=t["i_ao"] if self.need_nn else None,
                               d_oa=t["d_oa"] if self.dis_type == 1 and not cfg.is_cd_single_side else None,
@@ -196,18 +275,28 @@ class AttackRunner:
                               single_side=bool(cfg.is_cd_single_side), w_dis=float(cfg.dis_loss_weight),
                               w_hd=float(cfg.hd_loss_weight), w_curv=float(cfg.curv_loss_weight), out=self.geo_out)
             constrain = self.geo_out["constrain"]
-        check(lib.geoa3_attack_head(st, t["logits"].data_ptr(), self._p(constrain), x.data_ptr(), step, search_step,
-                                    t["dlogits"].data_ptr(), s), "attack_head")
+        check(lib.geoa3_attack_head_vote(st, t["logits"].data_ptr(), self._p(vote_logits),
+                                         self.eval_num if self.sub else 1,
+                                         self._p(constrain), x.data_ptr(), step, search_step,
+                                         t["dlogits"].data_ptr(), s), "attack_head")
         g_cls = None
         if cfg.cls_loss_type != "None":
             if self.native:
-                check(lib.geoa3_pointnet_backward(C.byref(self.packed.struct), x.data_ptr(), t["dlogits"].data_ptr(),
-                                                  self.b, self.n, t["g_cls"].data_ptr(), self.ws.data_ptr(), s),
+                check(lib.geoa3_pointnet_backward(C.byref(self.packed.struct), xe.data_ptr(), t["dlogits"].data_ptr(),
+                                                  self.b, ne, t["g_cls"].data_ptr(), self.ws.data_ptr(), s),
                       "pointnet_backward")
             else:
                 logits_ag.backward(t["dlogits"])
                 t["g_cls"].copy_(x_leaf.grad)
             g_cls = t["g_cls"]
+        g_geo = t["g_geo"] if constrain is not None else None
+        if self.sub:   # torch.gather's backward (Lib/utility.py:185): scatter the sample's gradient to the full cloud
+            for src, dst in ((g_cls, "g_cls_full"), (g_geo, "g_geo_full")):
+                if src is not None:
+                    check(lib.geoa3_pn2_gather_points_grad(src.data_ptr(), t["sub_idx"].data_ptr(), self.b, 3, self.n,
+                                                           ne, t[dst].data_ptr(), s), "gather_points_grad")
+            g_cls = t["g_cls_full"] if g_cls is not None else None
+            g_geo = t["g_geo_full"] if g_geo is not None else None
         pro_grad = bool(_cfg(cfg, "is_pro_grad", False))
         # optimiser scalars in double, as torch.optim.Adam forms them
         lr = cfg.lr * (0.9990 ** step if _cfg(cfg, "is_use_lr_scheduler", False) else 1.0)
@@ -216,20 +305,21 @@ class AttackRunner:
             step_size, sqrt_bc2, optim = lr / (1.0 - 0.9 ** tt), math.sqrt(1.0 - 0.999 ** tt), 0
         else:
             step_size, sqrt_bc2, optim = lr, 1.0, 1
-        check(lib.geoa3_attack_update(st, self._p(g_cls), self._p(t["g_geo"]) if constrain is not None else None,
+        check(lib.geoa3_attack_update(st, self._p(g_cls), self._p(g_geo),
                                       self.ori.data_ptr(), t["offset"].data_ptr(), t["m"].data_ptr(),
                                       t["v"].data_ptr(), x.data_ptr(), optim, step_size, sqrt_bc2,
                                       0.0 if pro_grad else float(_cfg(cfg, "cc_linf", 0.0)), s), "attack_update")
         if pro_grad:   # geoA3_attack.py:341-352: (real offset,) projection onto the normal, then lp_clip
+            pd, pi = t["proj_d"], t["proj_i"]
             if _cfg(cfg, "is_real_offset", False):
                 check(lib.geoa3_nn1_pair(x.data_ptr(), self.ori.data_ptr(), self.b, self.n, self.n,
-                                         t["d_ao"].data_ptr(), t["i_ao"].data_ptr(), None, None, s), "nn1_pair")
-                check(lib.geoa3_attack_project(0, self.ori.data_ptr(), None, t["i_ao"].data_ptr(),
+                                         pd.data_ptr(), pi.data_ptr(), None, None, s), "nn1_pair")
+                check(lib.geoa3_attack_project(0, self.ori.data_ptr(), None, pi.data_ptr(),
                                                t["offset"].data_ptr(), x.data_ptr(), self.b, self.n, 0.0, s),
                       "attack_project")
             check(lib.geoa3_nn1_pair(t["offset"].data_ptr(), self.ori.data_ptr(), self.b, self.n, self.n,
-                                     t["d_ao"].data_ptr(), t["i_ao"].data_ptr(), None, None, s), "nn1_pair")
-            check(lib.geoa3_attack_project(1, self.ori.data_ptr(), self.nrm.data_ptr(), t["i_ao"].data_ptr(),
+                                     pd.data_ptr(), pi.data_ptr(), None, None, s), "nn1_pair")
+            check(lib.geoa3_attack_project(1, self.ori.data_ptr(), self.nrm.data_ptr(), pi.data_ptr(),
                                            t["offset"].data_ptr(), x.data_ptr(), self.b, self.n,
                                            float(_cfg(cfg, "cc_linf", 0.0)), s), "attack_project")
 
@@ -260,8 +350,12 @@ class AttackRunner:
 
     def run(self, init_offsets: Optional[Sequence[Tensor]] = None, i: int = 0, loader_len: int = 1,
             verbose: bool = False, sync_last_label: Optional[Callable[[Tensor], None]] = None,
-            on_step: Optional[Callable[[int, int], None]] = None):
+            on_step: Optional[Callable[[int, int], None]] = None, hooks: Optional[dict] = None):
+        """hooks (parity runs): the reference's random draws as inputs -- sub_starts(search_step, step) -> [b],
+        vote_starts(search_step, step) -> [b, eval_num] (torch.randint of farthest_points_sample),
+        jitter_aux(search_step, step) -> (aux1, aux2) [b,ne] or jitter_noise(search_step, step, x) -> [b,3,ne]."""
         cfg = self.cfg
+        self.hooks = dict(hooks or {})
         for search_step in range(int(cfg.binary_max_steps)):
             if init_offsets is not None:
                 init = init_offsets[search_step]
@@ -303,7 +397,8 @@ def unpack_input(input_data, targeted: bool):
 
 
 def attack(net, input_data, cfg, i, loader_len, saved_dir=None, *, init_offsets=None, verbose=True,
-           global_batch=None, sync_last_label=None, runner_cache: Optional[dict] = None):
+           global_batch=None, sync_last_label=None, runner_cache: Optional[dict] = None,
+           hooks: Optional[dict] = None):
     """Drop-in for geoA3_attack.attack (same positional arguments, same 5-tuple).  Keyword-only extras:
     init_offsets (list of [b,3,n] step-0 offsets, one per binary step, for reproducible parity runs),
     global_batch / sync_last_label (set by geoa3_amd.distributed when the batch is sharded)."""
@@ -321,7 +416,7 @@ def attack(net, input_data, cfg, i, loader_len, saved_dir=None, *, init_offsets=
             runner_cache[key] = runner
     runner.cfg = cfg
     runner.setup(pc_ori, normal_ori, gt, target)
-    runner.run(init_offsets, i, loader_len, verbose, sync_last_label)
+    runner.run(init_offsets, i, loader_len, verbose, sync_last_label, hooks=hooks)
     return runner.results()
 
 

@@ -9,11 +9,16 @@ constexpr int HEAD_BLOCK = 256;
 // One workgroup per instance.  Wave 0 evaluates the classification loss and its gradient w.r.t. the
 // logits (geoA3_attack.py:105-127), lane 0 then runs the bookkeeping of geoA3_attack.py:297-310 and the
 // whole workgroup copies the iterate into best_attack when it improved.
+// vote_logits (optional, [B, eval_num, classes]): the dense-cloud success check of geoA3_attack.py:289-295 -- the
+// instance succeeds when MORE than half of its eval_num resampled clouds satisfy _compare, and its output_label is
+// the mode of their arg-max labels (torch.mode: the smallest of equally frequent values).
 __global__ __launch_bounds__(HEAD_BLOCK) void attack_head_kernel(geoa3_attack_state st, const float* __restrict__ logits,
+                                                                 const float* __restrict__ vote_logits, int eval_num,
                                                                  const float* __restrict__ constrain,
                                                                  const float* __restrict__ x, int step,
                                                                  int search_step, float* __restrict__ dlogits) {
   __shared__ int s_copy;
+  __shared__ int s_vote[GEOA3_WAVE];
   const int b = blockIdx.x, tid = threadIdx.x, C = st.classes;
   const float* lg = logits + (size_t)b * C;
   if (tid < GEOA3_WAVE) {
@@ -68,6 +73,41 @@ __global__ __launch_bounds__(HEAD_BLOCK) void attack_head_kernel(geoa3_attack_st
     } else {
       for (int c = lane; c < C; c += GEOA3_WAVE) dlogits[(size_t)b * C + c] = 0.f;
     }
+    bool ok = st.targeted ? (am == tgt) : (am != st.gt[b]);
+    if (vote_logits) {
+      int n_ok = 0;
+      for (int e = 0; e < eval_num; ++e) {
+        const float* vl = vote_logits + ((size_t)b * eval_num + e) * C;
+        float vm = -__builtin_inff();
+        int va = 0x7fffffff;
+        for (int c = lane; c < C; c += GEOA3_WAVE) {
+          const float v = vl[c];
+          if (v > vm) { vm = v; va = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float v2 = __shfl_xor(vm, o, 64);
+          const int i2 = __shfl_xor(va, o, 64);
+          if (v2 > vm || (v2 == vm && i2 < va)) { vm = v2; va = i2; }
+        }
+        n_ok += (st.targeted ? (va == tgt) : (va != st.gt[b])) ? 1 : 0;
+        if (lane == 0) s_vote[e] = va;
+      }
+      // mode of the eval_num labels: lane e counts the occurrences of its own label
+      int cnt = 0, lab = 0x7fffffff;
+      if (lane < eval_num) {
+        lab = s_vote[lane];
+        for (int e = 0; e < eval_num; ++e) cnt += (s_vote[e] == lab) ? 1 : 0;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int c2 = __shfl_xor(cnt, o, 64);
+        const int l2 = __shfl_xor(lab, o, 64);
+        if (c2 > cnt || (c2 == cnt && l2 < lab)) { cnt = c2; lab = l2; }
+      }
+      am = lab;
+      ok = (float)n_ok > 0.5f * (float)eval_num;
+    }
     if (lane == 0) {
       const float con = constrain ? constrain[b] : 0.f;
       const float ln = cls + st.scale_const[b] * con;
@@ -76,7 +116,6 @@ __global__ __launch_bounds__(HEAD_BLOCK) void attack_head_kernel(geoa3_attack_st
       if (st.loss_hist) st.loss_hist[(size_t)step * st.B + b] = ln;
       st.label[b] = am;
       if (b == st.B - 1) *st.last_label = am;
-      const bool ok = st.targeted ? (am == tgt) : (am != st.gt[b]);
       const float metric = st.prev_constrain[b];  // constrain of the PREVIOUS step (1e10 at step 0)
       int copy = 0;
       if (ok && metric < st.best_loss[b]) {
@@ -241,9 +280,16 @@ __global__ __launch_bounds__(256) void begin_search_step_kernel(geoa3_attack_sta
 
 extern "C" int geoa3_attack_head(const geoa3_attack_state* st, const float* logits, const float* constrain,
                                  const float* x, int step, int search_step, float* dlogits, void* stream) {
+  return geoa3_attack_head_vote(st, logits, nullptr, 0, constrain, x, step, search_step, dlogits, stream);
+}
+
+extern "C" int geoa3_attack_head_vote(const geoa3_attack_state* st, const float* logits, const float* vote_logits,
+                                      int eval_num, const float* constrain, const float* x, int step, int search_step,
+                                      float* dlogits, void* stream) {
   if (!st || !logits || !x || !dlogits || st->B <= 0 || st->classes <= 0) return GEOA3_EINVAL;
+  if (vote_logits && (eval_num <= 0 || eval_num > GEOA3_WAVE)) return GEOA3_EINVAL;
   hipLaunchKernelGGL(attack_head_kernel, dim3(st->B), dim3(HEAD_BLOCK), 0, geoa3_stream(stream), *st, logits,
-                     constrain, x, step, search_step, dlogits);
+                     vote_logits, eval_num, constrain, x, step, search_step, dlogits);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -29,15 +29,15 @@ __device__ __forceinline__ float kappa_point(float px, float py, float pz, float
 
 __global__ __launch_bounds__(256) void kappa_kernel(const float* __restrict__ pc, const float* __restrict__ normal,
                                                     const int32_t* __restrict__ knn_idx,
-                                                    const int32_t* __restrict__ nn_idx, int N, int k,
+                                                    const int32_t* __restrict__ nn_idx, int N, int Nn, int k,
                                                     float* __restrict__ kappa) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   const float* P = pc + (size_t)b * 3 * N;
-  const float* Nm = normal + (size_t)b * 3 * N;
+  const float* Nm = normal + (size_t)b * 3 * Nn;
   const int ni = nn_idx ? nn_idx[(size_t)b * N + i] : i;
-  const float nx = Nm[ni], ny = Nm[N + ni], nz = Nm[2 * N + ni];
+  const float nx = Nm[ni], ny = Nm[Nn + ni], nz = Nm[2 * Nn + ni];
   const int32_t* nb = knn_idx + ((size_t)b * N + i) * (k + 1);
   auto fetch = [&](int j, float& x, float& y, float& z) {
     x = P[j];
@@ -72,9 +72,10 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
   float* s_gz = sm + 5 * N;
   float* s_e = sm + 6 * N;     // kappa_adv - kappa_ori[nn]
   float* s_red = sm + 7 * N;   // [GEO_WAVES * 5] reduction scratch + results
+  const int Nr = A.Nr > 0 ? A.Nr : N;   // points of the clean cloud (dense-cloud path: N = npoint < Nr)
   const float* adv = A.adv + (size_t)b * 3 * N;
-  const float* ori = A.ori + (size_t)b * 3 * N;
-  const size_t bN = (size_t)b * N;
+  const float* ori = A.ori + (size_t)b * 3 * Nr;
+  const size_t bN = (size_t)b * N, bNr = (size_t)b * Nr;
   const bool do_curv = (A.w_curv != 0.f || A.dkappa != nullptr) && A.knn_adv != nullptr;
   const bool do_cd = A.dis_type == 1;
   const bool do_l2 = A.dis_type == 2;
@@ -98,28 +99,29 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
     if (do_cd) {
       const float d = A.d_ao[bN + i];
       sum_ao += d;
-      if (two_side) sum_oa += A.d_oa[bN + i];
     } else if (do_l2) {
-      const float dx = s_ax[i] - ori[i], dy = s_ay[i] - ori[N + i], dz = s_az[i] - ori[2 * N + i];
+      const float dx = s_ax[i] - ori[i], dy = s_ay[i] - ori[Nr + i], dz = s_az[i] - ori[2 * Nr + i];
       sum_ao += dx * dx + dy * dy + dz * dz;
     }
     if (do_hd) hd = better(hd, MaxIdx{A.d_ao[bN + i], i});
     if (do_curv) {
       const int ni = A.i_ao[bN + i];
-      const float* Nm = A.normal_ori + (size_t)b * 3 * N;
+      const float* Nm = A.normal_ori + (size_t)b * 3 * Nr;
       const int32_t* nb = A.knn_adv + (bN + i) * (size_t)(k + 1);
       auto fetch = [&](int j, float& x, float& y, float& z) {
         x = s_ax[j];
         y = s_ay[j];
         z = s_az[j];
       };
-      const float kap = kappa_point(s_ax[i], s_ay[i], s_az[i], Nm[ni], Nm[N + ni], Nm[2 * N + ni], nb, k, fetch);
-      const float e = kap - (A.kappa_ori ? A.kappa_ori[bN + ni] : 0.f);
+      const float kap = kappa_point(s_ax[i], s_ay[i], s_az[i], Nm[ni], Nm[Nr + ni], Nm[2 * Nr + ni], nb, k, fetch);
+      const float e = kap - (A.kappa_ori ? A.kappa_ori[bNr + ni] : 0.f);
       s_e[i] = e;
       sum_e2 += e * e;
       if (A.kappa_adv) A.kappa_adv[bN + i] = kap;
     }
   }
+  if (two_side)
+    for (int i = tid; i < Nr; i += GEO_BLOCK) sum_oa += A.d_oa[bNr + i];
   sum_ao = wave_sum(sum_ao);
   sum_oa = wave_sum(sum_oa);
   sum_e2 = wave_sum(sum_e2);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
     }
     const float invN = 1.0f / (float)N;
     float dis = 0.f;
-    if (do_cd) dis = a * invN + (two_side ? o * invN : 0.f);
+    if (do_cd) dis = a * invN + (two_side ? o * (1.0f / (float)Nr) : 0.f);
     if (do_l2) dis = a;
     const float hdv = do_hd ? h.v : 0.f;
     const float curv = do_curv ? e2 * invN : 0.f;
@@ -170,21 +172,31 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
   //      are scattered with LDS float atomics (ds_add_f32).
   const float invN = 1.0f / (float)N;
   const float c_cd = A.w_dis * invN * 2.0f;
+  const float c_cd_r = A.w_dis * (1.0f / (float)Nr) * 2.0f;
+  if (two_side && Nr != N) {  // ori point i pulls its nearest adversarial point (dense-cloud path: Nr > N)
+    for (int i = tid; i < Nr; i += GEO_BLOCK) {
+      const int a = A.i_oa[bNr + i];
+      const float dx = s_ax[a] - ori[i], dy = s_ay[a] - ori[Nr + i], dz = s_az[a] - ori[2 * Nr + i];
+      atomicAdd(&s_gx[a], c_cd_r * dx);
+      atomicAdd(&s_gy[a], c_cd_r * dy);
+      atomicAdd(&s_gz[a], c_cd_r * dz);
+    }
+  }
   for (int i = tid; i < N; i += GEO_BLOCK) {
     float gx = 0.f, gy = 0.f, gz = 0.f;
     const float px = s_ax[i], py = s_ay[i], pz = s_az[i];
     if (do_cd || do_hd) {
       const int j = A.i_ao[bN + i];
-      const float dx = px - ori[j], dy = py - ori[N + j], dz = pz - ori[2 * N + j];
+      const float dx = px - ori[j], dy = py - ori[Nr + j], dz = pz - ori[2 * Nr + j];
       float c = do_cd ? c_cd : 0.f;
       if (do_hd && i == hd_arg) c += A.w_hd * 2.0f;
       gx += c * dx;
       gy += c * dy;
       gz += c * dz;
     }
-    if (two_side) {  // ori point i pulls its nearest adversarial point
+    if (two_side && Nr == N) {  // ori point i pulls its nearest adversarial point
       const int a = A.i_oa[bN + i];
-      const float dx = s_ax[a] - ori[i], dy = s_ay[a] - ori[N + i], dz = s_az[a] - ori[2 * N + i];
+      const float dx = s_ax[a] - ori[i], dy = s_ay[a] - ori[Nr + i], dz = s_az[a] - ori[2 * Nr + i];
       atomicAdd(&s_gx[a], c_cd * dx);
       atomicAdd(&s_gy[a], c_cd * dy);
       atomicAdd(&s_gz[a], c_cd * dz);
@@ -192,13 +204,13 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
     if (do_l2) {
       const float c = A.w_dis * 2.0f;
       gx += c * (px - ori[i]);
-      gy += c * (py - ori[N + i]);
-      gz += c * (pz - ori[2 * N + i]);
+      gy += c * (py - ori[Nr + i]);
+      gz += c * (pz - ori[2 * Nr + i]);
     }
     if (do_curv) {
       const int ni = A.i_ao[bN + i];
-      const float* Nm = A.normal_ori + (size_t)b * 3 * N;
-      const float nx = Nm[ni], ny = Nm[N + ni], nz = Nm[2 * N + ni];
+      const float* Nm = A.normal_ori + (size_t)b * 3 * Nr;
+      const float nx = Nm[ni], ny = Nm[Nr + ni], nz = Nm[2 * Nr + ni];
       const int32_t* nb = A.knn_adv + (bN + i) * (size_t)(k + 1);
       const float dk = (A.dkappa ? A.dkappa[bN + i] : A.w_curv * invN * 2.0f * s_e[i]) / (float)k;
       for (int m = 1; m <= k; ++m) {
@@ -244,17 +256,20 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
 }  // namespace
 
 extern "C" int geoa3_kappa(const float* pc, const float* normal, const int32_t* knn_idx, const int32_t* nn_idx,
-                           int B, int N, int k, float* kappa, void* stream) {
-  if (!pc || !normal || !knn_idx || !kappa || B <= 0 || N <= 0 || k <= 0) return GEOA3_EINVAL;
+                           int B, int N, int Nn, int k, float* kappa, void* stream) {
+  if (!pc || !normal || !knn_idx || !kappa || B <= 0 || N <= 0 || k <= 0 || Nn < 0) return GEOA3_EINVAL;
+  if (Nn == 0) Nn = N;
+  if (!nn_idx && Nn != N) return GEOA3_EINVAL;
   dim3 grid((N + 255) / 256, B);
-  hipLaunchKernelGGL(kappa_kernel, grid, dim3(256), 0, geoa3_stream(stream), pc, normal, knn_idx, nn_idx, N, k,
-                     kappa);
+  hipLaunchKernelGGL(kappa_kernel, grid, dim3(256), 0, geoa3_stream(stream), pc, normal, knn_idx, nn_idx, N, Nn,
+                     k, kappa);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
 
 extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
-  if (!a || !a->adv || !a->ori || a->B <= 0 || a->N <= 0) return GEOA3_EINVAL;
+  if (!a || !a->adv || !a->ori || a->B <= 0 || a->N <= 0 || a->Nr < 0) return GEOA3_EINVAL;
+  if (a->dis_type == 2 && a->Nr > 0 && a->Nr != a->N) return GEOA3_EINVAL;  // norm_l2_loss needs equal sizes
   if (a->dis_type == 1 && (!a->d_ao || !a->i_ao)) return GEOA3_EINVAL;
   if (a->w_hd != 0.f && (!a->d_ao || !a->i_ao)) return GEOA3_EINVAL;
   if ((a->w_curv != 0.f || a->dkappa) && (!a->knn_adv || !a->normal_ori || !a->i_ao || a->k <= 0))

@@ -108,7 +108,8 @@ def kappa(pc: Tensor, normal: Tensor, knn_idx: Tensor, nn_idx: Optional[Tensor] 
     k = knn_idx.shape[2] - 1
     out = torch.empty(B, N, device=pc.device, dtype=torch.float32)
     check(_lib.load().geoa3_kappa(_p(pc, torch.float32), _p(normal, torch.float32), _p(knn_idx, torch.int32),
-                                  _p(nn_idx, torch.int32), B, N, k, _p(out), _stream()), "geoa3_kappa")
+                                  _p(nn_idx, torch.int32), B, N, int(normal.shape[2]), k, _p(out), _stream()),
+          "geoa3_kappa")
     return out
 
 
@@ -131,7 +132,7 @@ def geo_loss_grad(adv: Tensor, ori: Tensor, *, normal_ori=None, kappa_ori=None, 
                 kappa_ori=_p(kappa_ori), d_ao=_p(d_ao), i_ao=_p(i_ao, torch.int32) if i_ao is not None else None,
                 d_oa=_p(d_oa), i_oa=_p(i_oa, torch.int32) if i_oa is not None else None,
                 knn_adv=_p(knn_adv, torch.int32) if knn_adv is not None else None, dkappa=_p(dkappa),
-                B=B, N=N, k=k, dis_type=dis_type, single_side=int(single_side), w_dis=w_dis, w_hd=w_hd,
+                B=B, N=N, k=k, Nr=int(ori.shape[2]), dis_type=dis_type, single_side=int(single_side), w_dis=w_dis, w_hd=w_hd,
                 w_curv=w_curv, dis_loss=_p(o["dis_loss"]), hd_loss=_p(o["hd_loss"]), curv_loss=_p(o["curv_loss"]),
                 constrain=_p(o["constrain"]), kappa_adv=_p(o.get("kappa_adv")) if want_kappa else None,
                 grad=_p(o["grad"]) if want_grad else None)

@@ -75,9 +75,10 @@ int geoa3_graph_knn(const float* adv, const float* ori, const int32_t* gidx, con
  * (column 0, the nearest hit, is dropped exactly as the reference's [:, :, :, 1:] slice):
  *   kappa[b,i] = mean_m | < normalize(p[knn_idx[b,i,m]] - p_i), n_i > |,  m = 1..k.
  * nn_idx (optional, [B,N]): normals are taken from normal[:, nn_idx[b,i]] -- the
- * _get_kappa_adv form (Lib/loss_utils.py:64-82); NULL = normal[:, i]. */
+ * _get_kappa_adv form (Lib/loss_utils.py:64-82); NULL = normal[:, i].  normal is [B,3,Nn] (Nn = 0 means N;
+ * Nn != N only with nn_idx: the dense-cloud path, where pc is an npoint-sample of a cloud of Nn points). */
 int geoa3_kappa(const float* pc, const float* normal, const int32_t* knn_idx, const int32_t* nn_idx,
-                int B, int N, int k, float* kappa, void* stream);
+                int B, int N, int Nn, int k, float* kappa, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Objective level: the geometric part of _forward_step (Attacker/geoA3_attack.py:131-166) and its
@@ -86,18 +87,20 @@ int geoa3_kappa(const float* pc, const float* normal, const int32_t* knn_idx, co
 typedef struct geoa3_geo_args {
   /* inputs */
   const float* adv;        /* [B,3,N] current iterate                                  */
-  const float* ori;        /* [B,3,N] clean cloud                                      */
-  const float* normal_ori; /* [B,3,N]          (may be NULL when w_curv == 0)          */
-  const float* kappa_ori;  /* [B,N]            (may be NULL when w_curv == 0)          */
+  const float* ori;        /* [B,3,Nr] clean cloud                                     */
+  const float* normal_ori; /* [B,3,Nr]         (may be NULL when w_curv == 0)          */
+  const float* kappa_ori;  /* [B,Nr]           (may be NULL when w_curv == 0)          */
   const float* d_ao;       /* [B,N] adv->ori squared distance                          */
   const int32_t* i_ao;     /* [B,N] adv->ori index                                     */
-  const float* d_oa;       /* [B,N] ori->adv       (NULL when single_side or dis_type != CD) */
-  const int32_t* i_oa;     /* [B,N]                                                    */
+  const float* d_oa;       /* [B,Nr] ori->adv      (NULL when single_side or dis_type != CD) */
+  const int32_t* i_oa;     /* [B,Nr]                                                   */
   const int32_t* knn_adv;  /* [B,N,k+1] self K-NN of adv (NULL when w_curv == 0)       */
   const float* dkappa;     /* [B,N] optional upstream d L / d kappa_adv: when given, the curvature part of
                               `grad` is the vector-Jacobian product of _get_kappa_adv with it (operator-level
                               autograd) instead of the curvature_loss gradient                */
   int32_t B, N, k;
+  int32_t Nr;              /* points of ori / normal_ori / kappa_ori / d_oa / i_oa; 0 = N.  Nr > N is the dense-cloud
+                              path (--is_subsample_opt, geoA3_attack.py:283-284): adv is the npoint-sample */
   int32_t dis_type;        /* 0 = none, 1 = CD (chamfer_loss / pseudo_chamfer_loss), 2 = L2 (norm_l2_loss) */
   int32_t single_side;     /* --is_cd_single_side                                      */
   float w_dis, w_hd, w_curv; /* dis_loss_weight, hd_loss_weight, curv_loss_weight     */
@@ -195,6 +198,14 @@ typedef struct geoa3_attack_state {
  * dlogits[B,classes] already carries inv_global_batch. */
 int geoa3_attack_head(const geoa3_attack_state* st, const float* logits, const float* constrain,
                       const float* x, int step, int search_step, float* dlogits, void* stream);
+/* The dense-cloud form (--is_subsample_opt with more points than cfg.npoint, geoA3_attack.py:283-296): `logits` are
+ * those of the npoint-sample the objective is evaluated on (classification loss, dlogits); success and
+ * output_label come from vote_logits [B, eval_num, classes], the victim's answers on eval_num independent
+ * farthest-point resamplings of the full iterate: success = more than half of them satisfy _compare, label = their
+ * mode (smallest on ties, as torch.mode).  eval_num <= 64.  x / best_attack stay the FULL cloud (st->N points). */
+int geoa3_attack_head_vote(const geoa3_attack_state* st, const float* logits, const float* vote_logits, int eval_num,
+                           const float* constrain, const float* x, int step, int search_step, float* dlogits,
+                           void* stream);
 
 /* Per step, after both backward passes: g = g_cls + scale_const[b]*inv_global_batch*g_geo, then the
  * optimiser update of `offset` (torch.optim.Adam defaults or plain SGD, geoA3_attack.py:269-272,

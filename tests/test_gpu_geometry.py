@@ -223,3 +223,43 @@ def test_graph_pruned_search_is_bit_identical_to_brute_force(ops, N, K, Kg, scal
     # single-sided form
     d1, i1, n1, n2 = graph.nn1_pair(advD, both=False)
     assert n1 is None and torch.equal(i1, bi_ao) and torch.equal(d1, b_ao)
+
+
+@pytest.mark.parametrize("Na,Nr,k", [(64, 160, 4), (200, 1500, 16), (1024, 4096, 16)])
+def test_loss_utils_unequal_cloud_sizes(Na, Nr, k):
+    """The dense-cloud path (--is_subsample_opt, geoA3_attack.py:283-284): the adversarial cloud is an npoint-sample,
+    the clean cloud / normals / kappa_ori keep all Nr points.  Values and gradients against the oracle's autograd."""
+    from geoa3_amd import loss_utils as LU
+    B = 3
+    ori, nrm = O.make_synthetic_clouds(B, Nr, seed=Na + Nr)
+    g = torch.Generator().manual_seed(5)
+    pick = torch.stack([torch.randperm(Nr, generator=g)[:Na] for _ in range(B)])
+    adv0 = torch.gather(ori, 2, pick.unsqueeze(1).expand(B, 3, Na)) + 0.01 * torch.randn(B, 3, Na, generator=g)
+    kap_ori = O.get_kappa_ori(ori, nrm, k)
+    want, gwant = {}, {}
+    for name, fn in [("cd", O.chamfer_loss), ("pcd", O.pseudo_chamfer_loss), ("hd", O.hausdorff_loss)]:
+        a = adv0.clone().requires_grad_()
+        v = fn(a, ori)
+        v.sum().backward()
+        want[name], gwant[name] = v.detach(), a.grad
+    a = adv0.clone().requires_grad_()
+    kap_adv, _ = O.get_kappa_adv(a, ori, nrm, k)
+    curv = O.curvature_loss(a, ori, kap_adv, kap_ori)
+    curv.sum().backward()
+    want["curv"], gwant["curv"] = curv.detach(), a.grad
+    d_ori, d_nrm = dev(ori), dev(nrm)
+    d_kap = LU._get_kappa_ori(d_ori, d_nrm, k)
+    np.testing.assert_allclose(d_kap.cpu().numpy(), kap_ori.numpy(), rtol=2e-5, atol=2e-6)
+    for name, fn in [("cd", LU.chamfer_loss), ("pcd", LU.pseudo_chamfer_loss), ("hd", LU.hausdorff_loss)]:
+        a = dev(adv0).requires_grad_()
+        v = fn(a, d_ori)
+        np.testing.assert_allclose(v.detach().cpu().numpy(), want[name].numpy(), rtol=2e-5, atol=1e-8)
+        v.sum().backward()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), gwant[name].numpy(), rtol=1e-4, atol=1e-8)
+    a = dev(adv0).requires_grad_()
+    ka, _ = LU._get_kappa_adv(a, d_ori, d_nrm, k)
+    np.testing.assert_allclose(ka.detach().cpu().numpy(), kap_adv.detach().numpy(), rtol=2e-5, atol=2e-6)
+    c = LU.curvature_loss(a, d_ori, ka, d_kap)
+    np.testing.assert_allclose(c.detach().cpu().numpy(), want["curv"].numpy(), rtol=1e-4, atol=1e-8)
+    c.sum().backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), gwant["curv"].numpy(), rtol=2e-3, atol=2e-6)
