@@ -62,6 +62,22 @@ class ModelNet40(torch.utils.data.Dataset):
         return item
 
 
+class AdvModelNet40(torch.utils.data.Dataset):
+    """The directory of adversarial `.mat` files main_attack.py writes (Mat/adv_*.mat), as the reference's
+    Provider/defense_modelnet10_instance250.ModelNet40 reads it: item = [pc [3,N] f32, gt_label, attack_label]."""
+
+    def __init__(self, advdatadir):
+        self.advdatadir = advdatadir
+        self.filename = os.listdir(advdatadir)
+
+    def __len__(self):
+        return len(self.filename)
+
+    def __getitem__(self, index):
+        data = loadmat(os.path.join(self.advdatadir, self.filename[index]))
+        return [torch.FloatTensor(data["adversary_point_clouds"]), data["gt_label"], data["attack_label"]]
+
+
 def synthetic_clouds(M: int, N: int, seed: int = 0):
     """Seeded stand-in for the ModelNet instances: N points on a random ellipsoid (semi-axes U(0.3,1)),
     analytic unit normals, centred and scaled to unit max radius as Provider/gen_data_mat.py:153-157.

@@ -81,6 +81,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="fall back to seeded synthetic data / weights when the files are missing")
     p.add_argument("--out_root", default="Exps", type=str, help="root of the output tree (reference: Exps)")
     p.add_argument("--quiet", action="store_true", default=False)
+    p.add_argument("--synthetic_npoint", type=int, default=0,
+                   help="points per synthetic cloud when --synthetic writes the data file (default: --npoint)")
     p.add_argument("--graph_search", action="store_true", default=False,
                    help="answer the per-iteration NN searches from the clean cloud's neighbour table (same results)")
     return p
@@ -119,10 +121,12 @@ def saved_dir_name(cfg) -> str:
     return os.path.join(root, cfg.attack_label, name)
 
 
-def _write_outputs(saved_dir, name, cloud, gt, pred):
+def _write_outputs(saved_dir, name, cloud, gt, pred, est_normal=None):
     """One successful adversarial cloud: Mat/<name>.mat + PC/<name>.obj (main_attack.py:264-279)."""
-    sio.savemat(os.path.join(saved_dir, "Mat", name + ".mat"),
-                {"adversary_point_clouds": cloud, "gt_label": gt, "attack_label": pred})
+    mat = {"adversary_point_clouds": cloud, "gt_label": gt, "attack_label": pred}
+    if est_normal is not None:                                # --is_save_normal (main_attack.py:269-271)
+        mat["est_normal"] = est_normal
+    sio.savemat(os.path.join(saved_dir, "Mat", name + ".mat"), mat)
     with open(os.path.join(saved_dir, "PC", name + ".obj"), "w") as f:
         for m in range(cloud.shape[1]):
             f.write("v %f %f %f 0 0 0\n" % (cloud[0, m], cloud[1, m], cloud[2, m]))
@@ -134,6 +138,7 @@ def main(cfg):
     from geoa3_amd import attack as geoa3_attack
     from geoa3_amd.data import TEN_LABEL_INDEXES, ModelNet40, synthetic_state_dict, write_synthetic_mat
     from geoa3_amd.pointnet import PointNet
+    from geoa3_amd.utility import estimate_normal_via_ori_normal, farthest_points_sample
 
     if cfg.attack == "GeoA3_mesh":
         raise AssertionError("Not uploaded yet.")          # as the reference (main_attack.py:27-28)
@@ -164,12 +169,19 @@ def main(cfg):
     if not os.path.isfile(cfg.data_dir_file) and cfg.synthetic:
         if rank == 0:
             labels = [TEN_LABEL_INDEXES[i // 25] for i in range(250)]
-            write_synthetic_mat(cfg.data_dir_file, labels, cfg.npoint, seed=0)
+            write_synthetic_mat(cfg.data_dir_file, labels, cfg.synthetic_npoint or cfg.npoint, seed=0)
         if world > 1:
             dist.barrier()
     dataset = ModelNet40(data_mat_file=cfg.data_dir_file, attack_label=cfg.attack_label, resample_num=-1)
     loader = torch.utils.data.DataLoader(dataset, batch_size=cfg.batch_size, shuffle=False, drop_last=False,
                                          num_workers=0, pin_memory=True)
+    dense_iter = None
+    if cfg.is_save_normal and cfg.dense_data_dir_file is not None:   # main_attack.py:124-130
+        dense = ModelNet40(data_mat_file=cfg.dense_data_dir_file, attack_label=cfg.attack_label, resample_num=-1)
+        dense_iter = iter(torch.utils.data.DataLoader(dense, batch_size=cfg.batch_size, shuffle=False,
+                                                      drop_last=False, num_workers=0, pin_memory=True))
+    elif cfg.is_save_normal:
+        raise AssertionError("--is_save_normal needs --dense_data_dir_file (main_attack.py:124,246)")
 
     say("=>Loading model")
     model_path = os.path.join("Pretrained", cfg.arch, str(cfg.npoint), "model_best.pth.tar")
@@ -227,8 +239,18 @@ def main(cfg):
         adv_pc, targeted_label, success, best_attack_step, loss = out
         torch.cuda.synchronize()
         t_attack += time.perf_counter() - t0
+        saved_normal = None
+        if dense_iter is not None:                           # main_attack.py:196-210, 241-247
+            from geoa3_amd.attack import unpack_input
+            dense_data = next(dense_iter)
+            dense_point, dense_normal, _, _ = unpack_input(dense_data, False)
+            saved_normal = estimate_normal_via_ori_normal(adv_pc.contiguous(), dense_point.to(device).contiguous(),
+                                                          dense_normal.to(device).contiguous(), k=3).cpu().numpy()
         with torch.no_grad():                                # re-evaluation (main_attack.py:249-261)
-            test_pred = net(adv_pc.contiguous()).argmax(1)
+            eval_points = adv_pc.contiguous()
+            if eval_points.size(2) > cfg.npoint:
+                eval_points = farthest_points_sample(eval_points, cfg.npoint)
+            test_pred = net(eval_points).argmax(1)
         saved_pc = adv_pc.cpu().numpy()
         if rank == 0:
             for k in range(b):
@@ -236,7 +258,8 @@ def main(cfg):
                     num_attack_success += 1
                     name = "adv_" + str(cnt_ins + k // num_attack_classes) + "_gt" + str(gt_target[k].item()) + \
                            "_attack" + str(test_pred[k].item()) + "_expect" + str(targeted_label[k].item())
-                    _write_outputs(saved_dir, name, saved_pc[k], gt_target[k].item(), test_pred[k].item())
+                    _write_outputs(saved_dir, name, saved_pc[k], gt_target[k].item(), test_pred[k].item(),
+                                   None if saved_normal is None else saved_normal[k])
         cnt_ins += bs
         cnt_all += b
 

@@ -252,6 +252,20 @@ def main():
     atk = [run_attack(tag, kw, b, n, seed) for tag, (kw, b, n, seed) in AUX_ATK_CASES.items()]
     out["atk/cases"] = np.array(atk)
 
+    # ---------------------------------------------------------------- flag sets of the two command lines
+    import json
+    import re
+    for key, rel in [("cli/defense_flags_json", "defense.py"),
+                     ("cli/smooth_flags_json", os.path.join("Measurement", "compute_data_smoothness.py"))]:
+        src = open(os.path.join(REF, rel)).read()
+        flags = []
+        for m in re.finditer(r"parser\.add_argument\((.*?)\)\s*$", src, re.M):
+            body = m.group(1)
+            names = re.findall(r"'(-{1,2}[A-Za-z_0-9]+)'", body.split("default")[0] if "default" in body else body)
+            d = re.search(r"default=([^,\)]+)", body)
+            flags.append([names, d.group(1).strip() if d else None, "store_true" in body])
+        out[key] = np.array(json.dumps(flags))
+
     path = os.path.join(HERE, "geoa3_golden_aux.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), len(out), "arrays")

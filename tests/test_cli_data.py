@@ -63,3 +63,37 @@ def test_dataset_matches_reference_expansion(golden, tmp_path):
     dl = torch.utils.data.DataLoader(ModelNet40(mat, "Untarget"), batch_size=4)
     b = next(iter(dl))
     assert b[0].shape == (4, 1, 32, 3) and b[2].shape == (4, 1)
+
+
+def _check_flags(parser, ref):
+    actions = {}
+    for a in parser._actions:
+        for o in a.option_strings:
+            actions[o] = a
+    for names, default, store_true in ref:
+        for n in names:
+            assert n in actions, n
+        act = actions[names[-1]]
+        if store_true:
+            assert act.default is False and act.nargs == 0
+        else:
+            want = None if default == "None" else ast.literal_eval(default)
+            assert act.default == want and type(act.default) is type(want), (names, act.default, want)
+
+
+def test_defense_and_smoothness_flag_sets_match_reference():
+    import importlib.util
+    import numpy as np
+    aux = np.load(os.path.join(os.path.dirname(__file__), "golden", "geoa3_golden_aux.npz"))
+    import defense
+    ref = json.loads(str(aux["cli/defense_flags_json"]))
+    assert len(ref) == 13
+    _check_flags(defense.build_parser(), ref)
+    root = os.path.join(os.path.dirname(__file__), "..")
+    spec = importlib.util.spec_from_file_location("compute_data_smoothness",
+                                                  os.path.join(root, "Measurement", "compute_data_smoothness.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref = json.loads(str(aux["cli/smooth_flags_json"]))
+    assert len(ref) == 5
+    _check_flags(mod.build_parser(), ref)
