@@ -8,83 +8,116 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// conv_cm: one wavefront owns 32 columns (points) and ALL Co output channels; the weight matrix of the
-// instance sits in LDS (pitch K+1: bank-conflict-free column reads) and is staged ONCE per workgroup for
-// CONV_TILES x 128 points; the activations stream straight from HBM into the B operand (each element
-// is read once and reused Co/32 times from the register), 16 k-steps of loads in flight per wave.
-// (Measured: 8- and 16-byte-per-lane column vectorisation is slower here -- it quadruples the
-// accumulator registers and the kernel is latency-, not instruction-bound.)
+// conv_cm64: one wavefront owns 64 consecutive columns (points) and 64 output channels.  Every global access is a
+// 256-byte row (lane = column): measured on MI355X, a store instruction covering ONE 256-B row runs at 5.7 TB/s
+// while the same bytes as two 128-B segments in two rows (a 32x32 accumulator register as it stands) reach only
+// 2.2 TB/s (tools/bench_conv.py), which made the 32-column form of this kernel store-bound.  The MFMA operand
+// layouts (two rows x 32 columns per register) are produced in registers by v_permlane32_swap: swapping the upper
+// half of row 2s with the lower half of row 2s+1 turns two 64-column rows into the B operands of the two 32-column
+// blocks, and the same swap on a pair of accumulator registers turns them into two 64-column output rows.
+// K is consumed in chunks of 32 rows, double-buffered in registers: chunk c+1 is in flight while chunk c feeds the
+// matrix core; chunk 0 is requested before the weights are staged into LDS.
 // ------------------------------------------------------------------------------------------
-constexpr int CONV_TILES = 1;   // 128-point tiles per workgroup (more, longer workgroups measured slower)
+__device__ __forceinline__ void swap32(float& a, float& b) {   // a[32..63] <-> b[0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
 
-template <int CT>  // Co = 32*CT
-__global__ __launch_bounds__(256) void conv_cm_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [Co][K+1]
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = a.K, Co = 32 * CT, pitch = K + 1;
-  const float* W = a.W + (size_t)b * a.sWb;
+template <int NCH>  // K = CH * NCH
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void conv_cm64_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [64][K+1]: the 64 output rows of this row block
+  constexpr int CH = 16;   // rows of X per chunk (two chunks in registers)
+  constexpr int K = CH * NCH, pitch = K + 1;
+  const int b = blockIdx.y, rb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = blockIdx.x * 256 + wave * 64 + lane;
+  const bool live = col < a.N;
+  const float* X = a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
+  float xb[2][CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) xb[0][u] = X[(size_t)u * a.ldX];
+
+  const float* W = a.W + (size_t)b * a.sWb + (size_t)rb * 64 * a.sWco;
   if (a.sWk == 1 && (a.sWco & 3) == 0 && (a.sWb & 3) == 0) {   // rows are k-contiguous: 16-byte loads
-    for (int e = tid; e < Co * K / 4; e += 256) {
+    for (int e = tid; e < 64 * K / 4; e += 256) {
       const int co = e / (K / 4), k = (e - co * (K / 4)) * 4;
       const float4 w = *reinterpret_cast<const float4*>(W + (size_t)co * a.sWco + k);
       float* d = s_w + co * pitch + k;
       d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
     }
   } else if (a.sWk == 1) {
-    for (int e = tid; e < Co * K; e += 256) {
+    for (int e = tid; e < 64 * K; e += 256) {
       const int co = e / K, k = e - co * K;
       s_w[co * pitch + k] = W[(size_t)co * a.sWco + k];
     }
   } else {  // transposed storage: co is the contiguous index
-    for (int e = tid; e < Co * K; e += 256) {
-      const int k = e / Co, co = e - k * Co;
+    for (int e = tid; e < 64 * K; e += 256) {
+      const int k = e / 64, co = e - k * 64;
       s_w[co * pitch + k] = W[(size_t)co * a.sWco + (size_t)k * a.sWk];
     }
   }
   __syncthreads();
-  const int kh = lane >> 5;
-  const float* wrow = s_w + (lane & 31) * pitch + kh;
+  const float* wrow = s_w + (lane & 31) * pitch + (lane >> 5);
 
-  for (int tile = 0; tile < CONV_TILES; ++tile) {
-    const int col = (blockIdx.x * CONV_TILES + tile) * 128 + wave * 32 + (lane & 31);
-    if ((blockIdx.x * CONV_TILES + tile) * 128 >= a.N) break;   // workgroup-uniform
-    const bool live = col < a.N;
-    const int colc = live ? col : a.N - 1;
-    const float* X = a.X + (size_t)b * a.sXb + colc;
+  f32x16 acc[2][2];   // [column block][row tile]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
 
-    f32x16 acc[CT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    constexpr int U = 32;  // k-steps whose loads are in flight together (all of K = 64)
-    for (int s0 = 0; s0 < K / 2; s0 += U) {
-      float xr[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) xr[u] = X[(size_t)(2 * (s0 + u) + kh) * a.ldX];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = 2 * (s0 + u);
-#pragma unroll
-        for (int t = 0; t < CT; ++t) acc[t] = mfma32(wrow[t * 32 * pitch + k], xr[u], acc[t]);
-      }
+      for (int u = 0; u < CH; ++u) xb[(c + 1) & 1][u] = X[(size_t)(CH * (c + 1) + u) * a.ldX];
     }
+    float* x = xb[c & 1];
+#pragma unroll
+    for (int u = 0; u < CH / 2; ++u) {
+      swap32(x[2 * u], x[2 * u + 1]);
+      const float a0 = wrow[CH * c + 2 * u], a1 = wrow[32 * pitch + CH * c + 2 * u];
+      acc[0][0] = mfma32(a0, x[2 * u], acc[0][0]);
+      acc[1][0] = mfma32(a0, x[2 * u + 1], acc[1][0]);
+      acc[0][1] = mfma32(a1, x[2 * u], acc[0][1]);
+      acc[1][1] = mfma32(a1, x[2 * u + 1], acc[1][1]);
+    }
+  }
 
-    if (!live) continue;
-    float* Y = a.Y + (size_t)b * a.sYb + col;
-    const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
+  // epilogue: every pair of accumulator registers becomes two 64-column rows (row, row + 4)
+  float* Y = a.Y + (size_t)b * a.sYb + col;
+  const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
+  for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = t * 32 + mfma_row(r, lane);
-        float v = acc[t][r];
-        if (a.bias) v += a.bias[co];
-        if (a.relu) v = fmaxf(v, 0.f);
-        if (a.accumulate) v += Y[(size_t)co * a.ldY];
-        if (Z) v = Z[(size_t)co * a.ldZ] > 0.f ? v : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
-        Y[(size_t)co * a.ldY] = v;
+    for (int g = 0; g < 4; ++g) {
+      float v[8], z[8], y[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = acc[0][t][4 * g + i];
+        v[4 + i] = acc[1][t][4 * g + i];
+        swap32(v[i], v[4 + i]);    // v[i]: row base+i, v[4+i]: row base+4+i, lane = column
+      }
+      const int row0 = rb * 64 + t * 32 + 8 * g;   // rows row0 .. row0+7 in the order of v[]
+      if (live) {
+        if (Z) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) z[i] = Z[(size_t)(row0 + i) * a.ldZ];
+        }
+        if (a.accumulate) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) y[i] = Y[(size_t)(row0 + i) * a.ldY];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float o = v[i];
+          if (a.bias) o += a.bias[row0 + i];
+          if (a.relu) o = fmaxf(o, 0.f);
+          if (a.accumulate) o += y[i];
+          if (Z) o = z[i] > 0.f ? o : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
+          Y[(size_t)(row0 + i) * a.ldY] = o;
+        }
       }
     }
   }
@@ -170,15 +203,28 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
 }  // namespace
 
 int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
-  if (a.K % 32 != 0 || (a.Co != 64 && a.Co != 128)) return GEOA3_ENOSUPPORT;
-  const size_t lds = (size_t)a.Co * (a.K + 1) * sizeof(float);
-  dim3 grid((a.N + 128 * CONV_TILES - 1) / (128 * CONV_TILES), a.B);
-  if (a.Co == 64)
-    hipLaunchKernelGGL(conv_cm_kernel<2>, grid, dim3(256), lds, s, a);
+  if ((a.K != 64 && a.K != 128) || (a.Co != 64 && a.Co != 128)) return GEOA3_ENOSUPPORT;
+  const size_t lds = (size_t)64 * (a.K + 1) * sizeof(float);
+  dim3 grid((a.N + 255) / 256, a.B, a.Co / 64);
+  if (a.K == 64)
+    hipLaunchKernelGGL(conv_cm64_kernel<4>, grid, dim3(256), lds, s, a);
   else
-    hipLaunchKernelGGL(conv_cm_kernel<4>, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(conv_cm64_kernel<8>, grid, dim3(256), lds, s, a);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
+}
+
+extern "C" int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B,
+                                   int N, int K, int Co, int relu, void* stream) {
+  ConvArgs a{};
+  a.X = X; a.sXb = (long)K * N; a.ldX = N;
+  a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
+  a.bias = bias;
+  a.Z = Z; a.sZb = (long)Co * N; a.ldZ = N;
+  a.Y = Y; a.sYb = (long)Co * N; a.ldY = N;
+  a.Co = Co; a.K = K; a.N = N; a.B = B;
+  a.relu = relu;
+  return launch_conv_cm(a, geoa3_stream(stream));
 }
 
 int launch_fc(const FcArgs& a, hipStream_t s) {

@@ -316,6 +316,10 @@ int geoa3_sor_select(const float* dis, int B, int N, int mode, int drop_num, flo
  * ------------------------------------------------------------------------------------------ */
 int geoa3_profile_enable(int capacity);                 /* events for `capacity` launches per tag; 0 = off */
 int geoa3_profile_read(int tag, float* ms_host, int cap); /* waits for the recorded launches; returns count */
+/* One channel-major 1x1 convolution Y[B,Co,N] = act(W[Co,K] X[B,K,N] + bias) (gated by Z > 0 when given) of the
+ * PointNet trunk in isolation (K, Co in {64, 128}), for tools/bench_conv.py. */
+int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, int N, int K,
+                        int Co, int relu, void* stream);
 
 #ifdef __cplusplus
 }
