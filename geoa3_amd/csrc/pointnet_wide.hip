@@ -187,32 +187,36 @@ __global__ __launch_bounds__(WM_THREADS, OCC) void wide_max_kernel(WideArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Sparse backward.  One workgroup per (instance, 128-point tile), split in two 64-column halves of 128
-// threads; thread (ci, half) owns row ci of its half, so no two threads ever touch the same accumulator
+// Sparse backward.  One workgroup per (instance, 128-point tile), split in NP parts of 128/NP columns with 128
+// threads each; thread (ci, part) owns row ci of its part, so no two threads ever touch the same accumulator
 // and the summation order is fixed (deterministic, no atomics).
-// Per block of WB_BLOCK output channels: the first wave of each half compacts the (channel, tap) pairs
-// whose arg-max column falls into its half into an LDS hit list (ballot + popcount, in (co, tap) order);
-// then the 128 threads of the half walk ONLY the hits, 16 independent weight-row loads in flight.
+// Per block of WB_BLOCK output channels: the first wave of each part compacts the (channel, tap) pairs whose
+// arg-max column falls into its part into an LDS hit list (ballot + popcount, in (co, tap) order, the upstream
+// gradient stored next to it); then the 128 threads of the part walk ONLY the hits, WB_BATCH independent
+// weight-row loads in flight.  The walk is L2-latency bound, so the parts (NP = 4: 16 waves per workgroup) are
+// what keeps enough loads in flight: LDS (66 KB of accumulators) allows only two workgroups per CU.
 // ------------------------------------------------------------------------------------------
 constexpr int WB_COLS = 128;
-constexpr int WB_BLOCK = 512;   // output channels per compaction round
 constexpr int WB_BATCH = 16;
 
-template <int TAPS>
-__global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
+template <int TAPS, int NP, int WB_BLOCK>   // WB_BLOCK: output channels per compaction round
+__global__ __launch_bounds__(128 * NP) void wide_max_bwd_kernel(WideBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int PC = WB_COLS / NP;                                            // columns per part
   float* s_acc = smem;                                                        // [128 ci][WB_COLS + 1]
-  int* s_hit = reinterpret_cast<int*>(smem + WM_CI * (WB_COLS + 1));          // [2][WB_BLOCK*TAPS]
-  int* s_cnt = s_hit + 2 * WB_BLOCK * TAPS;                                   // [2]
+  int* s_hit = reinterpret_cast<int*>(smem + WM_CI * (WB_COLS + 1));          // [NP][WB_BLOCK*TAPS]
+  float* s_g = reinterpret_cast<float*>(s_hit + NP * WB_BLOCK * TAPS);        // [NP][WB_BLOCK*TAPS]
+  int* s_cnt = reinterpret_cast<int*>(s_g + NP * WB_BLOCK * TAPS);            // [NP]
   const int tid = threadIdx.x, b = blockIdx.y, m0 = blockIdx.x * WB_COLS;
-  const int ci = tid & 127, half = tid >> 7, lane = tid & 63;
-  const bool builder = (tid & 127) < 64;                                      // first wave of each half
+  const int ci = tid & 127, part = tid >> 7, lane = tid & 63;
+  const bool builder = (tid & 127) < 64;                                      // first wave of each part
   const float* gb = a.g + (size_t)b * a.Co;
   const int* argb = a.arg + (size_t)b * a.Co;
-  int* hits = s_hit + half * WB_BLOCK * TAPS;
+  int* hits = s_hit + part * WB_BLOCK * TAPS;
+  float* hitg = s_g + part * WB_BLOCK * TAPS;
   float* row = s_acc + ci * (WB_COLS + 1);
-  for (int j = half * 64; j < half * 64 + 64; ++j) row[j] = 0.f;
-  const int lo = m0 + half * 64, hi = lo + 64;
+  for (int j = part * PC; j < part * PC + PC; ++j) row[j] = 0.f;
+  const int lo = m0 + part * PC, hi = lo + PC;
 
   for (int cb = 0; cb < a.Co; cb += WB_BLOCK) {
     __syncthreads();  // the previous round's list has been consumed
@@ -228,14 +232,18 @@ __global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
           const int m = base + tap;
           const bool hit = g != 0.f && m >= lo && m < hi;
           const unsigned long long mask = __ballot(hit);
-          if (hit) hits[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (co * TAPS + tap) | ((m - m0) << 16);
+          if (hit) {
+            const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            hits[slot] = (co * TAPS + tap) | ((m - m0) << 16);
+            hitg[slot] = g;
+          }
           cnt += __popcll(mask);
         }
       }
-      if (lane == 0) s_cnt[half] = cnt;
+      if (lane == 0) s_cnt[part] = cnt;
     }
     __syncthreads();
-    const int cnt = s_cnt[half];
+    const int cnt = s_cnt[part];
     for (int h0 = 0; h0 < cnt; h0 += WB_BATCH) {
       float w[WB_BATCH], gg[WB_BATCH];
       int mm[WB_BATCH];
@@ -243,9 +251,8 @@ __global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
       for (int u = 0; u < WB_BATCH; ++u) {
         const bool ok = h0 + u < cnt;
         const int e = hits[ok ? h0 + u : cnt - 1];
-        const int kt = e & 0xffff;                      // co*TAPS + tap: row of the [Co*TAPS][128] weight view
-        w[u] = a.W[(size_t)kt * WM_CI + ci];
-        gg[u] = ok ? gb[kt / TAPS] : 0.f;
+        w[u] = a.W[(size_t)(e & 0xffff) * WM_CI + ci];   // row co*TAPS + tap of the [Co*TAPS][128] weight view
+        gg[u] = ok ? hitg[h0 + u] : 0.f;
         mm[u] = e >> 16;
       }
 #pragma unroll
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void wide_max_bwd_kernel(WideBwdArgs a) {
   const float* Z = a.Z + (size_t)b * a.sZb;
   const bool vec = ((a.ldX | a.ldZ) & 3) == 0;
 #pragma unroll 4
-  for (int e = tid; e < WM_CI * (WB_COLS / 4); e += 256) {
+  for (int e = tid; e < WM_CI * (WB_COLS / 4); e += 128 * NP) {
     const int c = e / (WB_COLS / 4), j = (e - c * (WB_COLS / 4)) * 4;
     const int m = m0 + j;
     const float* sa = s_acc + c * (WB_COLS + 1) + j;
@@ -302,19 +309,30 @@ int launch_wide_max(const WideArgs& a, hipStream_t s) {
   return GEOA3_OK;
 }
 
+extern "C" int geoa3_debug_wide_bwd(const float* g, const int32_t* arg, const float* W, const float* Z, float* dX, int B,
+                                    int N, int taps, void* stream) {
+  WideBwdArgs a{};
+  a.g = g; a.arg = arg; a.W = W;
+  a.Z = Z; a.sZb = (long)128 * N; a.ldZ = N;
+  a.dX = dX; a.sXb = (long)128 * N; a.ldX = N;
+  a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
+  return launch_wide_max_bwd(a, geoa3_stream(stream));
+}
+
+template <int TAPS, int NP, int WB_BLOCK>
+static void launch_wide_bwd_variant(const WideBwdArgs& a, hipStream_t s) {
+  dim3 grid((a.N + WB_COLS - 1) / WB_COLS, a.B);
+  const size_t lds = ((size_t)WM_CI * (WB_COLS + 1) + 2 * (size_t)NP * WB_BLOCK * TAPS + NP) * sizeof(float);
+  auto kern = wide_max_bwd_kernel<TAPS, NP, WB_BLOCK>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(128 * NP), lds, s, a);
+}
+
 int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s) {
   if (a.taps != 1 && a.taps != 3) return GEOA3_ENOSUPPORT;
-  dim3 grid((a.N + WB_COLS - 1) / WB_COLS, a.B);
-  const size_t lds = ((size_t)WM_CI * (WB_COLS + 1) + 2 * (size_t)WB_BLOCK * a.taps + 4) * sizeof(float);
-  if (a.taps == 1) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_max_bwd_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wide_max_bwd_kernel<1>, grid, dim3(256), lds, s, a);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_max_bwd_kernel<3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wide_max_bwd_kernel<3>, grid, dim3(256), lds, s, a);
-  }
+  // parts / compaction block picked on hardware (tools/bench_widebwd.py): 93 us / 164 us at B=250, N=1024
+  if (a.taps == 1) launch_wide_bwd_variant<1, 4, 256>(a, s);
+  else launch_wide_bwd_variant<3, 4, 128>(a, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

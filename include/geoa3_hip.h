@@ -318,6 +318,10 @@ int geoa3_profile_enable(int capacity);                 /* events for `capacity`
 int geoa3_profile_read(int tag, float* ms_host, int cap); /* waits for the recorded launches; returns count */
 /* One channel-major 1x1 convolution Y[B,Co,N] = act(W[Co,K] X[B,K,N] + bias) (gated by Z > 0 when given) of the
  * PointNet trunk in isolation (K, Co in {64, 128}), for tools/bench_conv.py. */
+/* The sparse arg-max backward of a 1024-wide layer in isolation (tools/bench_widebwd.py): g [B,1024], arg [B,1024],
+ * W [1024, taps*128], Z / dX [B,128,N]. */
+int geoa3_debug_wide_bwd(const float* g, const int32_t* arg, const float* W, const float* Z, float* dX, int B, int N,
+                         int taps, void* stream);
 int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, int N, int K,
                         int Co, int relu, void* stream);
 
