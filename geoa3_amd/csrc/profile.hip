@@ -9,6 +9,7 @@ struct Slot {
 };
 struct Prof {
   int cap = 0;
+  unsigned mask = ~0u;
   int n[GEOA3_PROF_TAGS] = {0};
   Slot* slots[GEOA3_PROF_TAGS] = {nullptr};
 } g_prof;
@@ -18,11 +19,13 @@ bool geoa3_prof_on() { return g_prof.cap > 0; }
 
 void geoa3_prof_begin(int tag, hipStream_t s) {
   if (g_prof.cap <= 0 || tag < 0 || tag >= GEOA3_PROF_TAGS || g_prof.n[tag] >= g_prof.cap) return;
+  if (!((g_prof.mask >> tag) & 1u)) return;
   (void)hipEventRecord(g_prof.slots[tag][g_prof.n[tag]].e0, s);
 }
 
 void geoa3_prof_end(int tag, hipStream_t s) {
   if (g_prof.cap <= 0 || tag < 0 || tag >= GEOA3_PROF_TAGS || g_prof.n[tag] >= g_prof.cap) return;
+  if (!((g_prof.mask >> tag) & 1u)) return;
   (void)hipEventRecord(g_prof.slots[tag][g_prof.n[tag]].e1, s);
   g_prof.n[tag]++;
 }
@@ -49,6 +52,11 @@ extern "C" int geoa3_profile_enable(int capacity) {
     }
   }
   g_prof.cap = capacity;
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_profile_select(unsigned mask) {
+  g_prof.mask = mask;
   return GEOA3_OK;
 }
 

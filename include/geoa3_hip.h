@@ -315,6 +315,8 @@ int geoa3_sor_select(const float* dis, int B, int N, int mode, int drop_num, flo
  *      3 = T-Net conv3+max (wide_max_kernel<1>).
  * ------------------------------------------------------------------------------------------ */
 int geoa3_profile_enable(int capacity);                 /* events for `capacity` launches per tag; 0 = off */
+int geoa3_profile_select(unsigned mask);                /* bit t set = tag t is recorded (default: all); an event
+                                                           pair costs ~6 us of stream time around the kernel */
 int geoa3_profile_read(int tag, float* ms_host, int cap); /* waits for the recorded launches; returns count */
 /* One channel-major 1x1 convolution Y[B,Co,N] = act(W[Co,K] X[B,K,N] + bias) (gated by Z > 0 when given) of the
  * PointNet trunk in isolation (K, Co in {64, 128}), for tools/bench_conv.py. */
