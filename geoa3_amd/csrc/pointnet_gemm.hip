@@ -159,19 +159,31 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // two register buffers of U k-groups: the loads of batch i+1 are in flight under the MFMAs of batch i
   constexpr int U = 4;
-  for (int k0 = kb; k0 < ke; k0 += 8 * U) {
-    float xa[U][4], wb[U][4];
+  float xa[2][U][4], wb[2][U][4];
+  auto load_batch = [&](int k0, float (&xd)[U][4], float (&wd)[U][4]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = k0 + 8 * u + 4 * h;
-      load4(xp, k, ke, xvec, xa[u]);
-      load4(wp, k, ke, wvec, wb[u]);
+      load4(xp, k, ke, xvec, xd[u]);
+      load4(wp, k, ke, wvec, wd[u]);
     }
+  };
+  auto mma_batch = [&](float (&xd)[U][4], float (&wd)[U][4]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = mfma32(xa[u][i], wb[u][i], acc);
+      for (int i = 0; i < 4; ++i) acc = mfma32(xd[u][i], wd[u][i], acc);
+  };
+  if (kb < ke) load_batch(kb, xa[0], wb[0]);
+  for (int k0 = kb; k0 < ke; k0 += 16 * U) {
+    if (k0 + 8 * U < ke) load_batch(k0 + 8 * U, xa[1], wb[1]);
+    mma_batch(xa[0], wb[0]);
+    if (k0 + 8 * U < ke) {
+      if (k0 + 16 * U < ke) load_batch(k0 + 16 * U, xa[0], wb[0]);
+      mma_batch(xa[1], wb[1]);
+    }
   }
   if (S > 1) {
     if (wave > 0) {
