@@ -19,23 +19,23 @@ import torch
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 
 
+# flag, type, default -- the reference's set (compute_data_smoothness.py:10-15); tests/test_cli_data.py checks it
+_FLAGS = (("datadir", str, "Data/modelnet40_1024_processed"), ("k", int, 16), ("k2", int, 16), ("print_freq", int, 50))
+
+
 def build_parser():
-    p = argparse.ArgumentParser(description="Smoothness Computing")
-    p.add_argument("--datadir", default="Data/modelnet40_1024_processed", type=str, metavar="DIR")
-    p.add_argument("--k", type=int, default=16)
-    p.add_argument("--k2", type=int, default=16)
-    p.add_argument("--print_freq", default=50, type=int)
-    p.add_argument("--is_not_mat", action="store_true", default=False)
-    return p
+    parser = argparse.ArgumentParser(description="Smoothness Computing")
+    for name, kind, default in _FLAGS:
+        parser.add_argument("--" + name, type=kind, default=default)
+    parser.add_argument("--is_not_mat", action="store_true", default=False)
+    return parser
 
 
 def read_off_lines_from_xyz(path, num_points):
-    """compute_data_smoothness.py:19-28."""
-    with open(path) as f:
-        lines = f.readlines()
-    if num_points == -1:
-        num_points = len(lines)
-    return [[float(x) for x in line.split()[0:3]] for line in lines[:num_points]]
+    """First three columns of the first num_points lines (-1: all) of a text cloud (compute_data_smoothness.py:19-28)."""
+    rows = [ln.split()[:3] for ln in open(path).read().splitlines()]
+    rows = rows if num_points == -1 else rows[:num_points]
+    return [[float(v) for v in r] for r in rows]
 
 
 def main(cfg):
