@@ -84,6 +84,9 @@ class AttackRunner:
         if self.sub:
             self.graph_search = False
         self.hooks = {}
+        # the 1-NN tables through the uniform-grid search (geom_grid.hip; same bits as the all-pairs kernel, which
+        # stays the path for clouds beyond 4096 points or when cfg.brute_force_nn1 is set)
+        self.grid_nn1 = max(n, self.ne) <= 4096 and not _cfg(cfg, "brute_force_nn1", False)
         ne = self.ne
         f32 = dict(device=device, dtype=torch.float32)
         i32 = dict(device=device, dtype=torch.int32)
@@ -146,6 +149,7 @@ class AttackRunner:
         t["best_step"].fill_(-1)
         t["best_bs"].fill_(-1)
         self.kappa_ori = None
+        self.nn1_seeded = False
         self.graph = None
         if self.graph_search:
             self.graph = ops.OriGraph(self.ori, 32 if (self.k + 1 if self.use_curv else 1) <= 24 else 64)
@@ -249,10 +253,19 @@ class AttackRunner:
                 self.graph.nn1_pair(xe, both, out=(t["d_ao"], t["i_ao"], t["d_oa"] if both else None,
                                                    t["i_oa"] if both else None))
             else:
-                check(lib.geoa3_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n,
-                                         t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
-                                         t["d_oa"].data_ptr() if both else None,
-                                         t["i_oa"].data_ptr() if both else None, s), "nn1_pair")
+                if self.grid_nn1:   # seeded with the tables of the previous iteration (in place)
+                    pa = t["i_ao"].data_ptr() if self.nn1_seeded else None
+                    pr = t["i_oa"].data_ptr() if self.nn1_seeded and both else None
+                    check(lib.geoa3_grid_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n, pa, pr,
+                                                  t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
+                                                  t["d_oa"].data_ptr() if both else None,
+                                                  t["i_oa"].data_ptr() if both else None, s), "grid_nn1_pair")
+                    self.nn1_seeded = not self.sub
+                else:
+                    check(lib.geoa3_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n,
+                                             t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
+                                             t["d_oa"].data_ptr() if both else None,
+                                             t["i_oa"].data_ptr() if both else None, s), "nn1_pair")
         knn_adv = None
         if self.use_curv:
             prior, out = t["knn"][self.knn_cur], t["knn"][1 - self.knn_cur]

@@ -1,0 +1,244 @@
+// Exact nearest-neighbour search through a uniform grid (gfx950).
+//
+// The all-pairs kernels of geom_nn.hip spend O(N^2) distance evaluations per instance although the clouds are
+// surfaces: the nearest neighbour of a point lies a few percent of the cloud's diameter away.  Here one workgroup
+// per (instance, direction) bins the searched cloud into a 16^3 grid over its bounding box -- counting sort in
+// LDS, rebuilt every call (~2 us).  Every query takes the distance to one real point as its radius (the point with
+// its own index: adv_i = ori_i + offset_i in the attack loop) and scans only the cells its ball touches.
+// Candidates are compared lexicographically on (distance, index) with the same un-fused distance as everywhere
+// else, and the cell range carries a margin far above float rounding, so the result is BIT-IDENTICAL to the
+// all-pairs search (tests/test_gpu_geometry.py) for any input: a query far from every point simply scans more
+// cells (in the limit: all of them, i.e. the all-pairs work).
+#include "geom_internal.h"
+#include "profile.h"
+
+namespace {
+
+constexpr int GT = 1024;              // threads per workgroup of the K = 1 kernel
+constexpr int GG = 16;                // cells per axis
+constexpr int GC = GG * GG * GG;      // 4096 cells
+constexpr int GW = GT / GEOA3_WAVE;   // 16 waves
+constexpr float G_INF = __builtin_inff();
+
+struct GridGeom {
+  float ox, oy, oz, h, inv_h;
+};
+
+__device__ __forceinline__ int grid_coord(float f) {
+  const int c = (int)floorf(f);
+  return c < 0 ? 0 : (c > GG - 1 ? GG - 1 : c);
+}
+
+// Bins the M points of P (planar, stride M) into the grid.  On return (after the trailing barrier) s_start[c] ..
+// s_start[c+1] delimit the points of cell c = (cx*GG + cy)*GG + cz in s_px/s_py/s_pz/s_pi.
+template <int T, int PPT>
+__device__ __forceinline__ GridGeom grid_build(const float* __restrict__ P, int M, int* s_start, int* s_fill,
+                                               float* s_px, float* s_py, float* s_pz, int* s_pi, float* s_red) {
+  constexpr int GT = T, GW = T / GEOA3_WAVE, CPT = GC / T;   // CPT: cell counters scanned per thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float px[PPT], py[PPT], pz[PPT];
+  float lox = G_INF, loy = G_INF, loz = G_INF, hix = -G_INF, hiy = -G_INF, hiz = -G_INF;
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int i = tid + p * GT;
+    if (i < M) {
+      px[p] = P[i];
+      py[p] = P[M + i];
+      pz[p] = P[2 * M + i];
+      lox = fminf(lox, px[p]); hix = fmaxf(hix, px[p]);
+      loy = fminf(loy, py[p]); hiy = fmaxf(hiy, py[p]);
+      loz = fminf(loz, pz[p]); hiz = fmaxf(hiz, pz[p]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lox = fminf(lox, __shfl_xor(lox, o, 64)); hix = fmaxf(hix, __shfl_xor(hix, o, 64));
+    loy = fminf(loy, __shfl_xor(loy, o, 64)); hiy = fmaxf(hiy, __shfl_xor(hiy, o, 64));
+    loz = fminf(loz, __shfl_xor(loz, o, 64)); hiz = fmaxf(hiz, __shfl_xor(hiz, o, 64));
+  }
+  if (lane == 0) {
+    float* r = s_red + wave * 6;
+    r[0] = lox; r[1] = loy; r[2] = loz; r[3] = hix; r[4] = hiy; r[5] = hiz;
+  }
+  for (int i = tid; i < GC; i += GT) s_fill[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < GW; ++w) {
+    const float* r = s_red + w * 6;
+    lox = fminf(lox, r[0]); loy = fminf(loy, r[1]); loz = fminf(loz, r[2]);
+    hix = fmaxf(hix, r[3]); hiy = fmaxf(hiy, r[4]); hiz = fmaxf(hiz, r[5]);
+  }
+  GridGeom g;
+  g.ox = lox; g.oy = loy; g.oz = loz;
+  const float ext = fmaxf(fmaxf(hix - lox, hiy - loy), hiz - loz);
+  g.h = ext * (1.0f / GG) * 1.00001f;      // cubic cells; the far faces lie strictly inside the last cell
+  if (!(g.h > 1e-30f)) g.h = 1.0f;         // all points coincide
+  g.inv_h = 1.0f / g.h;
+
+  int cell[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int i = tid + p * GT;
+    if (i < M) {
+      cell[p] = (grid_coord((px[p] - g.ox) * g.inv_h) * GG + grid_coord((py[p] - g.oy) * g.inv_h)) * GG +
+                grid_coord((pz[p] - g.oz) * g.inv_h);
+      atomicAdd(&s_fill[cell[p]], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the 4096 counters: CPT per thread, shuffle scan per wave, wave totals through LDS
+  int cnt[CPT];
+  int local = 0;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    cnt[i] = s_fill[CPT * tid + i];
+    local += cnt[i];
+  }
+  int incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  int* s_wsum = reinterpret_cast<int*>(s_red) + GW * 6;
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < GW; ++w) base += (w < wave) ? s_wsum[w] : 0;
+  int run = base + incl - local;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    s_start[CPT * tid + i] = run;
+    run += cnt[i];
+    s_fill[CPT * tid + i] = 0;
+  }
+  if (tid == GT - 1) s_start[GC] = run;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int i = tid + p * GT;
+    if (i < M) {
+      const int pos = s_start[cell[p]] + atomicAdd(&s_fill[cell[p]], 1);
+      s_px[pos] = px[p];
+      s_py[pos] = py[p];
+      s_pz[pos] = pz[p];
+      s_pi[pos] = i;
+    }
+  }
+  __syncthreads();
+  return g;
+}
+
+// Visits, as runs of consecutive sorted points, every cell that can hold a point within `rad` (world units) of the
+// query at grid coordinates (fx,fy,fz): the cells of one (x,y) column are adjacent in the cell order, and the z-range
+// of a column is the chord of the ball over that column.  A margin of 1e-4 cells covers the float rounding of the
+// cell assignment, so no point with a computed distance <= rad^2 is missed.
+template <typename Visit>
+__device__ __forceinline__ void grid_ball(const int* __restrict__ s_start, float fx, float fy, float fz, float rad,
+                                          float inv_h, Visit visit) {
+  const float rho = rad * inv_h * 1.00001f + 1e-4f;
+  const int x0 = grid_coord(fx - rho), x1 = grid_coord(fx + rho);
+  const int y0 = grid_coord(fy - rho), y1 = grid_coord(fy + rho);
+  const float rho2 = rho * rho;
+  for (int x = x0; x <= x1; ++x) {
+    const float ex = fmaxf(fmaxf((float)x - fx, fx - (float)(x + 1)), 0.f);   // distance to the slab [x, x+1]
+    for (int y = y0; y <= y1; ++y) {
+      const float ey = fmaxf(fmaxf((float)y - fy, fy - (float)(y + 1)), 0.f);
+      const float rem = rho2 - ex * ex - ey * ey;
+      if (rem < 0.f) continue;
+      const float zr = sqrtf(rem) + 1e-4f;
+      const int col = (x * GG + y) * GG;
+      visit(s_start[col + grid_coord(fz - zr)], s_start[col + grid_coord(fz + zr) + 1]);
+    }
+  }
+}
+
+template <int PPT>
+__global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ A, const float* __restrict__ R, int Na,
+                                                      int Nr, const int32_t* prior_ar, const int32_t* prior_ra,
+                                                      float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra) {
+  // prior_* (optional, may alias i_*): a searched-cloud index per query -- last iteration's answer -- used as the seed
+  extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+  const int b = blockIdx.x;
+  const bool swap = blockIdx.y != 0;
+  const int32_t* prior = swap ? prior_ra : prior_ar;
+  const int Nq = swap ? Nr : Na, M = swap ? Na : Nr;
+  const float* Q = (swap ? R : A) + (size_t)b * 3 * Nq;
+  const float* P = (swap ? A : R) + (size_t)b * 3 * M;
+  float* dout = (swap ? d_ra : d_ar) + (size_t)b * Nq;
+  int32_t* iout = (swap ? i_ra : i_ar) + (size_t)b * Nq;
+  int* s_start = reinterpret_cast<int*>(g_smem);            // [GC + 1]
+  int* s_fill = s_start + GC + 4;                            // [GC]
+  float* s_red = reinterpret_cast<float*>(s_fill + GC);      // [GW*6 + GW]
+  float* s_px = s_red + GW * 8;
+  float* s_py = s_px + M;
+  float* s_pz = s_py + M;
+  int* s_pi = reinterpret_cast<int*>(s_pz + M);
+  const GridGeom g = grid_build<GT, PPT>(P, M, s_start, s_fill, s_px, s_py, s_pz, s_pi, s_red);
+
+  for (int t = threadIdx.x; t < Nq; t += GT) {
+    // equal-sized clouds: walk the queries in the searched cloud's cell order (query i is a perturbation of point i
+    // in the attack loop), so that the lanes of a wavefront look at the same few cells
+    const int q = Nq == M ? s_pi[t] : t;
+    const float qx = Q[q], qy = Q[Nq + q], qz = Q[2 * Nq + q];
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    // seed: any real point gives a valid radius.  Last iteration's nearest neighbour when the caller has it,
+    // otherwise the point with the query's own index (adv_i = ori_i + offset_i in the attack loop)
+    int si = prior ? prior[(size_t)b * Nq + q] : q;
+    si = si < 0 ? 0 : (si >= M ? M - 1 : si);
+    float best = geoa3_sqdist(qx, qy, qz, P[si], P[M + si], P[2 * M + si]);
+    int bi = si;
+    grid_ball(s_start, fx, fy, fz, sqrtf(best), g.inv_h, [&](int s, int e) {
+      for (int j = s; j < e; ++j) {
+        const float d = geoa3_sqdist(qx, qy, qz, s_px[j], s_py[j], s_pz[j]);
+        const int i = s_pi[j];
+        const bool take = d < best || (d == best && i < bi);
+        best = take ? d : best;
+        bi = take ? i : bi;
+      }
+    });
+    dout[q] = best;
+    iout[q] = bi;
+  }
+}
+
+size_t grid_nn1_lds(int M) { return ((size_t)(GC + 4) + GC + GW * 8 + 4 * (size_t)M) * 4; }
+
+}  // namespace
+
+// Same contract as geoa3_launch_nn1 without `only`; returns GEOA3_ENOSUPPORT when a cloud does not fit the
+// workgroup (callers then use the all-pairs kernel).
+int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                          const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra,
+                          hipStream_t s) {
+  const int M = Na > Nr ? Na : Nr;
+  if (M > 4 * GT || (d_ra == nullptr) != (i_ra == nullptr)) return GEOA3_ENOSUPPORT;
+  const size_t lds = grid_nn1_lds(M);
+  dim3 grid(B, d_ra ? 2 : 1);
+#define GEOA3_GRID_CASE(PPT)                                                                                    \
+  if (M <= PPT * GT) {                                                                                          \
+    auto kern = grid_nn1_kernel<PPT>;                                                                           \
+    if (lds > 64 * 1024)                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(GT), lds, s, a, r, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra);                     \
+    GEOA3_CHECK_LAUNCH();                                                                                       \
+    return GEOA3_OK;                                                                                            \
+  }
+  GEOA3_GRID_CASE(1)
+  GEOA3_GRID_CASE(2)
+  GEOA3_GRID_CASE(4)
+#undef GEOA3_GRID_CASE
+  return GEOA3_ENOSUPPORT;
+}
+
+extern "C" int geoa3_grid_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                                   const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra,
+                                   void* stream) {
+  if (!a || !r || !d_ar || !i_ar || B <= 0 || Na <= 0 || Nr <= 0) return GEOA3_EINVAL;
+  geoa3_prof_begin(GEOA3_PROF_NN1, geoa3_stream(stream));
+  const int rc = geoa3_launch_grid_nn1(a, r, B, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, geoa3_stream(stream));
+  geoa3_prof_end(GEOA3_PROF_NN1, geoa3_stream(stream));
+  return rc;
+}

@@ -6,3 +6,6 @@ int geoa3_launch_nn1(const float* a, const float* r, int B, int Na, int Nr, floa
                      int32_t* i_ra, const uint8_t* only, hipStream_t s);
 int geoa3_launch_knn(const float* q, const float* r, int B, int Nq, int Nr, int K, const int32_t* prior, float* dists,
                      int32_t* idx, const uint8_t* only, hipStream_t s);
+// Grid-accelerated exact K=1 search (geom_grid.hip); GEOA3_ENOSUPPORT when a cloud exceeds 4096 points.
+int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                          const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, hipStream_t s);

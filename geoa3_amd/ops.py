@@ -32,8 +32,10 @@ def _p(t: Optional[Tensor], dtype=None) -> Optional[int]:
     return t.data_ptr()
 
 
-def nn1_pair(a: Tensor, r: Tensor, both: bool = True):
-    """a [B,3,Na], r [B,3,Nr] -> (d_ar [B,Na], i_ar int32 [B,Na], d_ra [B,Nr] | None, i_ra | None)."""
+def nn1_pair(a: Tensor, r: Tensor, both: bool = True, method: str = "brute", prior=None):
+    """a [B,3,Na], r [B,3,Nr] -> (d_ar [B,Na], i_ar int32 [B,Na], d_ra [B,Nr] | None, i_ra | None).
+    method: "brute" (all pairs) or "grid" (uniform-grid search, same bits; prior = (i_ar, i_ra) of a previous call
+    seeds its radii)."""
     B, _, Na = a.shape
     Nr = r.shape[2]
     d_ar = torch.empty(B, Na, device=a.device, dtype=torch.float32)
@@ -42,19 +44,29 @@ def nn1_pair(a: Tensor, r: Tensor, both: bool = True):
     if both:
         d_ra = torch.empty(B, Nr, device=a.device, dtype=torch.float32)
         i_ra = torch.empty(B, Nr, device=a.device, dtype=torch.int32)
-    check(_lib.load().geoa3_nn1_pair(_p(a, torch.float32), _p(r, torch.float32), B, Na, Nr, _p(d_ar), _p(i_ar),
-                                     _p(d_ra), _p(i_ra), _stream()), "geoa3_nn1_pair")
+    if method == "grid":
+        p_ar, p_ra = prior if prior is not None else (None, None)
+        check(_lib.load().geoa3_grid_nn1_pair(_p(a, torch.float32), _p(r, torch.float32), B, Na, Nr,
+                                              _p(p_ar, torch.int32) if p_ar is not None else None,
+                                              _p(p_ra, torch.int32) if p_ra is not None and both else None,
+                                              _p(d_ar), _p(i_ar), _p(d_ra), _p(i_ra), _stream()), "geoa3_grid_nn1_pair")
+    else:
+        check(_lib.load().geoa3_nn1_pair(_p(a, torch.float32), _p(r, torch.float32), B, Na, Nr, _p(d_ar), _p(i_ar),
+                                         _p(d_ra), _p(i_ra), _stream()), "geoa3_nn1_pair")
     return d_ar, i_ar, d_ra, i_ra
 
 
-def knn_planar(q: Tensor, r: Tensor, K: int, prior: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+def knn_planar(q: Tensor, r: Tensor, K: int, prior: Optional[Tensor] = None, out=None) -> Tuple[Tensor, Tensor]:
     """q [B,3,Nq], r [B,3,Nr] -> (dists [B,Nq,K] ascending, idx int32 [B,Nq,K])."""
     B, _, Nq = q.shape
     Nr = r.shape[2]
-    d = torch.empty(B, Nq, K, device=q.device, dtype=torch.float32)
-    i = torch.empty(B, Nq, K, device=q.device, dtype=torch.int32)
-    check(_lib.load().geoa3_knn(_p(q, torch.float32), _p(r, torch.float32), B, Nq, Nr, K,
-                                _p(prior, torch.int32), _p(d), _p(i), _stream()), "geoa3_knn")
+    if out is None:
+        d = torch.empty(B, Nq, K, device=q.device, dtype=torch.float32)
+        i = torch.empty(B, Nq, K, device=q.device, dtype=torch.int32)
+    else:
+        d, i = out
+    check(_lib.load().geoa3_knn(_p(q, torch.float32), _p(r, torch.float32), B, Nq, Nr, K, _p(prior, torch.int32),
+                                _p(d), _p(i), _stream()), "geoa3_knn")
     return d, i
 
 

@@ -50,6 +50,15 @@ const char* geoa3_strerror(int code);
 int geoa3_nn1_pair(const float* a, const float* r, int B, int Na, int Nr,
                    float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, void* stream);
 
+/* geoa3_nn1_pair through a uniform grid over the searched cloud (16^3 cells, rebuilt per call in LDS): every query
+ * scans the cells around it, shell by shell, until nothing outside can compete.  Bit-identical results for any input;
+ * O(N) instead of O(N^2) work per instance for surface-like clouds.  Clouds of at most 4096 points
+ * (GEOA3_ENOSUPPORT beyond).  prior_ar [B,Na] / prior_ra [B,Nr] (optional, MAY ALIAS i_ar / i_ra): an index into the
+ * searched cloud per query, e.g. last iteration's answer; it only seeds the search radius (default: the point with
+ * the query's own index), any value gives the exact result. */
+int geoa3_grid_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                        const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, void* stream);
+
 /* General K (1..GEOA3_KNN_MAX_K): dists/idx [B,Nq,K] ascending by (distance, index).
  * `prior` (optional, [B,Nq,K], int32, K DISTINCT valid indices per query, e.g. the previous
  * iteration's result) only seeds the pruning radius; the result is exact for any prior.

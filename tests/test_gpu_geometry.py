@@ -263,3 +263,44 @@ def test_loss_utils_unequal_cloud_sizes(Na, Nr, k):
     np.testing.assert_allclose(c.detach().cpu().numpy(), want["curv"].numpy(), rtol=1e-4, atol=1e-8)
     c.sum().backward()
     np.testing.assert_allclose(a.grad.cpu().numpy(), gwant["curv"].numpy(), rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,Na,Nr,kind", [(3, 1024, 1024, "attack"), (2, 1024, 1024, "far"), (2, 300, 777, "attack"),
+                                          (2, 64, 64, "dup"), (1, 4096, 4096, "attack"), (2, 1024, 4096, "attack"),
+                                          (2, 1000, 1000, "line"), (2, 128, 128, "same"), (1, 2500, 2049, "far")])
+def test_grid_nn1_is_bit_identical_to_brute_force(ops, B, Na, Nr, kind):
+    """Uniform-grid search == all-pairs search, bit for bit: attack-like offsets, queries far outside the searched
+    cloud's bounding box, duplicates / exact ties, degenerate clouds (collinear, all points equal)."""
+    g = torch.Generator().manual_seed(Na * 7 + Nr)
+    ori, _ = O.make_synthetic_clouds(B, max(Na, Nr), seed=Na + Nr)
+    r = ori[:, :, :Nr].contiguous()
+    a = ori[:, :, :Na].contiguous() if Na <= Nr else ori[:, :, :Na].contiguous()
+    a = a + 0.03 * torch.randn(B, 3, Na, generator=g)
+    if kind == "far":
+        a[:, :, : Na // 2] += torch.tensor([3.0, -2.0, 0.5]).view(1, 3, 1)
+        a[:, :, 5] = 1e3
+    elif kind == "dup":
+        a[:, :, 1] = a[:, :, 0]
+        r[:, :, 7] = r[:, :, 3]
+        a[:, :, 9] = r[:, :, 11]
+    elif kind == "line":
+        r[:, 1:, :] = 0.25
+        a[:, 2, :] = 0.25
+    elif kind == "same":
+        r[:] = r[:, :, :1]
+        a[:, :, ::2] = r[:, :, :1]
+    want = ops.nn1_pair(dev(a), dev(r))
+    got = ops.nn1_pair(dev(a), dev(r), method="grid")
+    for w, x in zip(want, got):
+        assert torch.equal(w, x)
+    d_ao, i_ao = O.knn_points(a.permute(0, 2, 1), r.permute(0, 2, 1), 1)
+    assert torch.equal(got[1].cpu().long(), i_ao[:, :, 0]) and torch.equal(got[0].cpu(), d_ao[:, :, 0])
+    one = ops.nn1_pair(dev(a), dev(r), both=False, method="grid")
+    assert one[2] is None and torch.equal(one[0], want[0]) and torch.equal(one[1], want[1])
+    # any prior (exact answers, garbage, out-of-range indices) only changes the work, never the result
+    for prior in ((want[1].clone(), want[3].clone()),
+                  (torch.randint(0, Nr, (B, Na), generator=g).int().cuda(), torch.randint(0, Na, (B, Nr), generator=g).int().cuda()),
+                  (torch.full((B, Na), 10 ** 6).int().cuda(), torch.full((B, Nr), -5).int().cuda())):
+        again = ops.nn1_pair(dev(a), dev(r), method="grid", prior=prior)
+        for w, x in zip(want, again):
+            assert torch.equal(w, x)

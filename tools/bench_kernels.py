@@ -40,6 +40,10 @@ def main():
     adv = (ori + 0.01 * torch.randn(B, 3, N, generator=g).cuda()).contiguous()
     res = {}
     res["nn1_pair_us"] = timeit(lambda: ops.nn1_pair(adv, ori), a.iters)
+    res["nn1_grid_us"] = timeit(lambda: ops.nn1_pair(adv, ori, method="grid"), a.iters)
+    far = (ori + 0.3 * torch.randn(B, 3, N, generator=g).cuda()).contiguous()
+    res["nn1_pair_far_us"] = timeit(lambda: ops.nn1_pair(far, ori), a.iters)
+    res["nn1_grid_far_us"] = timeit(lambda: ops.nn1_pair(far, ori, method="grid"), a.iters)
     flops = 8.0 * B * N * N
     res["nn1_pair_alg_GBps"] = 40.0 * B * N / res["nn1_pair_us"] / 1e3
     res["nn1_pair_valu_frac"] = flops / (res["nn1_pair_us"] * 1e-6) / 157.3e12
