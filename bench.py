@@ -218,7 +218,8 @@ def main():
             out["roofline"] = None
         if nn1_ms:
             cd_bytes = 40.0 * B * NPOINT
-            out["cd_kernel"] = {"kernel": "nn1_pair_kernel (1-NN both directions)", "avg_launch_us": round(nn1_ms * 1e3, 2),
+            out["cd_kernel"] = {"kernel": "grid_nn1_kernel (1-NN both directions, uniform-grid search; all-pairs "
+                                          "nn1_pair_kernel beyond 4096 points)", "avg_launch_us": round(nn1_ms * 1e3, 2),
                                 "hbm_GBps_algorithmic": round(cd_bytes / (nn1_ms * 1e-3) / 1e9, 2),
                                 "hbm_frac": round(cd_bytes / (nn1_ms * 1e-3) / PEAK_HBM, 5),
                                 "valu_frac": round(8.0 * B * NPOINT * NPOINT / (nn1_ms * 1e-3) / 157.3e12, 4)}
