@@ -40,6 +40,11 @@ class PointNetWeights(C.Structure):
         "f1", "fb1", "f2", "fb2", "f3", "fb3", "f1t", "f2t", "f3t")]
 
 
+class Sa1Weights(C.Structure):
+    """struct geoa3_sa1_weights"""
+    _fields_ = [(n, vp) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
+
+
 class AttackState(C.Structure):
     """struct geoa3_attack_state"""
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("classes", C.c_int32), ("targeted", C.c_int32),
@@ -82,6 +87,9 @@ SIGNATURES = {
     "geoa3_pn2_relu_grad": (C.c_int, [vp, vp, vp, C.c_long, vp]),
     "geoa3_pn2_bias_relu_max": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, C.c_int, vp, vp, vp]),
     "geoa3_pn2_bias_relu_max_grad": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_long, C.c_int, vp, vp]),
+    "geoa3_pn2_sa1_forward": (C.c_int, [vp, vp, vp, C.POINTER(Sa1Weights), C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "geoa3_pn2_sa1_backward": (C.c_int, [vp, vp, vp, C.POINTER(Sa1Weights), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
+                                         vp, vp]),
     "geoa3_fps_sample": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "geoa3_knn_normal": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_local_frames": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),

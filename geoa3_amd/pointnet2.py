@@ -279,6 +279,57 @@ def run_shared_mlp(mlp: nn.Sequential, x: Tensor, fuse_max: bool = False) -> Ten
     return h.view(B, -1, M, S)
 
 
+def _fold_triples(mlp: nn.Sequential):
+    """[(W [Co,Ci] with the BatchNorm scale folded in, shift [Co])] of an eval-mode build_shared_mlp stack, or None
+    when the stack is not Conv2d 1x1 (no bias) + eval BatchNorm2d + ReLU triples."""
+    layers = list(mlp)
+    if len(layers) % 3 != 0:
+        return None
+    out = []
+    for i in range(0, len(layers), 3):
+        conv, bn, act = layers[i], layers[i + 1], layers[i + 2]
+        if not (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.bias is None and
+                isinstance(bn, nn.BatchNorm2d) and not bn.training and isinstance(act, nn.ReLU)):
+            return None
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        out.append(((conv.weight.view(conv.out_channels, conv.in_channels) * scale.view(-1, 1)).float().contiguous(),
+                    (bn.bias - bn.running_mean * scale).float().contiguous()))
+    return out
+
+
+class _SA1Fused(torch.autograd.Function):
+    """geoa3_pn2_sa1_forward / _backward: grouped xyz -> MLP 3->64->64->128 -> max over 64 samples, one wavefront per
+    centroid, no activation in memory (pointnet2_sa.hip).  Differentiable in xyz and new_xyz (input-gradient only:
+    the attack never needs weight gradients)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, idx, w1, b1, w2, b2, w3, b3):
+        B, N, _ = xyz.shape
+        M = new_xyz.shape[1]
+        xyz, new_xyz = _chk(xyz.contiguous(), torch.float32), _chk(new_xyz.contiguous(), torch.float32)
+        out = torch.empty(B, M, 128, device=xyz.device, dtype=torch.float32)    # centroid-major rows
+        arg = torch.empty(B, M, 128, device=xyz.device, dtype=torch.uint8)
+        ws = _lib.Sa1Weights(*[t.data_ptr() for t in (w1, b1, w2, b2, w3, b3)])
+        check(_lib.load().geoa3_pn2_sa1_forward(xyz.data_ptr(), new_xyz.data_ptr(), _chk(idx, torch.int32).data_ptr(),
+                                                ws, B, N, M, out.data_ptr(), arg.data_ptr(), _s()), "sa1_forward")
+        ctx.save_for_backward(xyz, new_xyz, idx, out, arg, w1, b1, w2, b2, w3, b3)
+        return out.transpose(1, 2).contiguous()                                  # [B,128,M] as the reference
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz, new_xyz, idx, out, arg, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
+        B, N, _ = xyz.shape
+        M = new_xyz.shape[1]
+        gx = torch.empty_like(xyz)
+        gn = torch.empty_like(new_xyz)
+        ws = _lib.Sa1Weights(*[t.data_ptr() for t in (w1, b1, w2, b2, w3, b3)])
+        check(_lib.load().geoa3_pn2_sa1_backward(xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), ws, B, N, M,
+                                                 out.data_ptr(), arg.data_ptr(),
+                                                 g.transpose(1, 2).contiguous().data_ptr(),
+                                                 gx.data_ptr(), gn.data_ptr(), _s()), "sa1_backward")
+        return gx, gn, None, None, None, None, None, None, None
+
+
 class PointnetSAModuleMSG(nn.Module):
     def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True):
         super().__init__()
@@ -301,8 +352,27 @@ class PointnetSAModuleMSG(nn.Module):
             new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
+            fused = self._fused_level1(grouper, mlp, xyz, new_xyz, features)
+            if fused is not None:
+                outs.append(fused)
+                continue
             outs.append(run_shared_mlp(mlp, grouper(xyz, new_xyz, features), fuse_max=True))   # [B, C, npoint]
         return new_xyz, torch.cat(outs, dim=1)
+
+    fuse_level1 = True   # class-wide switch (tests compare the fused kernel with the layer-by-layer path)
+
+    def _fused_level1(self, grouper, mlp, xyz, new_xyz, features):
+        """The xyz-only 3->64->64->128 level with 64 samples per ball (SA_modules[0] of the SSG classifier) as ONE
+        kernel per direction; None when this level has another shape, is training, or keeps weight gradients."""
+        if not (self.fuse_level1 and features is None and isinstance(grouper, QueryAndGroup) and grouper.use_xyz and
+                grouper.nsample == 64 and xyz.is_cuda and not any(p.requires_grad for p in mlp.parameters())):
+            return None
+        folded = _fold_triples(mlp)
+        if folded is None or [tuple(w.shape) for w, _ in folded] != [(64, 3), (64, 64), (128, 64)]:
+            return None
+        idx = ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+        (w1, b1), (w2, b2), (w3, b3) = folded
+        return _SA1Fused.apply(xyz, new_xyz, idx, w1, b1, w2, b2, w3, b3)
 
 
 class PointnetSAModule(PointnetSAModuleMSG):

@@ -281,6 +281,25 @@ int geoa3_pn2_bias_relu_max(const float* z, const float* shift, int B, int C, lo
 int geoa3_pn2_bias_relu_max_grad(const float* g, const float* out, const int32_t* arg, int B, int C, long M, int S,
                                  float* dz, void* stream);
 
+/* First set-abstraction level of the SSG classifier, fused (PointNetPP_ssg.py:58-66: npoint 512, radius 0.2, nsample 64,
+ * mlp [3, 64, 64, 128]; pointnet2_modules.py:29-74, pointnet2_utils.py:296-333): grouped xyz (xyz[idx] - new_xyz) ->
+ * three Conv2d 1x1 + eval BatchNorm2d (folded into w / shift b by the host) + ReLU -> max over the 64 samples.
+ * xyz [B,N,3], new_xyz [B,M,3] point-major as in the reference; idx [B,M,64] from geoa3_pn2_ball_query;
+ * out [B,M,128] CENTROID-major (one contiguous 512-byte row per centroid; the caller transposes to the reference's
+ * [B,128,M]); arg [B,M,128] (u8: the arg-max sample, first on ties like F.max_pool2d) is what backward needs. */
+typedef struct geoa3_sa1_weights {
+  const float *w1, *b1;   /* [64,3],   [64]  */
+  const float *w2, *b2;   /* [64,64],  [64]  */
+  const float *w3, *b3;   /* [128,64], [128] */
+} geoa3_sa1_weights;
+int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B,
+                          int N, int M, float* out, uint8_t* arg, void* stream);
+/* grad_xyz [B,N,3] (zeroed here, scatter-add over idx) and grad_new_xyz [B,M,3] (= minus the per-centroid sum) from
+ * grad_out [B,M,128] (same layout as out); the hidden activations are recomputed, not stored. */
+int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B,
+                           int N, int M, const float* out, const uint8_t* arg, const float* grad_out, float* grad_xyz,
+                           float* grad_new_xyz, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense-cloud attack path, point-removal defence and smoothness measurement.
  * ------------------------------------------------------------------------------------------ */
