@@ -16,7 +16,8 @@
 
 namespace {
 
-constexpr int SA_T = 256;          // 4 wavefronts per workgroup, one centroid each per round
+constexpr int SA_TF = 256;         // forward: 4 wavefronts per workgroup (6 waves / 3 per SIMD measured slower)
+constexpr int SA_TB = 256;         // backward: 4 wavefronts (256 VGPRs: 2 waves/SIMD)
 constexpr int SA_P = 65;           // LDS pitch of the 64-wide weight rows (bank-conflict-free column reads)
 constexpr int SA_S = 64;           // samples per centroid
 
@@ -26,9 +27,9 @@ struct Sa1Lds {
   float* b2;   // [64]
   float* w3;   // [128][SA_P]
   float* b3;   // [128]
-  float* scratch;   // [4 waves][256]
+  float* scratch;   // [waves][256]
 };
-constexpr int SA1_LDS_FLOATS = 64 * 4 + 64 * SA_P + 64 + 128 * SA_P + 128 + 4 * 256;
+constexpr int sa1_lds_floats(int threads) { return 64 * 4 + 64 * SA_P + 64 + 128 * SA_P + 128 + (threads / 64) * 256; }
 
 __device__ __forceinline__ Sa1Lds sa1_carve(float* sm) {
   Sa1Lds L;
@@ -41,6 +42,7 @@ __device__ __forceinline__ Sa1Lds sa1_carve(float* sm) {
   return L;
 }
 
+template <int SA_T>
 __device__ __forceinline__ void sa1_stage(const geoa3_sa1_weights& w, const Sa1Lds& L) {
   const int tid = threadIdx.x;
   for (int e = tid; e < 64; e += SA_T) {
@@ -106,17 +108,17 @@ __device__ __forceinline__ void sa1_hidden(const Sa1Lds& L, float px, float py, 
     }
 }
 
-__global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void sa1_fwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+__global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) void sa1_fwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                        const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
                                                        int M, float* __restrict__ out, uint8_t* __restrict__ arg) {
   extern __shared__ __attribute__((aligned(16))) float sa_sm[];
   const Sa1Lds L = sa1_carve(sa_sm);
-  sa1_stage(w, L);
+  sa1_stage<SA_TF>(w, L);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* s_o = L.scratch + wave * 256;                       // [128] pooled outputs of this wave's centroid
   int* s_a = reinterpret_cast<int*>(s_o + 128);              // [128] their arg-max samples
   const long total = (long)B * M;
-  for (long c = (long)blockIdx.x * 4 + wave; c < total; c += (long)gridDim.x * 4) {
+  for (long c = (long)blockIdx.x * (SA_TF / 64) + wave; c < total; c += (long)gridDim.x * (SA_TF / 64)) {
     asm volatile("" ::: "memory");   // the weights stay in LDS: no hoisting of their loads out of the centroid loop
     const int b = (int)(c / M);
     const int i = idx[c * SA_S + lane];
@@ -176,19 +178,19 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
 }
 
-__global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void sa1_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+__global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void sa1_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                        const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
                                                        int M, const float* __restrict__ out,
                                                        const uint8_t* __restrict__ arg, const float* __restrict__ g,
                                                        float* __restrict__ dxyz, float* __restrict__ dnew) {
   extern __shared__ __attribute__((aligned(16))) float sa_sm[];
   const Sa1Lds L = sa1_carve(sa_sm);
-  sa1_stage(w, L);
+  sa1_stage<SA_TB>(w, L);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
   float* s_gz = L.scratch + wave * 256;                       // [128] pooled gradient through the output relu
   int* s_arg = reinterpret_cast<int*>(s_gz + 128);            // [128] arg-max sample of every channel
   const long total = (long)B * M;
-  for (long c = (long)blockIdx.x * 4 + wave; c < total; c += (long)gridDim.x * 4) {
+  for (long c = (long)blockIdx.x * (SA_TB / 64) + wave; c < total; c += (long)gridDim.x * (SA_TB / 64)) {
     asm volatile("" ::: "memory");   // the weights stay in LDS: no hoisting of their loads out of the centroid loop
     const int b = (int)(c / M);
     const int i = idx[c * SA_S + lane];
@@ -305,9 +307,9 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
 }
 
-int sa1_grid(int B, int M) {
-  const long groups = ((long)B * M + 3) / 4;
-  return (int)(groups < 256 * 2 ? groups : 256 * 2);   // persistent: 2 workgroups of 4 waves per CU (56 KB LDS each)
+int sa1_grid(int B, int M, int waves) {
+  const long groups = ((long)B * M + waves - 1) / waves;
+  return (int)(groups < 256 * 2 ? groups : 256 * 2);   // persistent: 2 workgroups per CU (56-58 KB LDS each)
 }
 
 }  // namespace
@@ -316,10 +318,10 @@ extern "C" int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, con
                                      const geoa3_sa1_weights* w, int B, int N, int M, float* out, uint8_t* arg,
                                      void* stream) {
   if (!xyz || !new_xyz || !idx || !w || !out || !arg || B <= 0 || N <= 0 || M <= 0) return GEOA3_EINVAL;
-  const size_t lds = (size_t)SA1_LDS_FLOATS * sizeof(float);
+  const size_t lds = (size_t)sa1_lds_floats(SA_TF) * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  hipLaunchKernelGGL(sa1_fwd_kernel, dim3(sa1_grid(B, M)), dim3(SA_T), lds, geoa3_stream(stream), xyz, new_xyz, idx, *w,
+  hipLaunchKernelGGL(sa1_fwd_kernel, dim3(sa1_grid(B, M, SA_TF / 64)), dim3(SA_TF), lds, geoa3_stream(stream), xyz, new_xyz, idx, *w,
                      B, N, M, out, arg);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
@@ -334,10 +336,10 @@ extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, co
     return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
   if (hipMemsetAsync(grad_xyz, 0, (size_t)B * N * 3 * sizeof(float), s) != hipSuccess) return GEOA3_ELAUNCH;
-  const size_t lds = (size_t)SA1_LDS_FLOATS * sizeof(float);
+  const size_t lds = (size_t)sa1_lds_floats(SA_TB) * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  hipLaunchKernelGGL(sa1_bwd_kernel, dim3(sa1_grid(B, M)), dim3(SA_T), lds, s, xyz, new_xyz, idx, *w, B, N, M, out, arg,
+  hipLaunchKernelGGL(sa1_bwd_kernel, dim3(sa1_grid(B, M, SA_TB / 64)), dim3(SA_TB), lds, s, xyz, new_xyz, idx, *w, B, N, M, out, arg,
                      grad_out, grad_xyz, grad_new_xyz);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
