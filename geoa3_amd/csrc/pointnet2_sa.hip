@@ -115,8 +115,6 @@ __global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   const Sa1Lds L = sa1_carve(sa_sm);
   sa1_stage<SA_TF>(w, L);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* s_o = L.scratch + wave * 256;                       // [128] pooled outputs of this wave's centroid
-  int* s_a = reinterpret_cast<int*>(s_o + 128);              // [128] their arg-max samples
   const long total = (long)B * M;
   for (long c = (long)blockIdx.x * (SA_TF / 64) + wave; c < total; c += (long)gridDim.x * (SA_TF / 64)) {
     asm volatile("" ::: "memory");   // the weights stay in LDS: no hoisting of their loads out of the centroid loop
@@ -130,6 +128,9 @@ __global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     sa1_hidden(L, px, py, pz, lane, h2, m1lo, m1hi);
 #pragma unroll 1
     for (int t3 = 0; t3 < 4; ++t3) {
+      // layer 3 TRANSPOSED: the layer-2 registers go in as the A operand (rows = samples), the weights as B (columns =
+      // channels), so a lane ends up with ONE channel and 32 of its samples in registers: the max over samples is
+      // lane-local plus one exchange between the register halves instead of a 32-lane shuffle reduction per register
       f32x16 a3[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -142,39 +143,33 @@ __global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float a = wr[t * 32 + (r & 3) + 8 * (r >> 2)];
-          a3[0] = mfma32(a, h2[0][t][r], a3[0]);
-          a3[1] = mfma32(a, h2[1][t][r], a3[1]);
+          a3[0] = mfma32(h2[0][t][r], a, a3[0]);
+          a3[1] = mfma32(h2[1][t][r], a, a3[1]);
           if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
-      // max over the 64 samples (first maximal sample wins, as F.max_pool2d), then shift + relu
+      // a3[cb][r]: channel t3*32 + (lane&31), sample cb*32 + (r&3) + 8*(r>>2) + 4*(lane>>5); ascending sample order,
+      // strict > : the first maximal sample wins, as F.max_pool2d
+      float v = -__builtin_inff();
+      int smp = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = a3[0][r];
-        int col = lane & 31;
-        if (a3[1][r] > v) {
-          v = a3[1][r];
-          col += 32;
-        }
+      for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          const float ov = __shfl_xor(v, o, 64);
-          const int oc = __shfl_xor(col, o, 64);
-          const bool take = ov > v || (ov == v && oc < col);
-          v = take ? ov : v;
-          col = take ? oc : col;
+        for (int r = 0; r < 16; ++r) {
+          const bool gt = a3[cb][r] > v;
+          v = gt ? a3[cb][r] : v;
+          smp = gt ? cb * 32 + mfma_row(r, lane) : smp;
         }
-        if ((lane & 31) == 0) {
-          const int row = t3 * 32 + mfma_row(r, lane);
-          s_o[row] = fmaxf(v + L.b3[row], 0.f);
-          s_a[row] = col;
-        }
+      const float ov = __shfl_xor(v, 32, 64);
+      const int os = __shfl_xor(smp, 32, 64);
+      const bool take = ov > v || (ov == v && os < smp);
+      v = take ? ov : v;
+      smp = take ? os : smp;
+      if (lane < 32) {   // 128 contiguous bytes of the centroid's row of out_t [B,M,128]
+        const int ch = t3 * 32 + lane;
+        out[(size_t)c * 128 + ch] = fmaxf(v + L.b3[ch], 0.f);
+        arg[(size_t)c * 128 + ch] = (uint8_t)smp;
       }
     }
-    // one 512-byte row of out_t [B,M,128] per centroid (the wave's own LDS slots: no barrier needed)
-    const float2 ov = *reinterpret_cast<const float2*>(s_o + 2 * lane);
-    *reinterpret_cast<float2*>(out + (size_t)c * 128 + 2 * lane) = ov;
-    arg[(size_t)c * 128 + 2 * lane] = (uint8_t)s_a[2 * lane];
-    arg[(size_t)c * 128 + 2 * lane + 1] = (uint8_t)s_a[2 * lane + 1];
   }
 }
 
