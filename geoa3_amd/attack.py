@@ -41,7 +41,10 @@ class AttackRunner:
             if _cfg(cfg, flag, False):
                 raise NotImplementedError("--%s is outside the accelerated hot path (SURVEY 8f)" % flag)
         if _cfg(cfg, "uniform_loss_weight", 0.0) != 0:
-            raise NotImplementedError("uniform_loss is never used by the reference defaults (SURVEY 2, row 2)")
+            # the reference's uniform_loss (Lib/loss_utils.py:151-189) calls pointnet2_utils without importing it:
+            # --uniform_loss_weight != 0 dies with a NameError there (geoA3_attack.py:170)
+            raise NotImplementedError("uniform_loss cannot run in the reference either (NameError: pointnet2_utils "
+                                      "is never imported in Lib/loss_utils.py); default weight 0")
         if cfg.dis_loss_type == "L2" and cfg.hd_loss_weight != 0:
             raise AssertionError("L2 distance needs hd_loss_weight == 0")  # geoA3_attack.py:140
         if cfg.optim not in ("adam", "sgd"):
