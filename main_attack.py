@@ -147,9 +147,15 @@ def main(cfg):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
+    local_rank = local_rank % ndev                          # several ranks may share a GPU in a functional test
     if world > 1 and not dist.is_initialized():
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GEOA3_DIST_BACKEND", "nccl")   # "gloo": functional test of the sharded path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     targeted = cfg.attack_label != "Untarget"
     say = (lambda *a: None) if (cfg.quiet or rank != 0) else print
