@@ -26,8 +26,6 @@ from .pointnet import PointNet
 
 Tensor = torch.Tensor
 
-_UNSUPPORTED = ("is_partial_var",)
-
 
 def _cfg(cfg, name, default):
     return getattr(cfg, name, default)
@@ -37,9 +35,6 @@ class AttackRunner:
     """Owns the device state of one batch of b attacks in flight and enqueues the loop."""
 
     def __init__(self, net: PointNet, b: int, n: int, cfg, device, global_batch: Optional[int] = None):
-        for flag in _UNSUPPORTED:
-            if _cfg(cfg, flag, False):
-                raise NotImplementedError("--%s is outside the accelerated hot path (SURVEY 8f)" % flag)
         if _cfg(cfg, "uniform_loss_weight", 0.0) != 0:
             # the reference's uniform_loss (Lib/loss_utils.py:151-189) calls pointnet2_utils without importing it:
             # --uniform_loss_weight != 0 dies with a NameError there (geoA3_attack.py:170)
@@ -77,7 +72,11 @@ class AttackRunner:
         # Dense-cloud path (geoA3_attack.py:283-296): the offset lives on all n points, the objective sees the
         # farthest-point sample of cfg.npoint of them, success is a vote over eval_num resamplings.
         self.npoint = int(_cfg(cfg, "npoint", n))
-        self.sub = bool(_cfg(cfg, "is_subsample_opt", False)) and n > self.npoint
+        # --is_partial_var (geoA3_attack.py:239-262): a [b,3,knn_range] offset on the neighbours of one random clean
+        # point, re-drawn (with a fresh optimiser) every 50 steps on top of the iterate reached so far
+        self.partial = bool(_cfg(cfg, "is_partial_var", False))
+        self.kr = int(_cfg(cfg, "knn_range", 3))
+        self.sub = bool(_cfg(cfg, "is_subsample_opt", False)) and n > self.npoint and not self.partial
         self.ne = self.npoint if self.sub else n          # points the objective is evaluated on
         self.eval_num = int(_cfg(cfg, "eval_num", 1))
         if self.sub and not 1 <= self.eval_num <= 64:
@@ -105,6 +104,9 @@ class AttackRunner:
             t["sub_idx"] = torch.zeros(b, ne, **i32)
             t["vote_idx"], t["vote_pts"] = torch.zeros(b * E, ne, **i32), z(b * E, 3, ne)
             t["vote_logits"] = z(b * E, self.classes)
+        if self.partial:
+            t["part"], t["pm"], t["pv"] = z(b, 3, self.kr), z(b, 3, self.kr), z(b, 3, self.kr)
+            t["pidx"], t["periodical"] = torch.zeros(b, self.kr, **i32), z(b, 3, n)
         if self.jitter:
             t["noise"], t["x_eval"] = z(b, 3, ne), z(b, 3, ne)
             if not self.sub:
@@ -178,8 +180,10 @@ class AttackRunner:
             loss_n=self._p(t["loss_n"]), loss_hist=self._p(t["loss_hist"]), last_label=self._p(t["last_label"]))
 
     # ------------------------------------------------------------------------------------
-    def begin_search_step(self, init_offset: Tensor):
+    def begin_search_step(self, init_offset: Optional[Tensor]):
         t = self.t
+        if self.partial:   # the offset is drawn inside the loop (every 50 steps): start from the clean cloud
+            init_offset = torch.zeros(self.b, 3, self.n, device=self.dev)
         init = init_offset.to(self.dev, torch.float32).contiguous()
         s = torch.cuda.current_stream().cuda_stream
         check(self.lib.geoa3_attack_begin_search_step(C.byref(self.state), self._p(self.ori), self._p(init),
@@ -203,6 +207,20 @@ class AttackRunner:
         s = torch.cuda.current_stream().cuda_stream
         st = C.byref(self.state)
         x = t["x"]                      # the full iterate pc_ori + offset, [b,3,n]
+        if self.partial and step % 50 == 0:   # geoA3_attack.py:240-262
+            hook = self.hooks.get("partial_points")
+            p0 = int(hook(search_step, step)) if hook else int(np.random.randint(self.n))
+            _, nbr = ops.knn_planar(self.ori[:, :, p0:p0 + 1].contiguous(), self.ori, self.kr + 1)
+            t["pidx"].copy_(nbr[:, 0, 1:])
+            hook = self.hooks.get("partial_inits")
+            t["part"].copy_(hook(search_step, step) if hook else torch.randn(self.b, 3, self.kr, device=self.dev) * 1e-3)
+            t["pm"].zero_()
+            t["pv"].zero_()
+            t["periodical"].copy_(x)    # the iterate of the last forward (its optimiser step is dropped, as :259-262)
+            check(lib.geoa3_attack_partial_step(st, None, None, t["pidx"].data_ptr(), self.kr,
+                                                t["periodical"].data_ptr(), t["part"].data_ptr(), None, None,
+                                                x.data_ptr(), -1, 0.0, 1.0, 0.0, 0, s), "attack_partial_step")
+            self.part_t = 0
         xe, ne = x, self.ne             # what the objective is evaluated on, [b,3,ne]
         vote_logits = None
         if self.sub:
@@ -313,6 +331,19 @@ class AttackRunner:
                                                            ne, t[dst].data_ptr(), s), "gather_points_grad")
             g_cls = t["g_cls_full"] if g_cls is not None else None
             g_geo = t["g_geo_full"] if g_geo is not None else None
+        if self.partial:
+            self.part_t += 1
+            if (step + 1) % 50 != 0:    # the step before a re-draw is never used (periodical_pc = input_all, :260)
+                lr = cfg.lr * (0.9990 ** (self.part_t - 1) if _cfg(cfg, "is_use_lr_scheduler", False) else 1.0)
+                if cfg.optim == "adam":
+                    args = (0, lr / (1.0 - 0.9 ** self.part_t), math.sqrt(1.0 - 0.999 ** self.part_t), 0.0, 0)
+                else:
+                    args = (1, lr, 1.0, 0.9, int(self.part_t == 1))
+                check(lib.geoa3_attack_partial_step(st, self._p(g_cls), self._p(g_geo), t["pidx"].data_ptr(), self.kr,
+                                                    t["periodical"].data_ptr(), t["part"].data_ptr(),
+                                                    t["pm"].data_ptr(), t["pv"].data_ptr(), x.data_ptr(), *args, s),
+                      "attack_partial_step")
+            return   # the projections / lp_clip act on a padded copy in the reference: no effect (:341-352)
         pro_grad = bool(_cfg(cfg, "is_pro_grad", False))
         # optimiser scalars in double, as torch.optim.Adam forms them
         lr = cfg.lr * (0.9990 ** step if _cfg(cfg, "is_use_lr_scheduler", False) else 1.0)
@@ -369,11 +400,15 @@ class AttackRunner:
             on_step: Optional[Callable[[int, int], None]] = None, hooks: Optional[dict] = None):
         """hooks (parity runs): the reference's random draws as inputs -- sub_starts(search_step, step) -> [b],
         vote_starts(search_step, step) -> [b, eval_num] (torch.randint of farthest_points_sample),
-        jitter_aux(search_step, step) -> (aux1, aux2) [b,ne] or jitter_noise(search_step, step, x) -> [b,3,ne]."""
+        jitter_aux(search_step, step) -> (aux1, aux2) [b,ne] or jitter_noise(search_step, step, x) -> [b,3,ne];
+        partial_points(search_step, step) -> int (np.random.randint) and partial_inits(search_step, step) ->
+        [b,3,knn_range] (nn.init.normal_) for --is_partial_var."""
         cfg = self.cfg
         self.hooks = dict(hooks or {})
         for search_step in range(int(cfg.binary_max_steps)):
-            if init_offsets is not None:
+            if self.partial:
+                init = None
+            elif init_offsets is not None:
                 init = init_offsets[search_step]
             else:  # nn.init.normal_(offset, mean=0, std=1e-3), geoA3_attack.py:264-266
                 init = torch.randn(self.b, 3, self.n, device=self.dev) * 1e-3

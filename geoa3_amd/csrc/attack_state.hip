@@ -276,7 +276,60 @@ __global__ __launch_bounds__(256) void begin_search_step_kernel(geoa3_attack_sta
   }
 }
 
+// --is_partial_var (geoA3_attack.py:239-262,278-281): the optimised variable is a [B,3,kr] offset on kr points of every
+// instance.  One thread per (instance, point): gather the full gradient, optimiser step, x = periodical + offset there.
+__global__ __launch_bounds__(256) void attack_partial_kernel(int B, int N, int kr, const float* __restrict__ scale_const,
+                                                             float inv_global_batch, const float* __restrict__ g_cls,
+                                                             const float* __restrict__ g_geo,
+                                                             const int32_t* __restrict__ pidx,
+                                                             const float* __restrict__ periodical,
+                                                             float* __restrict__ part, float* __restrict__ pm,
+                                                             float* __restrict__ pv, float* __restrict__ x, int optim,
+                                                             float step_size, float sqrt_bc2, float momentum, int first) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= B * kr) return;
+  const int b = p / kr, j = p - b * kr;
+  const int i = pidx[p];
+  const float cg = g_geo ? scale_const[b] * inv_global_batch : 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t e = ((size_t)b * 3 + c) * N + i, pe = ((size_t)b * 3 + c) * kr + j;
+    float w = part[pe];
+    if (optim >= 0) {
+      float g = g_cls ? g_cls[e] : 0.f;
+      if (g_geo) g += cg * g_geo[e];
+      if (optim == 0) {   // torch.optim.Adam defaults
+        const float m = pm[pe] * 0.9f + g * (1.0f - 0.9f);
+        const float v = pv[pe] * 0.999f + (g * g) * (1.0f - 0.999f);
+        pm[pe] = m;
+        pv[pe] = v;
+        w = w - step_size * (m / (sqrtf(v) / sqrt_bc2 + 1e-8f));
+      } else {            // torch.optim.SGD(momentum), geoA3_attack.py:252: buf = g at the first step
+        const float buf = first ? g : pm[pe] * momentum + g;
+        pm[pe] = buf;
+        w = w - step_size * buf;
+      }
+      part[pe] = w;
+    }
+    x[e] = periodical[e] + w;
+  }
+}
+
 }  // namespace
+
+extern "C" int geoa3_attack_partial_step(const geoa3_attack_state* st, const float* g_cls, const float* g_geo,
+                                         const int32_t* pidx, int kr, const float* periodical, float* part, float* pm,
+                                         float* pv, float* x, int optim, float step_size, float sqrt_bc2, float momentum,
+                                         int first, void* stream) {
+  if (!st || !pidx || !periodical || !part || !x || kr <= 0 || optim < -1 || optim > 1) return GEOA3_EINVAL;
+  if (optim >= 0 && (!pm || (optim == 0 && !pv))) return GEOA3_EINVAL;
+  const int total = st->B * kr;
+  hipLaunchKernelGGL(attack_partial_kernel, dim3((total + 255) / 256), dim3(256), 0, geoa3_stream(stream), st->B, st->N,
+                     kr, st->scale_const, st->inv_global_batch, g_cls, g_geo, pidx, periodical, part, pm, pv, x, optim,
+                     step_size, sqrt_bc2, momentum, first);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
 
 extern "C" int geoa3_attack_head(const geoa3_attack_state* st, const float* logits, const float* constrain,
                                  const float* x, int step, int search_step, float* dlogits, void* stream) {

@@ -225,6 +225,14 @@ int geoa3_attack_update(const geoa3_attack_state* st, const float* g_cls, const 
                         const float* ori, float* offset, float* adam_m, float* adam_v, float* x,
                         int optim, float step_size, float sqrt_bc2, float cc_linf, void* stream);
 
+/* --is_partial_var (geoA3_attack.py:239-262,278-281, Lib/utility.py:211-216): the optimised variable is `part`
+ * [B,3,kr] on the kr points pidx [B,kr] of every instance, x = periodical + pad(part).  optim -1: only writes
+ * x[:, :, pidx] = periodical + part (after a re-draw); 0: Adam step (scalars as geoa3_attack_update); 1: SGD with
+ * `momentum` (first != 0: the momentum buffer pm is initialised with the gradient, torch.optim.SGD). */
+int geoa3_attack_partial_step(const geoa3_attack_state* st, const float* g_cls, const float* g_geo, const int32_t* pidx,
+                              int kr, const float* periodical, float* part, float* pm, float* pv, float* x, int optim,
+                              float step_size, float sqrt_bc2, float momentum, int first, void* stream);
+
 /* The flag-gated projections that follow the optimiser step (--is_pro_grad / --is_real_offset,
  * geoA3_attack.py:59-85,341-347), one point per thread.
  *   mode 0 (find_offset, :79-85):  offset = x - ori[:, nn[b,i]]            (nn = nearest original of x)

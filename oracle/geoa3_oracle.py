@@ -331,6 +331,8 @@ class AttackCfg:
         self.jitter_k = 16
         self.jitter_sigma = 0.01
         self.jitter_clip = 0.05
+        self.is_partial_var = False
+        self.knn_range = 3
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -408,7 +410,7 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
            init_offsets: Sequence[Tensor], loss_divisor: Optional[int] = None,
            last_label_override: Optional[Sequence[int]] = None, last_label_hook=None,
            faithful_success_check: bool = False, trace: Optional[dict] = None,
-           sub_starts=None, vote_starts=None, jitter_noise=None):
+           sub_starts=None, vote_starts=None, jitter_noise=None, partial_points=None, partial_inits=None):
     """attack() (geoA3_attack.py:182-386) on already-unpacked [b,3,N] inputs.
 
     init_offsets[s] is the step-0 offset of binary step s (the reference draws it with
@@ -427,7 +429,13 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
     resamplings; the reference's torch.randint start indices are inputs: sub_starts(s, step) -> int64 [b],
     vote_starts(s, step) -> int64 [b, eval_num].  --is_pre_jitter_input (geoA3_attack.py:312-317):
     jitter_noise(s, step, x_cur) -> [b,3,m] is called every calculate_project_jitter_noise_iter steps (the
-    reference's estimate_perpendicular with its randn draws) and the objective is evaluated at x_cur + noise."""
+    reference's estimate_perpendicular with its randn draws) and the objective is evaluated at x_cur + noise.
+
+    --is_partial_var (geoA3_attack.py:239-262,278-281): every 50 steps a fresh [b,3,knn_range] offset on the
+    knn_range nearest clean neighbours of ONE random clean point (np.random.randint: partial_points(s, step) -> int;
+    nn.init.normal_: partial_inits(s, step) -> [b,3,knn_range]) with a fresh optimiser (Adam, or SGD with momentum
+    0.9), on top of the iterate reached so far; init_offsets is not used.  The projections / lp_clip act on the
+    padded copy only and therefore change nothing (geoA3_attack.py:341-352 assign to offset.data of a non-leaf)."""
     from . import aux_oracle as A
     targeted = cfg.attack_label != "Untarget"
     b, _, n = pc_ori.shape
@@ -450,15 +458,31 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
         iter_best_score = [-1] * b
         constrain = torch.ones(b) * 1e10
         output_label = -1
-        offset = init_offsets[s].clone().float().requires_grad_()
-        m = torch.zeros_like(offset)
-        v = torch.zeros_like(offset)
+        partial = bool(getattr(cfg, "is_partial_var", False))
+        if not partial:
+            offset = init_offsets[s].clone().float().requires_grad_()
+            m = torch.zeros_like(offset)
+            v = torch.zeros_like(offset)
+        x_prev = None
         lr = cfg.lr
         if trace is not None:
             trace["scale_const"].append(scale_const.clone())
         for step in range(cfg.iter_max_steps):
-            x = pc_ori + offset
-            sub = bool(getattr(cfg, "is_subsample_opt", False)) and n > cfg.npoint
+            if partial:
+                if step % 50 == 0:
+                    p0 = int(partial_points(s, step))
+                    _, nbr = knn_points(pc_ori[:, :, p0].unsqueeze(1), pc_ori.permute(0, 2, 1), cfg.knn_range + 1)
+                    nbr = nbr[:, 0, 1:]                                        # [b, knn_range]
+                    part = partial_inits(s, step).clone().float().requires_grad_()
+                    pm, pv, pt, pbuf = torch.zeros_like(part), torch.zeros_like(part), 0, None
+                    lr = cfg.lr
+                    periodical = x_prev.clone() if x_prev is not None else pc_ori.clone()
+                offset = torch.zeros(b, 3, n).scatter(2, nbr.unsqueeze(1).expand(b, 3, cfg.knn_range), part)
+                x = periodical + offset
+                x_prev = x.detach()
+            else:
+                x = pc_ori + offset
+            sub = bool(getattr(cfg, "is_subsample_opt", False)) and n > cfg.npoint and not partial
             if sub:   # geoA3_attack.py:283-284; the gather is differentiable, the selection is not
                 _, sel = A.farthest_points_sample(x.detach(), cfg.npoint, sub_starts(s, step))
                 x_cur = torch.gather(x, 2, sel.unsqueeze(1).expand(b, 3, cfg.npoint))
@@ -501,7 +525,20 @@ def attack(net, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Optional
             loss, loss_n, constrain = out[2], out[3], out[8]
             constrain = constrain.detach() if torch.is_tensor(constrain) else torch.zeros(b)
             all_loss[step] = loss_n.detach().tolist()
-            (grad,) = torch.autograd.grad(loss, offset)
+            (grad,) = torch.autograd.grad(loss, part if partial else offset)
+            if partial:   # fresh optimiser every 50 steps: Adam's step count restarts, SGD keeps a momentum buffer
+                with torch.no_grad():
+                    pt += 1
+                    if cfg.optim == "adam":
+                        adam_step(part, grad, pm, pv, pt, lr)
+                    elif cfg.optim == "sgd":
+                        pbuf = grad.clone() if pbuf is None else pbuf.mul_(0.9).add_(grad)
+                        part.add_(pbuf, alpha=-lr)
+                    else:
+                        raise AssertionError("Wrong optimizer!")
+                    if cfg.is_use_lr_scheduler:
+                        lr = lr * 0.9990
+                continue
             if trace is not None:
                 trace["offsets"].append(offset.detach().clone())
                 trace["loss_n"].append(loss_n.detach().clone())

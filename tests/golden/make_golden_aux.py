@@ -37,6 +37,10 @@ AUX_ATK_CASES = {
                             iter_max_steps=5, lr=0.002), 3, 160, 61),
     "subsample_vote1": (dict(is_subsample_opt=True, npoint=48, eval_num=1, curv_loss_knn=4, binary_max_steps=2,
                              iter_max_steps=4, lr=0.002, hd_loss_weight=0.0), 2, 96, 62),
+    "partial_var": (dict(is_partial_var=True, knn_range=3, curv_loss_knn=4, binary_max_steps=2, iter_max_steps=53,
+                         lr=0.01, npoint=64), 3, 64, 64),
+    "partial_var_sgd": (dict(is_partial_var=True, knn_range=5, optim="sgd", lr=0.05, is_use_lr_scheduler=True,
+                             curv_loss_knn=4, binary_max_steps=1, iter_max_steps=52, npoint=64), 2, 64, 65),
     "pre_jitter": (dict(is_pre_jitter_input=True, calculate_project_jitter_noise_iter=2, jitter_k=8,
                         jitter_sigma=0.01, jitter_clip=0.05, curv_loss_knn=4, binary_max_steps=1,
                         iter_max_steps=5, lr=0.002, npoint=64), 3, 64, 63),
@@ -197,11 +201,24 @@ def main():
         g = torch.Generator().manual_seed(seed + 1000)
         inits = [torch.randn(b, 3, n, generator=g) * 1e-3 for _ in range(cfg.binary_max_steps)]
         it = iter(inits)
+        part_inits, part_points = [], []
 
         def fake_normal_(t, mean=0.0, std=1.0):
             with torch.no_grad():
-                t.copy_(next(it))
+                if cfg.is_partial_var:      # a fresh [b,3,knn_range] draw every 50 steps (geoA3_attack.py:246-247)
+                    d = torch.randn(t.shape, generator=g) * std
+                    part_inits.append(d.clone())
+                    t.copy_(d)
+                else:
+                    t.copy_(next(it))
             return t
+
+        real_np_randint = np.random.randint
+
+        def fake_np_randint(*a, **k):
+            v = int(torch.randint(0, a[0], (1,), generator=g).item())
+            part_points.append(v)
+            return v
 
         real_normal_, real_fs, real_perp = nn.init.normal_, RA._forward_step, RA.estimate_perpendicular
         nn.init.normal_ = fake_normal_
@@ -219,6 +236,7 @@ def main():
             return r
 
         RA._forward_step, RA.estimate_perpendicular = fs_spy, perp_spy
+        np.random.randint = fake_np_randint
         data = [ori.permute(0, 2, 1).unsqueeze(1).contiguous(), nrm.permute(0, 2, 1).unsqueeze(1).contiguous(),
                 gt.view(b, 1)]
         so = sys.stdout
@@ -229,6 +247,7 @@ def main():
         finally:
             sys.stdout = so
             nn.init.normal_, RA._forward_step, RA.estimate_perpendicular = real_normal_, real_fs, real_perp
+            np.random.randint = real_np_randint
         pre = "atk/%s/" % tag
         out[pre + "ori"], out[pre + "nrm"], out[pre + "gt"] = t2n(ori), t2n(nrm), t2n(gt)
         out[pre + "inits"] = np.stack([t2n(t) for t in inits])
@@ -244,6 +263,9 @@ def main():
             out[pre + "sub_starts"] = np.stack([t2n(calls[i].view(-1)) for i in range(0, len(calls), per)])
             out[pre + "vote_starts"] = np.stack([np.stack([t2n(calls[i + 1 + k].view(-1)) for k in range(b)])
                                                  for i in range(0, len(calls), per)])
+        if cfg.is_partial_var:
+            out[pre + "part_inits"] = np.stack([t2n(t) for t in part_inits])
+            out[pre + "part_points"] = np.asarray(part_points, dtype=np.int64)
         if cfg.is_pre_jitter_input:
             out[pre + "noise"] = np.stack([t2n(t) for t in tr["noise"]])
             out[pre + "aux"] = np.stack([t2n(t) * cfg.jitter_sigma for t in d.randn_calls])

@@ -107,7 +107,13 @@ def _oracle_attack_case(aux, tag, jitter_from_golden=True):
                 return T(aux[pre + "noise"][j])
             return A.estimate_perpendicular(x, cfg.jitter_k, T(aux[pre + "aux"][2 * j]), T(aux[pre + "aux"][2 * j + 1]),
                                             cfg.jitter_clip)[0]
-    return cfg, (net, ori, nrm, gt, None, cfg, inits), dict(sub_starts=sub, vote_starts=vote, jitter_noise=jit)
+    pp = pi = None
+    if cfg.is_partial_var:   # one (point, init) draw per 50 steps, in run order
+        per = (iters + 49) // 50
+        pp = lambda s, step: int(aux[pre + "part_points"][s * per + step // 50])
+        pi = lambda s, step: T(aux[pre + "part_inits"][s * per + step // 50])
+    return cfg, (net, ori, nrm, gt, None, cfg, inits), dict(sub_starts=sub, vote_starts=vote, jitter_noise=jit,
+                                                            partial_points=pp, partial_inits=pi)
 
 
 @pytest.mark.parametrize("tag", list(AUX_ATK_CASES))
