@@ -8,6 +8,7 @@ namespace {
 
 struct Ws {  // workspace carve-up; every buffer starts on a 256-byte boundary
   // T-Net 3 (input transform)
+  unsigned long long* keys;   // [B][1024] packed running maxima of the 1024-wide layers (reused by all three)
   float *a1, *a2, *p3, *tf4, *tf5, *T3;
   int* i3;
   // trunk + T-Net 64 (feature transform)
@@ -32,6 +33,7 @@ Ws carve(void* base, int B, int N, int classes) {
   const size_t s64 = (size_t)B * 64 * N, s128 = (size_t)B * 128 * N, b = (size_t)B;
   w.a1 = (float*)take(s64);
   w.a2 = (float*)take(s128);
+  w.keys = (unsigned long long*)take(b * 1024 * 2);
   w.p3 = (float*)take(b * 1024);
   w.i3 = (int*)take(b * 1024);
   w.tf4 = (float*)take(b * 512);
@@ -110,9 +112,10 @@ int fc(const float* X, int K, const float* W, const float* bias, float* Y, int N
   return launch_fc(a, s);
 }
 
-int wide(const float* X, const float* W, const float* bias, float* out, int* arg, int taps, int B, int N,
-         hipStream_t s) {
+int wide(const float* X, const float* W, const float* bias, float* out, int* arg, unsigned long long* keys, int taps,
+         int B, int N, hipStream_t s) {
   WideArgs a{};
+  a.keys = keys;
   a.X = X; a.sXb = (long)128 * N; a.ldX = N;
   a.W = W; a.bias = bias; a.out = out; a.arg = arg;
   a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
@@ -131,9 +134,9 @@ int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, flo
 
 // transform_net.forward (Model/PointNet.py:78-87) after its first layer
 int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, float* act128, float* pooled, int* arg, float* f4,
-                  float* f5, float* T, int B, int N, hipStream_t s) {
+                  float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s) {
   TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s));
-  TRY(wide(act128, t.w3p, t.b3, pooled, arg, 1, B, N, s));
+  TRY(wide(act128, t.w3p, t.b3, pooled, arg, keys, 1, B, N, s));
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
   TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
   TRY(fc(f5, 256, t.f3, t.fb3, T, t.K * t.K, B, false, nullptr, s));
@@ -169,18 +172,18 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   const geoa3_pointnet_weights& p = *pw;
   // input transform (Model/PointNet.py:137-138)
   TRY(launch_conv_in3(x, nullptr, p.t3.w1, p.t3.b1, w.a1, B, N, s));
-  TRY(tnet_tail_fwd(p.t3, w.a1, w.a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, B, N, s));
+  TRY(tnet_tail_fwd(p.t3, w.a1, w.a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
   // trunk conv1, conv2 (:139-140)
   TRY(launch_conv_in3(x, w.T3, p.w1, p.b1, w.h1, B, N, s));
   TRY(conv(w.h1, 64, p.w2, p.b2, w.h2, 64, B, N, true, nullptr, false, s));
   // feature transform (:142-143)
   TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s));
-  TRY(tnet_tail_fwd(p.t64, w.c1, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, B, N, s));
+  TRY(tnet_tail_fwd(p.t64, w.c1, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
   TRY(transform64(w.h2, w.T64, w.h2p, true, B, N, s));
   // conv3, conv4, conv5 + max (:144-147)
   TRY(conv(w.h2p, 64, p.w3, p.b3, w.h3, 64, B, N, true, nullptr, false, s));
   TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s));
-  TRY(wide(w.h4, p.w5p, p.b5, w.p5, w.i5, 3, B, N, s));
+  TRY(wide(w.h4, p.w5p, p.b5, w.p5, w.i5, w.keys, 3, B, N, s));
   // classifier head (:150-152), dropout is the identity in eval mode
   TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));
   TRY(fc(w.f6, 512, p.f2, p.fb2, w.f7, 256, B, true, nullptr, s));

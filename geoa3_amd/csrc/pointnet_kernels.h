@@ -46,6 +46,7 @@ struct WideArgs {
   const float* W;                             // MFMA A-fragment order of [Co][TAPS*128] (pointnet_wide.hip)
   const float* bias;                          // [Co]
   float* out; int* arg;                       // [B][Co]
+  unsigned long long* keys;                   // [B][Co] scratch of the column-major kernel (packed running maxima)
   int Co, N, B, taps;
 };
 int launch_wide_max(const WideArgs& a, hipStream_t s);

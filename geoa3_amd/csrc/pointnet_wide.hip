@@ -8,6 +8,7 @@
 // deterministic gather-by-owner accumulation in LDS (no atomics).
 #include "pointnet_kernels.h"
 #include "profile.h"
+#include <cstdlib>
 
 namespace {
 
@@ -187,6 +188,141 @@ __global__ __launch_bounds__(WM_THREADS, OCC) void wide_max_kernel(WideArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Column-major form of the same layer.  A work unit is (instance, 64-point tile, half of the 1024 channels): the
+// activation tile [128 ci][64 + halo] is staged ONCE into LDS and serves four channel groups (each wave: 32 channels
+// per group, all of K in one sweep, no barrier inside), instead of being re-staged in K-chunks for every channel
+// group.  The MFMA runs with its operands swapped (activations as A, weights as B), so a lane ends up with ONE channel
+// and 32 of the tile's points in registers: the max over the tile is lane-local plus one exchange between the
+// register halves.  Tiles are combined through a 64-bit atomic max on (order-preserving value bits, ~point index) --
+// order independent, hence deterministic -- and a tiny second kernel decodes, adds the bias and applies the relu.
+// 8000 equal units over 768 resident workgroups balance to 97 % (the row-major form: 2000 units, 87 %).
+// ------------------------------------------------------------------------------------------
+constexpr int W2_COLS = 64;
+constexpr int W2_XP = W2_COLS + 2 * WM_HALO;     // 72
+constexpr int W2_GROUPS = 4;                     // channel groups of 128 per unit (half of the 1024 channels)
+
+__device__ __forceinline__ unsigned long long wide_key(float v, int col) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // order-preserving map of the float
+  return ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)col);   // ties: the LOWER point index wins
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(WM_THREADS, 3) void wide_max2_kernel(WideArgs a, int slots_per_xcd) {
+  constexpr int NGT = TAPS * 16;                 // fragment groups (8 k each) of one channel tile
+  constexpr int PF = 3;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [128][W2_XP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, l31 = lane & 31;
+  const int N = a.N, tiles = (N + W2_COLS - 1) / W2_COLS;
+  const int per_inst = tiles * 2;                                   // units of one instance
+  // XCD-aware static schedule: workgroup ids are dealt round-robin over the 8 XCDs; XCD x owns the instances
+  // b = x, x+8, ... and its slots walk that list of units with stride slots_per_xcd
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int inst_x = (a.B - xcd + 7) / 8;                           // instances owned by this XCD
+  const int units = inst_x * per_inst;
+  const bool xvec = (a.ldX & 3) == 0;
+  for (int u = slot; u < units; u += slots_per_xcd) {
+    const int q = u / per_inst, r = u - q * per_inst;
+    const int b = xcd + 8 * q, tile = r >> 1, half = r & 1;
+    const int n0 = tile * W2_COLS;
+    const float* X = a.X + (size_t)b * a.sXb;
+    __syncthreads();   // every wave is done with the previous tile
+    {
+      const bool interior = xvec && n0 >= WM_HALO && n0 + W2_COLS + WM_HALO <= N;
+      for (int e = tid; e < WM_CI * (W2_XP / 4); e += WM_THREADS) {
+        const int qd = e % (W2_XP / 4), c = e / (W2_XP / 4);
+        const int n = n0 - WM_HALO + qd * 4;
+        const float* src = X + (size_t)c * a.ldX;
+        float4 v;
+        if (interior || (n >= 0 && n + 3 < N && xvec)) {
+          v = *reinterpret_cast<const float4*>(src + n);
+        } else {
+          v.x = (n >= 0 && n < N) ? src[n] : 0.f;
+          v.y = (n + 1 >= 0 && n + 1 < N) ? src[n + 1] : 0.f;
+          v.z = (n + 2 >= 0 && n + 2 < N) ? src[n + 2] : 0.f;
+          v.w = (n + 3 >= 0 && n + 3 < N) ? src[n + 3] : 0.f;
+        }
+        *reinterpret_cast<float4*>(smem + c * W2_XP + qd * 4) = v;
+      }
+    }
+    __syncthreads();
+    const float* xb = smem + kh * 4 * W2_XP + WM_HALO + l31 - TAPS / 2;
+#pragma unroll 1
+    for (int g = 0; g < W2_GROUPS; ++g) {
+      const int co0 = (half * W2_GROUPS + g) * WM_CO + wave * 32;
+      const float4* Wp = reinterpret_cast<const float4*>(a.W) + (size_t)(co0 / 32) * NGT * 64 + lane;
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[0][i] = 0.f;
+        acc[1][i] = 0.f;
+      }
+      float4 wf[PF];
+#pragma unroll
+      for (int f = 0; f < PF; ++f) wf[f] = Wp[(size_t)f * 64];
+      float bq[8], bn[8];
+      auto read_b = [&](int f, float* d) {      // fragment group f = tap*16 + jj: rows 8jj + 4kh + i, column shift tap
+        const int tap = f >> 4, jj = f & 15;
+        const float* xp = xb + jj * 8 * W2_XP + tap;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[2 * i] = xp[i * W2_XP];
+          d[2 * i + 1] = xp[i * W2_XP + 32];
+        }
+      };
+      read_b(0, bq);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < NGT; ++f) {
+        const float4 w = wf[f % PF];
+        if (f + PF < NGT) wf[f % PF] = Wp[(size_t)(f + PF) * 64];
+        if (f + 1 < NGT) read_b(f + 1, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[0] = mfma32(bq[2 * i], wv[i], acc[0]);        // operands swapped: rows = points, columns = channels
+          acc[1] = mfma32(bq[2 * i + 1], wv[i], acc[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bq[i] = bn[i];
+      }
+      // lane: channel co0 + l31; acc[t][r]: point n0 + 32t + (r&3) + 8(r>>2) + 4kh.  Ascending point order, strict >
+      float v = -__builtin_inff();
+      int col = 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + 32 * t + mfma_row(r, lane);
+          const bool gt = n < N && acc[t][r] > v;
+          v = gt ? acc[t][r] : v;
+          col = gt ? n : col;
+        }
+      const float ov = __shfl_xor(v, 32, 64);
+      const int oc = __shfl_xor(col, 32, 64);
+      const bool take = ov > v || (ov == v && oc < col);
+      v = take ? ov : v;
+      col = take ? oc : col;
+      if (lane < 32) atomicMax(a.keys + (size_t)b * a.Co + co0 + lane, wide_key(v, col));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wide_finalize_kernel(const unsigned long long* __restrict__ keys,
+                                                            const float* __restrict__ bias, int Co, int total,
+                                                            float* __restrict__ out, int* __restrict__ arg) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const unsigned long long k = keys[e];
+  const unsigned u = (unsigned)(k >> 32);
+  const float v = __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+  out[e] = fmaxf(v + bias[e % Co], 0.f);
+  arg[e] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+}
+
+// ------------------------------------------------------------------------------------------
 // Sparse backward.  One workgroup per (instance, 128-point tile), split in NP parts of 128/NP columns with 128
 // threads each; thread (ci, part) owns row ci of its part, so no two threads ever touch the same accumulator
 // and the summation order is fixed (deterministic, no atomics).
@@ -300,6 +436,21 @@ static void launch_wide_variant(const WideArgs& a, hipStream_t s) {
 int launch_wide_max(const WideArgs& a, hipStream_t s) {
   if (a.Co != 8 * WM_CO || (a.taps != 1 && a.taps != 3)) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
+  static const bool colmajor = getenv("GEOA3_WIDE_ROWMAJOR") == nullptr;
+  if (colmajor && a.keys) {
+    geoa3_prof_begin(tag, s);
+    if (hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
+    const size_t lds = (size_t)WM_CI * W2_XP * sizeof(float);
+    const int slots = 96;   // per XCD: 768 resident workgroups of 4 waves
+    if (a.taps == 1) hipLaunchKernelGGL(wide_max2_kernel<1>, dim3(slots * 8), dim3(WM_THREADS), lds, s, a, slots);
+    else hipLaunchKernelGGL(wide_max2_kernel<3>, dim3(slots * 8), dim3(WM_THREADS), lds, s, a, slots);
+    const int total = a.B * a.Co;
+    hipLaunchKernelGGL(wide_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a.keys, a.bias, a.Co, total,
+                       a.out, a.arg);
+    geoa3_prof_end(tag, s);
+    GEOA3_CHECK_LAUNCH();
+    return GEOA3_OK;
+  }
   geoa3_prof_begin(tag, s);
   // chunk sizes / occupancy picked on hardware (profiles/): 3 workgroups of 4 waves per CU
   if (a.taps == 1) launch_wide_variant<1, 32, 2, 3>(a, s);
