@@ -202,13 +202,13 @@ def main():
                                    "curvature 1.0 k=%d), untargeted" % (1 if NPOINT == 1024 else 4, NPOINT, B, KNN),
                        "instances_per_gpu": B, "npoint": NPOINT, "knn": KNN, "classes": CLASSES,
                        "parallelism": "instance-sharded x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "wide_max_kernel<3> (conv5+bn5+relu+max, fp32 MFMA)",
+            "roofline": {"bound": "mfma", "kernel": "wide_max2_kernel<3> (conv5+bn5+relu+max, fp32 MFMA)",
                          "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_F32_MFMA / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_F32_MFMA, 4) if achieved else None,
                          "avg_launch_ms": round(conv5_ms, 4) if conv5_ms else None,
                          "algorithmic_flops_per_launch": conv5_flops, "traffic": None},   # traffic filled below
         }
-        tr, src = pmc_traffic("wide_max_kernel<3")
+        tr, src = pmc_traffic("wide_max2_kernel<3")
         if tr is not None and NPOINT == 1024 and B == INSTANCES:
             out["roofline"]["traffic"] = tr
             out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % src
