@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned long long wide_key(float v, int col) {
 template <int TAPS, int OCC, int W2_GROUPS>   // W2_GROUPS: channel groups of 128 per unit (8 / W2_GROUPS units per tile)
 __global__ __launch_bounds__(WM_THREADS, OCC) void wide_max2_kernel(WideArgs a, int slots_per_xcd) {
   constexpr int NGT = TAPS * 16;                 // fragment groups (8 k each) of one channel tile
-  constexpr int PF = 4;                          // NGT % PF == 0
+  constexpr int PF = TAPS == 1 ? 8 : 4;          // fragment loads in flight; NGT % PF == 0 (measured: 8 helps K = 128 only)
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [128][W2_XP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, l31 = lane & 31;
   const int N = a.N, tiles = (N + W2_COLS - 1) / W2_COLS;
