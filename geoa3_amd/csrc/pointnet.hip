@@ -9,10 +9,10 @@ namespace {
 struct Ws {  // workspace carve-up; every buffer starts on a 256-byte boundary
   // T-Net 3 (input transform)
   unsigned long long* keys;   // [B][1024] packed running maxima of the 1024-wide layers (reused by all three)
-  float *a1, *a2, *p3, *tf4, *tf5, *T3;
+  float *a2, *p3, *tf4, *tf5, *T3;
   int* i3;
   // trunk + T-Net 64 (feature transform)
-  float *h1, *h2, *c1, *c2, *q3, *qf4, *qf5, *T64;
+  float *h2, *c1, *c2, *q3, *qf4, *qf5, *T64;
   int* iq3;
   float *h2p, *h3, *h4, *p5, *f6, *f7;
   int* i5;
@@ -31,7 +31,6 @@ Ws carve(void* base, int B, int N, int classes) {
     return r;
   };
   const size_t s64 = (size_t)B * 64 * N, s128 = (size_t)B * 128 * N, b = (size_t)B;
-  w.a1 = (float*)take(s64);
   w.a2 = (float*)take(s128);
   w.keys = (unsigned long long*)take(b * 1024 * 2);
   w.p3 = (float*)take(b * 1024);
@@ -39,7 +38,6 @@ Ws carve(void* base, int B, int N, int classes) {
   w.tf4 = (float*)take(b * 512);
   w.tf5 = (float*)take(b * 256);
   w.T3 = (float*)take(b * 9);
-  w.h1 = (float*)take(s64);
   w.h2 = (float*)take(s64);
   w.c1 = (float*)take(s64);
   w.c2 = (float*)take(s128);
@@ -89,6 +87,32 @@ int conv(const float* X, int K, const float* W, const float* bias, float* Y, int
   return launch_conv_cm(a, s);
 }
 
+// Y = act(W relu(w1 (T^T x) + b1) + bias): the 3-channel first layer (Model/PointNet.py:79,137-139) folded into the
+// 64-input convolution that follows it; its activation is never written
+int conv_first(const float* x, const float* T, const float* w1, const float* b1, const float* W, const float* bias,
+               float* Y, int Co, int B, int N, hipStream_t s) {
+  ConvArgs a{};
+  a.x3 = x; a.T3 = T; a.w1 = w1; a.b1 = b1; a.produce_first = 1;
+  a.W = W; a.sWb = 0; a.sWco = 64; a.sWk = 1;
+  a.bias = bias;
+  a.Y = Y; a.sYb = (long)Co * N; a.ldY = N;
+  a.Co = Co; a.K = 64; a.N = N; a.B = B;
+  a.relu = 1;
+  return launch_conv_cm(a, s);
+}
+
+// G64 = relu'(first layer) * (W X): the input-gradient convolution whose mask is the first layer's sign, recomputed from x
+int conv_gate_first(const float* X, int K, const float* W, float* Y, const float* x, const float* T, const float* w1,
+                    const float* b1, int B, int N, hipStream_t s) {
+  ConvArgs a{};
+  a.X = X; a.sXb = (long)K * N; a.ldX = N;
+  a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
+  a.x3 = x; a.T3 = T; a.w1 = w1; a.b1 = b1; a.gate_first = 1;
+  a.Y = Y; a.sYb = (long)64 * N; a.ldY = N;
+  a.Co = 64; a.K = K; a.N = N; a.B = B;
+  return launch_conv_cm(a, s);
+}
+
 // per-instance 64x64 transform: transposed=true: Y[j][n] = sum_i T[i][j] X[i][n]; false: Y[i][n] = sum_j T[i][j] X[j][n]
 int transform64(const float* X, const float* T, float* Y, bool transposed, int B, int N, hipStream_t s) {
   ConvArgs a{};
@@ -133,9 +157,11 @@ int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, flo
 }
 
 // transform_net.forward (Model/PointNet.py:78-87) after its first layer
-int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, float* act128, float* pooled, int* arg, float* f4,
-                  float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s) {
-  TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s));
+// act64 == nullptr: the T-Net reads the cloud itself (K = 3) and its first layer is folded into conv2 (x3 given)
+int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* x3, float* act128, float* pooled,
+                  int* arg, float* f4, float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s) {
+  if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s));
+  else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s));
   TRY(wide(act128, t.w3p, t.b3, pooled, arg, keys, 1, B, N, s));
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
   TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
@@ -144,14 +170,15 @@ int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, float* act128
 }
 
 // d/d(transform) [B][K*K] -> gradient w.r.t. the pre-activation of the T-Net's first layer (G64 out)
-int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, const float* act128,
+int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, const float* x3, const float* act128,
              const float* pooled, const int* arg, const float* f4, const float* f5, Ws& w, float* G64out, int B, int N,
              hipStream_t s) {
   TRY(fc(gT, t.K * t.K, t.f3t, nullptr, w.g256, 256, B, false, f5, s));
   TRY(fc(w.g256, 256, t.f2t, nullptr, w.g512, 512, B, false, f4, s));
   TRY(fc(w.g512, 512, t.f1t, nullptr, w.g1024, 1024, B, false, pooled, s));
   TRY(wide_bwd(w.g1024, arg, t.w3, act128, w.G128, 1, B, N, s));
-  TRY(conv(w.G128, 128, t.w2t, nullptr, G64out, 64, B, N, false, act64, false, s));
+  if (act64) TRY(conv(w.G128, 128, t.w2t, nullptr, G64out, 64, B, N, false, act64, false, s));
+  else TRY(conv_gate_first(w.G128, 128, t.w2t, G64out, x3, nullptr, t.w1, t.b1, B, N, s));
   return 0;
 }
 
@@ -171,14 +198,12 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   Ws w = carve(workspace, B, N, pw->classes);
   const geoa3_pointnet_weights& p = *pw;
   // input transform (Model/PointNet.py:137-138)
-  TRY(launch_conv_in3(x, nullptr, p.t3.w1, p.t3.b1, w.a1, B, N, s));
-  TRY(tnet_tail_fwd(p.t3, w.a1, w.a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
+  TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
   // trunk conv1, conv2 (:139-140)
-  TRY(launch_conv_in3(x, w.T3, p.w1, p.b1, w.h1, B, N, s));
-  TRY(conv(w.h1, 64, p.w2, p.b2, w.h2, 64, B, N, true, nullptr, false, s));
+  TRY(conv_first(x, w.T3, p.w1, p.b1, p.w2, p.b2, w.h2, 64, B, N, s));
   // feature transform (:142-143)
   TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s));
-  TRY(tnet_tail_fwd(p.t64, w.c1, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
+  TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
   TRY(transform64(w.h2, w.T64, w.h2p, true, B, N, s));
   // conv3, conv4, conv5 + max (:144-147)
   TRY(conv(w.h2p, 64, p.w3, p.b3, w.h3, 64, B, N, true, nullptr, false, s));
@@ -215,7 +240,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     TRY(launch_fc(g, s));
   }
   TRY(transform64(w.G64b, w.T64, w.dh2, false, B, N, s));
-  TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
+  TRY(tnet_bwd(p.t64, w.gT64, w.c1, nullptr, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
   // dh2 += W_t64.conv1^T G64a, then the relu gate of h2
   {
     ConvArgs a{};
@@ -226,10 +251,10 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     a.Co = 64; a.K = 64; a.N = N; a.B = B; a.accumulate = 1;
     TRY(launch_conv_cm(a, s));
   }
-  TRY(conv(w.dh2, 64, p.w2t, nullptr, w.G64b, 64, B, N, false, w.h1, false, s));
+  TRY(conv_gate_first(w.dh2, 64, p.w2t, w.G64b, x, w.T3, p.w1, p.b1, B, N, s));
   // trunk conv1 + input transform: dx, dT3
   TRY(launch_conv_in3_bwd(w.G64b, p.w1, w.T3, x, dx, w.gT3, 0, B, N, s));
-  TRY(tnet_bwd(p.t3, w.gT3, w.a1, w.a2, w.p3, w.i3, w.tf4, w.tf5, w, w.G64a, B, N, s));
+  TRY(tnet_bwd(p.t3, w.gT3, nullptr, x, w.a2, w.p3, w.i3, w.tf4, w.tf5, w, w.G64a, B, N, s));
   TRY(launch_conv_in3_bwd(w.G64a, p.t3.w1, nullptr, x, dx, nullptr, 1, B, N, s));
   return GEOA3_OK;
 }

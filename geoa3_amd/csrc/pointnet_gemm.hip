@@ -24,7 +24,14 @@ __device__ __forceinline__ void swap32(float& a, float& b) {   // a[32..63] <-> 
   b = __uint_as_float(r[1]);
 }
 
-template <int NCH>  // K = CH * NCH
+// FIRST: the input rows are the 3-channel first layer, computed on the fly (ConvArgs::produce_first);
+// GFIRST: the output's relu gate is that first layer's sign, recomputed (ConvArgs::gate_first).  Both evaluate
+// relu(w1 . (T^T x) + b1) with ONE expression (first_layer), so the forward activation and the backward mask agree.
+__device__ __forceinline__ float first_layer(const float4 w, float p0, float p1, float p2) {
+  return w.x * p0 + w.y * p1 + w.z * p2 + w.w;
+}
+
+template <int NCH, bool FIRST, bool GFIRST>  // K = CH * NCH
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void conv_cm64_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [64][K+1]: the 64 output rows of this row block
   constexpr int CH = 16;   // rows of X per chunk (two chunks in registers)
@@ -32,10 +39,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
   const int b = blockIdx.y, rb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = blockIdx.x * 256 + wave * 64 + lane;
   const bool live = col < a.N;
-  const float* X = a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
+  const float* X = FIRST ? nullptr : a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
+  float4* s_w1 = reinterpret_cast<float4*>(s_w + 64 * pitch + 4);   // [64] (w1 row, b1) of the folded first layer
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f;                                // T^T x of this lane's point
+  if (FIRST || GFIRST) {
+    const float* xp = a.x3 + (size_t)b * 3 * a.N + (live ? col : a.N - 1);
+    const float x0 = xp[0], x1 = xp[a.N], x2 = xp[2 * (size_t)a.N];
+    p0 = x0;
+    p1 = x1;
+    p2 = x2;
+    if (a.T3) {   // bmm(pc^T, T)^T : x'[c] = sum_d x[d] T[d][c]   (Model/PointNet.py:138)
+      const float* t = a.T3 + (size_t)b * 9;
+      p0 = x0 * t[0] + x1 * t[3] + x2 * t[6];
+      p1 = x0 * t[1] + x1 * t[4] + x2 * t[7];
+      p2 = x0 * t[2] + x1 * t[5] + x2 * t[8];
+    }
+    if (tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
+  }
   float xb[2][CH];
+  if (!FIRST) {
 #pragma unroll
-  for (int u = 0; u < CH; ++u) xb[0][u] = X[(size_t)u * a.ldX];
+    for (int u = 0; u < CH; ++u) xb[0][u] = X[(size_t)u * a.ldX];
+  }
 
   const float* W = a.W + (size_t)b * a.sWb + (size_t)rb * 64 * a.sWco;
   if (a.sWk == 1 && (a.sWco & 3) == 0 && (a.sWb & 3) == 0) {   // rows are k-contiguous: 16-byte loads
@@ -69,7 +94,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
 
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    if (c + 1 < NCH) {
+    if (FIRST) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) xb[c & 1][u] = fmaxf(first_layer(s_w1[CH * c + u], p0, p1, p2), 0.f);
+    } else if (c + 1 < NCH) {
 #pragma unroll
       for (int u = 0; u < CH; ++u) xb[(c + 1) & 1][u] = X[(size_t)(CH * (c + 1) + u) * a.ldX];
     }
@@ -116,6 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
           if (a.relu) o = fmaxf(o, 0.f);
           if (a.accumulate) o += y[i];
           if (Z) o = z[i] > 0.f ? o : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
+          if (GFIRST) o = first_layer(s_w1[row0 + i], p0, p1, p2) > 0.f ? o : 0.f;
           Y[(size_t)(row0 + i) * a.ldY] = o;
         }
       }
@@ -216,12 +245,20 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
 
 int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
   if ((a.K != 64 && a.K != 128) || (a.Co != 64 && a.Co != 128)) return GEOA3_ENOSUPPORT;
-  const size_t lds = (size_t)64 * (a.K + 1) * sizeof(float);
+  if (a.produce_first && (a.K != 64 || !a.x3 || !a.w1 || !a.b1)) return GEOA3_EINVAL;
+  if (a.gate_first && (a.Co != 64 || !a.x3 || !a.w1 || !a.b1 || a.produce_first)) return GEOA3_EINVAL;
+  const size_t lds = ((size_t)64 * (a.K + 1) + 4 + 64 * 4) * sizeof(float);
   dim3 grid((a.N + 255) / 256, a.B, a.Co / 64);
-  if (a.K == 64)
-    hipLaunchKernelGGL(conv_cm64_kernel<4>, grid, dim3(256), lds, s, a);
+  if (a.produce_first)
+    hipLaunchKernelGGL((conv_cm64_kernel<4, true, false>), grid, dim3(256), lds, s, a);
+  else if (a.gate_first && a.K == 64)
+    hipLaunchKernelGGL((conv_cm64_kernel<4, false, true>), grid, dim3(256), lds, s, a);
+  else if (a.gate_first)
+    hipLaunchKernelGGL((conv_cm64_kernel<8, false, true>), grid, dim3(256), lds, s, a);
+  else if (a.K == 64)
+    hipLaunchKernelGGL((conv_cm64_kernel<4, false, false>), grid, dim3(256), lds, s, a);
   else
-    hipLaunchKernelGGL(conv_cm64_kernel<8>, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_cm64_kernel<8, false, false>), grid, dim3(256), lds, s, a);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -21,6 +21,14 @@ struct ConvArgs {
   float* Y; long sYb; int ldY;
   int Co, K, N, B;
   int relu, accumulate;
+  // First layer folded in (Model/PointNet.py:79,137-139: the 3-channel input layer behind the 3x3 input transform):
+  //   h[k][n] = relu( w1[k][:] . (T[b]^T x[b][:,n]) + b1[k] ),  k < 64.
+  // produce_first: the K = 64 input rows are COMPUTED from x3 instead of being read from X (X unused);
+  // gate_first:    the relu mask of the Co = 64 output rows is h > 0, recomputed instead of being read from Z.
+  const float* x3;                            // [B][3][N]
+  const float* T3;                            // [B][9] or null (identity)
+  const float* w1; const float* b1;           // [64][3], [64]
+  int produce_first, gate_first;
 };
 int launch_conv_cm(const ConvArgs& a, hipStream_t s);
 
@@ -60,10 +68,6 @@ struct WideBwdArgs {
   int Co, N, B, taps;
 };
 int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s);
-
-// First layers: Y[b][co][n] = relu( sum_c W[co][c] * (sum_d T[b][d][c] * x[b][d][n]) + bias[co] ), co < 64
-int launch_conv_in3(const float* x, const float* T /*[B][9] or null*/, const float* W /*[64][3]*/,
-                    const float* bias, float* Y /*[B][64][N]*/, int B, int N, hipStream_t s);
 
 // Backward of the first layers.  g [B][64][N] is d/d(pre-activation).  Computes
 //   dxp[c][n] = sum_co W[co][c] g[co][n];  dx[d][n] (+)= sum_c T[d][c] dxp[c][n] (T null: identity);

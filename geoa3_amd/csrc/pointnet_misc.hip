@@ -1,36 +1,9 @@
-// Small PointNet pieces that are not MFMA-shaped (gfx950): the 3-channel input layers with the 3x3 input
-// transform (Model/PointNet.py:79,137-139), their backward, and the 64x64 transform-gradient Gram product.
+// Small PointNet pieces that are not MFMA-shaped (gfx950): the backward of the 3-channel input layers with the 3x3
+// input transform (Model/PointNet.py:79,137-139).  Their forward is folded into the 64-input convolution that follows
+// (pointnet_gemm.hip, conv_cm64_kernel<.., FIRST>).
 #include "pointnet_kernels.h"
 
 namespace {
-
-// Y[b][co][n] = relu( W[co][:] . (T[b]^T x[b][:,n]) + bias[co] );  one thread per point, weights in LDS.
-__global__ __launch_bounds__(256) void conv_in3_kernel(const float* __restrict__ x, const float* __restrict__ T,
-                                                       const float* __restrict__ W, const float* __restrict__ bias,
-                                                       float* __restrict__ Y, int N) {
-  __shared__ float s_w[64 * 3], s_b[64], s_t[9];
-  const int b = blockIdx.y, tid = threadIdx.x;
-  if (tid < 192) s_w[tid] = W[tid];
-  if (tid < 64) s_b[tid] = bias[tid];
-  if (tid < 9) s_t[tid] = T ? T[(size_t)b * 9 + tid] : ((tid % 4 == 0) ? 1.f : 0.f);
-  __syncthreads();
-  const int n = blockIdx.x * 256 + tid;
-  if (n >= N) return;
-  const float* xb = x + (size_t)b * 3 * N;
-  const float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
-  float p0 = x0, p1 = x1, p2 = x2;
-  if (T) {  // bmm(pc^T, T)^T : x'[c] = sum_d x[d] T[d][c]
-    p0 = x0 * s_t[0] + x1 * s_t[3] + x2 * s_t[6];
-    p1 = x0 * s_t[1] + x1 * s_t[4] + x2 * s_t[7];
-    p2 = x0 * s_t[2] + x1 * s_t[5] + x2 * s_t[8];
-  }
-  float* yb = Y + (size_t)b * 64 * N + n;
-#pragma unroll 8
-  for (int co = 0; co < 64; ++co) {
-    const float v = s_w[co * 3] * p0 + s_w[co * 3 + 1] * p1 + s_w[co * 3 + 2] * p2 + s_b[co];
-    yb[(size_t)co * N] = fmaxf(v, 0.f);
-  }
-}
 
 // One workgroup per instance (deterministic dT reduction).
 __global__ __launch_bounds__(256) void conv_in3_bwd_kernel(const float* __restrict__ g, const float* __restrict__ W,
@@ -88,13 +61,6 @@ __global__ __launch_bounds__(256) void conv_in3_bwd_kernel(const float* __restri
 }
 
 }  // namespace
-
-int launch_conv_in3(const float* x, const float* T, const float* W, const float* bias, float* Y, int B, int N,
-                    hipStream_t s) {
-  hipLaunchKernelGGL(conv_in3_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, x, T, W, bias, Y, N);
-  GEOA3_CHECK_LAUNCH();
-  return GEOA3_OK;
-}
 
 int launch_conv_in3_bwd(const float* g, const float* W, const float* T, const float* x, float* dx, float* dT,
                         int accumulate, int B, int N, hipStream_t s) {
