@@ -17,7 +17,7 @@ struct Ws {  // workspace carve-up; every buffer starts on a 256-byte boundary
   float *h2p, *h3, *h4, *p5, *f6, *f7;
   int* i5;
   // backward temporaries
-  float *G128, *G64a, *G64b, *dh2, *g1024, *g512, *g256, *gT64, *gT3;
+  float *G128, *G64a, *G64b, *dh2, *g1024, *g512, *g256, *gT64, *gT3, *dTpart;
   size_t total;
 };
 
@@ -62,6 +62,7 @@ Ws carve(void* base, int B, int N, int classes) {
   w.g256 = (float*)take(b * 256);
   w.gT64 = (float*)take(b * 4096);
   w.gT3 = (float*)take(b * 16);
+  w.dTpart = (float*)take(b * 9 * (size_t)((N + 255) / 256));
   w.total = off;
   (void)classes;
   return w;
@@ -102,9 +103,13 @@ int conv_first(const float* x, const float* T, const float* w1, const float* b1,
 }
 
 // G64 = relu'(first layer) * (W X): the input-gradient convolution whose mask is the first layer's sign, recomputed from x
+// ... and, with dx != null, the first layer's own backward in the same kernel (no G64 in memory): dx (+)= T w1^T G64,
+// dTpart = per-workgroup partial sums of d/dT
 int conv_gate_first(const float* X, int K, const float* W, float* Y, const float* x, const float* T, const float* w1,
-                    const float* b1, int B, int N, hipStream_t s) {
+                    const float* b1, int B, int N, hipStream_t s, float* dx = nullptr, int accumulate = 0,
+                    float* dTpart = nullptr) {
   ConvArgs a{};
+  a.dx3 = dx; a.accumulate = accumulate; a.dTpart = dTpart;
   a.X = X; a.sXb = (long)K * N; a.ldX = N;
   a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
   a.x3 = x; a.T3 = T; a.w1 = w1; a.b1 = b1; a.gate_first = 1;
@@ -178,7 +183,7 @@ int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, c
   TRY(fc(w.g512, 512, t.f1t, nullptr, w.g1024, 1024, B, false, pooled, s));
   TRY(wide_bwd(w.g1024, arg, t.w3, act128, w.G128, 1, B, N, s));
   if (act64) TRY(conv(w.G128, 128, t.w2t, nullptr, G64out, 64, B, N, false, act64, false, s));
-  else TRY(conv_gate_first(w.G128, 128, t.w2t, G64out, x3, nullptr, t.w1, t.b1, B, N, s));
+  else TRY(conv_gate_first(w.G128, 128, t.w2t, nullptr, x3, nullptr, t.w1, t.b1, B, N, s, G64out /* = dx */, 1));
   return 0;
 }
 
@@ -251,10 +256,11 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     a.Co = 64; a.K = 64; a.N = N; a.B = B; a.accumulate = 1;
     TRY(launch_conv_cm(a, s));
   }
-  TRY(conv_gate_first(w.dh2, 64, p.w2t, w.G64b, x, w.T3, p.w1, p.b1, B, N, s));
-  // trunk conv1 + input transform: dx, dT3
-  TRY(launch_conv_in3_bwd(w.G64b, p.w1, w.T3, x, dx, w.gT3, 0, B, N, s));
-  TRY(tnet_bwd(p.t3, w.gT3, nullptr, x, w.a2, w.p3, w.i3, w.tf4, w.tf5, w, w.G64a, B, N, s));
-  TRY(launch_conv_in3_bwd(w.G64a, p.t3.w1, nullptr, x, dx, nullptr, 1, B, N, s));
+  // conv2 backward fused with trunk conv1 + input transform backward: dx, dT3 (partials per 256-point workgroup)
+  const int nparts = (N + 255) / 256;
+  TRY(conv_gate_first(w.dh2, 64, p.w2t, nullptr, x, w.T3, p.w1, p.b1, B, N, s, dx, 0, w.dTpart));
+  TRY(launch_reduce_dT(w.dTpart, nparts, w.gT3, B, s));
+  // T-Net(3) backward; its last kernel adds the T-Net branch into dx
+  TRY(tnet_bwd(p.t3, w.gT3, nullptr, x, w.a2, w.p3, w.i3, w.tf4, w.tf5, w, dx, B, N, s));
   return GEOA3_OK;
 }

@@ -31,7 +31,7 @@ __device__ __forceinline__ float first_layer(const float4 w, float p0, float p1,
   return w.x * p0 + w.y * p1 + w.z * p2 + w.w;
 }
 
-template <int NCH, bool FIRST, bool GFIRST>  // K = CH * NCH
+template <int NCH, bool FIRST, bool GFIRST, bool BWD3>  // K = CH * NCH; BWD3 needs GFIRST
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void conv_cm64_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [64][K+1]: the 64 output rows of this row block
   constexpr int CH = 16;   // rows of X per chunk (two chunks in registers)
@@ -42,9 +42,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
   const float* X = FIRST ? nullptr : a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
   float4* s_w1 = reinterpret_cast<float4*>(s_w + 64 * pitch + 4);   // [64] (w1 row, b1) of the folded first layer
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;                                // T^T x of this lane's point
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f;
   if (FIRST || GFIRST) {
     const float* xp = a.x3 + (size_t)b * 3 * a.N + (live ? col : a.N - 1);
-    const float x0 = xp[0], x1 = xp[a.N], x2 = xp[2 * (size_t)a.N];
+    x0 = xp[0];
+    x1 = xp[a.N];
+    x2 = xp[2 * (size_t)a.N];
     p0 = x0;
     p1 = x1;
     p2 = x2;
@@ -114,8 +117,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
   }
 
   // epilogue: every pair of accumulator registers becomes two 64-column rows (row, row + 4)
-  float* Y = a.Y + (size_t)b * a.sYb + col;
+  float* Y = BWD3 ? nullptr : a.Y + (size_t)b * a.sYb + col;
   const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f;   // BWD3: d/d(T^T x) of this lane's point, summed over the 64 rows
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -145,11 +149,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
           if (a.accumulate) o += y[i];
           if (Z) o = z[i] > 0.f ? o : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
           if (GFIRST) o = first_layer(s_w1[row0 + i], p0, p1, p2) > 0.f ? o : 0.f;
-          Y[(size_t)(row0 + i) * a.ldY] = o;
+          if (BWD3) {
+            const float4 w = s_w1[row0 + i];
+            q0 += w.x * o;
+            q1 += w.y * o;
+            q2 += w.z * o;
+          } else {
+            Y[(size_t)(row0 + i) * a.ldY] = o;
+          }
         }
       }
     }
   }
+  if (BWD3) {
+    // x' = T^T x  =>  dx[d] = sum_c T[d][c] q[c];  dT[d][c] = sum_n x[d][n] q[c][n]
+    if (!live) {
+      q0 = 0.f;
+      q1 = 0.f;
+      q2 = 0.f;
+    }
+    float d0 = q0, d1 = q1, d2 = q2;
+    if (a.T3) {
+      const float* t = a.T3 + (size_t)b * 9;
+      d0 = t[0] * q0 + t[1] * q1 + t[2] * q2;
+      d1 = t[3] * q0 + t[4] * q1 + t[5] * q2;
+      d2 = t[6] * q0 + t[7] * q1 + t[8] * q2;
+    }
+    if (live) {
+      float* dxp = a.dx3 + (size_t)b * 3 * a.N + col;
+      if (a.accumulate) {
+        d0 += dxp[0];
+        d1 += dxp[a.N];
+        d2 += dxp[2 * (size_t)a.N];
+      }
+      dxp[0] = d0;
+      dxp[a.N] = d1;
+      dxp[2 * (size_t)a.N] = d2;
+    }
+    if (a.dTpart) {   // workgroup-uniform
+      float* s_part = reinterpret_cast<float*>(s_w1 + 64);   // [4 waves][9]
+      const float prod[9] = {x0 * q0, x0 * q1, x0 * q2, x1 * q0, x1 * q1, x1 * q2, x2 * q0, x2 * q1, x2 * q2};
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float v = wave_sum(prod[i]);
+        if (lane == 0) s_part[wave * 9 + i] = v;
+      }
+      __syncthreads();
+      if (tid < 9)
+        a.dTpart[((size_t)b * gridDim.x + blockIdx.x) * 9 + tid] =
+            s_part[tid] + s_part[9 + tid] + s_part[18 + tid] + s_part[27 + tid];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_dT_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dT,
+                                                        int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int b = e / 9, i = e - b * 9;
+  float v = 0.f;
+  for (int w = 0; w < nparts; ++w) v += part[((size_t)b * nparts + w) * 9 + i];
+  dT[e] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -247,18 +307,23 @@ int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
   if ((a.K != 64 && a.K != 128) || (a.Co != 64 && a.Co != 128)) return GEOA3_ENOSUPPORT;
   if (a.produce_first && (a.K != 64 || !a.x3 || !a.w1 || !a.b1)) return GEOA3_EINVAL;
   if (a.gate_first && (a.Co != 64 || !a.x3 || !a.w1 || !a.b1 || a.produce_first)) return GEOA3_EINVAL;
-  const size_t lds = ((size_t)64 * (a.K + 1) + 4 + 64 * 4) * sizeof(float);
+  if (a.dx3 && !a.gate_first) return GEOA3_EINVAL;
+  const size_t lds = ((size_t)64 * (a.K + 1) + 4 + 64 * 4 + 40) * sizeof(float);
   dim3 grid((a.N + 255) / 256, a.B, a.Co / 64);
   if (a.produce_first)
-    hipLaunchKernelGGL((conv_cm64_kernel<4, true, false>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_cm64_kernel<4, true, false, false>), grid, dim3(256), lds, s, a);
+  else if (a.gate_first && a.dx3 && a.K == 64)
+    hipLaunchKernelGGL((conv_cm64_kernel<4, false, true, true>), grid, dim3(256), lds, s, a);
+  else if (a.gate_first && a.dx3)
+    hipLaunchKernelGGL((conv_cm64_kernel<8, false, true, true>), grid, dim3(256), lds, s, a);
   else if (a.gate_first && a.K == 64)
-    hipLaunchKernelGGL((conv_cm64_kernel<4, false, true>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_cm64_kernel<4, false, true, false>), grid, dim3(256), lds, s, a);
   else if (a.gate_first)
-    hipLaunchKernelGGL((conv_cm64_kernel<8, false, true>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_cm64_kernel<8, false, true, false>), grid, dim3(256), lds, s, a);
   else if (a.K == 64)
-    hipLaunchKernelGGL((conv_cm64_kernel<4, false, false>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_cm64_kernel<4, false, false, false>), grid, dim3(256), lds, s, a);
   else
-    hipLaunchKernelGGL((conv_cm64_kernel<8, false, false>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_cm64_kernel<8, false, false, false>), grid, dim3(256), lds, s, a);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
@@ -274,6 +339,12 @@ extern "C" int geoa3_debug_conv_cm(const float* X, const float* W, const float* 
   a.Co = Co; a.K = K; a.N = N; a.B = B;
   a.relu = relu;
   return launch_conv_cm(a, geoa3_stream(stream));
+}
+
+int launch_reduce_dT(const float* part, int nparts, float* dT, int B, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_dT_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, s, part, nparts, dT, B * 9);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
 }
 
 int launch_fc(const FcArgs& a, hipStream_t s) {

@@ -29,6 +29,11 @@ struct ConvArgs {
   const float* T3;                            // [B][9] or null (identity)
   const float* w1; const float* b1;           // [64][3], [64]
   int produce_first, gate_first;
+  // with gate_first: finish the first layer's backward in the epilogue instead of writing Y (Model/PointNet.py:79,
+  // 137-139 backward): q = w1^T (gated result), dx[b][d][n] (+)= sum_c T[d][c] q[c]  (`accumulate` selects +=), and,
+  // when dTpart != null, per-workgroup partial sums of dT[d][c] = sum_n x[d][n] q[c][n] into dTpart[b][gridDim.x][9]
+  float* dx3;                                 // [B][3][N] or null (= write Y as usual)
+  float* dTpart;
 };
 int launch_conv_cm(const ConvArgs& a, hipStream_t s);
 
@@ -69,9 +74,6 @@ struct WideBwdArgs {
 };
 int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s);
 
-// Backward of the first layers.  g [B][64][N] is d/d(pre-activation).  Computes
-//   dxp[c][n] = sum_co W[co][c] g[co][n];  dx[d][n] (+)= sum_c T[d][c] dxp[c][n] (T null: identity);
-//   dT[b][d][c] = sum_n x[d][n] dxp[c][n]  (when dT != null)
-int launch_conv_in3_bwd(const float* g, const float* W /*[64][3]*/, const float* T, const float* x, float* dx,
-                        float* dT, int accumulate, int B, int N, hipStream_t s);
+// dT[b][i] = sum_w part[b][w][i], i < 9, in a fixed order (the partial sums of ConvArgs::dTpart)
+int launch_reduce_dT(const float* part, int nparts, float* dT, int B, hipStream_t s);
 
