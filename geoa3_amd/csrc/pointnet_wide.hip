@@ -170,19 +170,18 @@ __global__ __launch_bounds__(256) void wide_finalize_kernel(const unsigned long 
 }
 
 // ------------------------------------------------------------------------------------------
-// Sparse backward.  One workgroup per (instance, 128-point tile), split in NP parts of 128/NP columns with 128
+// Sparse backward.  One workgroup per (instance, WB_COLS-point tile), split in NP parts of WB_COLS/NP columns with 128
 // threads each; thread (ci, part) owns row ci of its part, so no two threads ever touch the same accumulator
 // and the summation order is fixed (deterministic, no atomics).
 // Per block of WB_BLOCK output channels: the first wave of each part compacts the (channel, tap) pairs whose
 // arg-max column falls into its part into an LDS hit list (ballot + popcount, in (co, tap) order, the upstream
 // gradient stored next to it); then the 128 threads of the part walk ONLY the hits, WB_BATCH independent
-// weight-row loads in flight.  The walk is L2-latency bound, so the parts (NP = 4: 16 waves per workgroup) are
-// what keeps enough loads in flight: LDS (66 KB of accumulators) allows only two workgroups per CU.
+// weight-row loads in flight.  The walk is L2-latency bound and the write-out bandwidth bound; they do not overlap
+// inside a workgroup, so the tile is kept small (64 columns, 33 KB of accumulators): three workgroups per CU.
 // ------------------------------------------------------------------------------------------
-constexpr int WB_COLS = 128;
 constexpr int WB_BATCH = 16;
 
-template <int TAPS, int NP, int WB_BLOCK>   // WB_BLOCK: output channels per compaction round
+template <int TAPS, int NP, int WB_BLOCK, int WB_COLS>   // WB_BLOCK: output channels per compaction round
 __global__ __launch_bounds__(128 * NP) void wide_max_bwd_kernel(WideBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PC = WB_COLS / NP;                                            // columns per part
@@ -287,20 +286,21 @@ int launch_wide_max(const WideArgs& a, hipStream_t s) {
   return GEOA3_OK;
 }
 
-template <int TAPS, int NP, int WB_BLOCK>
+template <int TAPS, int NP, int WB_BLOCK, int WB_COLS>
 static void launch_wide_bwd_variant(const WideBwdArgs& a, hipStream_t s) {
   dim3 grid((a.N + WB_COLS - 1) / WB_COLS, a.B);
   const size_t lds = ((size_t)WM_CI * (WB_COLS + 1) + 2 * (size_t)NP * WB_BLOCK * TAPS + NP) * sizeof(float);
-  auto kern = wide_max_bwd_kernel<TAPS, NP, WB_BLOCK>;
+  auto kern = wide_max_bwd_kernel<TAPS, NP, WB_BLOCK, WB_COLS>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, grid, dim3(128 * NP), lds, s, a);
 }
 
 int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s) {
   if (a.taps != 1 && a.taps != 3) return GEOA3_ENOSUPPORT;
-  // parts / compaction block picked on hardware (tools/bench_widebwd.py): 93 us / 164 us at B=250, N=1024
-  if (a.taps == 1) launch_wide_bwd_variant<1, 4, 256>(a, s);
-  else launch_wide_bwd_variant<3, 4, 128>(a, s);
+  // tile width / parts / compaction block picked on hardware (tools/bench_widebwd.py): 64-column tiles leave room for
+  // three workgroups per CU, so one workgroup's write-out overlaps its neighbours' hit walks (95 / 150 us)
+  if (a.taps == 1) launch_wide_bwd_variant<1, 2, 256, 64>(a, s);
+  else launch_wide_bwd_variant<3, 2, 128, 64>(a, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
