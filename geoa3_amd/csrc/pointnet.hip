@@ -14,10 +14,10 @@ struct Ws {  // workspace carve-up; every buffer starts on a 256-byte boundary
   // trunk + T-Net 64 (feature transform)
   float *h2, *c1, *c2, *q3, *qf4, *qf5, *T64;
   int* iq3;
-  float *h2p, *h3, *h4, *p5, *f6, *f7;
+  float *W3eff, *h3, *h4, *p5, *f6, *f7;   // W3eff [B][64][64] = W3 T64^T
   int* i5;
   // backward temporaries
-  float *G128, *G64a, *G64b, *dh2, *g1024, *g512, *g256, *gT64, *gT3, *dTpart;
+  float *G128, *G64a, *P64, *dh2, *g1024, *g512, *g256, *gT64, *gT3, *dTpart;   // P64 [B][64][64] = h2 G64a^T
   size_t total;
 };
 
@@ -46,7 +46,7 @@ Ws carve(void* base, int B, int N, int classes) {
   w.qf4 = (float*)take(b * 512);
   w.qf5 = (float*)take(b * 256);
   w.T64 = (float*)take(b * 4096);
-  w.h2p = (float*)take(s64);
+  w.W3eff = (float*)take(b * 4096);
   w.h3 = (float*)take(s64);
   w.h4 = (float*)take(s128);
   w.p5 = (float*)take(b * 1024);
@@ -55,7 +55,7 @@ Ws carve(void* base, int B, int N, int classes) {
   w.f7 = (float*)take(b * 256);
   w.G128 = (float*)take(s128);
   w.G64a = (float*)take(s64);
-  w.G64b = (float*)take(s64);
+  w.P64 = (float*)take(b * 4096);
   w.dh2 = (float*)take(s64);
   w.g1024 = (float*)take(b * 1024);
   w.g512 = (float*)take(b * 512);
@@ -115,17 +115,6 @@ int conv_gate_first(const float* X, int K, const float* W, float* Y, const float
   a.x3 = x; a.T3 = T; a.w1 = w1; a.b1 = b1; a.gate_first = 1;
   a.Y = Y; a.sYb = (long)64 * N; a.ldY = N;
   a.Co = 64; a.K = K; a.N = N; a.B = B;
-  return launch_conv_cm(a, s);
-}
-
-// per-instance 64x64 transform: transposed=true: Y[j][n] = sum_i T[i][j] X[i][n]; false: Y[i][n] = sum_j T[i][j] X[j][n]
-int transform64(const float* X, const float* T, float* Y, bool transposed, int B, int N, hipStream_t s) {
-  ConvArgs a{};
-  a.X = X; a.sXb = (long)64 * N; a.ldX = N;
-  a.W = T; a.sWb = 4096;
-  if (transposed) { a.sWco = 1; a.sWk = 64; } else { a.sWco = 64; a.sWk = 1; }
-  a.Y = Y; a.sYb = (long)64 * N; a.ldY = N;
-  a.Co = 64; a.K = 64; a.N = N; a.B = B;
   return launch_conv_cm(a, s);
 }
 
@@ -209,9 +198,24 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   // feature transform (:142-143)
   TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s));
   TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
-  TRY(transform64(w.h2, w.T64, w.h2p, true, B, N, s));
-  // conv3, conv4, conv5 + max (:144-147)
-  TRY(conv(w.h2p, 64, p.w3, p.b3, w.h3, 64, B, N, true, nullptr, false, s));
+  // feature transform folded into conv3 (:143-144): W3 (T64^T h2) = (W3 T64^T) h2 -- one 64^3 product per instance
+  // instead of a pass over [B,64,N]
+  {
+    FcArgs g{};   // W3eff[b][o][i] = sum_j W3[o][j] T64[b][i][j]
+    g.X = p.w3; g.ldX = 64; g.sXb = 0;
+    g.W = w.T64; g.ldW = 64; g.sWb = 4096;
+    g.Y = w.W3eff; g.ldY = 64; g.sYb = 4096;
+    g.M = 64; g.Nout = 64; g.K = 64; g.batch = B;
+    TRY(launch_fc(g, s));
+    ConvArgs a{};
+    a.X = w.h2; a.sXb = (long)64 * N; a.ldX = N;
+    a.W = w.W3eff; a.sWb = 4096; a.sWco = 64; a.sWk = 1;
+    a.bias = p.b3;
+    a.Y = w.h3; a.sYb = (long)64 * N; a.ldY = N;
+    a.Co = 64; a.K = 64; a.N = N; a.B = B; a.relu = 1;
+    TRY(launch_conv_cm(a, s));
+  }
+  // conv4, conv5 + max (:145-147)
   TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s));
   TRY(wide(w.h4, p.w5p, p.b5, w.p5, w.i5, w.keys, 3, B, N, s));
   // classifier head (:150-152), dropout is the identity in eval mode
@@ -234,17 +238,28 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   // max + conv5 (sparse), conv4, conv3
   TRY(wide_bwd(w.g1024, w.i5, p.w5, w.h4, w.G128, 3, B, N, s));
   TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, w.h3, false, s));
-  TRY(conv(w.G64a, 64, p.w3t, nullptr, w.G64b, 64, B, N, false, nullptr, false, s));   // d/d(h2')
-  // feature transform: h2' = T64^T h2
-  {  // dT64[b][i][j] = sum_n h2[b][i][n] dh2'[b][j][n]: the batched NT product of the FC kernel (K = N)
-    FcArgs g{};
+  // conv3 + feature transform, merged as in forward (G64a = d/d(pre-activation of h3)):
+  //   dT64[b][i][j] = sum_n h2[i][n] (W3^T G64a)[j][n] = ((h2 G64a^T) W3)[i][j];   dh2 = T64 W3^T G64a = W3eff^T G64a
+  {
+    FcArgs g{};   // P[b][i][o] = sum_n h2[b][i][n] G64a[b][o][n]: the batched NT product of the FC kernel (K = N)
     g.X = w.h2; g.ldX = N; g.sXb = (long)64 * N;
-    g.W = w.G64b; g.ldW = N; g.sWb = (long)64 * N;
-    g.Y = w.gT64; g.ldY = 64; g.sYb = 4096;
+    g.W = w.G64a; g.ldW = N; g.sWb = (long)64 * N;
+    g.Y = w.P64; g.ldY = 64; g.sYb = 4096;
     g.M = 64; g.Nout = 64; g.K = N; g.batch = B; g.ksplit = 8;
     TRY(launch_fc(g, s));
+    FcArgs q{};   // dT64[b][i][j] = sum_o P[b][i][o] W3[o][j]
+    q.X = w.P64; q.ldX = 64; q.sXb = 4096;
+    q.W = p.w3t; q.ldW = 64; q.sWb = 0;
+    q.Y = w.gT64; q.ldY = 64; q.sYb = 4096;
+    q.M = 64; q.Nout = 64; q.K = 64; q.batch = B;
+    TRY(launch_fc(q, s));
+    ConvArgs a{};   // dh2[b][i][n] = sum_o W3eff[b][o][i] G64a[b][o][n]
+    a.X = w.G64a; a.sXb = (long)64 * N; a.ldX = N;
+    a.W = w.W3eff; a.sWb = 4096; a.sWco = 1; a.sWk = 64;
+    a.Y = w.dh2; a.sYb = (long)64 * N; a.ldY = N;
+    a.Co = 64; a.K = 64; a.N = N; a.B = B;
+    TRY(launch_conv_cm(a, s));
   }
-  TRY(transform64(w.G64b, w.T64, w.dh2, false, B, N, s));
   TRY(tnet_bwd(p.t64, w.gT64, w.c1, nullptr, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
   // dh2 += W_t64.conv1^T G64a, then the relu gate of h2
   {
