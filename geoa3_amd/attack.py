@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, Optional, Sequence
 
 import numpy as np
 import torch
