@@ -101,6 +101,97 @@ __global__ __launch_bounds__(FPS_T) void fps_sample_kernel(const float* __restri
   }
 }
 
+// Faster form for clouds that fit LDS (N <= 8192): the arg-max is a max over 64-bit keys (distance bits, ~index) --
+// distances are >= 0, so their bit patterns order like unsigned integers, and the complemented index makes the LOWEST
+// index win a tie -- reduced inside a wavefront with DPP row operations (quad_perm, row_half_mirror, row_mirror,
+// row_bcast15/31: ~10 cycles per step instead of a ds_bpermute round trip), across wavefronts through one LDS slot
+// per wave, and the winner's coordinates are an LDS read of the staged cloud.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
+  const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+  return o > v ? o : v;
+}
+// max over the 16 lanes of every DPP row (all 16 lanes end with it)
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
+  v = dpp_max_u64<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_max_u64<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_max_u64<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_max_u64<0x140, 0xF>(v);   // row_mirror
+  return v;
+}
+// max over the wavefront, returned uniformly (read from lane 63)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  v = row16_max_u64(v);
+  v = dpp_max_u64<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v = dpp_max_u64<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int FT, int PPT>   // FT threads, PPT points per thread: fewer, fatter waves make the per-round barrier cheaper
+__global__ __launch_bounds__(FT) void fps_sample_lds_kernel(const float* __restrict__ pc, int N, int m,
+                                                               const int32_t* __restrict__ start,
+                                                               int32_t* __restrict__ idx_out,
+                                                               float* __restrict__ pts_out) {
+  extern __shared__ __attribute__((aligned(16))) float s_cloud[];   // [3][N]
+  __shared__ unsigned long long s_key[2][FT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* P = pc + (size_t)b * 3 * N;
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int i = tid + p * FT;
+    const bool ok = i < N;
+    px[p] = ok ? P[i] : 0.f;
+    py[p] = ok ? P[N + i] : 0.f;
+    pz[p] = ok ? P[2 * N + i] : 0.f;
+    dist[p] = ok ? INF : -1.f;
+    if (ok) {
+      s_cloud[i] = px[p];
+      s_cloud[N + i] = py[p];
+      s_cloud[2 * N + i] = pz[p];
+    }
+  }
+  int cur = start[b];
+  cur = cur < 0 ? 0 : (cur >= N ? N - 1 : cur);
+  __syncthreads();
+  for (int r = 0; r < m; ++r) {
+    const float cx = s_cloud[cur], cy = s_cloud[N + cur], cz = s_cloud[2 * N + cur];
+    if (tid == 0) {
+      idx_out[(size_t)b * m + r] = cur;
+      if (pts_out) {
+        pts_out[((size_t)b * 3 + 0) * m + r] = cx;
+        pts_out[((size_t)b * 3 + 1) * m + r] = cy;
+        pts_out[((size_t)b * 3 + 2) * m + r] = cz;
+      }
+    }
+    if (r == m - 1) break;
+    unsigned long long key = 0ull;   // padding lanes: below every real key (real distances are >= 0 -> bits >= 0)
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int i = tid + p * FT;
+      const float d = sqrtf(geoa3_sqdist(px[p], py[p], pz[p], cx, cy, cz));
+      dist[p] = fminf(dist[p], d);
+      if (i < N) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(dist[p]) << 32) | (0xFFFFFFFFu - (unsigned)i);
+        key = k > key ? k : key;
+      }
+    }
+    key = wave_max_u64(key);
+    const int buf = r & 1;
+    if (lane == 0) s_key[buf][wave] = key;
+    __syncthreads();
+    unsigned long long k2 = lane < FT / 64 ? s_key[buf][lane] : 0ull;
+    k2 = row16_max_u64(k2);           // at most 16 waves: one DPP row
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)k2);
+    cur = (int)(0xFFFFFFFFu - lo);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // estimate_normal_via_ori_normal (Lib/utility.py:91-108) from the cross K-NN table of adv against ori.
 // ------------------------------------------------------------------------------------------
@@ -435,6 +526,20 @@ extern "C" int geoa3_fps_sample(const float* pc, int B, int N, int m, const int3
                                 void* stream) {
   if (!pc || !start || !idx || B <= 0 || N <= 0 || m <= 0) return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
+#define GEOA3_FPS_LDS_CASE(FT, PPT)                                                                              \
+  if (N <= PPT * FT) {                                                                                           \
+    const size_t lds = (size_t)3 * N * sizeof(float);                                                            \
+    auto kern = fps_sample_lds_kernel<FT, PPT>;                                                                  \
+    if (lds > 48 * 1024)                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                       \
+    hipLaunchKernelGGL(kern, dim3(B), dim3(FT), lds, s, pc, N, m, start, idx, pts);                              \
+    GEOA3_CHECK_LAUNCH();                                                                                        \
+    return GEOA3_OK;                                                                                             \
+  }
+  // 512 threads measured best (1024: 8 % slower, 256: 8-19 %): 0.33 ms for 512 of 1024 points, 1.30 ms for 1024 of 4096
+  GEOA3_FPS_LDS_CASE(512, 2) GEOA3_FPS_LDS_CASE(512, 4) GEOA3_FPS_LDS_CASE(512, 8) GEOA3_FPS_LDS_CASE(512, 16)
+#undef GEOA3_FPS_LDS_CASE
 #define GEOA3_FPS_CASE(PPT)                                                                                      \
   if (N <= PPT * FPS_T) {                                                                                        \
     hipLaunchKernelGGL(fps_sample_kernel<PPT>, dim3(B), dim3(FPS_T), 0, s, pc, N, m, start, idx, pts);           \
