@@ -35,3 +35,33 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ------------------------------------------------------------------------------------------
+// Max over 64-bit keys with DPP row operations (~10 cycles per step instead of a ds_bpermute round trip): the
+// arg-max reductions of the farthest-point samplers pack (value bits, complemented index) into one key.
+// ------------------------------------------------------------------------------------------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
+  const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+  return o > v ? o : v;
+}
+// max over the 16 lanes of every DPP row (all 16 lanes end with it)
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
+  v = dpp_max_u64<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_max_u64<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_max_u64<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_max_u64<0x140, 0xF>(v);   // row_mirror
+  return v;
+}
+// max over the wavefront, returned uniformly (read from lane 63)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  v = row16_max_u64(v);
+  v = dpp_max_u64<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v = dpp_max_u64<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}

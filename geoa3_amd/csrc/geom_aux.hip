@@ -104,34 +104,8 @@ __global__ __launch_bounds__(FPS_T) void fps_sample_kernel(const float* __restri
 // Faster form for clouds that fit LDS (N <= 8192): the arg-max is a max over 64-bit keys (distance bits, ~index) --
 // distances are >= 0, so their bit patterns order like unsigned integers, and the complemented index makes the LOWEST
 // index win a tie -- reduced inside a wavefront with DPP row operations (quad_perm, row_half_mirror, row_mirror,
-// row_bcast15/31: ~10 cycles per step instead of a ds_bpermute round trip), across wavefronts through one LDS slot
-// per wave, and the winner's coordinates are an LDS read of the staged cloud.
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
-  const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
-  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
-  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-  return o > v ? o : v;
-}
-// max over the 16 lanes of every DPP row (all 16 lanes end with it)
-__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
-  v = dpp_max_u64<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-  v = dpp_max_u64<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-  v = dpp_max_u64<0x141, 0xF>(v);   // row_half_mirror
-  v = dpp_max_u64<0x140, 0xF>(v);   // row_mirror
-  return v;
-}
-// max over the wavefront, returned uniformly (read from lane 63)
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  v = row16_max_u64(v);
-  v = dpp_max_u64<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
-  v = dpp_max_u64<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
+// row_bcast15/31: common.h), across wavefronts through one LDS slot per wave, and the winner's coordinates are an
+// LDS read of the staged cloud.
 template <int FT, int PPT>   // FT threads, PPT points per thread: fewer, fatter waves make the per-round barrier cheaper
 __global__ __launch_bounds__(FT) void fps_sample_lds_kernel(const float* __restrict__ pc, int N, int m,
                                                                const int32_t* __restrict__ start,

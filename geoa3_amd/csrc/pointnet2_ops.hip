@@ -25,38 +25,20 @@ __device__ __forceinline__ float sq3(float dx, float dy, float dz) {
 }
 
 // ------------------------------------------------------------------------------------------
-// FPS: one workgroup per cloud, every thread keeps PPT points and their running distances in registers;
-// a round is: distance update -> wave arg-max (shuffles) -> cross-wave arg-max through LDS (2 barriers).
+// FPS: one workgroup of 512 threads per cloud; every thread keeps up to 16 points and their running distances in
+// registers, the cloud also sits in LDS so that the coordinates of the point selected in the previous round are an
+// LDS read.  The reference's arg-max order -- larger distance, then lower (k mod T), then lower k -- is a max over
+// 64-bit keys (distance bits | ~(k mod T) | ~k; distances are >= 0 so their bits order like integers; skipped points
+// and padding carry key 0), reduced with DPP row operations inside a wavefront (common.h) and through one LDS slot per
+// wave across wavefronts: ONE barrier per round, no global traffic.  0.66 ms -> see DESIGN for 512 of 1024 points.
 // ------------------------------------------------------------------------------------------
-constexpr int FPS_BLOCK = 1024;
-constexpr int FPS_PPT = 8;  // up to 8192 points per cloud
+constexpr int FPS_BLOCK = 512;
+constexpr int FPS_PPT = 16;  // up to 8192 points per cloud
 
-struct Best {
-  float v;
-  int t, k;  // t = k mod T (the reference thread that owns k)
-};
-__device__ __forceinline__ Best fps_better(Best a, Best b) {
-  const bool take = b.v > a.v || (b.v == a.v && (b.t < a.t || (b.t == a.t && b.k < a.k)));
-  // member-wise selects: `take ? b : a` on the struct is lowered through a scratch (stack) copy by hipcc
-  return Best{take ? b.v : a.v, take ? b.t : a.t, take ? b.k : a.k};
-}
-__device__ __forceinline__ Best wave_best(Best best) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    Best other{__shfl_xor(best.v, o, 64), __shfl_xor(best.t, o, 64), __shfl_xor(best.k, o, 64)};
-    best = fps_better(best, other);
-  }
-  return best;
-}
-
-// One workgroup per cloud; the cloud also sits in LDS so that the coordinates of the point selected in the previous
-// round are an LDS read, not a dependent global load.  A round = distance update (registers) -> wave arg-max
-// (shuffles) -> 16 partial results through LDS -> every wave reduces them redundantly: 2 barriers, no global traffic.
 __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict__ xyz, int N, int m, int T,
                                                         float* __restrict__ temp, int32_t* __restrict__ idxs) {
   extern __shared__ __attribute__((aligned(16))) float s_p[];   // [N][3]
-  __shared__ float s_v[2][FPS_BLOCK / 64];
-  __shared__ int s_t[2][FPS_BLOCK / 64], s_k[2][FPS_BLOCK / 64];
+  __shared__ unsigned long long s_key[2][FPS_BLOCK / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* P = xyz + (size_t)b * N * 3;
   for (int e = tid; e < N * 3; e += FPS_BLOCK) s_p[e] = P[e];
@@ -78,7 +60,7 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict_
   __syncthreads();
   for (int j = 1; j < m; ++j) {
     const float x1 = s_p[old * 3], y1 = s_p[old * 3 + 1], z1 = s_p[old * 3 + 2];
-    Best best{-1.f, 0x7fffffff, 0x7fffffff};
+    unsigned long long key = 0ull;
 #pragma unroll
     for (int i = 0; i < FPS_PPT; ++i) {
       if (i * FPS_BLOCK < N) {   // uniform: skips the register slots this cloud does not use
@@ -87,22 +69,21 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict_
         const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
         const float d2 = u ? fminf(d, td[i]) : td[i];
         td[i] = d2;
-        const Best cand{u ? d2 : -2.f, k & (T - 1), k};
-        best = fps_better(best, cand);
+        const unsigned tie = ((unsigned)(k & (T - 1)) << 16) | (unsigned)k;   // k < 8192, T <= 512
+        const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (0xFFFFFFFFu - tie);
+        key = (u && kk > key) ? kk : key;
       }
     }
-    best = wave_best(best);
+    key = wave_max_u64(key);
     const int buf = j & 1;   // double buffered: the next round's writes cannot race this round's reads
-    if (lane == 0) {
-      s_v[buf][wave] = best.v;
-      s_t[buf][wave] = best.t;
-      s_k[buf][wave] = best.k;
-    }
+    if (lane == 0) s_key[buf][wave] = key;
     __syncthreads();
-    Best r{-1.f, 0x7fffffff, 0x7fffffff};
-    if (lane < FPS_BLOCK / 64) r = Best{s_v[buf][lane], s_t[buf][lane], s_k[buf][lane]};
-    r = wave_best(r);
-    old = r.v < 0.f ? 0 : r.k;  // every point skipped: the reference's reduction returns its initial index 0
+    unsigned long long k2 = lane < FPS_BLOCK / 64 ? s_key[buf][lane] : 0ull;
+    k2 = row16_max_u64(k2);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)k2);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(k2 >> 32));
+    // every point skipped: the reference's reduction returns its initial index 0
+    old = (lo == 0u && hi == 0u) ? 0 : (int)((0xFFFFFFFFu - lo) & 0xFFFFu);
     if (tid == 0) idxs[(size_t)b * m + j] = old;
   }
   if (temp) {
