@@ -24,16 +24,30 @@ __device__ __forceinline__ float geoa3_sqdist(float ax, float ay, float az, floa
   return s + zz;
 }
 
-// wave-wide (64 lanes) reductions via DPP-lowered shuffles
+// wave-wide (64 lanes) reductions with DPP row operations (quad_perm, row_half_mirror, row_mirror, row_bcast15/31):
+// ~10 cycles per step where __shfl_xor compiles to a ds_bpermute round trip through the LDS crossbar.  The result is
+// read from lane 63 and returned uniformly.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_f32(float v, float old) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<0xB1, 0xF>(v, 0.f);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E, 0xF>(v, 0.f);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141, 0xF>(v, 0.f);   // row_half_mirror
+  v += dpp_f32<0x140, 0xF>(v, 0.f);   // row_mirror: every lane of a row holds the row sum
+  v += dpp_f32<0x142, 0xA>(v, 0.f);   // row_bcast15: rows 1 and 3 add the sum of the row before them
+  v += dpp_f32<0x143, 0xC>(v, 0.f);   // row_bcast31: rows 2 and 3 add the sum of rows 0-1
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dpp_f32<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dpp_f32<0x141, 0xF>(v, v));
+  v = fmaxf(v, dpp_f32<0x140, 0xF>(v, v));
+  v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ------------------------------------------------------------------------------------------
