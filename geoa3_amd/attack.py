@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Callable, Optional, Sequence
 
 import numpy as np
@@ -131,6 +132,8 @@ class AttackRunner:
         if self.use_curv:
             t["knn"] = [torch.zeros(b, ne, self.k + 1, **i32) for _ in range(2)]
             t["knn_d"] = z(b, ne, self.k + 1)
+            self.knn_slab = os.environ.get("GEOA3_KNN_SLAB", "1") != "0"
+            t["knn_scratch"] = ops.knn_self_scratch(b, ne, device)
         if self.native:
             nbytes = self.lib.geoa3_pointnet_workspace_bytes(b * self.eval_num if self.sub else b, ne, self.classes)
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -293,9 +296,10 @@ class AttackRunner:
             if self.graph is not None:
                 self.graph.knn_self(xe, self.k + 1, out=(t["knn_d"], out), prior=prior)
             else:
-                check(lib.geoa3_knn(xe.data_ptr(), xe.data_ptr(), self.b, ne, ne, self.k + 1,
-                                    prior.data_ptr() if self.knn_seeded else None, t["knn_d"].data_ptr(),
-                                    out.data_ptr(), s), "knn")
+                check(lib.geoa3_knn_self(xe.data_ptr(), self.b, ne, self.k + 1,
+                                         prior.data_ptr() if self.knn_seeded else None, t["knn_d"].data_ptr(),
+                                         out.data_ptr(), t["knn_scratch"].data_ptr() if self.knn_slab else None, s),
+                      "knn_self")
             self.knn_seeded = True
             self.knn_cur = 1 - self.knn_cur
             knn_adv = out

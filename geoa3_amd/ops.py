@@ -70,6 +70,25 @@ def knn_planar(q: Tensor, r: Tensor, K: int, prior: Optional[Tensor] = None, out
     return d, i
 
 
+def knn_self_scratch(B: int, N: int, device) -> Tensor:
+    """Scratch buffer of geoa3_knn_self for [B,3,N] clouds."""
+    return torch.empty(int(_lib.load().geoa3_knn_self_scratch_bytes(B, N)), dtype=torch.uint8, device=device)
+
+
+def knn_self_planar(pc: Tensor, K: int, prior: Optional[Tensor] = None, scratch: Optional[Tensor] = None,
+                    out=None) -> Tuple[Tensor, Tensor]:
+    """== knn_planar(pc, pc, K, prior) bit for bit; slab-pruned when prior and scratch are given."""
+    B, _, N = pc.shape
+    if out is None:
+        d = torch.empty(B, N, K, device=pc.device, dtype=torch.float32)
+        i = torch.empty(B, N, K, device=pc.device, dtype=torch.int32)
+    else:
+        d, i = out
+    check(_lib.load().geoa3_knn_self(_p(pc, torch.float32), B, N, K, _p(prior, torch.int32), _p(d), _p(i),
+                                     _p(scratch), _stream()), "geoa3_knn_self")
+    return d, i
+
+
 class OriGraph:
     """Neighbour table of a CLEAN batch for the graph-pruned searches (include/geoa3_hip.h geoa3_graph_*):
     built once per batch with the brute-force K-NN, stored neighbour-major [B,Kg,N]."""

@@ -225,6 +225,46 @@ def test_graph_pruned_search_is_bit_identical_to_brute_force(ops, N, K, Kg, scal
     assert n1 is None and torch.equal(i1, bi_ao) and torch.equal(d1, b_ao)
 
 
+@pytest.mark.parametrize("N,K,scale", [(1024, 17, 0.002), (1024, 17, 0.05), (1024, 17, 0.6), (700, 9, 0.02),
+                                       (4096, 33, 0.01), (2048, 64, 0.01), (300, 17, 0.0), (40, 17, 0.05),
+                                       (8192, 5, 0.01), (9000, 5, 0.01)])
+def test_slab_pruned_self_knn_is_bit_identical_to_brute_force(ops, N, K, scale):
+    """geoa3_knn_self (slab pruning along the longest axis) against the all-pairs kernel and the oracle: good priors
+    (the clean cloud's table), stale priors (a different cloud's table), degenerate priors (duplicates / out of range:
+    the unpruned second pass) and no prior; duplicate points give exact ties."""
+    B = 3
+    ori, _ = O.make_synthetic_clouds(B, N, seed=N + K)
+    g = torch.Generator().manual_seed(23)
+    off = scale * torch.randn(B, 3, N, generator=g)
+    off[:, :, : N // 2] *= 0.1
+    adv = ori + off
+    if N > 12:
+        adv[:, :, 5] = adv[:, :, 4]
+        adv[:, :, 9] = adv[:, :, 11]
+    adv[1, 0] *= 0.05                                # a cloud whose longest axis is not x
+    oriD, advD = dev(ori), dev(adv)
+    kk = min(K, N)
+    bd, bi = ops.knn_planar(advD, advD, kk)
+    if N <= 4096:
+        od, oi = O.knn_points(adv.permute(0, 2, 1), adv.permute(0, 2, 1), kk)
+        assert torch.equal(bi.cpu().long(), oi) and torch.equal(bd.cpu(), od)
+    scratch = ops.knn_self_scratch(B, N, advD.device)
+    _, clean = ops.knn_planar(oriD, oriD, kk)
+    stale = torch.roll(clean, 1, 0).contiguous()
+    bad = clean.clone()
+    bad[:, ::3, 1] = bad[:, ::3, 0]                  # duplicates: fewer than K distinct candidates within the radius
+    bad[:, 1::7, 2] = N + 5                          # out of range: no radius
+    for prior in (clean, stale, bad, None):
+        d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch)
+        assert torch.equal(i, bi) and torch.equal(d, bd)
+    d, i = ops.knn_self_planar(advD, kk, prior=clean, scratch=None)
+    assert torch.equal(i, bi) and torch.equal(d, bd)
+    # in place over the prior (the loop's double buffer may alias)
+    tbl = clean.clone()
+    d, i = ops.knn_self_planar(advD, kk, prior=tbl, scratch=scratch, out=(torch.empty_like(bd), tbl))
+    assert torch.equal(tbl, bi)
+
+
 @pytest.mark.parametrize("Na,Nr,k", [(64, 160, 4), (200, 1500, 16), (1024, 4096, 16)])
 def test_loss_utils_unequal_cloud_sizes(Na, Nr, k):
     """The dense-cloud path (--is_subsample_opt, geoA3_attack.py:283-284): the adversarial cloud is an npoint-sample,
