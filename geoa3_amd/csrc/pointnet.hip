@@ -130,10 +130,11 @@ int fc(const float* X, int K, const float* W, const float* bias, float* Y, int N
   return launch_fc(a, s);
 }
 
-int wide(const float* X, const float* W, const float* bias, float* out, int* arg, unsigned long long* keys, int taps,
-         int B, int N, hipStream_t s) {
+int wide(const float* X, const float* W, const void* Wh, float unscale, const float* bias, float* out, int* arg,
+         unsigned long long* keys, int taps, int B, int N, hipStream_t s) {
   WideArgs a{};
   a.keys = keys;
+  a.Wh = Wh; a.unscale = unscale;
   a.X = X; a.sXb = (long)128 * N; a.ldX = N;
   a.W = W; a.bias = bias; a.out = out; a.arg = arg;
   a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
@@ -156,7 +157,7 @@ int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* 
                   int* arg, float* f4, float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s) {
   if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s));
   else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s));
-  TRY(wide(act128, t.w3p, t.b3, pooled, arg, keys, 1, B, N, s));
+  TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s));
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
   TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
   TRY(fc(f5, 256, t.f3, t.fb3, T, t.K * t.K, B, false, nullptr, s));
@@ -217,7 +218,7 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   }
   // conv4, conv5 + max (:145-147)
   TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s));
-  TRY(wide(w.h4, p.w5p, p.b5, w.p5, w.i5, w.keys, 3, B, N, s));
+  TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s));
   // classifier head (:150-152), dropout is the identity in eval mode
   TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));
   TRY(fc(w.f6, 512, p.f2, p.fb2, w.f7, 256, B, true, nullptr, s));

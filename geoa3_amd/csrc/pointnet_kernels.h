@@ -61,8 +61,19 @@ struct WideArgs {
   float* out; int* arg;                       // [B][Co]
   unsigned long long* keys;                   // [B][Co] scratch of the column-major kernel (packed running maxima)
   int Co, N, B, taps;
+  const void* Wh;                             // split-fp16 fragments (pointnet_wide_split.hip) or null = fp32 MFMA
+  float unscale;                              // 1 / (power-of-two scale of Wh)
 };
-int launch_wide_max(const WideArgs& a, hipStream_t s);
+int launch_wide_max(const WideArgs& a, hipStream_t s);          // dispatches on a.Wh
+int launch_wide_max_split(const WideArgs& a, hipStream_t s);    // pointnet_wide_split.hip
+void launch_wide_finalize(const WideArgs& a, hipStream_t s);    // keys -> out (bias + relu), arg
+
+// packed running maximum of the 1024-wide layers: (order-preserving value bits, ~point index) under a 64-bit atomicMax
+__device__ __forceinline__ unsigned long long wide_key(float v, int col) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // order-preserving map of the float
+  return ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)col);   // ties: the LOWER point index wins
+}
 
 // dX[b][ci][m] = relu'(Z) * sum_{co,tap : arg[b][co]+tap-(TAPS/2) == m} W[co][tap*128+ci] * g[b][co]
 struct WideBwdArgs {

@@ -36,12 +36,6 @@ constexpr int WM_HALO = 4;     // halo on both sides of a staged activation row 
 constexpr int W2_COLS = 64;
 constexpr int W2_XP = W2_COLS + 2 * WM_HALO;     // 72
 
-__device__ __forceinline__ unsigned long long wide_key(float v, int col) {
-  unsigned u = __float_as_uint(v);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // order-preserving map of the float
-  return ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)col);   // ties: the LOWER point index wins
-}
-
 template <int TAPS, int OCC, int W2_GROUPS>   // W2_GROUPS: channel groups of 128 per unit (8 / W2_GROUPS units per tile)
 __global__ __launch_bounds__(WM_THREADS, OCC) void wide_max2_kernel(WideArgs a, int slots_per_xcd) {
   constexpr int NGT = TAPS * 16;                 // fragment groups (8 k each) of one channel tile
@@ -268,7 +262,14 @@ __global__ __launch_bounds__(128 * NP) void wide_max_bwd_kernel(WideBwdArgs a) {
 
 }  // namespace
 
+void launch_wide_finalize(const WideArgs& a, hipStream_t s) {
+  const int total = a.B * a.Co;
+  hipLaunchKernelGGL(wide_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a.keys, a.bias, a.Co, total,
+                     a.out, a.arg);
+}
+
 int launch_wide_max(const WideArgs& a, hipStream_t s) {
+  if (a.Wh) return launch_wide_max_split(a, s);
   if (a.Co != 8 * WM_CO || (a.taps != 1 && a.taps != 3) || !a.keys) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
   geoa3_prof_begin(tag, s);
@@ -278,9 +279,7 @@ int launch_wide_max(const WideArgs& a, hipStream_t s) {
                                              // picked on hardware: 4 waves per SIMD and quarter units were slower)
   if (a.taps == 1) hipLaunchKernelGGL((wide_max2_kernel<1, OCC, 8>), dim3(SLOTS * 8), dim3(WM_THREADS), lds, s, a, SLOTS);
   else hipLaunchKernelGGL((wide_max2_kernel<3, OCC, 4>), dim3(SLOTS * 8), dim3(WM_THREADS), lds, s, a, SLOTS);
-  const int total = a.B * a.Co;
-  hipLaunchKernelGGL(wide_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a.keys, a.bias, a.Co, total,
-                     a.out, a.arg);
+  launch_wide_finalize(a, s);
   geoa3_prof_end(tag, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;

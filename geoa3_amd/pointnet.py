@@ -9,6 +9,7 @@ There is no CPU forward: a CPU input raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -42,6 +43,22 @@ def pack_wide_fragments(w: Tensor, taps: int) -> Tensor:
     return v.permute(0, 2, 3, 4, 1, 5).reshape(-1, 4).contiguous()   # T, tap, j, (h, r) = lane, i
 
 
+def pack_wide_split(w: Tensor, taps: int):
+    """[Co, taps*128] fp32 -> (fragments, unscale) for csrc/pointnet_wide_split.hip: v = w * 2^e (max |v| in
+    [2^13, 2^14)), hi = rn16(v), lo = rn16((v - hi) * 2^11) -- |v - hi - lo 2^-11| <= 2^-24 |v| -- as an fp16 tensor
+    [T = Co/32][s = K/16][piece][lane = 32h + r][j]  =  piece(w[32T + r][16s + 8h + j]);  unscale = 2^-e."""
+    w = w.float()
+    co, K = w.shape
+    amax = float(w.abs().max())
+    e = 13 - int(torch.frexp(torch.tensor(amax)).exponent) + 1 if amax > 0 else 0   # amax * 2^e in [2^13, 2^14)
+    v = torch.ldexp(w, torch.tensor(e))
+    hi = v.half()
+    lo = ((v - hi.float()) * 2048.0).half()
+    frag = torch.stack((hi, lo), 0).reshape(2, co // 32, 32, K // 16, 2, 8)       # p, T, r, s, h, j
+    frag = frag.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1, 8)              # T, s, p, (h, r), j
+    return frag, float(2.0 ** -e)
+
+
 def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     eps = 1e-3  # transform_net.eps, Model/PointNet.py:59
     sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
@@ -57,7 +74,9 @@ def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     out["f3"], out["fb3"] = _fold(sub["fc3.weight"], sub["fc3.bias"], sub, None, eps)
     for n in ("f1", "f2", "f3"):
         out[n + "t"] = out[n].t()
-    return {k: v.float().contiguous() for k, v in out.items()}
+    out = {k: v.float().contiguous() for k, v in out.items()}
+    out["w3h"], out["w3h_unscale"] = pack_wide_split(out["w3"], 1)
+    return out
 
 
 def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
@@ -79,26 +98,48 @@ def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
     for n in ("f1", "f2", "f3"):
         t[n + "t"] = t[n].t()
     out.update({k: v.float().contiguous() for k, v in t.items()})
+    out["w5h"], out["w5h_unscale"] = pack_wide_split(out["w5"], 3)
     return out
+
+
+WIDE_MODES = ("f32", "f16x2")
+
+
+def default_wide_mode() -> str:
+    """Arithmetic of the three 1024-wide layers: 'f32' = fp32 MFMA (exact fmaf chains), 'f16x2' = split-fp16 operands
+    on the f16 matrix pipe with fp32 accumulation (csrc/pointnet_wide_split.hip).  GEOA3_WIDE_MODE overrides."""
+    mode = os.environ.get("GEOA3_WIDE_MODE", "f32")
+    if mode not in WIDE_MODES:
+        raise ValueError("GEOA3_WIDE_MODE must be one of %s" % (WIDE_MODES,))
+    return mode
 
 
 class PackedPointNet:
     """Device copies of the packed weights + the ctypes struct handed to the library."""
 
-    def __init__(self, sd: Dict[str, Tensor], device: torch.device):
+    def __init__(self, sd: Dict[str, Tensor], device: torch.device, wide_mode: Optional[str] = None):
         packed = pack_pointnet({k: v.detach().cpu() for k, v in sd.items()})
         self.classes = int(packed["f3"].shape[0])
+        self.wide_mode = wide_mode or default_wide_mode()
+        split = self.wide_mode == "f16x2"
         self._keep = []
 
-        def dev(t: Tensor) -> int:
+        def dev(t) -> Optional[int]:
+            if not isinstance(t, Tensor):
+                return t                       # the float scales
             d = t.to(device).contiguous()
             self._keep.append(d)
             return d.data_ptr()
 
-        def tnet(p: Dict[str, Tensor], K: int) -> TnetWeights:
-            return TnetWeights(K=K, **{f[0]: dev(p[f[0]]) for f in TnetWeights._fields_ if f[0] != "K"})
+        def pick(p: Dict[str, object], name: str):
+            if name in ("w3h", "w5h") and not split:
+                return None
+            return dev(p[name])
 
-        fields = {f[0]: dev(packed[f[0]]) for f in PointNetWeights._fields_ if f[0] not in ("classes", "t3", "t64")}
+        def tnet(p: Dict[str, Tensor], K: int) -> TnetWeights:
+            return TnetWeights(K=K, **{f[0]: pick(p, f[0]) for f in TnetWeights._fields_ if f[0] != "K"})
+
+        fields = {f[0]: pick(packed, f[0]) for f in PointNetWeights._fields_ if f[0] not in ("classes", "t3", "t64")}
         self.struct = PointNetWeights(classes=self.classes, t3=tnet(packed["t3"], 3), t64=tnet(packed["t64"], 64),
                                       **fields)
 
@@ -183,14 +224,15 @@ class PointNet(nn.Module):
         self._packed: Optional[PackedPointNet] = None
         self._packed_key = None
         self._ws_cache: dict = {}
+        self.wide_mode: Optional[str] = None       # None = GEOA3_WIDE_MODE / 'f32'; see default_wide_mode()
 
     def _weights_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (str(device), self.wide_mode or default_wide_mode()) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def packed(self, device) -> PackedPointNet:
         key = self._weights_key(device)
         if self._packed is None or key != self._packed_key:
-            self._packed = PackedPointNet(self.state_dict(), device)
+            self._packed = PackedPointNet(self.state_dict(), device, self.wide_mode)
             self._packed_key = key
         return self._packed
 

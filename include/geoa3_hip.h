@@ -149,6 +149,8 @@ typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 
   const float *f2, *fb2;    /* fc2+bn5 [256,512]  */
   const float *f3, *fb3;    /* fc3     [K*K,256]  */
   const float *f1t, *f2t, *f3t; /* transposes: [1024,512], [512,256], [256,K*K] */
+  const void *w3h;          /* optional (NULL = fp32 MFMA): w3 as split-fp16 fragments, see w5h */
+  float w3h_unscale;
 } geoa3_tnet_weights;
 
 typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 */
@@ -166,6 +168,13 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
   const float *f2, *fb2;    /* fc2+bn7 [256,512]  */
   const float *f3, *fb3;    /* fc3     [classes,256] */
   const float *f1t, *f2t, *f3t; /* [1024,512] [512,256] [256,classes] */
+  const void *w5h;          /* optional (NULL = the 1024-wide layers run on the fp32 MFMA): w5 * 2^e as TWO fp16 values per
+                               weight, hi = rn16(v), lo = rn16((v - hi) * 2^11), in MFMA 32x32x16 fragment order
+                               [T = co/32][s = k/16][piece hi,lo][lane 0..63][j 0..7] = piece(w5[32T + (lane&31)][16s +
+                               8(lane>>5) + j]); the layer then evaluates a*w = a_hi*w_hi + 2^-11 (a_hi*w_lo + a_lo*w_hi)
+                               on the f16 matrix pipe with fp32 accumulation (csrc/pointnet_wide_split.hip).  Both or
+                               neither of the T-Nets' w3h must be given with it. */
+  float w5h_unscale;        /* 2^-e */
 } geoa3_pointnet_weights;
 
 /* bytes of scratch the forward+backward pair needs for a batch of B clouds of N points */
