@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void wide_finalize_kernel(const unsigned long 
   const unsigned long long k = keys[e];
   const unsigned u = (unsigned)(k >> 32);
   const float v = __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
-  out[e] = fmaxf(v + bias[e % Co], 0.f);
+  out[e] = v != v ? v : fmaxf(v + bias[e % Co], 0.f);   // NaN (poisoned by the split kernel's range check) stays NaN
   arg[e] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
 }
 

@@ -1,21 +1,26 @@
-// The 1024-wide layers of pointnet_wide.hip on the f16 matrix pipe with SPLIT fp32 operands (opt-in, gfx950).
+// The 1024-wide layers of pointnet_wide.hip on the f16 matrix pipe with SPLIT fp32 operands (gfx950).
 //
-// gfx950 has no tf32/xf32 MFMA and its fp32 MFMA runs at 1/16 of the 16-bit rate.  Every fp32 operand x is therefore
-// carried as two fp16 values,
-//     hi = rn16(x),   lo = rn16((x - hi) * 2^11)            (|x - hi - lo * 2^-11| <= 2^-24 |x|: half an fp32 ulp),
-// and a product a*w is evaluated as  a_hi*w_hi  +  2^-11 * (a_hi*w_lo + a_lo*w_hi)  with fp32 accumulation in the
-// matrix core (`v_mfma_f32_32x32x16_f16`; products of fp16 values are exact in fp32); the dropped a_lo*w_lo term is
-// 2^-24 relative.  The hi*hi sums and the cross sums run in SEPARATE accumulators (the 2^11 keeps the low parts out
-// of fp16's subnormal range) and are combined once per output.  Three 32-cycle MFMAs do the work of eight 64-cycle
-// fp32 ones.  Range: |activation| < 65504 (larger values overflow fp16 to inf and surface as NaN logits); weights are
-// pre-scaled by a power of two on the host (geoa3_amd/pointnet.py pack_wide_split) and the result is scaled back.
+// gfx950 has no tf32/xf32 MFMA and its fp32 MFMA runs at 1/16 of the 16-bit rate.  Every fp32 operand v (after a
+// power-of-two scaling that puts the largest magnitude of its tensor / tile into [2^13, 2^14)) is carried as two fp16
+// values,
+//     hi = rn16(v),   lo = rn16(v - hi)                   (|v - hi - lo| <= 2^-24 |v| while lo is a normal fp16),
+// and a product a*w is evaluated as  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi  with fp32 accumulation in the matrix core
+// (`v_mfma_f32_32x32x16_f16`; a product of two fp16 values is exact in fp32).  The dropped a_lo*w_lo term is 2^-24
+// relative.  Three 32-cycle MFMAs do the work of eight 64-cycle fp32 ones.  Error model: an operand smaller than
+// 2^-16 of the largest one of its tile has a subnormal (possibly flushed) lo part and keeps 11 bits -- an absolute
+// error below 2^-28 of the largest term, i.e. 1/16 ulp of a sum that contains it.  Measured (tools/wide_accuracy.py):
+// the logits' and the input gradient's error against a float64 evaluation equals that of the fp32 MFMA kernel and of
+// the fp32 CPU oracle.
+// The activation scale is chosen PER WORK UNIT from the tile's own maximum while it is staged (no range restriction;
+// a non-finite activation poisons the instance's features with NaN); the weights are scaled on the host
+// (geoa3_amd/pointnet.py pack_wide_split); the maxima are scaled back before they are published.
 //
 // Structure (differences from wide_max2_kernel): a work unit is (instance, 128-point tile, GROUPS x 128 channels); the
 // activation tile is split while it is staged and stored POINT-major in LDS ([piece][point + halo][128 ci] fp16, rows
 // padded to 272 B), so the A operand of a k-step (8 consecutive ci of one point) is one conflict-free ds_read_b128 and
-// the taps of conv5 are row offsets; each wave owns 32 channels x 128 points (4 tiles x 2 accumulators); the weight
-// fragments stream from L2 (2 x 16 B per lane per k-step of 16) through a register ring across the channel groups.
-// Epilogue, keys and the finalize kernel are those of the fp32 path.
+// the taps of conv5 are row offsets; each wave owns CB x 32 channels x 128 points (4 point tiles per channel tile);
+// the weight fragments stream from L2 (2 x 16 B per lane per channel tile and k-step of 16) through a register ring
+// across the channel groups.  Epilogue, keys and the finalize kernel are those of the fp32 path.
 #include "pointnet_kernels.h"
 #include "profile.h"
 
@@ -29,13 +34,21 @@ constexpr int SP_ROWS = SP_PTS + 2;          // + one halo point on either side 
 constexpr int SP_ROWB = 272;                 // bytes per LDS row: 128 fp16 + 16 B pad (row stride = 4 banks mod 64)
 constexpr int SP_PIECEB = SP_ROWS * SP_ROWB; // 35,360
 constexpr int SP_LDS = 2 * SP_PIECEB;        // 70,720 B: two workgroups per CU
-constexpr float SP_LO = 2048.f, SP_ILO = 1.f / 2048.f;
 
-template <int TAPS, int OCC, int GROUPS>
+__device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+
+// CB: channel tiles of 32 per wave (1: a workgroup covers 128 channels per group step, 2: 256)
+template <int TAPS, int OCC, int GROUPS, int CB, int PIPE>
 __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a, int slots_per_xcd) {
   constexpr int KS = TAPS * 8;               // k-steps of 16 per channel tile
-  constexpr int PF = 4;                      // k-steps of weight fragments in flight (2 x 16 B each); KS % PF == 0
+  constexpr int PF = CB == 1 ? 4 : 2;        // k-steps of weight fragments in flight; 8 % PF == 0
+  constexpr int NBLK = KS / PF, BPT = 8 / PF;   // blocks of PF k-steps; blocks per tap
+  constexpr int GSTEPS = GROUPS / CB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ float s_max[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, l31 = lane & 31;
   const int N = a.N, tiles = (N + SP_PTS - 1) / SP_PTS;
   constexpr int SPLIT = 8 / GROUPS;
@@ -49,132 +62,204 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
     const int b = xcd + 8 * q, tile = r / SPLIT, half = r - tile * SPLIT;
     const int n0 = tile * SP_PTS;
     const float* X = a.X + (size_t)b * a.sXb;
-    __syncthreads();   // every wave is done with the previous tile
-    // stage + split: wave w takes the channel octets w, w+4, ..; a lane one point: 8 coalesced row reads, two 16-B
-    // LDS writes (row p of the image = point n0 - 1 + p)
-#pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
-      const int p = pass * 64 + lane;
-      if (p >= SP_ROWS) break;                     // pass 2: the two rows of the right halo only (wave-uniform exit
-      const int n = n0 - 1 + p;                    //         for lanes >= 2 would diverge: they idle instead)
-      const bool in = n >= 0 && n < N;
+    // ---- stage: every value of the tile goes through registers once: maximum -> scale -> split -> LDS.
+    // Wave w takes the channel octets w, w+4, ..; a lane one point per pass (rows 1..128 of the image = points
+    // n0 .. n0+127): 8 coalesced row reads per octet.  conv5's two halo rows (points n0-1, n0+128): one value per
+    // thread.
+    float xv[2][4][8], xhalo = 0.f;
+    {
       int ldx = a.ldX;
-      asm volatile("" : "+s"(ldx));                // opaque: keeps the 32 row offsets from being hoisted out of the
-                                                   // unit loop (they were spilled to scratch)
-      const float* px = X + (in ? n : 0);
+      asm volatile("" : "+s"(ldx));              // opaque: keeps the row offsets from being hoisted out of the unit
+                                                 // loop (they were spilled to scratch)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int n = n0 + pass * 64 + lane;
+        const bool in = n < N;
+        const float* px = X + (in ? n : 0);
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float v = px[(size_t)(((wave + 4 * oc) * 8 + i) * ldx)];
+            xv[pass][oc][i] = in ? v : 0.f;
+          }
+      }
+      if (TAPS == 3) {
+        const int n = tid < 128 ? n0 - 1 : n0 + SP_PTS;
+        if (n >= 0 && n < N) xhalo = X[(size_t)((tid & 127) * ldx) + n];
+      }
+    }
+    float m = __builtin_fabsf(xhalo);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+      for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = fmaxf(m, __builtin_fabsf(xv[pass][oc][i]));   // NaN is caught through xs below
+    m = wave_max(m);
+    __syncthreads();   // every wave is done with the previous tile (LDS image and s_max)
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    // scale = 2^e with max * 2^e in [2^13, 2^14)
+    unsigned E = (__float_as_uint(m) >> 23) & 0xffu;
+    bool bad = E == 255u;    // inf (a NaN does not survive fmaxf: caught below)
+    E = E < 14u ? 14u : (E > 254u ? 254u : E);
+    const float scale = __uint_as_float((267u - E) << 23), unscale = a.unscale * __uint_as_float((E - 13u) << 23);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int p = 1 + pass * 64 + lane;
 #pragma unroll
       for (int oc = 0; oc < 4; ++oc) {
-        const int c8 = (wave + 4 * oc) * 8;
-        float x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = px[(size_t)((c8 + i) * ldx)];
         half8 hi, lo;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float xv = in ? x[i] : 0.f;
-          const _Float16 h = (_Float16)xv;
+          const float xs = xv[pass][oc][i] * scale;
+          bad |= xs != xs;
+          _Float16 h, l;
+          split16(xs, h, l);
           hi[i] = h;
-          lo[i] = (_Float16)((xv - (float)h) * SP_LO);
+          lo[i] = l;
         }
-        unsigned char* dst = smem_raw + p * SP_ROWB + c8 * 2;
+        unsigned char* dst = smem_raw + p * SP_ROWB + (wave + 4 * oc) * 16;
         *reinterpret_cast<half8*>(dst) = hi;
         *reinterpret_cast<half8*>(dst + SP_PIECEB) = lo;
       }
     }
-    __syncthreads();
+    if (TAPS == 3) {
+      const float xs = xhalo * scale;
+      bad |= xs != xs;
+      _Float16 h, l;
+      split16(xs, h, l);
+      unsigned char* dst = smem_raw + (tid < 128 ? 0 : SP_ROWS - 1) * SP_ROWB + (tid & 127) * 2;
+      *reinterpret_cast<_Float16*>(dst) = h;
+      *reinterpret_cast<_Float16*>(dst + SP_PIECEB) = l;
+    }
+    if (__syncthreads_or(bad))   // loud, not silently wrong: key ~0 decodes to NaN in wide_finalize_kernel
+      for (int c = tid; c < a.Co; c += SP_THREADS) atomicMax(a.keys + (size_t)b * a.Co + c, ~0ull);
     // A operand of lane (r = l31, h = kh), tile t, k-step s (tap = s / 8, ci0 = 16 (s % 8)):
     //   row 32t + r + tap (+1 without taps), bytes (ci0 + 8h) * 2
     const unsigned char* abase = smem_raw + (l31 + (TAPS == 1 ? 1 : 0)) * SP_ROWB + kh * 16;
-    auto wbase = [&](int g) {
-      const int co = (half * GROUPS + g) * 128 + wave * 32;
+    // fragments of the wave's channel tile c (< CB) of group step g: [T][s][piece][lane]
+    auto wbase = [&](int g, int c) {
+      const int co = (half * GROUPS + g * CB) * 128 + wave * 32 * CB + 32 * c;
       return Wall + (size_t)(co / 32) * KS * 2 * 64 + lane;
     };
-    half8 wf[PF][2];
-    {
-      const half8* W0 = wbase(0);
+    half8 wf[PF][CB][2];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const half8* W0 = wbase(0, c);
 #pragma unroll
       for (int f = 0; f < PF; ++f) {
-        wf[f][0] = W0[(size_t)(2 * f) * 64];
-        wf[f][1] = W0[(size_t)(2 * f + 1) * 64];
+        wf[f][c][0] = W0[(size_t)(2 * f) * 64];
+        wf[f][c][1] = W0[(size_t)(2 * f + 1) * 64];
       }
     }
 #pragma unroll 1
-    for (int g = 0; g < GROUPS; ++g) {
-      const int co0 = (half * GROUPS + g) * 128 + wave * 32;
-      const half8* Wp = wbase(g);
-      const half8* Wn = wbase(g + 1 < GROUPS ? g + 1 : g);
-      f32x16 ah[4], ax[4];
+    for (int g = 0; g < GSTEPS; ++g) {
+      const half8 *Wp[CB], *Wn[CB];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int c = 0; c < CB; ++c) {
+        Wp[c] = wbase(g, c);
+        Wn[c] = wbase(g + 1 < GSTEPS ? g + 1 : g, c);
+      }
+      f32x16 acc[CB][4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          ah[t][i] = 0.f;
-          ax[t][i] = 0.f;
-        }
+      for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[c][t][i] = 0.f;
       // software pipeline over (k-step, tile): the A fragments of the next tile-step are read from LDS while the
-      // three MFMAs of the current one run; the scheduling barriers keep the compiler from hoisting every read of
-      // the unrolled body to its top (that version spilled 800 registers)
+      // MFMAs of the current one run
       auto lds_rd = [&](const unsigned char* base, int f, int t, half8& h, half8& l) {
         const unsigned char* ap = base + 32 * t * SP_ROWB + f * 32;
         h = *reinterpret_cast<const half8*>(ap);
         l = *reinterpret_cast<const half8*>(ap + SP_PIECEB);
       };
-      half8 xh, xl, nh, nl;
-      lds_rd(abase, 0, 0, xh, xl);
+      // tile-step j = 4 f + t of the current block (j >= 4 PF: the next block's first step)
+      auto rd_step = [&](const unsigned char* ap0, const unsigned char* ap1, int j, half8& h, half8& l) {
+        if (j < 4 * PF) lds_rd(ap0, j >> 2, j & 3, h, l);
+        else lds_rd(ap1, (j - 4 * PF) >> 2, (j - 4 * PF) & 3, h, l);
+      };
+      half8 qh[2], ql[2];
+      rd_step(abase, abase, 0, qh[0], ql[0]);
 #pragma unroll 1
-      for (int s4 = 0; s4 < KS / PF; ++s4) {
-        // k-steps 4 s4 .. 4 s4 + 3: tap = s4 / 2, ci0 = 64 (s4 & 1) + 16 f
-        const unsigned char* ap0 = abase + (s4 >> 1) * SP_ROWB + (s4 & 1) * 128;
-        const int s5 = s4 + 1 < KS / PF ? s4 + 1 : s4;
-        const unsigned char* ap1 = abase + (s5 >> 1) * SP_ROWB + (s5 & 1) * 128;
-        const half8* src = s4 + 1 < KS / PF ? Wp + (size_t)(2 * PF * 64) * (s4 + 1) : Wn;
+      for (int sb = 0; sb < NBLK; ++sb) {
+        // k-steps PF sb .. PF sb + PF - 1: tap = sb / BPT, ci0 = 16 PF (sb % BPT) + 16 f
+        const unsigned char* ap0 = abase + (sb / BPT) * SP_ROWB + (sb % BPT) * (PF * 32);
+        const int sn = sb + 1 < NBLK ? sb + 1 : sb;
+        const unsigned char* ap1 = abase + (sn / BPT) * SP_ROWB + (sn % BPT) * (PF * 32);
 #pragma unroll
         for (int f = 0; f < PF; ++f) {
-          const half8 wh = wf[f][0], wl = wf[f][1];
-          wf[f][0] = src[(2 * f) * 64];
-          wf[f][1] = src[(2 * f + 1) * 64];
+          half8 wh[CB], wl[CB];
+#pragma unroll
+          for (int c = 0; c < CB; ++c) {
+            wh[c] = wf[f][c][0];
+            wl[c] = wf[f][c][1];
+            const half8* src = sb + 1 < NBLK ? Wp[c] + (size_t)(2 * PF * 64) * (sb + 1) : Wn[c];
+            wf[f][c][0] = src[(2 * f) * 64];
+            wf[f][c][1] = src[(2 * f + 1) * 64];
+          }
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            if (t < 3) lds_rd(ap0, f, t + 1, nh, nl);
-            else if (f < PF - 1) lds_rd(ap0, f + 1, 0, nh, nl);
-            else lds_rd(ap1, 0, 0, nh, nl);
-            __builtin_amdgcn_sched_barrier(0);
+            const int j = 4 * f + t;
+            rd_step(ap0, ap1, j + 1, qh[(j + 1) & 1], ql[(j + 1) & 1]);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            const half8 xh = qh[j & 1], xl = ql[j & 1];
             // operands swapped as in the fp32 kernel: rows = points, columns = channels
-            ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, ah[t], 0, 0, 0);
-            ax[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, ax[t], 0, 0, 0);
-            ax[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, ax[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            xh = nh;
-            xl = nl;
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+              acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[c], acc[c][t], 0, 0, 0);
+              acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[c], acc[c][t], 0, 0, 0);
+              acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[c], acc[c][t], 0, 0, 0);
+            }
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
       // lane: channel co0 + l31; acc[t][r]: point n0 + 32t + (r&3) + 8(r>>2) + 4kh.  Ascending point order, strict >
-      float v = -__builtin_inff();
-      int col = 0;
+      const bool full = n0 + SP_PTS <= N;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int c = 0; c < CB; ++c) {
+        const int co0 = (half * GROUPS + g * CB) * 128 + wave * 32 * CB + 32 * c;
+        float v = -__builtin_inff();
+        int col = 0;
+        if (full) {
 #pragma unroll
-        for (int r16 = 0; r16 < 16; ++r16) {
-          const int n = n0 + 32 * t + mfma_row(r16, lane);
-          const float val = (ah[t][r16] + ax[t][r16] * SP_ILO) * a.unscale;
-          const bool gt = n < N && val > v;
-          v = gt ? val : v;
-          col = gt ? n : col;
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+              const bool gt = acc[c][t][r16] > v;
+              v = gt ? acc[c][t][r16] : v;
+              col = gt ? 32 * t + mfma_row(r16, 0) : col;
+            }
+          col += n0 + 4 * kh;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+              const int n = n0 + 32 * t + mfma_row(r16, lane);
+              const bool gt = n < N && acc[c][t][r16] > v;
+              v = gt ? acc[c][t][r16] : v;
+              col = gt ? n : col;
+            }
         }
-      const float ov = __shfl_xor(v, 32, 64);
-      const int oc = __shfl_xor(col, 32, 64);
-      const bool take = ov > v || (ov == v && oc < col);
-      v = take ? ov : v;
-      col = take ? oc : col;
-      if (lane < 32) atomicMax(a.keys + (size_t)b * a.Co + co0 + lane, wide_key(v, col));
+        const float ov = __shfl_xor(v, 32, 64);
+        const int oc = __shfl_xor(col, 32, 64);
+        const bool take = ov > v || (ov == v && oc < col);
+        v = take ? ov : v;
+        col = take ? oc : col;
+        if (lane < 32) atomicMax(a.keys + (size_t)b * a.Co + co0 + lane, wide_key(v * unscale, col));
+      }
     }
   }
 }
 
-template <int TAPS, int OCC, int GROUPS>
+template <int TAPS, int OCC, int GROUPS, int CB, int PIPE>
 void launch_variant(const WideArgs& a, hipStream_t s) {
-  auto kern = wide_split_kernel<TAPS, OCC, GROUPS>;
+  auto kern = wide_split_kernel<TAPS, OCC, GROUPS, CB, PIPE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
   constexpr int SLOTS = 32 * OCC;
   hipLaunchKernelGGL(kern, dim3(SLOTS * 8), dim3(SP_THREADS), SP_LDS, s, a, SLOTS);
@@ -182,15 +267,45 @@ void launch_variant(const WideArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int g_split_variant = 0;   // tuning hook of tools/bench_wide.py (geoa3_debug_wide_fwd): 0 = the shipped configuration
+
 int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
   if (a.Co != 1024 || (a.taps != 1 && a.taps != 3) || !a.keys || !a.Wh) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
   geoa3_prof_begin(tag, s);
   if (hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
-  if (a.taps == 1) launch_variant<1, 2, 8>(a, s);
-  else launch_variant<3, 2, 4>(a, s);
+  if (a.taps == 1) {
+    switch (g_split_variant) {
+      case 1: launch_variant<1, 2, 8, 2, 0>(a, s); break;
+      case 2: launch_variant<1, 2, 8, 1, 1>(a, s); break;
+      case 3: launch_variant<1, 2, 4, 1, 0>(a, s); break;
+      default: launch_variant<1, 2, 8, 1, 0>(a, s);
+    }
+  } else {
+    switch (g_split_variant) {
+      case 1: launch_variant<3, 2, 4, 2, 0>(a, s); break;
+      case 2: launch_variant<3, 2, 4, 1, 1>(a, s); break;
+      case 3: launch_variant<3, 2, 8, 1, 0>(a, s); break;
+      default: launch_variant<3, 2, 4, 1, 0>(a, s);
+    }
+  }
   launch_wide_finalize(a, s);
   geoa3_prof_end(tag, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
+}
+
+// One 1024-wide layer in isolation (tools/bench_wide.py, tests): Wp = fp32 fragments, Wh = split fragments or NULL.
+extern "C" int geoa3_debug_wide_fwd(const float* X, const float* Wp, const void* Wh, float unscale, const float* bias,
+                                    float* out, int32_t* arg, void* keys, int B, int N, int taps, int variant,
+                                    void* stream) {
+  WideArgs a{};
+  a.X = X; a.sXb = (long)128 * N; a.ldX = N;
+  a.W = Wp; a.Wh = Wh; a.unscale = unscale; a.bias = bias;
+  a.out = out; a.arg = arg; a.keys = (unsigned long long*)keys;
+  a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
+  g_split_variant = variant;
+  const int rc = launch_wide_max(a, geoa3_stream(stream));
+  g_split_variant = 0;
+  return rc;
 }

@@ -45,7 +45,8 @@ def pack_wide_fragments(w: Tensor, taps: int) -> Tensor:
 
 def pack_wide_split(w: Tensor, taps: int):
     """[Co, taps*128] fp32 -> (fragments, unscale) for csrc/pointnet_wide_split.hip: v = w * 2^e (max |v| in
-    [2^13, 2^14)), hi = rn16(v), lo = rn16((v - hi) * 2^11) -- |v - hi - lo 2^-11| <= 2^-24 |v| -- as an fp16 tensor
+    [2^13, 2^14)), hi = rn16(v), lo = rn16(v - hi) -- |v - hi - lo| <= 2^-24 |v| while lo is a normal fp16, i.e. for
+    every weight above 2^-16 of the largest -- as an fp16 tensor
     [T = Co/32][s = K/16][piece][lane = 32h + r][j]  =  piece(w[32T + r][16s + 8h + j]);  unscale = 2^-e."""
     w = w.float()
     co, K = w.shape
@@ -53,7 +54,7 @@ def pack_wide_split(w: Tensor, taps: int):
     e = 13 - int(torch.frexp(torch.tensor(amax)).exponent) + 1 if amax > 0 else 0   # amax * 2^e in [2^13, 2^14)
     v = torch.ldexp(w, torch.tensor(e))
     hi = v.half()
-    lo = ((v - hi.float()) * 2048.0).half()
+    lo = (v - hi.float()).half()
     frag = torch.stack((hi, lo), 0).reshape(2, co // 32, 32, K // 16, 2, 8)       # p, T, r, s, h, j
     frag = frag.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1, 8)              # T, s, p, (h, r), j
     return frag, float(2.0 ** -e)

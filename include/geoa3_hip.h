@@ -168,12 +168,12 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
   const float *f2, *fb2;    /* fc2+bn7 [256,512]  */
   const float *f3, *fb3;    /* fc3     [classes,256] */
   const float *f1t, *f2t, *f3t; /* [1024,512] [512,256] [256,classes] */
-  const void *w5h;          /* optional (NULL = the 1024-wide layers run on the fp32 MFMA): w5 * 2^e as TWO fp16 values per
-                               weight, hi = rn16(v), lo = rn16((v - hi) * 2^11), in MFMA 32x32x16 fragment order
+  const void *w5h;          /* optional (NULL = the 1024-wide layers run on the fp32 MFMA): v = w5 * 2^e as TWO fp16 values
+                               per weight, hi = rn16(v), lo = rn16(v - hi), in MFMA 32x32x16 fragment order
                                [T = co/32][s = k/16][piece hi,lo][lane 0..63][j 0..7] = piece(w5[32T + (lane&31)][16s +
-                               8(lane>>5) + j]); the layer then evaluates a*w = a_hi*w_hi + 2^-11 (a_hi*w_lo + a_lo*w_hi)
-                               on the f16 matrix pipe with fp32 accumulation (csrc/pointnet_wide_split.hip).  Both or
-                               neither of the T-Nets' w3h must be given with it. */
+                               8(lane>>5) + j]); the layer then evaluates a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the
+                               f16 matrix pipe with fp32 accumulation (csrc/pointnet_wide_split.hip).  Both or neither
+                               of the T-Nets' w3h must be given with it. */
   float w5h_unscale;        /* 2^-e */
 } geoa3_pointnet_weights;
 
@@ -379,6 +379,8 @@ int geoa3_profile_read(int tag, float* ms_host, int cap); /* waits for the recor
  * W [1024, taps*128], Z / dX [B,128,N]. */
 int geoa3_debug_wide_bwd(const float* g, const int32_t* arg, const float* W, const float* Z, float* dX, int B, int N,
                          int taps, void* stream);
+int geoa3_debug_wide_fwd(const float* X, const float* Wp, const void* Wh, float unscale, const float* bias, float* out,
+                         int32_t* arg, void* keys, int B, int N, int taps, int variant, void* stream);
 int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, int N, int K,
                         int Co, int relu, void* stream);
 

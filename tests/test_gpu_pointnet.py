@@ -21,14 +21,15 @@ def net(request):
 
 
 def assert_grad_close(got, ref):
-    """Input gradient: rtol 2e-3 / atol 2e-4 of the largest entry.  A channel whose two best points are closer than
-    the summation-order noise (~1e-7 relative) may take its arg-max at the other point -- the gradient of that one
-    channel then lands on another point; at most 0.05 % of the entries may differ for that reason (each such entry
-    still within 1 % of the largest gradient)."""
+    """Input gradient [B,3,N]: rtol 2e-3 / atol 2e-4 of the largest entry.  A channel of a max-pooled layer whose two
+    best points are closer than the rounding noise of the dot products (~1e-7 relative: about 3e-5 of the 3 x 1024
+    pooled channels of an instance) may take its arg-max at the other point; the whole gradient of that one channel
+    then lands on other points (2 points x 3 coordinates, x 3 taps for conv5).  Budget: 18 entries per allowed flip,
+    ceil(5e-5 * 3072 * B) flips."""
     scale = np.abs(ref).max()
     bad = np.abs(got - ref) > 2e-3 * np.abs(ref) + 2e-4 * scale
-    assert bad.mean() <= 5e-4, "%d of %d gradient entries differ" % (bad.sum(), bad.size)
-    assert np.abs(got - ref).max() <= 1e-2 * scale
+    flips = int(np.ceil(5e-5 * 3072 * got.shape[0]))
+    assert bad.sum() <= 18 * flips, "%d of %d gradient entries differ" % (bad.sum(), bad.size)
 
 
 @pytest.mark.parametrize("tag", ["n64", "n256", "n1024"])
@@ -69,12 +70,12 @@ def test_batch_independence(net):
             assert torch.equal(net(x[k:k + 1].contiguous())[0], full[k])
 
 
-@pytest.mark.parametrize("scale", [1e-3, 1.0, 300.0])
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 300.0, 1e6])
 def test_wide_split_operand_range(scale):
-    """f16x2 mode carries every fp32 operand of the 1024-wide layers as two fp16 values (hi, 2^11 * lo): activations
-    of very different magnitude going into conv5 / the T-Nets' conv3 (here through the BatchNorm scale of the layer in
-    front of them) must keep fp32-level agreement with the oracle; beyond fp16's range (65504) the result must be
-    loud (NaN), never silently wrong."""
+    """f16x2 mode carries every fp32 operand of the 1024-wide layers as two fp16 values after a power-of-two scaling
+    taken from the tile's own maximum: activations of very different magnitude going into conv5 / the T-Nets' conv3
+    (here through the BatchNorm scale of the layer in front of them) -- far outside fp16's own range -- must keep
+    fp32-level agreement with the oracle."""
     from geoa3_amd.pointnet import PointNet
     sd = O.make_pointnet_state_dict(40, seed=2)
     for name in ("bn4", "input_transform.bn2", "feature_transform.bn2"):
@@ -82,19 +83,60 @@ def test_wide_split_operand_range(scale):
         sd[name + ".bias"] = sd[name + ".bias"] * scale
     pc, _ = O.make_synthetic_clouds(4, 300, seed=8)
     lo = O.pointnet_forward(sd, pc)
-    outs = {}
     for mode in ("f32", "f16x2"):
         n = PointNet(40)
         n.load_state_dict(sd)
         n.wide_mode = mode
+        n = n.cuda().eval()
         with torch.no_grad():
-            outs[mode] = n.cuda().eval()(pc.cuda()).cpu()
-        np.testing.assert_allclose(outs[mode].numpy(), lo.numpy(), rtol=1e-4, atol=1e-4 * float(lo.abs().max()))
-    # out of range: the hi part overflows to inf and the logits are NaN
-    for name in ("bn4",):
-        sd[name + ".weight"] = sd[name + ".weight"] * 1e6
-    n = PointNet(40)
-    n.load_state_dict(sd)
-    n.wide_mode = "f16x2"
-    with torch.no_grad():
-        assert not torch.isfinite(n.cuda().eval()(pc.cuda())).all()
+            out = n(pc.cuda()).cpu()
+            np.testing.assert_allclose(out.numpy(), lo.numpy(), rtol=1e-4, atol=1e-4 * float(lo.abs().max()))
+
+
+@pytest.mark.parametrize("taps,N", [(3, 1024), (1, 1024), (3, 200), (1, 77), (3, 128)])
+def test_wide_layer_both_modes_against_float64(taps, N):
+    """One 1024-wide layer (conv + bias + relu + max over points, arg-max) through geoa3_debug_wide_fwd in both
+    arithmetic modes against a float64 evaluation: values to fp32 rounding of a K = 128 * taps dot product; the
+    arg-max is the float64 one wherever the float64 runner-up is not within rounding noise; a non-finite activation
+    poisons that instance's features with NaN in f16x2 mode (loud, never silently dropped by the max)."""
+    from geoa3_amd import _lib
+    from geoa3_amd.pointnet import pack_wide_fragments, pack_wide_split
+    lib = _lib.load()
+    B = 5
+    g = torch.Generator().manual_seed(taps * 1000 + N)
+    X = (torch.randn(B, 128, N, generator=g) * torch.logspace(-3, 2, 128).view(1, 128, 1)).relu()
+    X[1] *= 1e-9
+    X[3] *= 1e7
+    W = torch.randn(1024, taps * 128, generator=g) * 0.05
+    bias = torch.randn(1024, generator=g)
+    conv = torch.nn.functional.conv1d(X.double(), W.double().view(1024, taps, 128).permute(0, 2, 1), padding=taps // 2)
+    ref, ref_arg = conv.max(dim=2)
+    second = conv.scatter(2, ref_arg.unsqueeze(2), -float("inf")).max(dim=2).values
+    ref_out = (ref + bias.double()).clamp_min(0)
+    mag = torch.nn.functional.conv1d(X.double().abs(), W.double().abs().view(1024, taps, 128).permute(0, 2, 1),
+                                     padding=taps // 2).max(dim=2).values          # bound on sum |a w|
+    Wp, (Wh, uns) = pack_wide_fragments(W, taps).cuda(), pack_wide_split(W, taps)
+    Wh, Xd, bd = Wh.cuda(), X.cuda(), bias.cuda()
+    out = torch.empty(B, 1024, device="cuda")
+    arg = torch.empty(B, 1024, device="cuda", dtype=torch.int32)
+    keys = torch.empty(B, 1024, device="cuda", dtype=torch.int64)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(split, x):
+        _lib.check(lib.geoa3_debug_wide_fwd(x.data_ptr(), Wp.data_ptr(), Wh.data_ptr() if split else None, uns,
+                                            bd.data_ptr(), out.data_ptr(), arg.data_ptr(), keys.data_ptr(), B, N, taps,
+                                            0, s), "geoa3_debug_wide_fwd")
+        return out.cpu().double(), arg.cpu().long()
+
+    for split in (False, True):
+        o, a = run(split, Xd)
+        tol = 4e-6 * mag + 2e-7 * (ref.abs() + bias.double().abs())   # ~ sqrt(K) 2^-24 sum |a w|, + the bias add
+        assert ((o - ref_out).abs() <= tol).all(), (split, float(((o - ref_out).abs() / tol).max()))
+        clear = (ref - second) > 2 * tol
+        assert clear.float().mean() > 0.7    # (instance 1: the bias dominates, nothing is clear there)
+        assert torch.equal(a[clear], ref_arg[clear])
+    bad = Xd.clone()
+    bad[2, 5, N // 2] = float("inf")
+    bad[4, 100, 0] = float("nan")
+    o, _ = run(True, bad)
+    assert torch.isnan(o[2]).all() and torch.isnan(o[4]).all() and torch.isfinite(o[[0, 1, 3]]).all()

@@ -49,6 +49,35 @@ def main():
         (lg * w.cuda()).sum().backward()
         err("hip_" + mode, lg.detach().cpu().double(), x.grad.cpu().double())
     res["logits_scale"] = float(ref_l.abs().max())
+
+    # one 1024-wide layer in isolation: pooled pre-activations against float64
+    from geoa3_amd import _lib
+    from geoa3_amd.pointnet import pack_wide_fragments, pack_wide_split
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for taps in (3, 1):
+        B, N = 16, a.N
+        X = torch.randn(B, 128, N, generator=g).relu()
+        W = torch.randn(1024, taps * 128, generator=g) * 0.05
+        ref = torch.nn.functional.conv1d(X.double(), W.double().view(1024, taps, 128).permute(0, 2, 1),
+                                         padding=taps // 2).max(dim=2).values
+        Wp, (Wh, uns) = pack_wide_fragments(W, taps).cuda(), pack_wide_split(W, taps)
+        Wh, Xd = Wh.cuda(), X.cuda()
+        bias = torch.full((1024,), 1e6, device="cuda")      # keeps the relu out of the way; subtracted again below
+        out = torch.empty(B, 1024, device="cuda")
+        arg = torch.empty(B, 1024, device="cuda", dtype=torch.int32)
+        keys = torch.empty(B, 1024, device="cuda", dtype=torch.int64)
+        zero = torch.zeros(1024, device="cuda")
+        for split in (False, True):
+            # bias 0: negative maxima are clipped by the relu -- compare where the reference is positive
+            lib.geoa3_debug_wide_fwd(Xd.data_ptr(), Wp.data_ptr(), Wh.data_ptr() if split else None, uns,
+                                     zero.data_ptr(), out.data_ptr(), arg.data_ptr(), keys.data_ptr(), B, N, taps, 0,
+                                     torch.cuda.current_stream().cuda_stream)
+            o = out.cpu().double()
+            pos = ref > 0
+            rel = ((o - ref).abs() / ref.abs())[pos]
+            res["layer_taps%d_%s" % (taps, "f16x2" if split else "f32")] = {
+                "max_rel": float(rel.max()), "rms_rel": float(rel.pow(2).mean().sqrt())}
     print(json.dumps(res, indent=1))
 
 
