@@ -31,6 +31,7 @@ NPOINT = 1024
 KNN = 16
 CLASSES = 40
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: dense fp32 matrix peak (spec)
+PEAK_F16_MFMA = 2.5e15    # dense f16 / bf16 matrix peak (spec, without 2:1 sparsity)
 PEAK_HBM = 8.0e12
 
 
@@ -95,6 +96,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-mode", action="store_true",
+                    help="skip the second, shorter measurement in the other arithmetic mode of the 1024-wide layers")
     ap.add_argument("--instances", type=int, default=INSTANCES, help="instances per GPU (default 250)")
     ap.add_argument("--npoint", type=int, default=NPOINT, help="points per cloud (configs[4]: 4096)")
     ap.add_argument("--knn", type=int, default=KNN, help="curv_loss_knn (configs[4]: 32)")
@@ -129,8 +132,6 @@ def main():
     from geoa3_amd.data import synthetic_clouds, synthetic_state_dict
 
     B = a.instances
-    total = a.warmup + a.steps
-    cfg = cfg_config2(total)
     if a.arch == "PointNet":
         net = PointNet(CLASSES)
         net.load_state_dict(synthetic_state_dict(CLASSES, seed=0, device=dev))
@@ -143,11 +144,6 @@ def main():
     ori, nrm = ori.to(dev), nrm.to(dev)
     with torch.no_grad():
         gt = net(ori).argmax(1)
-    runner = AttackRunner(net, B, NPOINT, cfg, dev, global_batch=B * world)
-    runner.setup(ori, nrm, gt, gt)
-    g = torch.Generator(device="cpu").manual_seed(7 + rank)
-    init = (torch.randn(B, 3, NPOINT, generator=g) * 1e-3).to(dev)
-    runner.begin_search_step(init)
     lib = _lib.load()
 
     def barrier():
@@ -156,60 +152,112 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(a.warmup):
-        runner.step(s, 0)
-    barrier()
-    # HIP events around the DOMINANT kernel only inside the timed region (an event pair costs ~6 us of stream time);
-    # the other kernels' durations come from a few extra, untimed iterations afterwards
-    lib.geoa3_profile_enable(a.steps)
-    lib.geoa3_profile_select(1)
-    t0 = time.perf_counter()
-    for s in range(a.warmup, total):
-        runner.step(s, 0)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def measure(wide_mode, steps, warmup):
+        """`warmup` untimed + exactly `steps` timed inner iterations with the 1024-wide layers in `wide_mode`;
+        returns (seconds, max over ranks; per-kernel average ms of conv5 / nn1 / knn / T-Net wide)."""
+        total = warmup + steps
+        cfg = cfg_config2(total + 16)
+        if a.arch == "PointNet":
+            net.wide_mode = wide_mode
+        runner = AttackRunner(net, B, NPOINT, cfg, dev, global_batch=B * world)
+        runner.setup(ori, nrm, gt, gt)
+        g = torch.Generator(device="cpu").manual_seed(7 + rank)
+        init = (torch.randn(B, 3, NPOINT, generator=g) * 1e-3).to(dev)
+        runner.begin_search_step(init)
+        for s in range(warmup):
+            runner.step(s, 0)
+        barrier()
+        # HIP events around the DOMINANT kernel only inside the timed region (an event pair costs ~6 us of stream
+        # time); the other kernels' durations come from a few extra, untimed iterations afterwards
+        lib.geoa3_profile_enable(steps)
+        lib.geoa3_profile_select(1)
+        t0 = time.perf_counter()
+        for s in range(warmup, total):
+            runner.step(s, 0)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
 
-    def kernel_ms(tag):
-        buf = (C.c_float * a.steps)()
-        n = lib.geoa3_profile_read(tag, buf, a.steps)
-        return (sum(buf[:n]) / n) if n > 0 else None
+        def kernel_ms(tag):
+            buf = (C.c_float * steps)()
+            n = lib.geoa3_profile_read(tag, buf, steps)
+            return (sum(buf[:n]) / n) if n > 0 else None
 
-    conv5_ms = kernel_ms(0)
-    extra = min(a.steps, 10)
-    lib.geoa3_profile_select(0xE)
-    for s in range(total, total + extra):
-        runner.step(s % cfg.iter_max_steps, 0)
-    torch.cuda.synchronize()
-    nn1_ms, knn_ms, tnet_ms = (kernel_ms(t) for t in (1, 2, 3))
-    lib.geoa3_profile_select(0xFFFFFFFF)
-    lib.geoa3_profile_enable(0)
+        conv5_ms = kernel_ms(0)
+        extra = min(steps, 10)
+        lib.geoa3_profile_select(0xE)
+        for s in range(total, total + extra):
+            runner.step(s, 0)
+        torch.cuda.synchronize()
+        nn1_ms, knn_ms, tnet_ms = (kernel_ms(t) for t in (1, 2, 3))
+        lib.geoa3_profile_select(0xFFFFFFFF)
+        lib.geoa3_profile_enable(0)
+        return dt, conv5_ms, nn1_ms, knn_ms, tnet_ms, extra
+
+    from geoa3_amd.pointnet import default_wide_mode
+    mode = default_wide_mode() if a.arch == "PointNet" else None
+    dt, conv5_ms, nn1_ms, knn_ms, tnet_ms, extra = measure(mode, a.steps, a.warmup)
+    other = None
+    if a.arch == "PointNet" and not a.single_mode:
+        # the same loop with the 1024-wide layers in the other arithmetic mode, shorter, reported beside the headline
+        omode = "f32" if mode == "f16x2" else "f16x2"
+        osteps = max(10, min(a.steps, 40))
+        odt, oconv5, _, _, otnet, _ = measure(omode, osteps, min(a.warmup, 5))
+        other = (omode, osteps, odt, oconv5, otnet)
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = (B * world * a.steps / dt) / INSTANCES
         conv5_flops = 2.0 * B * NPOINT * 1024 * 384          # algorithmic: 1024 outputs x (3 taps x 128) MACs / point
-        achieved = conv5_flops / (conv5_ms * 1e-3) / 1e12 if conv5_ms else None
+
+        def roofline(m, ms):
+            """conv5 + max: fp32 MFMA against the fp32 matrix peak; split mode against the dense f16 peak with the
+            flops the scheme EXECUTES (3 f16 MFMA products per fp32 product)."""
+            if not ms:
+                return None
+            if m == "f16x2":
+                ach = 3.0 * conv5_flops / (ms * 1e-3)
+                return {"bound": "mfma", "kernel": "wide_split_kernel<3> (conv5+bn5+relu+max; split-fp16 operands, "
+                                                   "3 f16 MFMA products per fp32 product, fp32 accumulate)",
+                        "achieved": round(ach / 1e12, 1), "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F16_MFMA, 4), "avg_launch_ms": round(ms, 4),
+                        "algorithmic_flops_per_launch": conv5_flops, "executed_mfma_flops_per_launch": 3.0 * conv5_flops,
+                        "fp32_equivalent_TFLOPs": round(conv5_flops / (ms * 1e-3) / 1e12, 1),
+                        "note": "MI355X_MICROARCH.md: a tuned 8192^3 bf16 GEMM sustains 1247 TFLOP/s on random data "
+                                "(the chip lowers its clock under 16-bit MFMA load)", "traffic": None}
+            ach = conv5_flops / (ms * 1e-3)
+            return {"bound": "mfma", "kernel": "wide_max2_kernel<3> (conv5+bn5+relu+max, fp32 MFMA)",
+                    "achieved": round(ach / 1e12, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA, 4), "avg_launch_ms": round(ms, 4),
+                    "algorithmic_flops_per_launch": conv5_flops, "traffic": None}
+
         out = {
             "metric": "attack-iterations/sec (B=250, N=%d)" % NPOINT, "value": round(value, 3),
             "unit": "iterations/s of a 250-instance batch", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if mode != "f16x2" else
+                     "f32 (values, accumulation and every kernel but the three 1024-wide layers; those carry each fp32 "
+                     "operand as two fp16 values on the f16 MFMA with fp32 accumulation -- error against float64 no "
+                     "larger than the fp32 MFMA kernel's, tools/wide_accuracy.py; GEOA3_WIDE_MODE=f32 selects fp32 MFMA)",
+            "data": "synthetic",
             "config": {"workload": "configs[%d]: PointNet %d-pt, %d instances per GPU, full GeoA3 (CE + CD 1.0 + HD 0.1 + "
                                    "curvature 1.0 k=%d), untargeted" % (1 if NPOINT == 1024 else 4, NPOINT, B, KNN),
                        "instances_per_gpu": B, "npoint": NPOINT, "knn": KNN, "classes": CLASSES,
-                       "parallelism": "instance-sharded x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "wide_max2_kernel<3> (conv5+bn5+relu+max, fp32 MFMA)",
-                         "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_F32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_F32_MFMA, 4) if achieved else None,
-                         "avg_launch_ms": round(conv5_ms, 4) if conv5_ms else None,
-                         "algorithmic_flops_per_launch": conv5_flops, "traffic": None},   # traffic filled below
+                       "wide_mode": mode, "parallelism": "instance-sharded x%d" % world},
+            "roofline": roofline(mode, conv5_ms),
         }
-        tr, src = pmc_traffic("wide_max2_kernel<3")
-        if tr is not None and NPOINT == 1024 and B == INSTANCES:
+        if other is not None:
+            omode, osteps, odt, oconv5, otnet = other
+            out["other_wide_mode"] = {"wide_mode": omode, "value": round((B * world * osteps / odt) / INSTANCES, 3),
+                                      "ms_per_step": round(odt / osteps * 1e3, 4), "steps": osteps,
+                                      "roofline": roofline(omode, oconv5),
+                                      "kernels_ms": {"conv5_wide_max": oconv5, "tnet_wide_max(x2)": otnet}}
+        tr, src = pmc_traffic("wide_split_kernel<3" if mode == "f16x2" else "wide_max2_kernel<3")
+        if tr is not None and NPOINT == 1024 and B == INSTANCES and out["roofline"]:
             out["roofline"]["traffic"] = tr
             out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % src
         if a.arch != "PointNet":   # configs[3]: the MLPs are MIOpen/hipBLASLt kernels, no single hand-written dominant kernel

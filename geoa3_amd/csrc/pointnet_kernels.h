@@ -63,6 +63,7 @@ struct WideArgs {
   int Co, N, B, taps;
   const void* Wh;                             // split-fp16 fragments (pointnet_wide_split.hip) or null = fp32 MFMA
   float unscale;                              // 1 / (power-of-two scale of Wh)
+  unsigned long long* stamps;                 // diagnostics (tools/bench_wide.py --stamps): s_memtime trace of workgroup 0
 };
 int launch_wide_max(const WideArgs& a, hipStream_t s);          // dispatches on a.Wh
 int launch_wide_max_split(const WideArgs& a, hipStream_t s);    // pointnet_wide_split.hip

@@ -41,7 +41,7 @@ __device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
 }
 
 // CB: channel tiles of 32 per wave (1: a workgroup covers 128 channels per group step, 2: 256)
-template <int TAPS, int OCC, int GROUPS, int CB, int PIPE>
+template <int TAPS, int OCC, int GROUPS, int CB, int PIPE, bool DESYNC>
 __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a, int slots_per_xcd) {
   constexpr int KS = TAPS * 8;               // k-steps of 16 per channel tile
   constexpr int PF = CB == 1 ? 4 : 2;        // k-steps of weight fragments in flight; 8 % PF == 0
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
   constexpr int GSTEPS = GROUPS / CB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ float s_max[4];
+  // packed maxima of the current unit, published (atomicMax) while the NEXT unit is being staged: keeps the atomics
+  // out of the in-order vmcnt queue in front of the weight stream (on its own within run-to-run noise)
+  __shared__ unsigned long long s_keys[4][GROUPS][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, l31 = lane & 31;
   const int N = a.N, tiles = (N + SP_PTS - 1) / SP_PTS;
   constexpr int SPLIT = 8 / GROUPS;
@@ -57,11 +60,40 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
   const int inst_x = (a.B - xcd + 7) / 8;
   const int units = inst_x * per_inst;
   const half8* Wall = reinterpret_cast<const half8*>(a.Wh);
-  for (int u = slot; u < units; u += slots_per_xcd) {
+  // The two workgroups that share a CU start together and do identical work.  DESYNC: the workgroup in the odd wave
+  // slot of its SIMD (HW_ID.wave_id) runs half of its first unit's channel groups first and the other half at the very
+  // end (one extra staging pass), which shifts its phases by half a period, so one workgroup's staging and epilogues
+  // run under the other's MFMAs.  (s_memtime trace, tools/bench_wide.py --stamps: per unit 7 % waiting for the tile,
+  // 7 % splitting it, 4 x 20.7 % channel groups of which 2 % epilogue.)  Worth 0-10 % depending on the device: the
+  // kernel sits at the clock-limited ceiling of the 16-bit matrix pipe (1.25 PFLOP/s executed at 1.86 GHz, 66 % busy).
+  bool late = false;
+  if (DESYNC) {
+    if (tid == 0) s_max[0] = __int_as_float(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1);   // HW_REG_HW_ID[3:0]
+    __syncthreads();
+    late = __float_as_int(s_max[0]) != 0;
+  }
+  const int nmine = units > slot ? (units - slot + slots_per_xcd - 1) / slots_per_xcd : 0;
+  late = late && nmine > 0 && GSTEPS > 1;
+  int nstamp = 0;
+  auto stamp = [&]() {   // diagnostic build only (a.stamps != null): wave 0 of workgroup 0 records s_memtime
+    if (a.stamps && blockIdx.x == 0 && tid == 0 && nstamp < 255) a.stamps[1 + nstamp++] = __builtin_amdgcn_s_memtime();
+  };
+  int pend_b = -1, pend_co = 0, pend_n = 0;     // unit whose maxima wait in s_keys: instance, first channel, tiles
+  auto flush = [&]() {
+    if (pend_b < 0) return;
+    for (int i = kh; i < pend_n; i += 2)       // the two half-waves publish two channel tiles per instruction
+      atomicMax(a.keys + (size_t)pend_b * a.Co + pend_co + (i / CB) * (128 * CB) + (i % CB) * 32 + l31, s_keys[wave][i][l31]);
+    pend_b = -1;
+  };
+  for (int it = 0; it < nmine + (late ? 1 : 0); ++it) {
+    const int u = slot + (it == nmine ? 0 : it) * slots_per_xcd;
+    const int g_begin = late && it == nmine ? GSTEPS / 2 : 0;
+    const int g_end = late && it == 0 ? GSTEPS / 2 : GSTEPS;
     const int q = u / per_inst, r = u - q * per_inst;
     const int b = xcd + 8 * q, tile = r / SPLIT, half = r - tile * SPLIT;
     const int n0 = tile * SP_PTS;
     const float* X = a.X + (size_t)b * a.sXb;
+    stamp();
     // ---- stage: every value of the tile goes through registers once: maximum -> scale -> split -> LDS.
     // Wave w takes the channel octets w, w+4, ..; a lane one point per pass (rows 1..128 of the image = points
     // n0 .. n0+127): 8 coalesced row reads per octet.  conv5's two halo rows (points n0-1, n0+128): one value per
@@ -97,6 +129,8 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
 #pragma unroll
         for (int i = 0; i < 8; ++i) m = fmaxf(m, __builtin_fabsf(xv[pass][oc][i]));   // NaN is caught through xs below
     m = wave_max(m);
+    stamp();
+    flush();           // the previous unit's maxima, behind this unit's loads
     __syncthreads();   // every wave is done with the previous tile (LDS image and s_max)
     if (lane == 0) s_max[wave] = m;
     __syncthreads();
@@ -137,6 +171,7 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
     }
     if (__syncthreads_or(bad))   // loud, not silently wrong: key ~0 decodes to NaN in wide_finalize_kernel
       for (int c = tid; c < a.Co; c += SP_THREADS) atomicMax(a.keys + (size_t)b * a.Co + c, ~0ull);
+    stamp();
     // A operand of lane (r = l31, h = kh), tile t, k-step s (tap = s / 8, ci0 = 16 (s % 8)):
     //   row 32t + r + tap (+1 without taps), bytes (ci0 + 8h) * 2
     const unsigned char* abase = smem_raw + (l31 + (TAPS == 1 ? 1 : 0)) * SP_ROWB + kh * 16;
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
     half8 wf[PF][CB][2];
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
-      const half8* W0 = wbase(0, c);
+      const half8* W0 = wbase(g_begin, c);
 #pragma unroll
       for (int f = 0; f < PF; ++f) {
         wf[f][c][0] = W0[(size_t)(2 * f) * 64];
@@ -156,12 +191,12 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
       }
     }
 #pragma unroll 1
-    for (int g = 0; g < GSTEPS; ++g) {
+    for (int g = g_begin; g < g_end; ++g) {
       const half8 *Wp[CB], *Wn[CB];
 #pragma unroll
       for (int c = 0; c < CB; ++c) {
         Wp[c] = wbase(g, c);
-        Wn[c] = wbase(g + 1 < GSTEPS ? g + 1 : g, c);
+        Wn[c] = wbase(g + 1 < g_end ? g + 1 : g, c);
       }
       f32x16 acc[CB][4];
 #pragma unroll
@@ -170,13 +205,57 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[c][t][i] = 0.f;
-      // software pipeline over (k-step, tile): the A fragments of the next tile-step are read from LDS while the
-      // MFMAs of the current one run
       auto lds_rd = [&](const unsigned char* base, int f, int t, half8& h, half8& l) {
         const unsigned char* ap = base + 32 * t * SP_ROWB + f * 32;
         h = *reinterpret_cast<const half8*>(ap);
         l = *reinterpret_cast<const half8*>(ap + SP_PIECEB);
       };
+      if (PIPE == 2) {
+        // software pipeline over k-steps: the eight A fragments (4 point tiles x hi, lo) of k-step s+1 are requested
+        // from LDS before the 12 x CB MFMAs of k-step s are issued (the compiler's own schedule reused one register
+        // for the lo fragments: read, wait, MFMA, four exposed LDS latencies per k-step)
+        half8 A[2][4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lds_rd(abase, 0, t, A[0][t][0], A[0][t][1]);
+#pragma unroll 1
+        for (int sb = 0; sb < NBLK; ++sb) {
+          const unsigned char* ap0 = abase + (sb / BPT) * SP_ROWB + (sb % BPT) * (PF * 32);
+          const int sn = sb + 1 < NBLK ? sb + 1 : sb;
+          const unsigned char* ap1 = abase + (sn / BPT) * SP_ROWB + (sn % BPT) * (PF * 32);
+#pragma unroll
+          for (int f = 0; f < PF; ++f) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int cur = f & 1, nxt = cur ^ 1;          // PF is even: the buffers line up across blocks
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if (f + 1 < PF) lds_rd(ap0, f + 1, t, A[nxt][t][0], A[nxt][t][1]);
+              else lds_rd(ap1, 0, t, A[nxt][t][0], A[nxt][t][1]);
+            }
+            half8 wh[CB], wl[CB];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+              wh[c] = wf[f][c][0];
+              wl[c] = wf[f][c][1];
+              const half8* src = sb + 1 < NBLK ? Wp[c] + (size_t)(2 * PF * 64) * (sb + 1) : Wn[c];
+              wf[f][c][0] = src[(2 * f) * 64];
+              wf[f][c][1] = src[(2 * f + 1) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int c = 0; c < CB; ++c) {
+                acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[cur][t][0], wh[c], acc[c][t], 0, 0, 0);
+                acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[cur][t][0], wl[c], acc[c][t], 0, 0, 0);
+                acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[cur][t][1], wh[c], acc[c][t], 0, 0, 0);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
+      // software pipeline over (k-step, tile): the A fragments of the next tile-step are read from LDS while the
+      // MFMAs of the current one run
       // tile-step j = 4 f + t of the current block (j >= 4 PF: the next block's first step)
       auto rd_step = [&](const unsigned char* ap0, const unsigned char* ap1, int j, half8& h, half8& l) {
         if (j < 4 * PF) lds_rd(ap0, j >> 2, j & 3, h, l);
@@ -218,11 +297,12 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
           }
         }
       }
+      }
+      stamp();
       // lane: channel co0 + l31; acc[t][r]: point n0 + 32t + (r&3) + 8(r>>2) + 4kh.  Ascending point order, strict >
       const bool full = n0 + SP_PTS <= N;
 #pragma unroll
       for (int c = 0; c < CB; ++c) {
-        const int co0 = (half * GROUPS + g * CB) * 128 + wave * 32 * CB + 32 * c;
         float v = -__builtin_inff();
         int col = 0;
         if (full) {
@@ -251,15 +331,21 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
         const bool take = ov > v || (ov == v && oc < col);
         v = take ? ov : v;
         col = take ? oc : col;
-        if (lane < 32) atomicMax(a.keys + (size_t)b * a.Co + co0 + lane, wide_key(v * unscale, col));
+        if (lane < 32) s_keys[wave][(g - g_begin) * CB + c][lane] = wide_key(v * unscale, col);
       }
     }
+    stamp();
+    pend_b = b;
+    pend_co = (half * GROUPS + g_begin * CB) * 128 + wave * 32 * CB;
+    pend_n = (g_end - g_begin) * CB;
   }
+  flush();
+  if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[0] = nstamp;
 }
 
-template <int TAPS, int OCC, int GROUPS, int CB, int PIPE>
+template <int TAPS, int OCC, int GROUPS, int CB, int PIPE, bool DESYNC>
 void launch_variant(const WideArgs& a, hipStream_t s) {
-  auto kern = wide_split_kernel<TAPS, OCC, GROUPS, CB, PIPE>;
+  auto kern = wide_split_kernel<TAPS, OCC, GROUPS, CB, PIPE, DESYNC>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
   constexpr int SLOTS = 32 * OCC;
   hipLaunchKernelGGL(kern, dim3(SLOTS * 8), dim3(SP_THREADS), SP_LDS, s, a, SLOTS);
@@ -274,19 +360,18 @@ int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
   geoa3_prof_begin(tag, s);
   if (hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
+  // variants measured on hardware (tools/bench_wide.py 0 1 2): within +-5 % of each other and of run-to-run noise
   if (a.taps == 1) {
     switch (g_split_variant) {
-      case 1: launch_variant<1, 2, 8, 2, 0>(a, s); break;
-      case 2: launch_variant<1, 2, 8, 1, 1>(a, s); break;
-      case 3: launch_variant<1, 2, 4, 1, 0>(a, s); break;
-      default: launch_variant<1, 2, 8, 1, 0>(a, s);
+      case 1: launch_variant<1, 2, 8, 1, 2, true>(a, s); break;
+      case 2: launch_variant<1, 2, 8, 1, 0, false>(a, s); break;
+      default: launch_variant<1, 2, 8, 1, 0, true>(a, s);
     }
   } else {
     switch (g_split_variant) {
-      case 1: launch_variant<3, 2, 4, 2, 0>(a, s); break;
-      case 2: launch_variant<3, 2, 4, 1, 1>(a, s); break;
-      case 3: launch_variant<3, 2, 8, 1, 0>(a, s); break;
-      default: launch_variant<3, 2, 4, 1, 0>(a, s);
+      case 1: launch_variant<3, 2, 4, 1, 0, true>(a, s); break;
+      case 2: launch_variant<3, 2, 4, 1, 2, false>(a, s); break;
+      default: launch_variant<3, 2, 4, 1, 2, true>(a, s);
     }
   }
   launch_wide_finalize(a, s);
@@ -298,12 +383,13 @@ int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
 // One 1024-wide layer in isolation (tools/bench_wide.py, tests): Wp = fp32 fragments, Wh = split fragments or NULL.
 extern "C" int geoa3_debug_wide_fwd(const float* X, const float* Wp, const void* Wh, float unscale, const float* bias,
                                     float* out, int32_t* arg, void* keys, int B, int N, int taps, int variant,
-                                    void* stream) {
+                                    void* stamps, void* stream) {
   WideArgs a{};
   a.X = X; a.sXb = (long)128 * N; a.ldX = N;
   a.W = Wp; a.Wh = Wh; a.unscale = unscale; a.bias = bias;
   a.out = out; a.arg = arg; a.keys = (unsigned long long*)keys;
   a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
+  a.stamps = (unsigned long long*)stamps;
   g_split_variant = variant;
   const int rc = launch_wide_max(a, geoa3_stream(stream));
   g_split_variant = 0;

@@ -107,9 +107,10 @@ WIDE_MODES = ("f32", "f16x2")
 
 
 def default_wide_mode() -> str:
-    """Arithmetic of the three 1024-wide layers: 'f32' = fp32 MFMA (exact fmaf chains), 'f16x2' = split-fp16 operands
-    on the f16 matrix pipe with fp32 accumulation (csrc/pointnet_wide_split.hip).  GEOA3_WIDE_MODE overrides."""
-    mode = os.environ.get("GEOA3_WIDE_MODE", "f32")
+    """Arithmetic of the three 1024-wide layers.  'f16x2' (default): every fp32 operand carried as two fp16 values on
+    the f16 matrix pipe, fp32 accumulation (csrc/pointnet_wide_split.hip; error against float64 no larger than the
+    fp32 MFMA kernel's, 3.3x faster).  'f32': fp32 MFMA (exact fmaf chains).  GEOA3_WIDE_MODE overrides."""
+    mode = os.environ.get("GEOA3_WIDE_MODE", "f16x2")
     if mode not in WIDE_MODES:
         raise ValueError("GEOA3_WIDE_MODE must be one of %s" % (WIDE_MODES,))
     return mode
@@ -225,7 +226,7 @@ class PointNet(nn.Module):
         self._packed: Optional[PackedPointNet] = None
         self._packed_key = None
         self._ws_cache: dict = {}
-        self.wide_mode: Optional[str] = None       # None = GEOA3_WIDE_MODE / 'f32'; see default_wide_mode()
+        self.wide_mode: Optional[str] = None       # None = GEOA3_WIDE_MODE / 'f16x2'; see default_wide_mode()
 
     def _weights_key(self, device):
         return (str(device), self.wide_mode or default_wide_mode()) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))

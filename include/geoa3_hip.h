@@ -380,7 +380,7 @@ int geoa3_profile_read(int tag, float* ms_host, int cap); /* waits for the recor
 int geoa3_debug_wide_bwd(const float* g, const int32_t* arg, const float* W, const float* Z, float* dX, int B, int N,
                          int taps, void* stream);
 int geoa3_debug_wide_fwd(const float* X, const float* Wp, const void* Wh, float unscale, const float* bias, float* out,
-                         int32_t* arg, void* keys, int B, int N, int taps, int variant, void* stream);
+                         int32_t* arg, void* keys, int B, int N, int taps, int variant, void* stamps, void* stream);
 int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, int N, int K,
                         int Co, int relu, void* stream);
 

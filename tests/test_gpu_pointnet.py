@@ -125,7 +125,7 @@ def test_wide_layer_both_modes_against_float64(taps, N):
     def run(split, x):
         _lib.check(lib.geoa3_debug_wide_fwd(x.data_ptr(), Wp.data_ptr(), Wh.data_ptr() if split else None, uns,
                                             bd.data_ptr(), out.data_ptr(), arg.data_ptr(), keys.data_ptr(), B, N, taps,
-                                            0, s), "geoa3_debug_wide_fwd")
+                                            0, None, s), "geoa3_debug_wide_fwd")
         return out.cpu().double(), arg.cpu().long()
 
     for split in (False, True):

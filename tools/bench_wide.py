@@ -4,7 +4,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 from geoa3_amd import _lib  # noqa: E402
 from geoa3_amd.pointnet import pack_wide_fragments, pack_wide_split  # noqa: E402
 from tools.bench_conv import timeit  # noqa: E402
@@ -12,7 +13,8 @@ from tools.bench_conv import timeit  # noqa: E402
 
 def main():
     lib = _lib.load()
-    variants = [int(v) for v in sys.argv[1:]] or [0]
+    variants = [int(v) for v in sys.argv[1:] if v != "--stamps"] or [0]
+    want_stamps = "--stamps" in sys.argv
     B, N = 250, 1024
     s = torch.cuda.current_stream().cuda_stream
     for taps in (3, 1):
@@ -27,16 +29,23 @@ def main():
         keys = torch.empty(B, 1024, device="cuda", dtype=torch.int64)
         flops = 2.0 * B * N * 1024 * 128 * taps
 
-        def run(split, variant):
+        def run(split, variant, stamps=None):
             return lib.geoa3_debug_wide_fwd(X.data_ptr(), Wp.data_ptr(), Wh.data_ptr() if split else None, uns,
                                             bias.data_ptr(), out.data_ptr(), arg.data_ptr(), keys.data_ptr(), B, N,
-                                            taps, variant, s)
+                                            taps, variant, stamps, s)
         us = timeit(lambda: run(False, 0))
         ref = out.clone()
         print("taps=%d fp32 MFMA      : %7.1f us  %6.1f TF" % (taps, us, flops / us / 1e6))
         for v in variants:
             us = timeit(lambda: run(True, v))
             err = float((out - ref).abs().max() / ref.abs().max())
+            if want_stamps:
+                st = torch.zeros(256, device="cuda", dtype=torch.int64)
+                run(True, v, st.data_ptr())
+                torch.cuda.synchronize()
+                st = st.cpu().tolist()
+                t = st[1:1 + st[0]]
+                print("   s_memtime deltas of workgroup 0 / wave 0 (cycles):", [t[i + 1] - t[i] for i in range(len(t) - 1)])
             print("taps=%d split variant %d: %7.1f us  %6.1f TF-equivalent (%.0f TF on the f16 pipe)  max rel diff %.1e"
                   % (taps, v, us, flops / us / 1e6, 3 * flops / us / 1e6, err))
 

@@ -72,7 +72,7 @@ def main():
             # bias 0: negative maxima are clipped by the relu -- compare where the reference is positive
             lib.geoa3_debug_wide_fwd(Xd.data_ptr(), Wp.data_ptr(), Wh.data_ptr() if split else None, uns,
                                      zero.data_ptr(), out.data_ptr(), arg.data_ptr(), keys.data_ptr(), B, N, taps, 0,
-                                     torch.cuda.current_stream().cuda_stream)
+                                     None, torch.cuda.current_stream().cuda_stream)
             o = out.cpu().double()
             pos = ref > 0
             rel = ((o - ref).abs() / ref.abs())[pos]
