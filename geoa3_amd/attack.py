@@ -13,6 +13,7 @@ Reference quirks kept on purpose:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 import os
@@ -87,6 +88,16 @@ class AttackRunner:
         if self.sub:
             self.graph_search = False
         self.hooks = {}
+        # The geometry kernels of an iteration (1-NN, K-NN, losses: VALU / latency bound) do not depend on the victim's
+        # forward (MFMA / HBM bound): they are enqueued on a second HIP stream between two events, so the hardware
+        # runs them beside it (GEOA3_GEO_STREAM=0: everything on the current stream).  Same kernels, same results.
+        # Measured: 2.78 -> 2.72 ms/iteration (N = 4096: 12.7 -> 11.7); joining only after the backward (head without
+        # the constrain loss, added afterwards) gained nothing more: the kernels slow each other down.
+        self.geo_stream = (torch.cuda.Stream(device=device)
+                           if os.environ.get("GEOA3_GEO_STREAM", "1") != "0" and torch.device(device).type == "cuda"
+                           else None)
+        self.ev_x, self.ev_geo = ((torch.cuda.Event(), torch.cuda.Event()) if self.geo_stream is not None
+                                  else (None, None))
         # the 1-NN tables through the uniform-grid search (geom_grid.hip; same bits as the all-pairs kernel, which
         # stays the path for clouds beyond 4096 points or when cfg.brute_force_nn1 is set)
         self.grid_nn1 = max(n, self.ne) <= 4096 and not _cfg(cfg, "brute_force_nn1", False)
@@ -259,6 +270,12 @@ class AttackRunner:
             torch.add(xe, t["noise"], out=t["x_eval"])
             xe = t["x_eval"]
         logits_ag = x_leaf = None
+        main = torch.cuda.current_stream()
+        sg, geo_ctx = s, None
+        if self.geo_stream is not None:     # xe is final on the main stream: the geometry may start
+            self.ev_x.record(main)
+            self.geo_stream.wait_event(self.ev_x)
+            sg = self.geo_stream.cuda_stream
         if self.native:
             check(lib.geoa3_pointnet_forward(C.byref(self.packed.struct), xe.data_ptr(), self.b, ne,
                                              t["logits"].data_ptr(), self.ws.data_ptr(), s), "pointnet_forward")
@@ -270,49 +287,53 @@ class AttackRunner:
                 raise _lib.Geoa3Error("the victim returned logits of shape %s, expected %s (set cfg.classes)"
                                       % (tuple(logits_ag.shape), tuple(t["logits"].shape)))
             t["logits"].copy_(logits_ag.detach())
-        constrain = None
-        if self.need_nn:
-            both = self.dis_type == 1 and not cfg.is_cd_single_side
-            if self.graph is not None:
-                self.graph.nn1_pair(xe, both, out=(t["d_ao"], t["i_ao"], t["d_oa"] if both else None,
-                                                   t["i_oa"] if both else None))
-            else:
-                if self.grid_nn1:   # seeded with the tables of the previous iteration (in place)
-                    pa = t["i_ao"].data_ptr() if self.nn1_seeded else None
-                    pr = t["i_oa"].data_ptr() if self.nn1_seeded and both else None
-                    check(lib.geoa3_grid_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n, pa, pr,
-                                                  t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
-                                                  t["d_oa"].data_ptr() if both else None,
-                                                  t["i_oa"].data_ptr() if both else None, s), "grid_nn1_pair")
-                    self.nn1_seeded = not self.sub
+        with (torch.cuda.stream(self.geo_stream) if self.geo_stream is not None else contextlib.nullcontext()):
+            constrain = None
+            if self.need_nn:
+                both = self.dis_type == 1 and not cfg.is_cd_single_side
+                if self.graph is not None:
+                    self.graph.nn1_pair(xe, both, out=(t["d_ao"], t["i_ao"], t["d_oa"] if both else None,
+                                                       t["i_oa"] if both else None))
                 else:
-                    check(lib.geoa3_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n,
-                                             t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
-                                             t["d_oa"].data_ptr() if both else None,
-                                             t["i_oa"].data_ptr() if both else None, s), "nn1_pair")
-        knn_adv = None
-        if self.use_curv:
-            prior, out = t["knn"][self.knn_cur], t["knn"][1 - self.knn_cur]
-            if self.graph is not None:
-                self.graph.knn_self(xe, self.k + 1, out=(t["knn_d"], out), prior=prior)
-            else:
-                check(lib.geoa3_knn_self(xe.data_ptr(), self.b, ne, self.k + 1,
-                                         prior.data_ptr() if self.knn_seeded else None, t["knn_d"].data_ptr(),
-                                         out.data_ptr(), t["knn_scratch"].data_ptr() if self.knn_slab else None, s),
-                      "knn_self")
-            self.knn_seeded = True
-            self.knn_cur = 1 - self.knn_cur
-            knn_adv = out
-        if self.dis_type != 0 or cfg.hd_loss_weight != 0 or self.use_curv:
-            ops.geo_loss_grad(xe, self.ori, normal_ori=self.nrm if self.use_curv else None,
-                              kappa_ori=self.kappa_ori, d_ao=t["d_ao"] if self.need_nn else None,
-                              i_ao=t["i_ao"] if self.need_nn else None,
-                              d_oa=t["d_oa"] if self.dis_type == 1 and not cfg.is_cd_single_side else None,
-                              i_oa=t["i_oa"] if self.dis_type == 1 and not cfg.is_cd_single_side else None,
-                              knn_adv=knn_adv, k=self.k if self.use_curv else 0, dis_type=self.dis_type,
-                              single_side=bool(cfg.is_cd_single_side), w_dis=float(cfg.dis_loss_weight),
-                              w_hd=float(cfg.hd_loss_weight), w_curv=float(cfg.curv_loss_weight), out=self.geo_out)
-            constrain = self.geo_out["constrain"]
+                    if self.grid_nn1:   # seeded with the tables of the previous iteration (in place)
+                        pa = t["i_ao"].data_ptr() if self.nn1_seeded else None
+                        pr = t["i_oa"].data_ptr() if self.nn1_seeded and both else None
+                        check(lib.geoa3_grid_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n, pa, pr,
+                                                      t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
+                                                      t["d_oa"].data_ptr() if both else None,
+                                                      t["i_oa"].data_ptr() if both else None, sg), "grid_nn1_pair")
+                        self.nn1_seeded = not self.sub
+                    else:
+                        check(lib.geoa3_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n,
+                                                 t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
+                                                 t["d_oa"].data_ptr() if both else None,
+                                                 t["i_oa"].data_ptr() if both else None, sg), "nn1_pair")
+            knn_adv = None
+            if self.use_curv:
+                prior, out = t["knn"][self.knn_cur], t["knn"][1 - self.knn_cur]
+                if self.graph is not None:
+                    self.graph.knn_self(xe, self.k + 1, out=(t["knn_d"], out), prior=prior)
+                else:
+                    check(lib.geoa3_knn_self(xe.data_ptr(), self.b, ne, self.k + 1,
+                                             prior.data_ptr() if self.knn_seeded else None, t["knn_d"].data_ptr(),
+                                             out.data_ptr(), t["knn_scratch"].data_ptr() if self.knn_slab else None, sg),
+                          "knn_self")
+                self.knn_seeded = True
+                self.knn_cur = 1 - self.knn_cur
+                knn_adv = out
+            if self.dis_type != 0 or cfg.hd_loss_weight != 0 or self.use_curv:
+                ops.geo_loss_grad(xe, self.ori, normal_ori=self.nrm if self.use_curv else None,
+                                  kappa_ori=self.kappa_ori, d_ao=t["d_ao"] if self.need_nn else None,
+                                  i_ao=t["i_ao"] if self.need_nn else None,
+                                  d_oa=t["d_oa"] if self.dis_type == 1 and not cfg.is_cd_single_side else None,
+                                  i_oa=t["i_oa"] if self.dis_type == 1 and not cfg.is_cd_single_side else None,
+                                  knn_adv=knn_adv, k=self.k if self.use_curv else 0, dis_type=self.dis_type,
+                                  single_side=bool(cfg.is_cd_single_side), w_dis=float(cfg.dis_loss_weight),
+                                  w_hd=float(cfg.hd_loss_weight), w_curv=float(cfg.curv_loss_weight), out=self.geo_out)
+                constrain = self.geo_out["constrain"]
+        if self.geo_stream is not None:     # join: the head needs the constrain loss, the update the gradient
+            self.ev_geo.record(self.geo_stream)
+            main.wait_event(self.ev_geo)
         check(lib.geoa3_attack_head_vote(st, t["logits"].data_ptr(), self._p(vote_logits),
                                          self.eval_num if self.sub else 1,
                                          self._p(constrain), x.data_ptr(), step, search_step,
