@@ -189,9 +189,11 @@ def main():
         conv5_ms = kernel_ms(0)
         extra = min(steps, 10)
         lib.geoa3_profile_select(0xE)
+        geo_stream, runner.geo_stream = runner.geo_stream, None   # one stream: durations of the kernels on their own
         for s in range(total, total + extra):
             runner.step(s, 0)
         torch.cuda.synchronize()
+        runner.geo_stream = geo_stream
         nn1_ms, knn_ms, tnet_ms = (kernel_ms(t) for t in (1, 2, 3))
         lib.geoa3_profile_select(0xFFFFFFFF)
         lib.geoa3_profile_enable(0)
@@ -273,7 +275,8 @@ def main():
                                 "valu_frac": round(8.0 * B * NPOINT * NPOINT / (nn1_ms * 1e-3) / 157.3e12, 4)}
         out["kernels_ms"] = {"conv5_wide_max": conv5_ms, "tnet_wide_max(x2)": tnet_ms, "nn1_pair": nn1_ms, "knn": knn_ms,
                              "note": "conv5: HIP events inside the timed region; the others: %d untimed iterations "
-                                     "right after it" % extra}
+                                     "right after it, on ONE stream (in the timed loop the geometry kernels run on a "
+                                     "second stream beside the victim's forward)" % extra}
         if not a.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline()

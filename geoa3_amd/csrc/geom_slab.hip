@@ -123,6 +123,20 @@ __global__ __launch_bounds__(SB_T) void slab_bin_kernel(const float* __restrict_
   if (tid == 0) geo[b] = SlabGeo{alo, inv_w, axis, 0};
 }
 
+typedef float slab_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab_sqdist2(float qx, float qy, float qz, float x0, float x1, float y0, float y1,
+                                             float z0, float z1, float& d0, float& d1) {
+#pragma clang fp contract(off)
+  const slab_f2 dx = slab_f2{qx, qx} - slab_f2{x0, x1};
+  const slab_f2 dy = slab_f2{qy, qy} - slab_f2{y0, y1};
+  const slab_f2 dz = slab_f2{qz, qz} - slab_f2{z0, z1};
+  const slab_f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  const slab_f2 s = xx + yy;
+  const slab_f2 d = s + zz;
+  d0 = d.x;
+  d1 = d.y;
+}
+
 __device__ __forceinline__ bool slab_lex_less(float da, int ia, float db, int ib) {
   return (da < db) || (da == db && ia < ib);
 }
@@ -234,12 +248,14 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
         const float4 rx = *reinterpret_cast<const float4*>(&s_ref[j]);
         const float4 ry = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK + j]);
         const float4 rz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK + j]);
-        const float rxa[4] = {rx.x, rx.y, rx.z, rx.w};
-        const float rya[4] = {ry.x, ry.y, ry.z, ry.w};
-        const float rza[4] = {rz.x, rz.y, rz.z, rz.w};
+        // two candidates per instruction: v_pk_add_f32 / v_pk_mul_f32 are IEEE per component, so with contraction off
+        // the distances are the bits of geoa3_sqdist (3 sub + 3 mul + 2 add = 4 packed instructions per point)
+        float da[4];
+        slab_sqdist2(qx, qy, qz, rx.x, rx.y, ry.x, ry.y, rz.x, rz.y, da[0], da[1]);
+        slab_sqdist2(qx, qy, qz, rx.z, rx.w, ry.z, ry.w, rz.z, rz.w, da[2], da[3]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float d = geoa3_sqdist(qx, qy, qz, rxa[u], rya[u], rza[u]);
+          const float d = da[u];
           if (d <= tau) {
             s_cd[cnt * SK_BLOCK + tid] = d;
             s_ci[cnt * SK_BLOCK + tid] = s_id[j + u];
