@@ -18,6 +18,8 @@ struct Ws {  // workspace carve-up; every buffer starts on a 256-byte boundary
   int* i5;
   // backward temporaries
   float *G128, *G64a, *P64, *dh2, *g1024, *g512, *g256, *gT64, *gT3, *dTpart;   // P64 [B][64][64] = h2 G64a^T
+  // relu gates of the stored activations as bit masks [B][ceil(N/64)][C] x 64 bit (ConvArgs::Ymask / Zmask)
+  unsigned long long *m_a2, *m_h2, *m_c1, *m_c2, *m_h3, *m_h4;
   size_t total;
 };
 
@@ -63,6 +65,13 @@ Ws carve(void* base, int B, int N, int classes) {
   w.gT64 = (float*)take(b * 4096);
   w.gT3 = (float*)take(b * 16);
   w.dTpart = (float*)take(b * 9 * (size_t)((N + 255) / 256));
+  const size_t n64 = (size_t)(N + 63) / 64;
+  w.m_a2 = (unsigned long long*)take(b * 128 * n64 * 2);
+  w.m_h2 = (unsigned long long*)take(b * 64 * n64 * 2);
+  w.m_c1 = (unsigned long long*)take(b * 64 * n64 * 2);
+  w.m_c2 = (unsigned long long*)take(b * 128 * n64 * 2);
+  w.m_h3 = (unsigned long long*)take(b * 64 * n64 * 2);
+  w.m_h4 = (unsigned long long*)take(b * 128 * n64 * 2);
   w.total = off;
   (void)classes;
   return w;
@@ -76,8 +85,10 @@ Ws carve(void* base, int B, int N, int classes) {
 
 // Y = act(W X + bias) over [B][K][N] -> [B][Co][N]; shared weights [Co][K]
 int conv(const float* X, int K, const float* W, const float* bias, float* Y, int Co, int B, int N, bool relu,
-         const float* Z, bool accumulate, hipStream_t s) {
+         const float* Z, bool accumulate, hipStream_t s, unsigned long long* Ymask = nullptr,
+         const unsigned long long* Zmask = nullptr) {
   ConvArgs a{};
+  a.Ymask = Ymask; a.Zmask = Zmask;
   a.X = X; a.sXb = (long)K * N; a.ldX = N;
   a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
   a.bias = bias;
@@ -91,8 +102,9 @@ int conv(const float* X, int K, const float* W, const float* bias, float* Y, int
 // Y = act(W relu(w1 (T^T x) + b1) + bias): the 3-channel first layer (Model/PointNet.py:79,137-139) folded into the
 // 64-input convolution that follows it; its activation is never written
 int conv_first(const float* x, const float* T, const float* w1, const float* b1, const float* W, const float* bias,
-               float* Y, int Co, int B, int N, hipStream_t s) {
+               float* Y, int Co, int B, int N, hipStream_t s, unsigned long long* Ymask) {
   ConvArgs a{};
+  a.Ymask = Ymask;
   a.x3 = x; a.T3 = T; a.w1 = w1; a.b1 = b1; a.produce_first = 1;
   a.W = W; a.sWb = 0; a.sWco = 64; a.sWk = 1;
   a.bias = bias;
@@ -141,9 +153,10 @@ int wide(const float* X, const float* W, const void* Wh, float unscale, const fl
   return launch_wide_max(a, s);
 }
 
-int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, float* dX, int taps, int B, int N,
-             hipStream_t s) {
+int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, const unsigned long long* Zmask, float* dX,
+             int taps, int B, int N, hipStream_t s) {
   WideBwdArgs a{};
+  a.Zmask = Zmask;
   a.g = g; a.arg = arg; a.W = W;
   a.Z = Z; a.sZb = (long)128 * N; a.ldZ = N;
   a.dX = dX; a.sXb = (long)128 * N; a.ldX = N;
@@ -153,10 +166,11 @@ int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, flo
 
 // transform_net.forward (Model/PointNet.py:78-87) after its first layer
 // act64 == nullptr: the T-Net reads the cloud itself (K = 3) and its first layer is folded into conv2 (x3 given)
-int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* x3, float* act128, float* pooled,
+int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* x3, float* act128,
+                  unsigned long long* m128, float* pooled,
                   int* arg, float* f4, float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s) {
-  if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s));
-  else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s));
+  if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s, m128));
+  else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s, m128));
   TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s));
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
   TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
@@ -165,14 +179,15 @@ int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* 
 }
 
 // d/d(transform) [B][K*K] -> gradient w.r.t. the pre-activation of the T-Net's first layer (G64 out)
-int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, const float* x3, const float* act128,
+int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, const unsigned long long* m64,
+             const float* x3, const float* act128, const unsigned long long* m128,
              const float* pooled, const int* arg, const float* f4, const float* f5, Ws& w, float* G64out, int B, int N,
              hipStream_t s) {
   TRY(fc(gT, t.K * t.K, t.f3t, nullptr, w.g256, 256, B, false, f5, s));
   TRY(fc(w.g256, 256, t.f2t, nullptr, w.g512, 512, B, false, f4, s));
   TRY(fc(w.g512, 512, t.f1t, nullptr, w.g1024, 1024, B, false, pooled, s));
-  TRY(wide_bwd(w.g1024, arg, t.w3, act128, w.G128, 1, B, N, s));
-  if (act64) TRY(conv(w.G128, 128, t.w2t, nullptr, G64out, 64, B, N, false, act64, false, s));
+  TRY(wide_bwd(w.g1024, arg, t.w3, act128, m128, w.G128, 1, B, N, s));
+  if (act64) TRY(conv(w.G128, 128, t.w2t, nullptr, G64out, 64, B, N, false, nullptr, false, s, nullptr, m64));
   else TRY(conv_gate_first(w.G128, 128, t.w2t, nullptr, x3, nullptr, t.w1, t.b1, B, N, s, G64out /* = dx */, 1));
   return 0;
 }
@@ -193,12 +208,12 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   Ws w = carve(workspace, B, N, pw->classes);
   const geoa3_pointnet_weights& p = *pw;
   // input transform (Model/PointNet.py:137-138)
-  TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
+  TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
   // trunk conv1, conv2 (:139-140)
-  TRY(conv_first(x, w.T3, p.w1, p.b1, p.w2, p.b2, w.h2, 64, B, N, s));
+  TRY(conv_first(x, w.T3, p.w1, p.b1, p.w2, p.b2, w.h2, 64, B, N, s, w.m_h2));
   // feature transform (:142-143)
-  TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s));
-  TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
+  TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s, w.m_c1));
+  TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
   // feature transform folded into conv3 (:143-144): W3 (T64^T h2) = (W3 T64^T) h2 -- one 64^3 product per instance
   // instead of a pass over [B,64,N]
   {
@@ -213,11 +228,12 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
     a.W = w.W3eff; a.sWb = 4096; a.sWco = 64; a.sWk = 1;
     a.bias = p.b3;
     a.Y = w.h3; a.sYb = (long)64 * N; a.ldY = N;
+    a.Ymask = w.m_h3;
     a.Co = 64; a.K = 64; a.N = N; a.B = B; a.relu = 1;
     TRY(launch_conv_cm(a, s));
   }
   // conv4, conv5 + max (:145-147)
-  TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s));
+  TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s, w.m_h4));
   TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s));
   // classifier head (:150-152), dropout is the identity in eval mode
   TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));
@@ -237,8 +253,8 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.f6, s));
   TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, 1024, B, false, w.p5, s));
   // max + conv5 (sparse), conv4, conv3
-  TRY(wide_bwd(w.g1024, w.i5, p.w5, w.h4, w.G128, 3, B, N, s));
-  TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, w.h3, false, s));
+  TRY(wide_bwd(w.g1024, w.i5, p.w5, w.h4, w.m_h4, w.G128, 3, B, N, s));
+  TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, nullptr, false, s, nullptr, w.m_h3));
   // conv3 + feature transform, merged as in forward (G64a = d/d(pre-activation of h3)):
   //   dT64[b][i][j] = sum_n h2[i][n] (W3^T G64a)[j][n] = ((h2 G64a^T) W3)[i][j];   dh2 = T64 W3^T G64a = W3eff^T G64a
   {
@@ -261,13 +277,13 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     a.Co = 64; a.K = 64; a.N = N; a.B = B;
     TRY(launch_conv_cm(a, s));
   }
-  TRY(tnet_bwd(p.t64, w.gT64, w.c1, nullptr, w.c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
+  TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.m_c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
   // dh2 += W_t64.conv1^T G64a, then the relu gate of h2
   {
     ConvArgs a{};
     a.X = w.G64a; a.sXb = (long)64 * N; a.ldX = N;
     a.W = p.t64.w1; a.sWb = 0; a.sWco = 1; a.sWk = 64;  // W^T through the strided loader
-    a.Z = w.h2; a.sZb = (long)64 * N; a.ldZ = N;
+    a.Zmask = w.m_h2;
     a.Y = w.dh2; a.sYb = (long)64 * N; a.ldY = N;
     a.Co = 64; a.K = 64; a.N = N; a.B = B; a.accumulate = 1;
     TRY(launch_conv_cm(a, s));
@@ -277,6 +293,6 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   TRY(conv_gate_first(w.dh2, 64, p.w2t, nullptr, x, w.T3, p.w1, p.b1, B, N, s, dx, 0, w.dTpart));
   TRY(launch_reduce_dT(w.dTpart, nparts, w.gT3, B, s));
   // T-Net(3) backward; its last kernel adds the T-Net branch into dx
-  TRY(tnet_bwd(p.t3, w.gT3, nullptr, x, w.a2, w.p3, w.i3, w.tf4, w.tf5, w, dx, B, N, s));
+  TRY(tnet_bwd(p.t3, w.gT3, nullptr, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w, dx, B, N, s));
   return GEOA3_OK;
 }

@@ -119,6 +119,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
   // epilogue: every pair of accumulator registers becomes two 64-column rows (row, row + 4)
   float* Y = BWD3 ? nullptr : a.Y + (size_t)b * a.sYb + col;
   const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
+  // bit masks: one 64-bit word per (row, this wave's 64 columns), stored [B][column block][row]: the 64 rows of a
+  // wave are one 512-byte run (a store of 8 scattered bytes per row cost more than the row reads it saved)
+  const int n64 = (a.N + 63) >> 6;
+  const size_t mword = ((size_t)b * n64 + (size_t)(blockIdx.x * 4 + wave)) * a.Co;
+  const bool wave_live = blockIdx.x * 256 + wave * 64 < a.N;
+  unsigned long long mymask = 0ull;    // Ymask: lane r collects the word of row rb*64 + r
   float q0 = 0.f, q1 = 0.f, q2 = 0.f;   // BWD3: d/d(T^T x) of this lane's point, summed over the 64 rows
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -132,6 +138,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         swap32(v[i], v[4 + i]);    // v[i]: row base+i, v[4+i]: row base+4+i, lane = column
       }
       const int row0 = rb * 64 + t * 32 + 8 * g;   // rows row0 .. row0+7 in the order of v[]
+      if (a.Zmask && wave_live) {                  // wave-uniform 8-byte loads: bit `lane` gates this lane's column
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned long long m = a.Zmask[mword + row0 + i];
+          z[i] = (m >> lane) & 1ull ? 1.f : 0.f;
+        }
+      }
       if (live) {
         if (Z) {
 #pragma unroll
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
           if (a.bias) o += a.bias[row0 + i];
           if (a.relu) o = fmaxf(o, 0.f);
           if (a.accumulate) o += y[i];
-          if (Z) o = z[i] > 0.f ? o : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
+          if (Z || a.Zmask) o = z[i] > 0.f ? o : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
           if (GFIRST) o = first_layer(s_w1[row0 + i], p0, p1, p2) > 0.f ? o : 0.f;
           if (BWD3) {
             const float4 w = s_w1[row0 + i];
@@ -157,10 +170,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
           } else {
             Y[(size_t)(row0 + i) * a.ldY] = o;
           }
+          v[i] = o;
+        }
+      }
+      if (a.Ymask && wave_live) {   // wave-uniform branch: the whole wave takes part in the ballots
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned long long m = __ballot(live && v[i] > 0.f);
+          if (lane == t * 32 + 8 * g + i) mymask = m;
         }
       }
     }
   }
+  if (a.Ymask && wave_live) a.Ymask[mword + rb * 64 + lane] = mymask;
   if (BWD3) {
     // x' = T^T x  =>  dx[d] = sum_c T[d][c] q[c];  dT[d][c] = sum_n x[d][n] q[c][n]
     if (!live) {

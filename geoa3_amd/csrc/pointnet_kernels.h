@@ -18,6 +18,11 @@ struct ConvArgs {
   const float* W; long sWb; int sWco, sWk;   // element (co,k) at W + b*sWb + co*sWco + k*sWk
   const float* bias;                          // [Co] or null
   const float* Z; long sZb; int ldZ;          // relu mask source (keep where Z > 0) or null
+  // the same gate as one BIT per element, [B][ceil(N/64)][Co] 64-bit words (bit j of word (w, row) = column 64w + j): written
+  // by the forward layer that produces the activation (Ymask, with relu), read by the backward layer instead of the
+  // fp32 activation (Zmask): 32x fewer gate bytes
+  const unsigned long long* Zmask;
+  unsigned long long* Ymask;
   float* Y; long sYb; int ldY;
   int Co, K, N, B;
   int relu, accumulate;
@@ -80,7 +85,8 @@ __device__ __forceinline__ unsigned long long wide_key(float v, int col) {
 struct WideBwdArgs {
   const float* g; const int* arg;             // [B][Co]
   const float* W;                             // [Co][TAPS*128]
-  const float* Z; long sZb; int ldZ;          // activation whose relu gates the result ([B][128][N])
+  const float* Z; long sZb; int ldZ;          // activation whose relu gates the result ([B][128][N]), or
+  const unsigned long long* Zmask;            // its bit mask [B][ceil(N/64)][128] (ConvArgs::Ymask)
   float* dX; long sXb; int ldX;               // [B][128][N]
   int Co, N, B, taps;
 };

@@ -238,6 +238,29 @@ __global__ __launch_bounds__(128 * NP) void wide_max_bwd_kernel(WideBwdArgs a) {
   __syncthreads();
   // write out with the relu gate of the layer input: 4 consecutive points per thread (16-byte loads / stores)
   float* dX = a.dX + (size_t)b * a.sXb;
+  if (a.Zmask && WB_COLS == 64) {   // the gate as one bit per element: one 64-bit word per (channel, this tile)
+    const unsigned long long* mk = a.Zmask + ((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * WM_CI;   // [B][tile][ci]
+    const bool vec = (a.ldX & 3) == 0;
+#pragma unroll 4
+    for (int e = tid; e < WM_CI * (WB_COLS / 4); e += 128 * NP) {
+      const int c = e / (WB_COLS / 4), j = (e - c * (WB_COLS / 4)) * 4;
+      const int m = m0 + j;
+      const float* sa = s_acc + c * (WB_COLS + 1) + j;
+      const unsigned bits = (unsigned)(mk[c] >> j) & 15u;
+      if (vec && m + 3 < a.N) {
+        float4 v;
+        v.x = bits & 1u ? sa[0] : 0.f;
+        v.y = bits & 2u ? sa[1] : 0.f;
+        v.z = bits & 4u ? sa[2] : 0.f;
+        v.w = bits & 8u ? sa[3] : 0.f;
+        *reinterpret_cast<float4*>(dX + (size_t)c * a.ldX + m) = v;
+      } else {
+        for (int i = 0; i < 4; ++i)
+          if (m + i < a.N) dX[(size_t)c * a.ldX + m + i] = (bits >> i) & 1u ? sa[i] : 0.f;
+      }
+    }
+    return;
+  }
   const float* Z = a.Z + (size_t)b * a.sZb;
   const bool vec = ((a.ldX | a.ldZ) & 3) == 0;
 #pragma unroll 4
