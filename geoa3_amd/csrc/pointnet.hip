@@ -77,6 +77,10 @@ Ws carve(void* base, int B, int N, int classes) {
   return w;
 }
 
+// arithmetic of the narrow convolutions for the call in flight: 1 = split-fp16 operands (set from the weights struct:
+// the callers that hand over split wide-layer fragments get the whole network on the f16 matrix pipe)
+thread_local int tl_split = 0;
+
 #define TRY(expr)             \
   do {                        \
     int rc__ = (expr);        \
@@ -88,6 +92,7 @@ int conv(const float* X, int K, const float* W, const float* bias, float* Y, int
          const float* Z, bool accumulate, hipStream_t s, unsigned long long* Ymask = nullptr,
          const unsigned long long* Zmask = nullptr) {
   ConvArgs a{};
+  a.split = tl_split;
   a.Ymask = Ymask; a.Zmask = Zmask;
   a.X = X; a.sXb = (long)K * N; a.ldX = N;
   a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
@@ -104,6 +109,7 @@ int conv(const float* X, int K, const float* W, const float* bias, float* Y, int
 int conv_first(const float* x, const float* T, const float* w1, const float* b1, const float* W, const float* bias,
                float* Y, int Co, int B, int N, hipStream_t s, unsigned long long* Ymask) {
   ConvArgs a{};
+  a.split = tl_split;
   a.Ymask = Ymask;
   a.x3 = x; a.T3 = T; a.w1 = w1; a.b1 = b1; a.produce_first = 1;
   a.W = W; a.sWb = 0; a.sWco = 64; a.sWk = 1;
@@ -121,6 +127,7 @@ int conv_gate_first(const float* X, int K, const float* W, float* Y, const float
                     const float* b1, int B, int N, hipStream_t s, float* dx = nullptr, int accumulate = 0,
                     float* dTpart = nullptr) {
   ConvArgs a{};
+  a.split = tl_split;
   a.dx3 = dx; a.accumulate = accumulate; a.dTpart = dTpart;
   a.X = X; a.sXb = (long)K * N; a.ldX = N;
   a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
@@ -207,6 +214,7 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   hipStream_t s = geoa3_stream(stream);
   Ws w = carve(workspace, B, N, pw->classes);
   const geoa3_pointnet_weights& p = *pw;
+  tl_split = p.w5h != nullptr;
   // input transform (Model/PointNet.py:137-138)
   TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
   // trunk conv1, conv2 (:139-140)
@@ -224,6 +232,7 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
     g.M = 64; g.Nout = 64; g.K = 64; g.batch = B;
     TRY(launch_fc(g, s));
     ConvArgs a{};
+    a.split = tl_split;
     a.X = w.h2; a.sXb = (long)64 * N; a.ldX = N;
     a.W = w.W3eff; a.sWb = 4096; a.sWco = 64; a.sWk = 1;
     a.bias = p.b3;
@@ -248,6 +257,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   hipStream_t s = geoa3_stream(stream);
   Ws w = carve(workspace, B, N, pw->classes);
   const geoa3_pointnet_weights& p = *pw;
+  tl_split = p.w5h != nullptr;
   // classifier head
   TRY(fc(dlogits, p.classes, p.f3t, nullptr, w.g256, 256, B, false, w.f7, s));
   TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.f6, s));
@@ -271,6 +281,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     q.M = 64; q.Nout = 64; q.K = 64; q.batch = B;
     TRY(launch_fc(q, s));
     ConvArgs a{};   // dh2[b][i][n] = sum_o W3eff[b][o][i] G64a[b][o][n]
+    a.split = tl_split;
     a.X = w.G64a; a.sXb = (long)64 * N; a.ldX = N;
     a.W = w.W3eff; a.sWb = 4096; a.sWco = 1; a.sWk = 64;
     a.Y = w.dh2; a.sYb = (long)64 * N; a.ldY = N;
@@ -281,6 +292,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   // dh2 += W_t64.conv1^T G64a, then the relu gate of h2
   {
     ConvArgs a{};
+    a.split = tl_split;
     a.X = w.G64a; a.sXb = (long)64 * N; a.ldX = N;
     a.W = p.t64.w1; a.sWb = 0; a.sWco = 1; a.sWk = 64;  // W^T through the strided loader
     a.Zmask = w.m_h2;

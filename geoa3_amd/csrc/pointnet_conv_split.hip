@@ -1,0 +1,313 @@
+// conv_cm64 of pointnet_gemm.hip on the f16 matrix pipe with split fp32 operands (the arithmetic of
+// pointnet_wide_split.hip: v = hi + lo, a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulation).
+//
+// Why: against a plain copy of the same bytes (5.1 TB/s) the fp32-MFMA form runs at 2.4-3.9 TB/s -- its 64-cycle
+// fp32 MFMAs (14 / 27 us of matrix time for the 64- / 128-wide layers at peak) do not hide behind the memory phases
+// of a kernel whose workgroups are all resident at once.  Three 32-cycle f16 MFMAs per 16 k replace eight fp32 ones.
+//
+// Same structure as conv_cm64_kernel: one wavefront = 64 columns (lane = point) x 64 output channels, every global
+// access one 256-byte row, K in chunks of 16 rows double-buffered in registers.  Differences:
+//   * the 64 x K weight block is scaled by a power of two from its own maximum, split, and kept in LDS as two fp16
+//     images [64][K] (rows padded by 16 B: the A operand of a k-step is one conflict-free ds_read_b128);
+//   * a chunk of 16 rows is one k-step: v_permlane32_swap of rows (j, 8 + j) yields, for both 32-column blocks, the
+//     B-operand element j of lanes (column, k half) -- the same swap that builds the fp32 operands;
+//   * the activation scale is a RUNNING per-wave power of two: when a later chunk's maximum exceeds the range of the
+//     current scale, the accumulators are rescaled (exact) and the scale shrinks; a chunk of smaller values keeps
+//     the scale (its error is relative to the wave's largest values, as in the wide kernels).  Deterministic, and a
+//     function of the wave's own columns only: rows of a batched run stay bit-identical to batch-1 runs.
+#include "pointnet_kernels.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void cs_swap32(float& a, float& b) {   // a[32..63] <-> b[0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float cs_first_layer(const float4 w, float p0, float p1, float p2) {
+  return w.x * p0 + w.y * p1 + w.z * p2 + w.w;   // the expression of pointnet_gemm.hip first_layer (same bits)
+}
+// biased exponent E of m clamped to [14, 254]; scale 2^(140 - E) puts m into [2^13, 2^14); unscale 2^(E - 140)
+__device__ __forceinline__ unsigned cs_exp(float m) {
+  const unsigned E = (__float_as_uint(m) >> 23) & 0xffu;
+  return E < 14u ? 14u : (E > 254u ? 254u : E);
+}
+__device__ __forceinline__ float cs_scale(unsigned E) { return __uint_as_float((267u - E) << 23); }
+__device__ __forceinline__ float cs_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
+
+template <int NCH, bool FIRST, bool GFIRST, bool BWD3>  // K = 16 * NCH; BWD3 needs GFIRST
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void conv_cm64s_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
+  constexpr int CH = 16, K = CH * NCH;
+  constexpr int PITCH = K * 2 + 16;                      // bytes per weight row and piece
+  unsigned char* s_wh = cs_smem;                         // [64][PITCH] hi
+  unsigned char* s_wl = cs_smem + 64 * PITCH;            // [64][PITCH] lo
+  float4* s_w1 = reinterpret_cast<float4*>(cs_smem + 2 * 64 * PITCH);   // [64] (w1 row, b1) of the folded first layer
+  float* s_part = reinterpret_cast<float*>(s_w1 + 64);   // [4 waves][9]
+  float* s_red = s_part + 40;                            // [4]
+  const int b = blockIdx.y, rb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = blockIdx.x * 256 + wave * 64 + lane;
+  const bool live = col < a.N;
+  const float* X = FIRST ? nullptr : a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f;                    // T^T x of this lane's point
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+  if (FIRST || GFIRST) {
+    const float* xp = a.x3 + (size_t)b * 3 * a.N + (live ? col : a.N - 1);
+    x0 = xp[0];
+    x1 = xp[a.N];
+    x2 = xp[2 * (size_t)a.N];
+    p0 = x0;
+    p1 = x1;
+    p2 = x2;
+    if (a.T3) {   // bmm(pc^T, T)^T : x'[c] = sum_d x[d] T[d][c]   (Model/PointNet.py:138)
+      const float* t = a.T3 + (size_t)b * 9;
+      p0 = x0 * t[0] + x1 * t[3] + x2 * t[6];
+      p1 = x0 * t[1] + x1 * t[4] + x2 * t[7];
+      p2 = x0 * t[2] + x1 * t[5] + x2 * t[8];
+    }
+    if (tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
+  }
+  float xb[2][CH];
+  if (!FIRST) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) xb[0][u] = X[(size_t)u * a.ldX];
+  }
+
+  // ---- weights: 64 x K values, K / 4 per thread (element e = tid + 256 i: row e / K, k = e % K), maximum, split
+  constexpr int WPT = 64 * K / 256;
+  float wv[WPT];
+  {
+    const float* W = a.W + (size_t)b * a.sWb + (size_t)rb * 64 * a.sWco;
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int e = tid + 256 * i;
+      int co, k;
+      if (a.sWk == 1) {     // rows are k-contiguous
+        co = e / K;
+        k = e - co * K;
+      } else {              // transposed storage: co is the contiguous index
+        k = e / 64;
+        co = e - k * 64;
+      }
+      wv[i] = W[(size_t)co * a.sWco + (size_t)k * a.sWk];
+      m = fmaxf(m, __builtin_fabsf(wv[i]));
+    }
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+  }
+  __syncthreads();
+  const unsigned Ew = cs_exp(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
+  {
+    const float sw = cs_scale(Ew);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int e = tid + 256 * i;
+      int co, k;
+      if (a.sWk == 1) {
+        co = e / K;
+        k = e - co * K;
+      } else {
+        k = e / 64;
+        co = e - k * 64;
+      }
+      const float v = wv[i] * sw;
+      const _Float16 h = (_Float16)v;
+      *reinterpret_cast<_Float16*>(s_wh + co * PITCH + k * 2) = h;
+      *reinterpret_cast<_Float16*>(s_wl + co * PITCH + k * 2) = (_Float16)(v - (float)h);
+    }
+  }
+  __syncthreads();
+  const unsigned char* arow = s_wh + (lane & 31) * PITCH + (lane >> 5) * 16;   // A operand: row r, k = 8h + j
+
+  f32x16 acc[2][2];   // [column block][row tile]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+
+  unsigned Ex = 14u;   // running exponent of the wave's activation scale
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (FIRST) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) xb[c & 1][u] = fmaxf(cs_first_layer(s_w1[CH * c + u], p0, p1, p2), 0.f);
+    } else if (c + 1 < NCH) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) xb[(c + 1) & 1][u] = X[(size_t)(CH * (c + 1) + u) * a.ldX];
+    }
+    float* x = xb[c & 1];
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) m = fmaxf(m, __builtin_fabsf(live ? x[u] : 0.f));
+    const unsigned E = cs_exp(wave_max(m));
+    if (E > Ex) {   // wave-uniform: larger values than any chunk before -- shrink the scale, rescale the sums (exact)
+      if (c > 0) {
+        const unsigned d = E - Ex;
+        const float f = d > 126u ? 0.f : __uint_as_float((127u - d) << 23);   // 2^-(E - Ex)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][t][r] *= f;
+      }
+      Ex = E;
+    }
+    const float sx = cs_scale(Ex);
+    half8 xh[2], xl[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v0 = x[j] * sx, v1 = x[8 + j] * sx;
+      cs_swap32(v0, v1);    // v0: column block 0, v1: column block 1; lanes (column, k half)
+      const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+      xh[0][j] = h0;
+      xl[0][j] = (_Float16)(v0 - (float)h0);
+      xh[1][j] = h1;
+      xl[1][j] = (_Float16)(v1 - (float)h1);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const half8 wh = *reinterpret_cast<const half8*>(arow + t * 32 * PITCH + c * 32);
+      const half8 wl = *reinterpret_cast<const half8*>(arow + t * 32 * PITCH + c * 32 + 64 * PITCH);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[cb], acc[cb][t], 0, 0, 0);
+        acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[cb], acc[cb][t], 0, 0, 0);
+        acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[cb], acc[cb][t], 0, 0, 0);
+      }
+    }
+  }
+  const float unscale = cs_unscale(Ex) * cs_unscale(Ew);
+
+  // epilogue: every pair of accumulator registers becomes two 64-column rows (row, row + 4)
+  float* Y = BWD3 ? nullptr : a.Y + (size_t)b * a.sYb + col;
+  const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
+  const int n64 = (a.N + 63) >> 6;
+  const size_t mword = ((size_t)b * n64 + (size_t)(blockIdx.x * 4 + wave)) * a.Co;   // bit masks [B][column block][row]
+  const bool wave_live = blockIdx.x * 256 + wave * 64 < a.N;
+  unsigned long long mymask = 0ull;
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f;   // BWD3: d/d(T^T x) of this lane's point, summed over the 64 rows
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v[8], z[8], y[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = acc[0][t][4 * g + i];
+        v[4 + i] = acc[1][t][4 * g + i];
+        cs_swap32(v[i], v[4 + i]);    // v[i]: row base+i, v[4+i]: row base+4+i, lane = column
+      }
+      const int row0 = rb * 64 + t * 32 + 8 * g;   // rows row0 .. row0+7 in the order of v[]
+      if (a.Zmask && wave_live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned long long mk = a.Zmask[mword + row0 + i];
+          z[i] = (mk >> lane) & 1ull ? 1.f : 0.f;
+        }
+      }
+      if (live) {
+        if (Z) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) z[i] = Z[(size_t)(row0 + i) * a.ldZ];
+        }
+        if (a.accumulate) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) y[i] = Y[(size_t)(row0 + i) * a.ldY];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float o = v[i] * unscale;
+          if (a.bias) o += a.bias[row0 + i];
+          if (a.relu) o = fmaxf(o, 0.f);
+          if (a.accumulate) o += y[i];
+          if (Z || a.Zmask) o = z[i] > 0.f ? o : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
+          if (GFIRST) o = cs_first_layer(s_w1[row0 + i], p0, p1, p2) > 0.f ? o : 0.f;
+          if (BWD3) {
+            const float4 w = s_w1[row0 + i];
+            q0 += w.x * o;
+            q1 += w.y * o;
+            q2 += w.z * o;
+          } else {
+            Y[(size_t)(row0 + i) * a.ldY] = o;
+          }
+          v[i] = o;
+        }
+      }
+      if (a.Ymask && wave_live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned long long mk = __ballot(live && v[i] > 0.f);
+          if (lane == t * 32 + 8 * g + i) mymask = mk;
+        }
+      }
+    }
+  }
+  if (a.Ymask && wave_live) a.Ymask[mword + rb * 64 + lane] = mymask;
+  if (BWD3) {
+    // x' = T^T x  =>  dx[d] = sum_c T[d][c] q[c];  dT[d][c] = sum_n x[d][n] q[c][n]
+    if (!live) {
+      q0 = 0.f;
+      q1 = 0.f;
+      q2 = 0.f;
+    }
+    float d0 = q0, d1 = q1, d2 = q2;
+    if (a.T3) {
+      const float* t = a.T3 + (size_t)b * 9;
+      d0 = t[0] * q0 + t[1] * q1 + t[2] * q2;
+      d1 = t[3] * q0 + t[4] * q1 + t[5] * q2;
+      d2 = t[6] * q0 + t[7] * q1 + t[8] * q2;
+    }
+    if (live) {
+      float* dxp = a.dx3 + (size_t)b * 3 * a.N + col;
+      if (a.accumulate) {
+        d0 += dxp[0];
+        d1 += dxp[a.N];
+        d2 += dxp[2 * (size_t)a.N];
+      }
+      dxp[0] = d0;
+      dxp[a.N] = d1;
+      dxp[2 * (size_t)a.N] = d2;
+    }
+    if (a.dTpart) {   // workgroup-uniform
+      const float prod[9] = {x0 * q0, x0 * q1, x0 * q2, x1 * q0, x1 * q1, x1 * q2, x2 * q0, x2 * q1, x2 * q2};
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float v = wave_sum(prod[i]);
+        if (lane == 0) s_part[wave * 9 + i] = v;
+      }
+      __syncthreads();
+      if (tid < 9)
+        a.dTpart[((size_t)b * gridDim.x + blockIdx.x) * 9 + tid] =
+            s_part[tid] + s_part[9 + tid] + s_part[18 + tid] + s_part[27 + tid];
+    }
+  }
+}
+
+}  // namespace
+
+int launch_conv_cm_split(const ConvArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)2 * 64 * (a.K * 2 + 16) + 64 * 16 + 44 * 4;
+  dim3 grid((a.N + 255) / 256, a.B, a.Co / 64);
+  if (a.produce_first)
+    hipLaunchKernelGGL((conv_cm64s_kernel<4, true, false, false>), grid, dim3(256), lds, s, a);
+  else if (a.gate_first && a.dx3 && a.K == 64)
+    hipLaunchKernelGGL((conv_cm64s_kernel<4, false, true, true>), grid, dim3(256), lds, s, a);
+  else if (a.gate_first && a.dx3)
+    hipLaunchKernelGGL((conv_cm64s_kernel<8, false, true, true>), grid, dim3(256), lds, s, a);
+  else if (a.gate_first && a.K == 64)
+    hipLaunchKernelGGL((conv_cm64s_kernel<4, false, true, false>), grid, dim3(256), lds, s, a);
+  else if (a.gate_first)
+    hipLaunchKernelGGL((conv_cm64s_kernel<8, false, true, false>), grid, dim3(256), lds, s, a);
+  else if (a.K == 64)
+    hipLaunchKernelGGL((conv_cm64s_kernel<4, false, false, false>), grid, dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL((conv_cm64s_kernel<8, false, false, false>), grid, dim3(256), lds, s, a);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}

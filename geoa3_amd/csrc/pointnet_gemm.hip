@@ -330,6 +330,7 @@ int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
   if (a.produce_first && (a.K != 64 || !a.x3 || !a.w1 || !a.b1)) return GEOA3_EINVAL;
   if (a.gate_first && (a.Co != 64 || !a.x3 || !a.w1 || !a.b1 || a.produce_first)) return GEOA3_EINVAL;
   if (a.dx3 && !a.gate_first) return GEOA3_EINVAL;
+  if (a.split) return launch_conv_cm_split(a, s);
   const size_t lds = ((size_t)64 * (a.K + 1) + 4 + 64 * 4 + 40) * sizeof(float);
   dim3 grid((a.N + 255) / 256, a.B, a.Co / 64);
   if (a.produce_first)
@@ -351,8 +352,9 @@ int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
 }
 
 extern "C" int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B,
-                                   int N, int K, int Co, int relu, void* stream) {
+                                   int N, int K, int Co, int relu, int split, void* stream) {
   ConvArgs a{};
+  a.split = split;
   a.X = X; a.sXb = (long)K * N; a.ldX = N;
   a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
   a.bias = bias;

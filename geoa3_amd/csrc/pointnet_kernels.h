@@ -39,8 +39,10 @@ struct ConvArgs {
   // when dTpart != null, per-workgroup partial sums of dT[d][c] = sum_n x[d][n] q[c][n] into dTpart[b][gridDim.x][9]
   float* dx3;                                 // [B][3][N] or null (= write Y as usual)
   float* dTpart;
+  int split;                                  // 1: split-fp16 operands on the f16 matrix pipe (pointnet_conv_split.hip)
 };
-int launch_conv_cm(const ConvArgs& a, hipStream_t s);
+int launch_conv_cm(const ConvArgs& a, hipStream_t s);         // dispatches on a.split
+int launch_conv_cm_split(const ConvArgs& a, hipStream_t s);
 
 // Y[m][o] = epi( sum_k X[m][k] * W[o][k] + bias[o] )   (fully connected layers, both directions)
 struct FcArgs {

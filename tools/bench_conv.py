@@ -36,11 +36,16 @@ def main():
         s = torch.cuda.current_stream().cuda_stream
         print("   fill_ of Y: %.1f us; copy_ Y<-Y2: %.1f us" % (timeit(lambda: Y.fill_(1.0)),
                                                               timeit(lambda: Y.copy_(ref))))
-        fn = lambda: lib.geoa3_debug_conv_cm(X.data_ptr(), W.data_ptr(), bias.data_ptr(),
-                                             Z.data_ptr() if gate else None, Y.data_ptr(), B, N, K, Co, 1, s)
-        us = timeit(fn)
-        err = (Y - ref).abs().max().item()
-        print("K=%3d Co=%3d gate=%d: %6.1f us  %5.2f TB/s  (%.0f MB)  maxerr %.2e" % (K, Co, gate, us, mb / us, mb, err))
+        ref64 = torch.relu(torch.einsum("ok,bkn->bon", W.double(), X.double()) + bias.double().view(1, -1, 1))
+        if gate:
+            ref64 = ref64 * (Z > 0)
+        for split in (0, 1):
+            fn = lambda: lib.geoa3_debug_conv_cm(X.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                                 Z.data_ptr() if gate else None, Y.data_ptr(), B, N, K, Co, 1, split, s)
+            us = timeit(fn)
+            err = (Y.double() - ref64).abs().max().item()
+            print("K=%3d Co=%3d gate=%d %s: %6.1f us  %5.2f TB/s  (%.0f MB)  max err vs float64 %.2e"
+                  % (K, Co, gate, "split fp16" if split else "fp32 MFMA ", us, mb / us, mb, err))
 
 
 if __name__ == "__main__":
