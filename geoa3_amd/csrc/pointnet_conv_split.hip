@@ -38,7 +38,7 @@ __device__ __forceinline__ float cs_scale(unsigned E) { return __uint_as_float((
 __device__ __forceinline__ float cs_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
 
 template <int NCH, bool FIRST, bool GFIRST, bool BWD3>  // K = 16 * NCH; BWD3 needs GFIRST
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void conv_cm64s_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_cm64s_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
   constexpr int CH = 16, K = CH * NCH;
   constexpr int PITCH = K * 2 + 16;                      // bytes per weight row and piece
