@@ -273,7 +273,10 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     g.W = w.G64a; g.ldW = N; g.sWb = (long)64 * N;
     g.Y = w.P64; g.ldY = 64; g.sYb = 4096;
     g.M = 64; g.Nout = 64; g.K = N; g.batch = B; g.ksplit = 8;
-    TRY(launch_fc(g, s));
+    // f16 matrix pipe; partial sums of the four workgroups per instance go through dh2 (written only afterwards:
+    // 4 * 4096 floats per instance fit its 64 * N from N = 256 on, and gram64_parts(N) is 1 below N = 385)
+    if (tl_split) TRY(launch_gram64(w.h2, w.G64a, B, N, w.P64, w.dh2, s));
+    else TRY(launch_fc(g, s));
     FcArgs q{};   // dT64[b][i][j] = sum_o P[b][i][o] W3[o][j]
     q.X = w.P64; q.ldX = 64; q.sXb = 4096;
     q.W = p.w3t; q.ldW = 64; q.sWb = 0;

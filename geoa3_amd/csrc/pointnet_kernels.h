@@ -94,6 +94,10 @@ struct WideBwdArgs {
 };
 int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s);
 
+// P[b][i][o] = sum_n A[b][i][n] G[b][o][n], A and G [B][64][N], split-fp16 operands (pointnet_gram.hip)
+int gram64_parts(int N);
+int launch_gram64(const float* A, const float* G, int B, int N, float* P, float* scratch, hipStream_t s);
+
 // dT[b][i] = sum_w part[b][w][i], i < 9, in a fixed order (the partial sums of ConvArgs::dTpart)
 int launch_reduce_dT(const float* part, int nparts, float* dT, int B, hipStream_t s);
 
