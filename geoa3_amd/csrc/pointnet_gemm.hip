@@ -382,3 +382,15 @@ int launch_fc(const FcArgs& a, hipStream_t s) {
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
+
+// One fully connected layer in isolation (tools/bench_fc.py): Y[M][Nout] = relu?(X[M][K] W[Nout][K]^T + bias)
+extern "C" int geoa3_debug_fc(const float* X, const float* W, const float* bias, float* Y, int M, int Nout, int K,
+                              int relu, int ksplit, void* stream) {
+  FcArgs a{};
+  a.X = X; a.ldX = K;
+  a.W = W; a.ldW = K;
+  a.bias = bias;
+  a.Y = Y; a.ldY = Nout;
+  a.M = M; a.Nout = Nout; a.K = K; a.relu = relu; a.ksplit = ksplit;
+  return launch_fc(a, geoa3_stream(stream));
+}

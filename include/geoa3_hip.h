@@ -381,6 +381,8 @@ int geoa3_debug_wide_bwd(const float* g, const int32_t* arg, const float* W, con
                          int taps, void* stream);
 int geoa3_debug_wide_fwd(const float* X, const float* Wp, const void* Wh, float unscale, const float* bias, float* out,
                          int32_t* arg, void* keys, int B, int N, int taps, int variant, void* stamps, void* stream);
+int geoa3_debug_fc(const float* X, const float* W, const float* bias, float* Y, int M, int Nout, int K, int relu,
+                   int ksplit, void* stream);
 int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, int N, int K,
                         int Co, int relu, int split /* 1: split-fp16 operands */, void* stream);
 
