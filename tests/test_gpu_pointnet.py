@@ -140,3 +140,37 @@ def test_wide_layer_both_modes_against_float64(taps, N):
     bad[4, 100, 0] = float("nan")
     o, _ = run(True, bad)
     assert torch.isnan(o[2]).all() and torch.isnan(o[4]).all() and torch.isfinite(o[[0, 1, 3]]).all()
+
+
+@pytest.mark.parametrize("K,Co,N,gate", [(64, 64, 1024, False), (64, 128, 300, False), (128, 64, 1000, True),
+                                        (64, 64, 77, True), (128, 128, 256, False)])
+def test_narrow_convolution_both_modes_against_float64(K, Co, N, gate):
+    """conv_cm64 (fp32 MFMA) and conv_cm64s (split-fp16 operands, running per-wave scale) through
+    geoa3_debug_conv_cm against a float64 evaluation: the same bound for both.  Rows of very different magnitude
+    (the running scale has to shrink from chunk to chunk and rescale its sums), an all-zero instance, ragged N."""
+    from geoa3_amd import _lib
+    lib = _lib.load()
+    B = 4
+    g = torch.Generator().manual_seed(K * 7 + Co + N)
+    X = torch.randn(B, K, N, generator=g) * torch.logspace(-4, 3, K).view(1, K, 1)   # later chunks are larger
+    X[2] = 0.0
+    X[3] *= 1e-12
+    W = torch.randn(Co, K, generator=g) * 0.1
+    bias = torch.randn(Co, generator=g) * (X.abs().max() * 0.01)
+    Z = torch.randn(B, Co, N, generator=g) if gate else None
+    pre = torch.einsum("ok,bkn->bon", W.double(), X.double())
+    ref = torch.relu(pre + bias.double().view(1, -1, 1))
+    if gate:
+        ref = ref * (Z > 0)
+    mag = torch.einsum("ok,bkn->bon", W.double().abs(), X.double().abs())
+    tol = 2e-6 * mag + 2e-7 * (pre.abs() + bias.double().abs().view(1, -1, 1)) + 1e-30
+    Xd, Wd, bd = X.cuda(), W.cuda(), bias.cuda()
+    Zd = Z.cuda() if gate else None
+    s = torch.cuda.current_stream().cuda_stream
+    for split in (0, 1):
+        Y = torch.full((B, Co, N), float("nan"), device="cuda")
+        _lib.check(lib.geoa3_debug_conv_cm(Xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(),
+                                           Zd.data_ptr() if gate else None, Y.data_ptr(), B, N, K, Co, 1, split, s),
+                   "geoa3_debug_conv_cm")
+        err = (Y.cpu().double() - ref).abs()
+        assert (err <= tol).all(), (split, float((err / tol).max()))
