@@ -153,6 +153,7 @@ int wide(const float* X, const float* W, const void* Wh, float unscale, const fl
          unsigned long long* keys, int taps, int B, int N, hipStream_t s) {
   WideArgs a{};
   a.keys = keys;
+  a.keys_clean = 1;   // zeroed once per forward; every finalize leaves them zero
   a.Wh = Wh; a.unscale = unscale;
   a.X = X; a.sXb = (long)128 * N; a.ldX = N;
   a.W = W; a.bias = bias; a.out = out; a.arg = arg;
@@ -215,6 +216,7 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   Ws w = carve(workspace, B, N, pw->classes);
   const geoa3_pointnet_weights& p = *pw;
   tl_split = p.w5h != nullptr;
+  if (hipMemsetAsync(w.keys, 0, (size_t)B * 1024 * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
   // input transform (Model/PointNet.py:137-138)
   TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
   // trunk conv1, conv2 (:139-140)

@@ -70,6 +70,7 @@ struct WideArgs {
   int Co, N, B, taps;
   const void* Wh;                             // split-fp16 fragments (pointnet_wide_split.hip) or null = fp32 MFMA
   float unscale;                              // 1 / (power-of-two scale of Wh)
+  int keys_clean;                             // 1: keys are already zero (wide_finalize_kernel leaves them zero): no memset
   unsigned long long* stamps;                 // diagnostics (tools/bench_wide.py --stamps): s_memtime trace of workgroup 0
 };
 int launch_wide_max(const WideArgs& a, hipStream_t s);          // dispatches on a.Wh

@@ -151,12 +151,13 @@ __global__ __launch_bounds__(WM_THREADS, OCC) void wide_max2_kernel(WideArgs a, 
   }
 }
 
-__global__ __launch_bounds__(256) void wide_finalize_kernel(const unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(256) void wide_finalize_kernel(unsigned long long* __restrict__ keys,
                                                             const float* __restrict__ bias, int Co, int total,
                                                             float* __restrict__ out, int* __restrict__ arg) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const unsigned long long k = keys[e];
+  keys[e] = 0ull;   // left clean for the next wide layer (WideArgs::keys_clean)
   const unsigned u = (unsigned)(k >> 32);
   const float v = __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
   out[e] = v != v ? v : fmaxf(v + bias[e % Co], 0.f);   // NaN (poisoned by the split kernel's range check) stays NaN
@@ -296,7 +297,9 @@ int launch_wide_max(const WideArgs& a, hipStream_t s) {
   if (a.Co != 8 * WM_CO || (a.taps != 1 && a.taps != 3) || !a.keys) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
   geoa3_prof_begin(tag, s);
-  if (hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
+  if (!a.keys_clean &&
+      hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess)
+    return GEOA3_ELAUNCH;
   const size_t lds = (size_t)WM_CI * W2_XP * sizeof(float);
   constexpr int OCC = 3, SLOTS = 32 * OCC;   // per XCD: 768 resident workgroups of 4 waves (occupancy / unit size
                                              // picked on hardware: 4 waves per SIMD and quarter units were slower)

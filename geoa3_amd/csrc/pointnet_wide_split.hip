@@ -359,7 +359,9 @@ int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
   if (a.Co != 1024 || (a.taps != 1 && a.taps != 3) || !a.keys || !a.Wh) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
   geoa3_prof_begin(tag, s);
-  if (hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
+  if (!a.keys_clean &&
+      hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess)
+    return GEOA3_ELAUNCH;
   // variants measured on hardware (tools/bench_wide.py 0 1 2): within +-5 % of each other and of run-to-run noise
   if (a.taps == 1) {
     switch (g_split_variant) {
