@@ -241,10 +241,12 @@ def main():
             "unit": "iterations/s of a 250-instance batch", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if mode != "f16x2" else
-                     "f32 (values, accumulation and every kernel but the three 1024-wide layers; those carry each fp32 "
-                     "operand as two fp16 values on the f16 MFMA with fp32 accumulation -- error against float64 no "
-                     "larger than the fp32 MFMA kernel's, tools/wide_accuracy.py; GEOA3_WIDE_MODE=f32 selects fp32 MFMA)",
+            "dtype": "f32",
+            "arithmetic": "fp32 MFMA throughout" if mode != "f16x2" else
+                          "fp32 values and fp32 accumulation everywhere; the convolutions (1024-wide layers, 64/128-wide "
+                          "layers, Gram product) carry each fp32 operand as two fp16 values on the f16 MFMA (3 products "
+                          "per fp32 product) -- error against float64 no larger than the fp32 MFMA kernels', "
+                          "tools/wide_accuracy.py, DESIGN.md 4a; GEOA3_WIDE_MODE=f32 selects fp32 MFMA (other_wide_mode)",
             "data": "synthetic",
             "config": {"workload": "configs[%d]: PointNet %d-pt, %d instances per GPU, full GeoA3 (CE + CD 1.0 + HD 0.1 + "
                                    "curvature 1.0 k=%d), untargeted" % (1 if NPOINT == 1024 else 4, NPOINT, B, KNN),
