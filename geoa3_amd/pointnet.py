@@ -107,9 +107,11 @@ WIDE_MODES = ("f32", "f16x2")
 
 
 def default_wide_mode() -> str:
-    """Arithmetic of the three 1024-wide layers.  'f16x2' (default): every fp32 operand carried as two fp16 values on
-    the f16 matrix pipe, fp32 accumulation (csrc/pointnet_wide_split.hip; error against float64 no larger than the
-    fp32 MFMA kernel's, 3.3x faster).  'f32': fp32 MFMA (exact fmaf chains).  GEOA3_WIDE_MODE overrides."""
+    """Arithmetic of the network's convolutions (the three 1024-wide layers, the 64/128-wide layers in both directions,
+    the Gram product of the backward).  'f16x2' (default): every fp32 operand carried as two fp16 values on the f16
+    matrix pipe, fp32 accumulation (csrc/pointnet_wide_split.hip, pointnet_conv_split.hip, pointnet_gram.hip; error
+    against float64 no larger than the fp32 MFMA kernels', iteration 1.8x faster).  'f32': fp32 MFMA throughout (exact
+    fmaf chains).  GEOA3_WIDE_MODE overrides."""
     mode = os.environ.get("GEOA3_WIDE_MODE", "f16x2")
     if mode not in WIDE_MODES:
         raise ValueError("GEOA3_WIDE_MODE must be one of %s" % (WIDE_MODES,))
