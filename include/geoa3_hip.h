@@ -173,7 +173,9 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
                                [T = co/32][s = k/16][piece hi,lo][lane 0..63][j 0..7] = piece(w5[32T + (lane&31)][16s +
                                8(lane>>5) + j]); the layer then evaluates a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the
                                f16 matrix pipe with fp32 accumulation (csrc/pointnet_wide_split.hip).  Both or neither
-                               of the T-Nets' w3h must be given with it. */
+                               of the T-Nets' w3h must be given with it.  Given, the 64/128-wide convolutions and the
+                               Gram product of the backward use the same arithmetic (they split their fp32 weights
+                               themselves: csrc/pointnet_conv_split.hip, pointnet_gram.hip); NULL = fp32 MFMA throughout. */
   float w5h_unscale;        /* 2^-e */
 } geoa3_pointnet_weights;
 
