@@ -38,7 +38,7 @@ __device__ __forceinline__ float cs_scale(unsigned E) { return __uint_as_float((
 __device__ __forceinline__ float cs_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
 
 template <int NCH, bool FIRST, bool GFIRST, bool BWD3>  // K = 16 * NCH; BWD3 needs GFIRST
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_cm64s_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 4 : 2, NCH <= 8 ? 4 : 2))) void conv_cm64s_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
   constexpr int CH = 16, K = CH * NCH;
   constexpr int PITCH = K * 2 + 16;                      // bytes per weight row and piece
@@ -47,8 +47,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   float4* s_w1 = reinterpret_cast<float4*>(cs_smem + 2 * 64 * PITCH);   // [64] (w1 row, b1) of the folded first layer
   float* s_part = reinterpret_cast<float*>(s_w1 + 64);   // [4 waves][9]
   float* s_red = s_part + 40;                            // [4]
-  const int b = blockIdx.y, rb = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = blockIdx.x * 256 + wave * 64 + lane;
+  // grid (row blocks, column blocks, instances): the row blocks of one column tile are dispatched back to back, so
+  // the tile is read from HBM once and from L2 by the others (with the row block as grid.z a 256-channel layer read
+  // its input four times)
+  const int rb = blockIdx.x, cblk = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = cblk * 256 + wave * 64 + lane;
   const bool live = col < a.N;
   const float* X = FIRST ? nullptr : a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;                    // T^T x of this lane's point
@@ -75,11 +78,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int u = 0; u < CH; ++u) xb[0][u] = X[(size_t)u * a.ldX];
   }
 
-  // ---- weights: 64 x K values, K / 4 per thread (element e = tid + 256 i: row e / K, k = e % K), maximum, split
+  // ---- weights: 64 x K values, K / 4 per thread (element e = tid + 256 i: row e / K, k = e % K), maximum, split.
+  // K <= 128: the values stay in registers between the two passes; K = 256: they are read again (L2)
   constexpr int WPT = 64 * K / 256;
-  float wv[WPT];
+  constexpr bool WKEEP = NCH <= 8;
+  float wv[WKEEP ? WPT : 1];
+  const float* W = a.W + (size_t)b * a.sWb + (size_t)rb * 64 * a.sWco;
   {
-    const float* W = a.W + (size_t)b * a.sWb + (size_t)rb * 64 * a.sWco;
     float m = 0.f;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
@@ -92,8 +97,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         k = e / 64;
         co = e - k * 64;
       }
-      wv[i] = W[(size_t)co * a.sWco + (size_t)k * a.sWk];
-      m = fmaxf(m, __builtin_fabsf(wv[i]));
+      const float v = W[(size_t)co * a.sWco + (size_t)k * a.sWk];
+      if (WKEEP) wv[i] = v;
+      m = fmaxf(m, __builtin_fabsf(v));
     }
     m = wave_max(m);
     if (lane == 0) s_red[wave] = m;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         k = e / 64;
         co = e - k * 64;
       }
-      const float v = wv[i] * sw;
+      const float v = (WKEEP ? wv[i] : W[(size_t)co * a.sWco + (size_t)k * a.sWk]) * sw;
       const _Float16 h = (_Float16)v;
       *reinterpret_cast<_Float16*>(s_wh + co * PITCH + k * 2) = h;
       *reinterpret_cast<_Float16*>(s_wl + co * PITCH + k * 2) = (_Float16)(v - (float)h);
@@ -188,8 +194,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   float* Y = BWD3 ? nullptr : a.Y + (size_t)b * a.sYb + col;
   const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
   const int n64 = (a.N + 63) >> 6;
-  const size_t mword = ((size_t)b * n64 + (size_t)(blockIdx.x * 4 + wave)) * a.Co;   // bit masks [B][column block][row]
-  const bool wave_live = blockIdx.x * 256 + wave * 64 < a.N;
+  const size_t mword = ((size_t)b * n64 + (size_t)(cblk * 4 + wave)) * a.Co;   // bit masks [B][column block][row]
+  const bool wave_live = cblk * 256 + wave * 64 < a.N;
   unsigned long long mymask = 0ull;
   float q0 = 0.f, q1 = 0.f, q2 = 0.f;   // BWD3: d/d(T^T x) of this lane's point, summed over the 64 rows
 #pragma unroll
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
       __syncthreads();
       if (tid < 9)
-        a.dTpart[((size_t)b * gridDim.x + blockIdx.x) * 9 + tid] =
+        a.dTpart[((size_t)b * gridDim.y + cblk) * 9 + tid] =
             s_part[tid] + s_part[9 + tid] + s_part[18 + tid] + s_part[27 + tid];
     }
   }
@@ -292,8 +298,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }  // namespace
 
 int launch_conv_cm_split(const ConvArgs& a, hipStream_t s) {
+  if ((a.K != 64 && a.K != 128 && a.K != 256) || a.Co <= 0 || a.Co % 64 != 0) return GEOA3_ENOSUPPORT;
   const size_t lds = (size_t)2 * 64 * (a.K * 2 + 16) + 64 * 16 + 44 * 4;
-  dim3 grid((a.N + 255) / 256, a.B, a.Co / 64);
+  dim3 grid(a.Co / 64, (a.N + 255) / 256, a.B);
+  if (a.K == 256) {   // PointNet++ level 2 (geoa3_conv1x1): plain layers only; 68.8 KB of LDS
+    if (a.produce_first || a.gate_first) return GEOA3_ENOSUPPORT;
+    auto kern = conv_cm64s_kernel<16, false, false, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    GEOA3_CHECK_LAUNCH();
+    return GEOA3_OK;
+  }
   if (a.produce_first)
     hipLaunchKernelGGL((conv_cm64s_kernel<4, true, false, false>), grid, dim3(256), lds, s, a);
   else if (a.gate_first && a.dx3 && a.K == 64)

@@ -326,11 +326,11 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
 }  // namespace
 
 int launch_conv_cm(const ConvArgs& a, hipStream_t s) {
-  if ((a.K != 64 && a.K != 128) || (a.Co != 64 && a.Co != 128)) return GEOA3_ENOSUPPORT;
   if (a.produce_first && (a.K != 64 || !a.x3 || !a.w1 || !a.b1)) return GEOA3_EINVAL;
   if (a.gate_first && (a.Co != 64 || !a.x3 || !a.w1 || !a.b1 || a.produce_first)) return GEOA3_EINVAL;
   if (a.dx3 && !a.gate_first) return GEOA3_EINVAL;
   if (a.split) return launch_conv_cm_split(a, s);
+  if ((a.K != 64 && a.K != 128) || (a.Co != 64 && a.Co != 128)) return GEOA3_ENOSUPPORT;
   const size_t lds = ((size_t)64 * (a.K + 1) + 4 + 64 * 4 + 40) * sizeof(float);
   dim3 grid((a.N + 255) / 256, a.B, a.Co / 64);
   if (a.produce_first)
@@ -393,4 +393,21 @@ extern "C" int geoa3_debug_fc(const float* X, const float* W, const float* bias,
   a.Y = Y; a.ldY = Nout;
   a.M = M; a.Nout = Nout; a.K = K; a.relu = relu; a.ksplit = ksplit;
   return launch_fc(a, geoa3_stream(stream));
+}
+
+// Channel-major 1x1 convolution as an operator (geoa3_amd/pointnet2.py: the shared MLPs of PointNet++ level 2):
+// Y[b][co][n] = epi( sum_k W[co][k] X[b][k][n] ),  epi = (+ bias[co]) (relu) (keep where Z[b][co][n] > 0)
+extern "C" int geoa3_conv1x1(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, long N,
+                             int K, int Co, int relu, void* stream) {
+  if (!X || !W || !Y || B <= 0 || N <= 0 || N > 0x7fffffffL) return GEOA3_EINVAL;
+  ConvArgs a{};
+  a.split = 1;
+  a.X = X; a.sXb = (long)K * N; a.ldX = (int)N;
+  a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
+  a.bias = bias;
+  a.Z = Z; a.sZb = (long)Co * N; a.ldZ = (int)N;
+  a.Y = Y; a.sYb = (long)Co * N; a.ldY = (int)N;
+  a.Co = Co; a.K = K; a.N = (int)N; a.B = B;
+  a.relu = relu;
+  return launch_conv_cm(a, geoa3_stream(stream));
 }

@@ -249,6 +249,60 @@ class _BiasReluMax(torch.autograd.Function):
         return dz, None, None, None
 
 
+fuse_tail = True   # module-wide switch (tests compare the fused tail with the GEMM + tail-pass path)
+
+
+def _conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor], gate: Optional[Tensor], relu: bool) -> Tensor:
+    """geoa3_conv1x1: [B,K,L] -> [B,Co,L] with the epilogue fused (csrc/pointnet_conv_split.hip)."""
+    B, K, L = x.shape
+    Co = w.shape[0]
+    y = torch.empty(B, Co, L, device=x.device, dtype=torch.float32)
+    check(_lib.load().geoa3_conv1x1(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    gate.data_ptr() if gate is not None else None, y.data_ptr(), B, L, K, Co,
+                                    1 if relu else 0, _s()), "geoa3_conv1x1")
+    return y
+
+
+class _SharedTail(torch.autograd.Function):
+    """Layers 2.. of a shared MLP with frozen weights, ending in the max over the S samples, on the HIP 1x1-convolution
+    operator: relu(W h + shift) is ONE kernel per layer (no separate bias/relu pass), the last layer's bias + relu +
+    max is the existing tail kernel, and in backward every input-gradient product carries the relu gate of the layer
+    below in its epilogue (no relu_grad pass).  Returns [B,C,M]; gradient w.r.t. the input activation only."""
+
+    @staticmethod
+    def forward(ctx, h, M, S, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        acts = [h]
+        for w, b in zip(ws[:-1], bs[:-1]):
+            acts.append(_conv1x1(acts[-1], w, b, None, True))
+        z = _conv1x1(acts[-1], ws[-1], None, None, False)
+        B, C, _ = z.shape
+        out = torch.empty(B, C, M, device=z.device, dtype=torch.float32)
+        arg = torch.empty(B, C, M, device=z.device, dtype=torch.int32)
+        check(_lib.load().geoa3_pn2_bias_relu_max(z.data_ptr(), bs[-1].data_ptr(), B, C, M, S, out.data_ptr(),
+                                                  arg.data_ptr(), _s()), "bias_relu_max")
+        ctx.save_for_backward(out, arg, *acts[1:])
+        ctx.wts = [w.t().contiguous() for w in ws]
+        ctx.S = S
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, arg, *acts = ctx.saved_tensors          # acts: the relu'd outputs of layers 2 .. last-1
+        B, C, M = out.shape
+        dz = torch.empty(B, C, M * ctx.S, device=out.device, dtype=torch.float32)
+        check(_lib.load().geoa3_pn2_bias_relu_max_grad(g.contiguous().data_ptr(), out.data_ptr(), arg.data_ptr(), B, C, M,
+                                                       ctx.S, dz.data_ptr(), _s()), "bias_relu_max_grad")
+        for i in range(len(ctx.wts) - 1, -1, -1):   # d/d(input of layer i), gated by that input's relu when it is ours
+            dz = _conv1x1(dz, ctx.wts[i], None, acts[i - 1] if i > 0 else None, False)
+        return (dz, None, None) + (None,) * (2 * len(ctx.wts))
+
+
+def _tail_eligible(folded, first: int) -> bool:
+    """Layers first.. can run on geoa3_conv1x1 in both directions: K and Co in {64,128,256} / multiples of 64."""
+    return all(w.shape[1] in (64, 128, 256) and w.shape[0] in (64, 128, 256) for w, _ in folded[first:])
+
+
 def run_shared_mlp(mlp: nn.Sequential, x: Tensor, fuse_max: bool = False) -> Tensor:
     """Apply a build_shared_mlp() stack to x [B,C,M,S] (eval mode).  Each Conv2d 1x1 + BatchNorm2d + ReLU triple is
     ONE channel GEMM (hipBLASLt; BatchNorm's running-statistics scale folded into the weights) followed by ONE
@@ -268,6 +322,15 @@ def run_shared_mlp(mlp: nn.Sequential, x: Tensor, fuse_max: bool = False) -> Ten
         return F.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1) if fuse_max else y
     B, _, M, S = x.shape
     h = x.reshape(B, x.shape[1], M * S)
+    # frozen weights (the attack's victim) + the max at the end: the first layer (K = Ci + 3, not a multiple of 64)
+    # stays a GEMM + tail pass, the remaining layers run on the fused HIP operator
+    if (fuse_max and fuse_tail and len(triples) >= 2 and not any(p.requires_grad for p in mlp.parameters())):
+        folded = _fold_triples(mlp)
+        if folded is not None and _tail_eligible(folded, 1):
+            (w0, b0) = folded[0]
+            h = _BiasRelu.apply(torch.matmul(w0, h), b0)
+            flat = [t for wb in folded[1:] for t in wb]
+            return _SharedTail.apply(h.contiguous(), M, S, *flat)
     for n, (conv, bn) in enumerate(triples):
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
         shift = (bn.bias - bn.running_mean * scale).contiguous()

@@ -310,6 +310,15 @@ int geoa3_pn2_bias_relu_max(const float* z, const float* shift, int B, int C, lo
 int geoa3_pn2_bias_relu_max_grad(const float* g, const float* out, const int32_t* arg, int B, int C, long M, int S,
                                  float* dz, void* stream);
 
+/* Channel-major 1x1 convolution with fused epilogue, the shared-MLP layer of pointnet2_modules.py:57-64 (Conv2d 1x1 +
+ * eval BatchNorm2d folded into W / bias + ReLU) on [B,K,N] -> [B,Co,N] (N = npoint * nsample, contiguous):
+ *   Y[b][co][n] = epi( sum_k W[co][k] X[b][k][n] ),  epi = (+ bias[co] if bias) (relu if relu) (0 where Z[b][co][n] <= 0 if Z)
+ * K in {64, 128, 256}, Co a multiple of 64; fp32 in and out, split-fp16 operands on the f16 matrix pipe inside
+ * (csrc/pointnet_conv_split.hip).  The input-gradient of such a layer is the same call with W^T and Z = the layer's
+ * input activation. */
+int geoa3_conv1x1(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, long N, int K,
+                  int Co, int relu, void* stream);
+
 /* First set-abstraction level of the SSG classifier, fused (PointNetPP_ssg.py:58-66: npoint 512, radius 0.2, nsample 64,
  * mlp [3, 64, 64, 128]; pointnet2_modules.py:29-74, pointnet2_utils.py:296-333): grouped xyz (xyz[idx] - new_xyz) ->
  * three Conv2d 1x1 + eval BatchNorm2d (folded into w / shift b by the host) + ReLU -> max over the 64 samples.

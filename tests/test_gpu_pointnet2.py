@@ -173,3 +173,36 @@ def test_fused_first_level_operator(pn2):
     scale = xb.grad.abs().max().item()
     np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
     np.testing.assert_allclose(na.grad.cpu().numpy(), nb.grad.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
+
+
+@pytest.mark.parametrize("tag", ["n1024", "n700"])
+def test_fused_shared_mlp_tail_matches_gemm_path_and_reference(pn2, golden, tag):
+    """Level 2's layers 2-3 on the HIP 1x1-convolution operator (split-fp16 operands, bias / relu / relu-gate fused
+    into the epilogues) against the GEMM + tail-pass path and the reference's own logits / input gradient."""
+    sd = P2.make_pn2_state_dict(0)
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    pre = "pn2/%s/" % tag
+    w = T(golden[pre + "w"]).cuda()
+    res = {}
+    for fused in (True, False):
+        pn2.fuse_tail = fused
+        try:
+            x = T(golden[pre + "pc"]).cuda().requires_grad_()
+            logits = net(x)
+            (logits * w).sum().backward()
+            res[fused] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
+        finally:
+            pn2.fuse_tail = True
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(res[True][0], golden[pre + "logits"], rtol=1e-3, atol=2e-3)
+    ref = golden[pre + "g_pc"].copy()
+    for got in (res[True][1], res[False][1]):
+        for a in (ref, got):
+            a[:, :, 8] += a[:, :, 9]
+            a[:, :, 9] = 0
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=5e-3, atol=5e-4 * np.abs(ref).max())
+    np.testing.assert_allclose(res[True][1], ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max())
