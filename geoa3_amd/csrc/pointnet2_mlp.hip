@@ -131,7 +131,51 @@ __global__ __launch_bounds__(256) void bias_relu_max_grad_kernel(const float* __
   *reinterpret_cast<float4*>(dz + e) = v;
 }
 
+// y[row][s] = relu(z[row][s] + shift[row]) in place; one wavefront per row
+__global__ __launch_bounds__(256) void shift_relu_kernel(float* __restrict__ z, const float* __restrict__ shift, long rows,
+                                                         int S) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float sh = shift[row];
+  float* zr = z + row * S;
+  for (int s = threadIdx.x & 63; s < S; s += 64) zr[s] = fmaxf(zr[s] + sh, 0.f);
+}
+
+// dz[row][s] = y[row][s] > 0 ? g[row][s] : 0;  dshift[row] = sum_s dz[row][s] (lanes in a fixed order)
+__global__ __launch_bounds__(256) void shift_relu_grad_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                              float* __restrict__ dz, float* __restrict__ dshift,
+                                                              long rows, int S) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float v = y[row * S + s] > 0.f ? g[row * S + s] : 0.f;
+    dz[row * S + s] = v;
+    acc += v;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dshift[row] = acc;
+}
+
 }  // namespace
+
+extern "C" int geoa3_pn2_shift_relu(float* z, const float* shift, long rows, int S, void* stream) {
+  if (!z || !shift || rows <= 0 || S <= 0 || (rows + 3) / 4 > 2147483647L) return GEOA3_EINVAL;
+  hipLaunchKernelGGL(shift_relu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, geoa3_stream(stream), z, shift,
+                     rows, S);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_shift_relu_grad(const float* y, const float* g, float* dz, float* dshift, long rows, int S,
+                                         void* stream) {
+  if (!y || !g || !dz || !dshift || rows <= 0 || S <= 0 || (rows + 3) / 4 > 2147483647L) return GEOA3_EINVAL;
+  hipLaunchKernelGGL(shift_relu_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, geoa3_stream(stream), y, g,
+                     dz, dshift, rows, S);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
 
 extern "C" int geoa3_pn2_bias_relu(float* z, const float* shift, int B, int C, long L, void* stream) {
   if (!z || !shift || B <= 0 || C <= 0 || L <= 0) return GEOA3_EINVAL;

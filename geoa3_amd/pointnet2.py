@@ -225,6 +225,28 @@ class _BiasRelu(torch.autograd.Function):
         return g, None
 
 
+class _ShiftRelu(torch.autograd.Function):
+    """y[b,c,m,s] = relu(z[b,c,m,s] + shift[b,c,m]) in place on the gathered pre-transformed layer."""
+
+    @staticmethod
+    def forward(ctx, z, shift):
+        B, C, M, S = z.shape
+        check(_lib.load().geoa3_pn2_shift_relu(z.data_ptr(), shift.data_ptr(), B * C * M, S, _s()), "shift_relu")
+        ctx.mark_dirty(z)
+        ctx.save_for_backward(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        B, C, M, S = y.shape
+        g = g.contiguous()
+        dshift = torch.empty(B, C, M, device=y.device, dtype=torch.float32)
+        check(_lib.load().geoa3_pn2_shift_relu_grad(y.data_ptr(), g.data_ptr(), g.data_ptr(), dshift.data_ptr(),
+                                                    B * C * M, S, _s()), "shift_relu_grad")
+        return g, dshift
+
+
 class _BiasReluMax(torch.autograd.Function):
     """out[b,c,m] = max_s relu(z[b,c,m,s] + shift[c]) without writing the activated tensor."""
 
@@ -416,6 +438,8 @@ class PointnetSAModuleMSG(nn.Module):
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             fused = self._fused_level1(grouper, mlp, xyz, new_xyz, features)
+            if fused is None:
+                fused = self._pretransformed_level(grouper, mlp, xyz, new_xyz, features)
             if fused is not None:
                 outs.append(fused)
                 continue
@@ -423,6 +447,30 @@ class PointnetSAModuleMSG(nn.Module):
         return new_xyz, torch.cat(outs, dim=1)
 
     fuse_level1 = True   # class-wide switch (tests compare the fused kernel with the layer-by-layer path)
+    pretransform = True  # class-wide switch: first layer applied before the grouping (see _pretransformed_level)
+
+    def _pretransformed_level(self, grouper, mlp, xyz, new_xyz, features):
+        """A level with features (SA_modules[1] of the SSG classifier), frozen weights: its first layer is linear in
+        the gathered inputs, W [xyz_j - c_m ; f_j] = (W_x xyz + W_f f)_j - (W_x c)_m, so it is applied to the N
+        un-grouped points once (two small GEMMs) and the RESULT is gathered; the grouped [B, C+3, npoint, nsample]
+        tensor, the cat and the K = C + 3 GEMM over npoint * nsample columns never exist.  The remaining layers run on
+        the fused convolution operator (_SharedTail).  None when the level has another shape."""
+        if not (self.pretransform and fuse_tail and features is not None and isinstance(grouper, QueryAndGroup) and
+                grouper.use_xyz and xyz.is_cuda and not mlp.training and
+                not any(p.requires_grad for p in mlp.parameters())):
+            return None
+        folded = _fold_triples(mlp)
+        if folded is None or len(folded) < 2 or not _tail_eligible(folded, 1):
+            return None
+        (w0, b0) = folded[0]                                       # [Co, 3 + C]: xyz columns first (QueryAndGroup's cat)
+        idx = ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+        wx, wf = w0[:, :3].contiguous(), w0[:, 3:].contiguous()
+        r = torch.matmul(wf, features) + torch.matmul(wx, xyz.transpose(1, 2))          # [B, Co, N]
+        shift = b0.view(1, -1, 1) - torch.matmul(wx, new_xyz.transpose(1, 2))           # [B, Co, npoint]
+        h = _ShiftRelu.apply(grouping_operation(r.contiguous(), idx), shift.contiguous())   # [B, Co, npoint, nsample]
+        B, Co, M, S = h.shape
+        flat = [t for wb in folded[1:] for t in wb]
+        return _SharedTail.apply(h.view(B, Co, M * S), M, S, *flat)
 
     def _fused_level1(self, grouper, mlp, xyz, new_xyz, features):
         """The xyz-only 3->64->64->128 level with 64 samples per ball (SA_modules[0] of the SSG classifier) as ONE

@@ -304,6 +304,15 @@ int geoa3_pn2_group_points_grad(const float* grad_out, const int32_t* idx, int B
  *   bias_relu_max:       out [B,C,M] = relu(max_s z[B,C,M,S] + shift[c]), arg = first maximising s (F.max_pool2d)
  *   bias_relu_max_grad:  dz [B,C,M,S] = (s == arg && out > 0) ? g : 0 */
 int geoa3_pn2_bias_relu(float* z, const float* shift, int B, int C, long L, void* stream);
+/* The first layer of a set-abstraction MLP is linear in the gathered inputs, W [xyz_j - c_m ; f_j] = (W_x xyz + W_f f)_j
+ * - (W_x c)_m: it is applied to the npoint UN-grouped columns once and the result gathered (geoa3_pn2_group_points);
+ * what remains per grouped element is a shift per (instance, channel, centre) and the relu:
+ *   shift_relu:       z[row][s] <- relu(z[row][s] + shift[row]),  row = (b, c, m), s < S   (in place)
+ *   shift_relu_grad:  dz = y > 0 ? g : 0,  dshift[row] = sum_s dz[row][s]
+ * (replaces the grouping of xyz, the cat and the K = C + 3 GEMM over npoint * nsample columns of
+ * pointnet2_utils.py:318-331 + pointnet2_modules.py:57-64). */
+int geoa3_pn2_shift_relu(float* z, const float* shift, long rows, int S, void* stream);
+int geoa3_pn2_shift_relu_grad(const float* y, const float* g, float* dz, float* dshift, long rows, int S, void* stream);
 int geoa3_pn2_relu_grad(const float* y, const float* g, float* dz, long total, void* stream);
 int geoa3_pn2_bias_relu_max(const float* z, const float* shift, int B, int C, long M, int S, float* out, int32_t* arg,
                             void* stream);

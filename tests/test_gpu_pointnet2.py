@@ -206,3 +206,36 @@ def test_fused_shared_mlp_tail_matches_gemm_path_and_reference(pn2, golden, tag)
             a[:, :, 9] = 0
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=5e-3, atol=5e-4 * np.abs(ref).max())
     np.testing.assert_allclose(res[True][1], ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag", ["n1024", "n700"])
+def test_pretransformed_level_matches_grouped_path_and_reference(pn2, golden, tag):
+    """SA level 2 with its first layer applied BEFORE the grouping (W [xyz_j - c ; f_j] = (W_x xyz + W_f f)_j - W_x c)
+    against the path that groups first (reference order of operations) and the reference's logits / input gradient."""
+    sd = P2.make_pn2_state_dict(0)
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    pre = "pn2/%s/" % tag
+    w = T(golden[pre + "w"]).cuda()
+    res = {}
+    for fused in (True, False):
+        pn2.PointnetSAModuleMSG.pretransform = fused
+        try:
+            x = T(golden[pre + "pc"]).cuda().requires_grad_()
+            logits = net(x)
+            (logits * w).sum().backward()
+            res[fused] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
+        finally:
+            pn2.PointnetSAModuleMSG.pretransform = True
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(res[True][0], golden[pre + "logits"], rtol=1e-3, atol=2e-3)
+    ref = golden[pre + "g_pc"].copy()
+    for got in (res[True][1], res[False][1]):
+        for a in (ref, got):
+            a[:, :, 8] += a[:, :, 9]
+            a[:, :, 9] = 0
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=5e-3, atol=5e-4 * np.abs(ref).max())
+    np.testing.assert_allclose(res[True][1], ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max())
