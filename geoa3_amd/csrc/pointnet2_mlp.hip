@@ -149,10 +149,14 @@ __global__ __launch_bounds__(256) void shift_relu_grad_kernel(const float* __res
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   float acc = 0.f;
-  for (int s = lane; s < S; s += 64) {
-    const float v = y[row * S + s] > 0.f ? g[row * S + s] : 0.f;
-    dz[row * S + s] = v;
-    acc += v;
+  if (y == nullptr) {   // g is already gated: only the row sums
+    for (int s = lane; s < S; s += 64) acc += g[row * S + s];
+  } else {
+    for (int s = lane; s < S; s += 64) {
+      const float v = y[row * S + s] > 0.f ? g[row * S + s] : 0.f;
+      dz[row * S + s] = v;
+      acc += v;
+    }
   }
   acc = wave_sum(acc);
   if (lane == 0) dshift[row] = acc;
@@ -170,7 +174,7 @@ extern "C" int geoa3_pn2_shift_relu(float* z, const float* shift, long rows, int
 
 extern "C" int geoa3_pn2_shift_relu_grad(const float* y, const float* g, float* dz, float* dshift, long rows, int S,
                                          void* stream) {
-  if (!y || !g || !dz || !dshift || rows <= 0 || S <= 0 || (rows + 3) / 4 > 2147483647L) return GEOA3_EINVAL;
+  if (!g || (y && !dz) || !dshift || rows <= 0 || S <= 0 || (rows + 3) / 4 > 2147483647L) return GEOA3_EINVAL;
   hipLaunchKernelGGL(shift_relu_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, geoa3_stream(stream), y, g,
                      dz, dshift, rows, S);
   GEOA3_CHECK_LAUNCH();

@@ -150,6 +150,16 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float* __restri
   if (e >= MS) return;
   out[((size_t)b * C + c) * MS + e] = points[((size_t)b * C + c) * N + idx[(size_t)b * MS + e]];
 }
+// out[b][c][j][k] = relu(points[b][c][idx[b][j][k]] + shift[b][c][j])  (geoa3_pn2_group_shift_relu)
+__global__ __launch_bounds__(256) void group_shift_relu_kernel(const float* __restrict__ points,
+                                                               const int32_t* __restrict__ idx,
+                                                               const float* __restrict__ shift, float* __restrict__ out,
+                                                               int C, int N, int M, int S) {
+  const int b = blockIdx.z, c = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x, MS = M * S;
+  if (e >= MS) return;
+  const size_t bc = (size_t)b * C + c;
+  out[bc * MS + e] = fmaxf(points[bc * N + idx[(size_t)b * MS + e]] + shift[bc * M + e / S], 0.f);
+}
 __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __restrict__ grad_out,
                                                                 const int32_t* __restrict__ idx,
                                                                 float* __restrict__ grad_points, int C, int N, int MS) {
@@ -248,6 +258,16 @@ extern "C" int geoa3_pn2_group_points(const float* points, const int32_t* idx, i
   const int MS = M * nsample;
   hipLaunchKernelGGL(group_points_kernel, dim3((MS + 255) / 256, C, B), dim3(256), 0, geoa3_stream(stream), points, idx,
                      out, C, N, MS);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_group_shift_relu(const float* points, const int32_t* idx, const float* shift, int B, int C, int N,
+                                          int M, int nsample, float* out, void* stream) {
+  if (!points || !idx || !shift || !out || B <= 0 || C <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
+  const int MS = M * nsample;
+  hipLaunchKernelGGL(group_shift_relu_kernel, dim3((MS + 255) / 256, C, B), dim3(256), 0, geoa3_stream(stream), points,
+                     idx, shift, out, C, N, M, nsample);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -225,28 +225,6 @@ class _BiasRelu(torch.autograd.Function):
         return g, None
 
 
-class _ShiftRelu(torch.autograd.Function):
-    """y[b,c,m,s] = relu(z[b,c,m,s] + shift[b,c,m]) in place on the gathered pre-transformed layer."""
-
-    @staticmethod
-    def forward(ctx, z, shift):
-        B, C, M, S = z.shape
-        check(_lib.load().geoa3_pn2_shift_relu(z.data_ptr(), shift.data_ptr(), B * C * M, S, _s()), "shift_relu")
-        ctx.mark_dirty(z)
-        ctx.save_for_backward(z)
-        return z
-
-    @staticmethod
-    def backward(ctx, g):
-        (y,) = ctx.saved_tensors
-        B, C, M, S = y.shape
-        g = g.contiguous()
-        dshift = torch.empty(B, C, M, device=y.device, dtype=torch.float32)
-        check(_lib.load().geoa3_pn2_shift_relu_grad(y.data_ptr(), g.data_ptr(), g.data_ptr(), dshift.data_ptr(),
-                                                    B * C * M, S, _s()), "shift_relu_grad")
-        return g, dshift
-
-
 class _BiasReluMax(torch.autograd.Function):
     """out[b,c,m] = max_s relu(z[b,c,m,s] + shift[c]) without writing the activated tensor."""
 
@@ -318,6 +296,57 @@ class _SharedTail(torch.autograd.Function):
         for i in range(len(ctx.wts) - 1, -1, -1):   # d/d(input of layer i), gated by that input's relu when it is ours
             dz = _conv1x1(dz, ctx.wts[i], None, acts[i - 1] if i > 0 else None, False)
         return (dz, None, None) + (None,) * (2 * len(ctx.wts))
+
+
+class _PretransformedSA(torch.autograd.Function):
+    """A whole set-abstraction level with frozen weights after its first layer has been applied to the un-grouped
+    points (PointnetSAModuleMSG._pretransformed_level): gather + shift + relu in one pass, the remaining layers on the
+    fused convolution operator, the max over the samples; in backward the last input-gradient convolution carries the
+    first layer's relu gate, so what is left is the row sums (d shift) and the scatter-add of the gather (d r).
+    forward(r [B,C,N], idx [B,M,S] int32, shift [B,C,M], *(W, shift) of layers 2..) -> [B,C_out,M]."""
+
+    @staticmethod
+    def forward(ctx, r, idx, shift, *wb):
+        lib = _lib.load()
+        B, C, N = r.shape
+        M, S = idx.shape[1], idx.shape[2]
+        h = torch.empty(B, C, M * S, device=r.device, dtype=torch.float32)
+        check(lib.geoa3_pn2_group_shift_relu(r.data_ptr(), idx.data_ptr(), shift.data_ptr(), B, C, N, M, S,
+                                             h.data_ptr(), _s()), "group_shift_relu")
+        ws, bs = wb[0::2], wb[1::2]
+        acts = [h]
+        for w, b in zip(ws[:-1], bs[:-1]):
+            acts.append(_conv1x1(acts[-1], w, b, None, True))
+        z = _conv1x1(acts[-1], ws[-1], None, None, False)
+        Co = z.shape[1]
+        out = torch.empty(B, Co, M, device=z.device, dtype=torch.float32)
+        arg = torch.empty(B, Co, M, device=z.device, dtype=torch.int32)
+        check(lib.geoa3_pn2_bias_relu_max(z.data_ptr(), bs[-1].data_ptr(), B, Co, M, S, out.data_ptr(), arg.data_ptr(),
+                                          _s()), "bias_relu_max")
+        ctx.save_for_backward(out, arg, idx, *acts)
+        ctx.wts = [w.t().contiguous() for w in ws]
+        ctx.dims = (N, M, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        out, arg, idx, *acts = ctx.saved_tensors      # acts[0]: the gathered first layer, acts[i]: output of layer i + 1
+        N, M, S = ctx.dims
+        B, Co, _ = out.shape
+        dz = torch.empty(B, Co, M * S, device=out.device, dtype=torch.float32)
+        check(lib.geoa3_pn2_bias_relu_max_grad(g.contiguous().data_ptr(), out.data_ptr(), arg.data_ptr(), B, Co, M, S,
+                                               dz.data_ptr(), _s()), "bias_relu_max_grad")
+        for i in range(len(ctx.wts) - 1, -1, -1):     # every product gated by the relu of the layer below
+            dz = _conv1x1(dz, ctx.wts[i], None, acts[i], False)
+        C = dz.shape[1]
+        dshift = torch.empty(B, C, M, device=dz.device, dtype=torch.float32)
+        check(lib.geoa3_pn2_shift_relu_grad(None, dz.data_ptr(), None, dshift.data_ptr(), B * C * M, S, _s()),
+              "shift_relu_grad")
+        dr = torch.empty(B, C, N, device=dz.device, dtype=torch.float32)
+        check(lib.geoa3_pn2_group_points_grad(dz.data_ptr(), idx.data_ptr(), B, C, N, M, S, dr.data_ptr(), _s()),
+              "group_points_grad")
+        return (dr, None, dshift) + (None,) * (2 * len(ctx.wts))
 
 
 def _tail_eligible(folded, first: int) -> bool:
@@ -467,10 +496,8 @@ class PointnetSAModuleMSG(nn.Module):
         wx, wf = w0[:, :3].contiguous(), w0[:, 3:].contiguous()
         r = torch.matmul(wf, features) + torch.matmul(wx, xyz.transpose(1, 2))          # [B, Co, N]
         shift = b0.view(1, -1, 1) - torch.matmul(wx, new_xyz.transpose(1, 2))           # [B, Co, npoint]
-        h = _ShiftRelu.apply(grouping_operation(r.contiguous(), idx), shift.contiguous())   # [B, Co, npoint, nsample]
-        B, Co, M, S = h.shape
         flat = [t for wb in folded[1:] for t in wb]
-        return _SharedTail.apply(h.view(B, Co, M * S), M, S, *flat)
+        return _PretransformedSA.apply(r.contiguous(), idx, shift.contiguous(), *flat)
 
     def _fused_level1(self, grouper, mlp, xyz, new_xyz, features):
         """The xyz-only 3->64->64->128 level with 64 samples per ball (SA_modules[0] of the SSG classifier) as ONE

@@ -312,6 +312,10 @@ int geoa3_pn2_bias_relu(float* z, const float* shift, int B, int C, long L, void
  * (replaces the grouping of xyz, the cat and the K = C + 3 GEMM over npoint * nsample columns of
  * pointnet2_utils.py:318-331 + pointnet2_modules.py:57-64). */
 int geoa3_pn2_shift_relu(float* z, const float* shift, long rows, int S, void* stream);
+/* gather + shift + relu in one pass: out[b][c][m][s] = relu(points[b][c][idx[b][m][s]] + shift[b][c][m]);
+ * shift_relu_grad with y == NULL: g is already gated, only dshift[row] = sum_s g[row][s] is formed */
+int geoa3_pn2_group_shift_relu(const float* points, const int32_t* idx, const float* shift, int B, int C, int N, int M,
+                               int nsample, float* out, void* stream);
 int geoa3_pn2_shift_relu_grad(const float* y, const float* g, float* dz, float* dshift, long rows, int S, void* stream);
 int geoa3_pn2_relu_grad(const float* y, const float* g, float* dz, long total, void* stream);
 int geoa3_pn2_bias_relu_max(const float* z, const float* shift, int B, int C, long M, int S, float* out, int32_t* arg,
