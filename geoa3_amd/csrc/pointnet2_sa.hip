@@ -5,46 +5,81 @@
 //
 // The reference materialises [B,64,512,64] and [B,128,512,64] activations (2.1 + 2.1 + 4.2 GB at B = 250) and walks
 // them once per layer and once more per layer in backward.  Here ONE WAVEFRONT owns one centroid: lane = sample.
-//   layer 1 (K = 3) on the VALU, lane-local; its 64 outputs per lane become the B operands of layer 2 by swapping
-//   register halves (v_permlane32_swap: two 64-sample rows -> the operands of the two 32-sample column blocks);
-//   layer 2 and 3 on the fp32 matrix core (32x32x2); the D registers of layer 2 ARE the B operands of layer 3 (a D
-//   register holds rows k and k+4 in its two halves, which is exactly one k-step when the A operand is read with the
-//   same pairing), so no activation ever leaves the registers; the max over samples is a shuffle reduction.
+//   layer 1 (K = 3) on the VALU, lane-local; layers 2 and 3 on the f16 matrix core with SPLIT fp32 operands (the
+//   arithmetic of pointnet_wide_split.hip: v = hi + lo, a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulation;
+//   per-wave power-of-two activation scales, weights scaled and split into fp16 LDS images when they are staged):
+//   * layer 2: a chunk of 16 layer-1 channels is one k-step; v_permlane32_swap of rows (j, 8 + j) yields the B operands
+//     of both 32-sample column blocks (as in pointnet_conv_split.hip);
+//   * layer 3 TRANSPOSED (activations as A: rows = samples; weights as B: columns = channels), so a lane ends with ONE
+//     channel and 32 of its samples: the max over samples is lane-local + one exchange.  The layer-2 accumulator
+//     registers 8s..8s+7 of a lane ARE its A fragment of a k-step -- channels in the accumulator's row order, which
+//     the weight image in LDS follows (position ks*16 + 8h + j <-> channel 32(ks>>1) + 16(ks&1) + 4h + (j&3) + 8(j>>2));
+//   no activation ever leaves the registers.
 // Backward recomputes the two hidden layers (cheaper than reading 6 GB), routes the pooled gradient through a one-hot
-// B operand, chains D->B again through W2^T, and finishes with the K = 3 contraction and the scatter to the points.
+// B operand against a W3^T image, chains the accumulator registers again as B operands against a W2^T image (same
+// row-order trick), and finishes with the K = 3 contraction and the scatter to the points.
+// The fp32-MFMA form of this file ran 1.67 ms forward / 2.61 ms backward at B = 250 (MFMA floors 1.4 / 1.9 ms).
 #include "pointnet_kernels.h"
 
 namespace {
 
 constexpr int SA_TF = 256;         // forward: 4 wavefronts per workgroup (6 waves / 3 per SIMD measured slower)
 constexpr int SA_TB = 256;         // backward: 4 wavefronts (256 VGPRs: 2 waves/SIMD)
-constexpr int SA_P = 65;           // LDS pitch of the 64-wide weight rows (bank-conflict-free column reads)
 constexpr int SA_S = 64;           // samples per centroid
+constexpr int SA_PH = 64 * 2 + 16;    // bytes per row of a 64-k fp16 image (conflict-free 16-byte reads)
+constexpr int SA_PH2 = 128 * 2 + 16;  // bytes per row of the 128-k image (W3^T)
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 struct Sa1Lds {
-  float* w1;   // [64][4]  (w0, w1, w2, shift)
-  float* w2;   // [64][SA_P]
-  float* b2;   // [64]
-  float* w3;   // [128][SA_P]
-  float* b3;   // [128]
-  float* scratch;   // [waves][256]
+  float* w1;            // [64][4]  (w0, w1, w2, shift)
+  float* b2;            // [64]
+  float* b3;            // [128]
+  float* scal;          // [2] 1 / scale of the w2 and w3 images; [2..9] reduction scratch
+  unsigned char* w2h;   // [64 out][64 k] hi, lo at + 64 * SA_PH       (A operand of layer 2)
+  unsigned char* w3h;   // forward: [128 out][64 positions] hi, lo at + 128 * SA_PH   (B operand of layer 3)
+                        // backward: W3^T [64 i][128 ch] hi, lo at + 64 * SA_PH2      (A operand of d h2)
+  unsigned char* w2t;   // backward: W2^T [64 i][64 positions] hi, lo at + 64 * SA_PH (A operand of d h1)
+  float* scratch;       // [waves][256]
 };
-constexpr int sa1_lds_floats(int threads) { return 64 * 4 + 64 * SA_P + 64 + 128 * SA_P + 128 + (threads / 64) * 256; }
+constexpr int sa1_lds_bytes(int threads, bool bwd) {
+  return (64 * 4 + 64 + 128 + 16) * 4 + 2 * 64 * SA_PH + (bwd ? 2 * 64 * SA_PH2 + 2 * 64 * SA_PH : 2 * 128 * SA_PH) +
+         (threads / 64) * 256 * 4;
+}
 
-__device__ __forceinline__ Sa1Lds sa1_carve(float* sm) {
+__device__ __forceinline__ Sa1Lds sa1_carve(float* sm, bool bwd) {
   Sa1Lds L;
   L.w1 = sm;
-  L.w2 = L.w1 + 64 * 4;
-  L.b2 = L.w2 + 64 * SA_P;
-  L.w3 = L.b2 + 64;
-  L.b3 = L.w3 + 128 * SA_P;
-  L.scratch = L.b3 + 128;
+  L.b2 = L.w1 + 64 * 4;
+  L.b3 = L.b2 + 64;
+  L.scal = L.b3 + 128;
+  L.w2h = reinterpret_cast<unsigned char*>(L.scal + 16);
+  L.w3h = L.w2h + 2 * 64 * SA_PH;
+  L.w2t = L.w3h + (bwd ? 2 * 64 * SA_PH2 : 2 * 128 * SA_PH);
+  L.scratch = reinterpret_cast<float*>(bwd ? L.w2t + 2 * 64 * SA_PH : L.w2t);
   return L;
 }
 
-template <int SA_T>
+// channel held at position p = ks*16 + 8h + j of a k-permuted image: the row order of the 32x32 accumulator
+__device__ __forceinline__ int sa_perm(int p) {
+  const int ks = p >> 4, h = (p >> 3) & 1, j = p & 7;
+  return 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h + (j & 3) + 8 * (j >> 2);
+}
+__device__ __forceinline__ unsigned sa_exp(float m) {
+  const unsigned E = (__float_as_uint(m) >> 23) & 0xffu;
+  return E < 14u ? 14u : (E > 254u ? 254u : E);
+}
+__device__ __forceinline__ float sa_scale(unsigned E) { return __uint_as_float((267u - E) << 23); }     // max -> [2^13, 2^14)
+__device__ __forceinline__ float sa_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
+__device__ __forceinline__ void sa_put(unsigned char* img, int lo_off, int off, float v) {
+  const _Float16 h = (_Float16)v;
+  *reinterpret_cast<_Float16*>(img + off) = h;
+  *reinterpret_cast<_Float16*>(img + lo_off + off) = (_Float16)(v - (float)h);
+}
+
+template <int SA_T, bool BWD>
 __device__ __forceinline__ void sa1_stage(const geoa3_sa1_weights& w, const Sa1Lds& L) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < 64; e += SA_T) {
     L.w1[4 * e + 0] = w.w1[3 * e + 0];
     L.w1[4 * e + 1] = w.w1[3 * e + 1];
@@ -53,8 +88,46 @@ __device__ __forceinline__ void sa1_stage(const geoa3_sa1_weights& w, const Sa1L
     L.b2[e] = w.b2[e];
   }
   for (int e = tid; e < 128; e += SA_T) L.b3[e] = w.b3[e];
-  for (int e = tid; e < 64 * 64; e += SA_T) L.w2[(e >> 6) * SA_P + (e & 63)] = w.w2[e];
-  for (int e = tid; e < 128 * 64; e += SA_T) L.w3[(e >> 6) * SA_P + (e & 63)] = w.w3[e];
+  float m2 = 0.f, m3 = 0.f;
+  for (int e = tid; e < 64 * 64; e += SA_T) m2 = fmaxf(m2, __builtin_fabsf(w.w2[e]));
+  for (int e = tid; e < 128 * 64; e += SA_T) m3 = fmaxf(m3, __builtin_fabsf(w.w3[e]));
+  m2 = wave_max(m2);
+  m3 = wave_max(m3);
+  if (lane == 0) {
+    L.scal[2 + wave] = m2;
+    L.scal[6 + wave] = m3;
+  }
+  __syncthreads();
+  float t2 = 0.f, t3 = 0.f;
+  for (int i = 0; i < SA_T / 64; ++i) {
+    t2 = fmaxf(t2, L.scal[2 + i]);
+    t3 = fmaxf(t3, L.scal[6 + i]);
+  }
+  const unsigned E2 = sa_exp(t2), E3 = sa_exp(t3);
+  const float s2 = sa_scale(E2), s3 = sa_scale(E3);
+  if (tid == 0) {
+    L.scal[0] = sa_unscale(E2);
+    L.scal[1] = sa_unscale(E3);
+  }
+  for (int e = tid; e < 64 * 64; e += SA_T) {   // W2 [out][k]: A operand of layer 2
+    const int o = e >> 6, k = e & 63;
+    sa_put(L.w2h, 64 * SA_PH, o * SA_PH + k * 2, w.w2[e] * s2);
+  }
+  if (!BWD) {
+    for (int e = tid; e < 128 * 64; e += SA_T) {   // W3 [out][position]: B operand of the transposed layer 3
+      const int o = e >> 6, p = e & 63;
+      sa_put(L.w3h, 128 * SA_PH, o * SA_PH + p * 2, w.w3[o * 64 + sa_perm(p)] * s3);
+    }
+  } else {
+    for (int e = tid; e < 128 * 64; e += SA_T) {   // W3^T [i][ch]: A operand of d h2 = W3^T dz3
+      const int ch = e >> 6, i = e & 63;
+      sa_put(L.w3h, 64 * SA_PH2, i * SA_PH2 + ch * 2, w.w3[e] * s3);
+    }
+    for (int e = tid; e < 64 * 64; e += SA_T) {    // W2^T [i][position]: A operand of d h1 = W2^T dz2
+      const int i = e >> 6, p = e & 63;
+      sa_put(L.w2t, 64 * SA_PH, i * SA_PH + p * 2, w.w2[sa_perm(p) * 64 + i] * s2);
+    }
+  }
   __syncthreads();
 }
 
@@ -87,24 +160,46 @@ __device__ __forceinline__ void sa1_hidden(const Sa1Lds& L, float px, float py, 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) h2[c][t][r] = 0.f;
-  const float* wr = L.w2 + (lane & 31) * SA_P + (lane >> 5);
+  float m = 0.f;
 #pragma unroll
-  for (int s = 0; s < 32; ++s) {
-    sa_swap32(h1[2 * s], h1[2 * s + 1]);
-    const float a0 = wr[2 * s], a1 = wr[32 * SA_P + 2 * s];
-    h2[0][0] = mfma32(a0, h1[2 * s], h2[0][0]);
-    h2[1][0] = mfma32(a0, h1[2 * s + 1], h2[1][0]);
-    h2[0][1] = mfma32(a1, h1[2 * s], h2[0][1]);
-    h2[1][1] = mfma32(a1, h1[2 * s + 1], h2[1][1]);
-    if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the operand loads next to their MFMAs (registers)
+  for (int k = 0; k < 64; ++k) m = fmaxf(m, h1[k]);          // h1 >= 0
+  const unsigned E = sa_exp(wave_max(m));
+  const float sx = sa_scale(E);
+  const unsigned char* wr = L.w2h + (lane & 31) * SA_PH + (lane >> 5) * 16;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {                                // 16 layer-1 channels = one k-step
+    half8 xh[2], xl[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v0 = h1[16 * c + j] * sx, v1 = h1[16 * c + 8 + j] * sx;
+      sa_swap32(v0, v1);                                       // v0: samples 0..31, v1: 32..63; lanes (sample, k half)
+      const _Float16 a0 = (_Float16)v0, a1 = (_Float16)v1;
+      xh[0][j] = a0;
+      xl[0][j] = (_Float16)(v0 - (float)a0);
+      xh[1][j] = a1;
+      xl[1][j] = (_Float16)(v1 - (float)a1);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + c * 32);
+      const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + c * 32 + 64 * SA_PH);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        h2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[cb], h2[cb][t], 0, 0, 0);
+        h2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[cb], h2[cb][t], 0, 0, 0);
+        h2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[cb], h2[cb][t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+  const float un = sa_unscale(E) * L.scal[0];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float bias = L.b2[t * 32 + mfma_row(r, lane)];
-      h2[0][t][r] = fmaxf(h2[0][t][r] + bias, 0.f);
-      h2[1][t][r] = fmaxf(h2[1][t][r] + bias, 0.f);
+      h2[0][t][r] = fmaxf(h2[0][t][r] * un + bias, 0.f);
+      h2[1][t][r] = fmaxf(h2[1][t][r] * un + bias, 0.f);
     }
 }
 
@@ -112,8 +207,8 @@ __global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                                                        const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
                                                        int M, float* __restrict__ out, uint8_t* __restrict__ arg) {
   extern __shared__ __attribute__((aligned(16))) float sa_sm[];
-  const Sa1Lds L = sa1_carve(sa_sm);
-  sa1_stage<SA_TF>(w, L);
+  const Sa1Lds L = sa1_carve(sa_sm, false);
+  sa1_stage<SA_TF, false>(w, L);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long total = (long)B * M;
   for (long c = (long)blockIdx.x * (SA_TF / 64) + wave; c < total; c += (long)gridDim.x * (SA_TF / 64)) {
@@ -126,6 +221,33 @@ __global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     f32x16 h2[2][2];
     unsigned m1lo, m1hi;
     sa1_hidden(L, px, py, pz, lane, h2, m1lo, m1hi);
+    // layer-2 activations -> the A fragments of the transposed layer 3: registers 8s..8s+7 of tile t are k-step
+    // ks = 2t + s (channels in the accumulator's row order, which the W3 image follows); one scale for the wave
+    half8 ah[2][4], al[2][4];
+    float un3;
+    {
+      float m = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, h2[cb][t][r]);     // h2 >= 0
+      const unsigned E = sa_exp(wave_max(m));
+      const float sx = sa_scale(E);
+      un3 = sa_unscale(E) * L.scal[1];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v = h2[cb][ks >> 1][8 * (ks & 1) + j] * sx;
+            const _Float16 a = (_Float16)v;
+            ah[cb][ks][j] = a;
+            al[cb][ks][j] = (_Float16)(v - (float)a);
+          }
+    }
 #pragma unroll 1
     for (int t3 = 0; t3 < 4; ++t3) {
       // layer 3 TRANSPOSED: the layer-2 registers go in as the A operand (rows = samples), the weights as B (columns =
@@ -137,16 +259,18 @@ __global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         a3[0][r] = 0.f;
         a3[1][r] = 0.f;
       }
-      const float* wr = L.w3 + (t3 * 32 + (lane & 31)) * SA_P + 4 * (lane >> 5);
+      const unsigned char* wr = L.w3h + (t3 * 32 + (lane & 31)) * SA_PH + (lane >> 5) * 16;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 bh = *reinterpret_cast<const half8*>(wr + ks * 32);
+        const half8 bl = *reinterpret_cast<const half8*>(wr + ks * 32 + 128 * SA_PH);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float a = wr[t * 32 + (r & 3) + 8 * (r >> 2)];
-          a3[0] = mfma32(h2[0][t][r], a, a3[0]);
-          a3[1] = mfma32(h2[1][t][r], a, a3[1]);
-          if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        for (int cb = 0; cb < 2; ++cb) {
+          a3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][ks], bh, a3[cb], 0, 0, 0);
+          a3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][ks], bl, a3[cb], 0, 0, 0);
+          a3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][ks], bh, a3[cb], 0, 0, 0);
         }
+      }
       // a3[cb][r]: channel t3*32 + (lane&31), sample cb*32 + (r&3) + 8*(r>>2) + 4*(lane>>5); ascending sample order,
       // strict > : the first maximal sample wins, as F.max_pool2d
       float v = -__builtin_inff();
@@ -166,7 +290,7 @@ __global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       smp = take ? os : smp;
       if (lane < 32) {   // 128 contiguous bytes of the centroid's row of out_t [B,M,128]
         const int ch = t3 * 32 + lane;
-        out[(size_t)c * 128 + ch] = fmaxf(v + L.b3[ch], 0.f);
+        out[(size_t)c * 128 + ch] = fmaxf(v * un3 + L.b3[ch], 0.f);   // the (positive) scale commutes with the max
         arg[(size_t)c * 128 + ch] = (uint8_t)smp;
       }
     }
@@ -179,8 +303,8 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                                                        const uint8_t* __restrict__ arg, const float* __restrict__ g,
                                                        float* __restrict__ dxyz, float* __restrict__ dnew) {
   extern __shared__ __attribute__((aligned(16))) float sa_sm[];
-  const Sa1Lds L = sa1_carve(sa_sm);
-  sa1_stage<SA_TB>(w, L);
+  const Sa1Lds L = sa1_carve(sa_sm, true);
+  sa1_stage<SA_TB, true>(w, L);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
   float* s_gz = L.scratch + wave * 256;                       // [128] pooled gradient through the output relu
   int* s_arg = reinterpret_cast<int*>(s_gz + 128);            // [128] arg-max sample of every channel
@@ -219,20 +343,44 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2[cb][t][r] = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < 64; ++s) {
-      const int ch = 2 * s + h;
-      const float gz = s_gz[ch];
-      const int am = s_arg[ch];
-      const float b0 = am == l31 ? gz : 0.f, b1 = am == 32 + l31 ? gz : 0.f;
-      const float a0 = L.w3[ch * SA_P + l31], a1 = L.w3[ch * SA_P + 32 + l31];
-      d2[0][0] = mfma32(a0, b0, d2[0][0]);
-      d2[1][0] = mfma32(a0, b1, d2[1][0]);
-      d2[0][1] = mfma32(a1, b0, d2[0][1]);
-      d2[1][1] = mfma32(a1, b1, d2[1][1]);
-      if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    float f2;   // d2 holds (d h2) / f2
+    {
+      // one-hot B operand: element j of lane (sample, k half) for k-step ks is channel ch = 16 ks + 8h + j, non-zero
+      // only in the lane of the channel's arg-max sample; the A operand is the W3^T image
+      float gm = fmaxf(__builtin_fabsf(s_gz[2 * lane]), __builtin_fabsf(s_gz[2 * lane + 1]));
+      const unsigned E = sa_exp(wave_max(gm));
+      const float sg = sa_scale(E);
+      f2 = sa_unscale(E) * L.scal[1];
+      const unsigned char* wr = L.w3h + l31 * SA_PH2 + h * 16;
+#pragma unroll 2
+      for (int ks = 0; ks < 8; ++ks) {
+        half8 bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ch = 16 * ks + 8 * h + j;
+          const float gz = s_gz[ch] * sg;
+          const int am = s_arg[ch];
+          const _Float16 gh = (_Float16)gz, gl = (_Float16)(gz - (float)gh), zero = (_Float16)0.f;
+          bh[0][j] = am == l31 ? gh : zero;
+          bl[0][j] = am == l31 ? gl : zero;
+          bh[1][j] = am == 32 + l31 ? gh : zero;
+          bl[1][j] = am == 32 + l31 ? gl : zero;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32);
+          const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32 + 64 * SA_PH2);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            d2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[cb], d2[cb][t], 0, 0, 0);
+            d2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[cb], d2[cb][t], 0, 0, 0);
+            d2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cb], d2[cb][t], 0, 0, 0);
+          }
+        }
+      }
     }
-    // through relu 2, then d h1 = W2^T dz2 with the D registers as B operands (rows k, k+4 in the two halves)
+    // through relu 2, then d h1 = W2^T dz2 with the accumulator registers as B operands (registers 8s..8s+7 of tile t
+    // = k-step 2t + s in the accumulator's row order; the W2^T image follows it)
     f32x16 d1[2][2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -240,20 +388,47 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1[cb][t][r] = 0.f;
+    float f1;   // d1 holds (d h1) / f1
+    {
+      float m = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float z0 = ((m2[0] >> (t * 16 + r)) & 1u) ? d2[0][t][r] : 0.f;
-        const float z1 = ((m2[1] >> (t * 16 + r)) & 1u) ? d2[1][t][r] : 0.f;
-        const int k = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float a0 = L.w2[k * SA_P + l31], a1 = L.w2[k * SA_P + 32 + l31];
-        d1[0][0] = mfma32(a0, z0, d1[0][0]);
-        d1[1][0] = mfma32(a0, z1, d1[1][0]);
-        d1[0][1] = mfma32(a1, z0, d1[0][1]);
-        d1[1][1] = mfma32(a1, z1, d1[1][1]);
-        if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            d2[cb][t][r] = ((m2[cb] >> (t * 16 + r)) & 1u) ? d2[cb][t][r] : 0.f;
+            m = fmaxf(m, __builtin_fabsf(d2[cb][t][r]));
+          }
+      const unsigned E = sa_exp(wave_max(m));
+      const float sx = sa_scale(E);
+      f1 = f2 * sa_unscale(E) * L.scal[0];
+      const unsigned char* wr = L.w2t + l31 * SA_PH + h * 16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        half8 bh[2], bl[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v = d2[cb][ks >> 1][8 * (ks & 1) + j] * sx;
+            const _Float16 a = (_Float16)v;
+            bh[cb][j] = a;
+            bl[cb][j] = (_Float16)(v - (float)a);
+          }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32);
+          const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32 + 64 * SA_PH);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            d1[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[cb], d1[cb][t], 0, 0, 0);
+            d1[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[cb], d1[cb][t], 0, 0, 0);
+            d1[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cb], d1[cb][t], 0, 0, 0);
+          }
+        }
       }
+    }
     // through relu 1 (mask of sample cb*32 + l31 lives in that lane) and the K = 3 layer
     float part[2][3];
 #pragma unroll
@@ -266,7 +441,7 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         for (int r = 0; r < 16; ++r) {
           const int kk = (r & 3) + 8 * (r >> 2) + 4 * h;     // bit within the word of tile t
           const bool on = (((t == 0 ? mlo : mhi) >> kk) & 1u) != 0u;
-          const float z = on ? d1[cb][t][r] : 0.f;
+          const float z = on ? d1[cb][t][r] * f1 : 0.f;
           const float4 wv = *reinterpret_cast<const float4*>(L.w1 + 4 * (t * 32 + kk));
           sx += wv.x * z;
           sy += wv.y * z;
@@ -304,7 +479,7 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
 int sa1_grid(int B, int M, int waves) {
   const long groups = ((long)B * M + waves - 1) / waves;
-  return (int)(groups < 256 * 2 ? groups : 256 * 2);   // persistent: 2 workgroups per CU (56-58 KB LDS each)
+  return (int)(groups < 256 * 2 ? groups : 256 * 2);   // persistent: 2 workgroups per CU (62 / 78 KB LDS each)
 }
 
 }  // namespace
@@ -313,7 +488,7 @@ extern "C" int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, con
                                      const geoa3_sa1_weights* w, int B, int N, int M, float* out, uint8_t* arg,
                                      void* stream) {
   if (!xyz || !new_xyz || !idx || !w || !out || !arg || B <= 0 || N <= 0 || M <= 0) return GEOA3_EINVAL;
-  const size_t lds = (size_t)sa1_lds_floats(SA_TF) * sizeof(float);
+  const size_t lds = (size_t)sa1_lds_bytes(SA_TF, false);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   hipLaunchKernelGGL(sa1_fwd_kernel, dim3(sa1_grid(B, M, SA_TF / 64)), dim3(SA_TF), lds, geoa3_stream(stream), xyz, new_xyz, idx, *w,
@@ -331,7 +506,7 @@ extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, co
     return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
   if (hipMemsetAsync(grad_xyz, 0, (size_t)B * N * 3 * sizeof(float), s) != hipSuccess) return GEOA3_ELAUNCH;
-  const size_t lds = (size_t)sa1_lds_floats(SA_TB) * sizeof(float);
+  const size_t lds = (size_t)sa1_lds_bytes(SA_TB, true);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   hipLaunchKernelGGL(sa1_bwd_kernel, dim3(sa1_grid(B, M, SA_TB / 64)), dim3(SA_TB), lds, s, xyz, new_xyz, idx, *w, B, N, M, out, arg,
