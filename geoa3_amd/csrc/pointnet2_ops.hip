@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __r
 constexpr int GPG_CT = 8;
 __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* __restrict__ grad_out,
                                                                   const int32_t* __restrict__ idx,
-                                                                  float* __restrict__ grad_points, int C, int N, int M) {
+                                                                  float* __restrict__ grad_points, int C, int N, int M,
+                                                                  float* __restrict__ rowsum) {
   extern __shared__ __attribute__((aligned(16))) float s_acc[];   // [GPG_CT][N]
   const int b = blockIdx.y, c0 = blockIdx.x * GPG_CT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = min(GPG_CT, C - c0);
@@ -197,6 +198,10 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
       const float s = wave_sum(dup ? v[c] : 0.f);
       if (lane == 0) atomicAdd(&s_acc[c * N + i], v[c] + s);
       else if (!dup) atomicAdd(&s_acc[c * N + i], v[c]);
+      if (rowsum) {   // sum over the row's 64 samples (d shift of the pre-transformed first layer), same pass
+        const float tot = wave_sum(v[c]);
+        if (lane == 0) rowsum[((size_t)b * C + c0 + c) * M + j] = tot;
+      }
     }
   }
   __syncthreads();
@@ -272,8 +277,23 @@ extern "C" int geoa3_pn2_group_shift_relu(const float* points, const int32_t* id
   return GEOA3_OK;
 }
 
+static int group_points_grad_impl(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int nsample,
+                                  float* grad_points, float* rowsum, void* stream);
+
 extern "C" int geoa3_pn2_group_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
                                            int nsample, float* grad_points, void* stream) {
+  return group_points_grad_impl(grad_out, idx, B, C, N, M, nsample, grad_points, nullptr, stream);
+}
+
+// + rowsum[b][c][m] = sum_s grad_out[b][c][m][s] in the same pass (nsample == 64 and C * N small enough for LDS only)
+extern "C" int geoa3_pn2_group_points_grad_sums(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                                                int nsample, float* grad_points, float* rowsum, void* stream) {
+  if (!rowsum || nsample != 64 || (size_t)GPG_CT * N * sizeof(float) > 128 * 1024) return GEOA3_ENOSUPPORT;
+  return group_points_grad_impl(grad_out, idx, B, C, N, M, nsample, grad_points, rowsum, stream);
+}
+
+static int group_points_grad_impl(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int nsample,
+                                  float* grad_points, float* rowsum, void* stream) {
   if (!grad_out || !idx || !grad_points || B <= 0 || C <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
   const int MS = M * nsample;
   const size_t lds = (size_t)GPG_CT * N * sizeof(float);
@@ -282,7 +302,7 @@ extern "C" int geoa3_pn2_group_points_grad(const float* grad_out, const int32_t*
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_points_grad64_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(group_points_grad64_kernel, dim3((C + GPG_CT - 1) / GPG_CT, B), dim3(256), lds,
-                       geoa3_stream(stream), grad_out, idx, grad_points, C, N, M);
+                       geoa3_stream(stream), grad_out, idx, grad_points, C, N, M, rowsum);
   } else {
     if (hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), geoa3_stream(stream)) != hipSuccess)
       return GEOA3_ELAUNCH;

@@ -341,11 +341,14 @@ class _PretransformedSA(torch.autograd.Function):
             dz = _conv1x1(dz, ctx.wts[i], None, acts[i], False)
         C = dz.shape[1]
         dshift = torch.empty(B, C, M, device=dz.device, dtype=torch.float32)
-        check(lib.geoa3_pn2_shift_relu_grad(None, dz.data_ptr(), None, dshift.data_ptr(), B * C * M, S, _s()),
-              "shift_relu_grad")
         dr = torch.empty(B, C, N, device=dz.device, dtype=torch.float32)
-        check(lib.geoa3_pn2_group_points_grad(dz.data_ptr(), idx.data_ptr(), B, C, N, M, S, dr.data_ptr(), _s()),
-              "group_points_grad")
+        rc = lib.geoa3_pn2_group_points_grad_sums(dz.data_ptr(), idx.data_ptr(), B, C, N, M, S, dr.data_ptr(),
+                                                  dshift.data_ptr(), _s())
+        if rc == _lib.ENOSUPPORT:   # other ball sizes: two passes
+            check(lib.geoa3_pn2_shift_relu_grad(None, dz.data_ptr(), None, dshift.data_ptr(), B * C * M, S, _s()),
+                  "shift_relu_grad")
+            rc = lib.geoa3_pn2_group_points_grad(dz.data_ptr(), idx.data_ptr(), B, C, N, M, S, dr.data_ptr(), _s())
+        check(rc, "group_points_grad")
         return (dr, None, dshift) + (None,) * (2 * len(ctx.wts))
 
 

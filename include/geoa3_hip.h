@@ -314,6 +314,10 @@ int geoa3_pn2_bias_relu(float* z, const float* shift, int B, int C, long L, void
 int geoa3_pn2_shift_relu(float* z, const float* shift, long rows, int S, void* stream);
 /* gather + shift + relu in one pass: out[b][c][m][s] = relu(points[b][c][idx[b][m][s]] + shift[b][c][m]);
  * shift_relu_grad with y == NULL: g is already gated, only dshift[row] = sum_s g[row][s] is formed */
+/* group_points_grad + rowsum[b][c][m] = sum_s grad_out[b][c][m][s] in the same pass (nsample == 64; GEOA3_ENOSUPPORT
+ * otherwise: use geoa3_pn2_shift_relu_grad with y == NULL) */
+int geoa3_pn2_group_points_grad_sums(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int nsample,
+                                     float* grad_points, float* rowsum, void* stream);
 int geoa3_pn2_group_shift_relu(const float* points, const int32_t* idx, const float* shift, int B, int C, int N, int M,
                                int nsample, float* out, void* stream);
 int geoa3_pn2_shift_relu_grad(const float* y, const float* g, float* dz, float* dshift, long rows, int S, void* stream);
