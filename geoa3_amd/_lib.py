@@ -107,6 +107,8 @@ SIGNATURES = {
     "geoa3_pn2_group_shift_relu": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_pn2_shift_relu": (C.c_int, [vp, vp, C.c_long, C.c_int, vp]),
     "geoa3_pn2_shift_relu_grad": (C.c_int, [vp, vp, vp, vp, C.c_long, C.c_int, vp]),
+    "geoa3_conv1x1_max64": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, vp]),
+    "geoa3_conv1x1_onehot64": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, vp]),
     "geoa3_conv1x1": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_debug_fc": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_debug_conv_cm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -37,7 +37,8 @@ __device__ __forceinline__ unsigned cs_exp(float m) {
 __device__ __forceinline__ float cs_scale(unsigned E) { return __uint_as_float((267u - E) << 23); }
 __device__ __forceinline__ float cs_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
 
-template <int NCH, bool FIRST, bool GFIRST, bool BWD3>  // K = 16 * NCH; BWD3 needs GFIRST
+template <int NCH, bool FIRST, bool GFIRST, bool BWD3, int PN2 = 0>  // K = 16 * NCH; BWD3 needs GFIRST;
+                                                                  // PN2: 1 = pooled output, 2 = one-hot input
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 4 : 2, NCH <= 8 ? 4 : 2))) void conv_cm64s_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
   constexpr int CH = 16, K = CH * NCH;
@@ -53,7 +54,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
   const int rb = blockIdx.x, cblk = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = cblk * 256 + wave * 64 + lane;
   const bool live = col < a.N;
-  const float* X = FIRST ? nullptr : a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
+  const float* X = (FIRST || PN2 == 2) ? nullptr : a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
+  // PN2: this wave's centre (its 64 columns are the centre's samples)
+  const int centres = a.N >> 6, centre = cblk * 4 + wave;
+  // one-hot input: oh_g / oh_arg are [B][centres][K] (k contiguous): lane l holds k = 4l .. 4l+3 of the wave's centre
+  float4 ohg = make_float4(0.f, 0.f, 0.f, 0.f);
+  int4 oha = make_int4(-1, -1, -1, -1);
+  if (PN2 == 2 && centre < centres) {
+    const size_t e = ((size_t)b * centres + centre) * (16 * NCH) + 4 * lane;
+    ohg = *reinterpret_cast<const float4*>(a.oh_g + e);
+    oha = *reinterpret_cast<const int4*>(a.oh_arg + e);
+  }
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;                    // T^T x of this lane's point
   float x0 = 0.f, x1 = 0.f, x2 = 0.f;
   if (FIRST || GFIRST) {
@@ -73,10 +84,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
     if (tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
   }
   float xb[2][CH];
-  if (!FIRST) {
+  auto load_rows = [&](int c, float (&d)[CH]) {
+    if (PN2 == 2) {
 #pragma unroll
-    for (int u = 0; u < CH; ++u) xb[0][u] = X[(size_t)u * a.ldX];
-  }
+      for (int u = 0; u < CH; ++u) {
+        const int src = 4 * c + (u >> 2);     // the lane that holds k = 16 c + u (component u & 3)
+        const float gsel = (u & 3) == 0 ? ohg.x : ((u & 3) == 1 ? ohg.y : ((u & 3) == 2 ? ohg.z : ohg.w));
+        const int asel = (u & 3) == 0 ? oha.x : ((u & 3) == 1 ? oha.y : ((u & 3) == 2 ? oha.z : oha.w));
+        const float gk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gsel), src));
+        const int ak = __builtin_amdgcn_readlane(asel, src);
+        d[u] = ak == lane ? gk : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) d[u] = X[(size_t)(CH * c + u) * a.ldX];
+    }
+  };
+  if (!FIRST) load_rows(0, xb[0]);
 
   // ---- weights: 64 x K values, K / 4 per thread (element e = tid + 256 i: row e / K, k = e % K), maximum, split.
   // K <= 128: the values stay in registers between the two passes; K = 256: they are read again (L2)
@@ -143,8 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
 #pragma unroll
       for (int u = 0; u < CH; ++u) xb[c & 1][u] = fmaxf(cs_first_layer(s_w1[CH * c + u], p0, p1, p2), 0.f);
     } else if (c + 1 < NCH) {
-#pragma unroll
-      for (int u = 0; u < CH; ++u) xb[(c + 1) & 1][u] = X[(size_t)(CH * (c + 1) + u) * a.ldX];
+      load_rows(c + 1, xb[(c + 1) & 1]);
     }
     float* x = xb[c & 1];
     float m = 0.f;
@@ -182,14 +205,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
       const half8 wl = *reinterpret_cast<const half8*>(arow + t * 32 * PITCH + c * 32 + 64 * PITCH);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[cb], acc[cb][t], 0, 0, 0);
-        acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[cb], acc[cb][t], 0, 0, 0);
-        acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[cb], acc[cb][t], 0, 0, 0);
+        if (PN2 == 1) {   // transposed: rows = samples, columns = channels (the max over samples becomes lane-local)
+          acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[cb], wh, acc[cb][t], 0, 0, 0);
+          acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[cb], wh, acc[cb][t], 0, 0, 0);
+          acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[cb], wl, acc[cb][t], 0, 0, 0);
+        } else {
+          acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[cb], acc[cb][t], 0, 0, 0);
+          acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[cb], acc[cb][t], 0, 0, 0);
+          acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[cb], acc[cb][t], 0, 0, 0);
+        }
       }
     }
   }
   const float unscale = cs_unscale(Ex) * cs_unscale(Ew);
 
+  if (PN2 == 1) {
+    // acc[cb][t][r]: channel rb*64 + 32t + (lane & 31), sample 32 cb + (r&3) + 8(r>>2) + 4(lane>>5) of the wave's centre:
+    // max over the 64 samples = 32 registers + one exchange between the lane halves; first maximal sample on ties
+    if (centre < centres) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float v = -__builtin_inff();
+        int smp = 0;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool gt = acc[cb][t][r] > v;
+            v = gt ? acc[cb][t][r] : v;
+            smp = gt ? 32 * cb + mfma_row(r, lane) : smp;
+          }
+        const float ov = __shfl_xor(v, 32, 64);
+        const int os = __shfl_xor(smp, 32, 64);
+        const bool take = ov > v || (ov == v && os < smp);
+        v = take ? ov : v;
+        smp = take ? os : smp;
+        if (lane < 32) {
+          const int co = rb * 64 + 32 * t + lane;
+          const size_t e = ((size_t)b * a.Co + co) * centres + centre;
+          a.pool_out[e] = fmaxf(v * unscale + a.pool_bias[co], 0.f);
+          a.pool_arg[e] = smp;
+        }
+      }
+    }
+    return;
+  }
   // epilogue: every pair of accumulator registers becomes two 64-column rows (row, row + 4)
   float* Y = BWD3 ? nullptr : a.Y + (size_t)b * a.sYb + col;
   const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
@@ -301,6 +361,20 @@ int launch_conv_cm_split(const ConvArgs& a, hipStream_t s) {
   if ((a.K != 64 && a.K != 128 && a.K != 256) || a.Co <= 0 || a.Co % 64 != 0) return GEOA3_ENOSUPPORT;
   const size_t lds = (size_t)2 * 64 * (a.K * 2 + 16) + 64 * 16 + 44 * 4;
   dim3 grid(a.Co / 64, (a.N + 255) / 256, a.B);
+  if (a.pool_out || a.oh_g) {   // PointNet++ forms: a wave = one centre
+    if (a.N % 64 != 0 || a.produce_first || a.gate_first) return GEOA3_ENOSUPPORT;
+    if (a.pool_out && (!a.pool_arg || !a.pool_bias || a.K != 128 || a.oh_g)) return GEOA3_ENOSUPPORT;
+    if (a.oh_g && (!a.oh_arg || a.K != 256)) return GEOA3_ENOSUPPORT;
+    if (a.pool_out) {
+      hipLaunchKernelGGL((conv_cm64s_kernel<8, false, false, false, 1>), grid, dim3(256), lds, s, a);
+    } else {
+      auto kern = conv_cm64s_kernel<16, false, false, false, 2>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    }
+    GEOA3_CHECK_LAUNCH();
+    return GEOA3_OK;
+  }
   if (a.K == 256) {   // PointNet++ level 2 (geoa3_conv1x1): plain layers only; 68.8 KB of LDS
     if (a.produce_first || a.gate_first) return GEOA3_ENOSUPPORT;
     auto kern = conv_cm64s_kernel<16, false, false, false>;

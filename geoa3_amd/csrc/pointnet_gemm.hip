@@ -411,3 +411,35 @@ extern "C" int geoa3_conv1x1(const float* X, const float* W, const float* bias, 
   a.relu = relu;
   return launch_conv_cm(a, geoa3_stream(stream));
 }
+
+// geoa3_conv1x1 whose output is max-pooled over each centre's 64 samples in the epilogue (the last layer of a
+// set-abstraction MLP + F.max_pool2d, pointnet2_modules.py:57-70): out[b][co][m] = relu(max_s (W x)[co][64 m + s] +
+// bias[co]), arg = the first maximal sample.  K = 128, Co a multiple of 64, N = 64 * centres.
+extern "C" int geoa3_conv1x1_max64(const float* X, const float* W, const float* bias, float* out, int32_t* arg, int B,
+                                   long N, int K, int Co, void* stream) {
+  if (!X || !W || !bias || !out || !arg || B <= 0 || N <= 0 || N > 0x7fffffffL) return GEOA3_EINVAL;
+  ConvArgs a{};
+  a.split = 1;
+  a.X = X; a.sXb = (long)K * N; a.ldX = (int)N;
+  a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
+  a.pool_out = out; a.pool_arg = arg; a.pool_bias = bias;
+  a.Co = Co; a.K = K; a.N = (int)N; a.B = B;
+  return launch_conv_cm(a, geoa3_stream(stream));
+}
+
+// Its input gradient: Y[b][co][64 m + s] = gate( sum_k W[co][k] * ((arg[b][m][k] == s) ? g[b][m][k] : 0) ), the sparse
+// gradient of the pooled layer formed in registers (g, arg CENTRE-major [B][centres][K]; g must already carry the pooled
+// output's relu gate); gate: keep
+// where Z[b][co][n] > 0 (the relu of the layer below).  K = 256.
+extern "C" int geoa3_conv1x1_onehot64(const float* g, const int32_t* arg, const float* W, const float* Z, float* Y, int B,
+                                      long N, int K, int Co, void* stream) {
+  if (!g || !arg || !W || !Y || B <= 0 || N <= 0 || N > 0x7fffffffL) return GEOA3_EINVAL;
+  ConvArgs a{};
+  a.split = 1;
+  a.oh_g = g; a.oh_arg = arg;
+  a.W = W; a.sWb = 0; a.sWco = K; a.sWk = 1;
+  a.Z = Z; a.sZb = (long)Co * N; a.ldZ = (int)N;
+  a.Y = Y; a.sYb = (long)Co * N; a.ldY = (int)N;
+  a.Co = Co; a.K = K; a.N = (int)N; a.B = B;
+  return launch_conv_cm(a, geoa3_stream(stream));
+}

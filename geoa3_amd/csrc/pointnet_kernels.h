@@ -40,6 +40,13 @@ struct ConvArgs {
   float* dx3;                                 // [B][3][N] or null (= write Y as usual)
   float* dTpart;
   int split;                                  // 1: split-fp16 operands on the f16 matrix pipe (pointnet_conv_split.hip)
+  // PointNet++ shared-MLP forms (split kernel only; a wave's 64 columns = the 64 samples of ONE centre, N % 64 == 0):
+  // pool_out: the output is max-pooled over each centre's samples in the epilogue instead of being written,
+  //           pool_out[b][co][m] = relu(max_s y + pool_bias[co]), pool_arg = first maximal sample (Y unused);
+  // oh_g:     the input is the pooled layer's sparse gradient, X[b][k][64 m + s] = (oh_arg[b][m][k] == s) ? oh_g[b][m][k]
+  //           : 0 (oh_* CENTRE-major [B][centres][K]), formed in registers (X unused)
+  float* pool_out; int32_t* pool_arg; const float* pool_bias;
+  const float* oh_g; const int32_t* oh_arg;
 };
 int launch_conv_cm(const ConvArgs& a, hipStream_t s);         // dispatches on a.split
 int launch_conv_cm_split(const ConvArgs& a, hipStream_t s);

@@ -317,12 +317,17 @@ class _PretransformedSA(torch.autograd.Function):
         acts = [h]
         for w, b in zip(ws[:-1], bs[:-1]):
             acts.append(_conv1x1(acts[-1], w, b, None, True))
-        z = _conv1x1(acts[-1], ws[-1], None, None, False)
-        Co = z.shape[1]
-        out = torch.empty(B, Co, M, device=z.device, dtype=torch.float32)
-        arg = torch.empty(B, Co, M, device=z.device, dtype=torch.int32)
-        check(lib.geoa3_pn2_bias_relu_max(z.data_ptr(), bs[-1].data_ptr(), B, Co, M, S, out.data_ptr(), arg.data_ptr(),
-                                          _s()), "bias_relu_max")
+        Co, Kl = ws[-1].shape
+        out = torch.empty(B, Co, M, device=r.device, dtype=torch.float32)
+        arg = torch.empty(B, Co, M, device=r.device, dtype=torch.int32)
+        ctx.pooled = S == 64 and Kl == 128          # the last layer + max over the samples as ONE kernel
+        if ctx.pooled:
+            check(lib.geoa3_conv1x1_max64(acts[-1].data_ptr(), ws[-1].data_ptr(), bs[-1].data_ptr(), out.data_ptr(),
+                                          arg.data_ptr(), B, M * S, Kl, Co, _s()), "conv1x1_max64")
+        else:
+            z = _conv1x1(acts[-1], ws[-1], None, None, False)
+            check(lib.geoa3_pn2_bias_relu_max(z.data_ptr(), bs[-1].data_ptr(), B, Co, M, S, out.data_ptr(),
+                                              arg.data_ptr(), _s()), "bias_relu_max")
         ctx.save_for_backward(out, arg, idx, *acts)
         ctx.wts = [w.t().contiguous() for w in ws]
         ctx.dims = (N, M, S)
@@ -334,10 +339,20 @@ class _PretransformedSA(torch.autograd.Function):
         out, arg, idx, *acts = ctx.saved_tensors      # acts[0]: the gathered first layer, acts[i]: output of layer i + 1
         N, M, S = ctx.dims
         B, Co, _ = out.shape
-        dz = torch.empty(B, Co, M * S, device=out.device, dtype=torch.float32)
-        check(lib.geoa3_pn2_bias_relu_max_grad(g.contiguous().data_ptr(), out.data_ptr(), arg.data_ptr(), B, Co, M, S,
-                                               dz.data_ptr(), _s()), "bias_relu_max_grad")
-        for i in range(len(ctx.wts) - 1, -1, -1):     # every product gated by the relu of the layer below
+        last = len(ctx.wts) - 1
+        if ctx.pooled and Co == 256:   # the pooled layer's sparse gradient is formed inside the convolution
+            gz = (g * (out > 0)).transpose(1, 2).contiguous()          # centre-major [B, M, Co]
+            argt = arg.transpose(1, 2).contiguous()
+            ci = ctx.wts[last].shape[0]
+            dz = torch.empty(B, ci, M * S, device=out.device, dtype=torch.float32)
+            check(lib.geoa3_conv1x1_onehot64(gz.data_ptr(), argt.data_ptr(), ctx.wts[last].data_ptr(), acts[last].data_ptr(),
+                                             dz.data_ptr(), B, M * S, Co, ci, _s()), "conv1x1_onehot64")
+            last -= 1
+        else:
+            dz = torch.empty(B, Co, M * S, device=out.device, dtype=torch.float32)
+            check(lib.geoa3_pn2_bias_relu_max_grad(g.contiguous().data_ptr(), out.data_ptr(), arg.data_ptr(), B, Co, M, S,
+                                                   dz.data_ptr(), _s()), "bias_relu_max_grad")
+        for i in range(last, -1, -1):                 # every product gated by the relu of the layer below
             dz = _conv1x1(dz, ctx.wts[i], None, acts[i], False)
         C = dz.shape[1]
         dshift = torch.empty(B, C, M, device=dz.device, dtype=torch.float32)

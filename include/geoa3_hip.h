@@ -336,6 +336,17 @@ int geoa3_pn2_bias_relu_max_grad(const float* g, const float* out, const int32_t
 int geoa3_conv1x1(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, long N, int K,
                   int Co, int relu, void* stream);
 
+/* The last layer of a set-abstraction MLP with F.max_pool2d over the 64 samples of a centre in its epilogue (the
+ * [B,Co,npoint,64] activation is never written): out[b][co][m] = relu(max_s (W x)[co][64 m + s] + bias[co]), arg = the
+ * first maximal sample (pointnet2_modules.py:57-70).  K = 128, Co a multiple of 64, N = 64 * npoint. */
+int geoa3_conv1x1_max64(const float* X, const float* W, const float* bias, float* out, int32_t* arg, int B, long N, int K,
+                        int Co, void* stream);
+/* ... and its input gradient: the pooled layer's sparse gradient ((arg == s) ? g : 0; g and arg CENTRE-major
+ * [B][npoint][K]; g must carry the pooled output's relu gate) is formed in registers, multiplied by W ([Co][K] = the transposed layer weight, K = 256) and gated by the
+ * relu of the layer below (keep where Z > 0). */
+int geoa3_conv1x1_onehot64(const float* g, const int32_t* arg, const float* W, const float* Z, float* Y, int B, long N,
+                           int K, int Co, void* stream);
+
 /* First set-abstraction level of the SSG classifier, fused (PointNetPP_ssg.py:58-66: npoint 512, radius 0.2, nsample 64,
  * mlp [3, 64, 64, 128]; pointnet2_modules.py:29-74, pointnet2_utils.py:296-333): grouped xyz (xyz[idx] - new_xyz) ->
  * three Conv2d 1x1 + eval BatchNorm2d (folded into w / shift b by the host) + ReLU -> max over the 64 samples.
