@@ -224,8 +224,6 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
           const unsigned char* ap1 = abase + (sn / BPT) * SP_ROWB + (sn % BPT) * (PF * 32);
 #pragma unroll
           for (int f = 0; f < PF; ++f) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int cur = f & 1, nxt = cur ^ 1;          // PF is even: the buffers line up across blocks
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
