@@ -36,7 +36,7 @@ def sources():
 def _digest(path: str) -> str:
     h = hashlib.sha1()
     for p in [path] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
-            os.path.join(HERE, "..", "include", "geoa3_hip.h")]:
+            os.path.join(HERE, "..", "include", "geoa3_hip.h"), os.path.join(HERE, "..", "include", "geoa3_hip_debug.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/geoa3_hip.h"
+#include "../../include/geoa3_hip_debug.h"
 
 #define GEOA3_WAVE 64
 

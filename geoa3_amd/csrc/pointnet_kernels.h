@@ -78,6 +78,7 @@ struct WideArgs {
   const void* Wh;                             // split-fp16 fragments (pointnet_wide_split.hip) or null = fp32 MFMA
   float unscale;                              // 1 / (power-of-two scale of Wh)
   int keys_clean;                             // 1: keys are already zero (wide_finalize_kernel leaves them zero): no memset
+  int variant;                                // tuning variant of the split kernel (geoa3_debug_wide_fwd; 0 = shipped)
   unsigned long long* stamps;                 // diagnostics (tools/bench_wide.py --stamps): s_memtime trace of workgroup 0
 };
 int launch_wide_max(const WideArgs& a, hipStream_t s);          // dispatches on a.Wh

@@ -351,8 +351,6 @@ void launch_variant(const WideArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int g_split_variant = 0;   // tuning hook of tools/bench_wide.py (geoa3_debug_wide_fwd): 0 = the shipped configuration
-
 int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
   if (a.Co != 1024 || (a.taps != 1 && a.taps != 3) || !a.keys || !a.Wh) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
@@ -362,13 +360,13 @@ int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
     return GEOA3_ELAUNCH;
   // variants measured on hardware (tools/bench_wide.py 0 1 2): within +-5 % of each other and of run-to-run noise
   if (a.taps == 1) {
-    switch (g_split_variant) {
+    switch (a.variant) {
       case 1: launch_variant<1, 2, 8, 1, 2, true>(a, s); break;
       case 2: launch_variant<1, 2, 8, 1, 0, false>(a, s); break;
       default: launch_variant<1, 2, 8, 1, 0, true>(a, s);
     }
   } else {
-    switch (g_split_variant) {
+    switch (a.variant) {
       case 1: launch_variant<3, 2, 4, 1, 0, true>(a, s); break;
       case 2: launch_variant<3, 2, 4, 1, 2, false>(a, s); break;
       default: launch_variant<3, 2, 4, 1, 2, true>(a, s);
@@ -390,8 +388,6 @@ extern "C" int geoa3_debug_wide_fwd(const float* X, const float* Wp, const void*
   a.out = out; a.arg = arg; a.keys = (unsigned long long*)keys;
   a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
   a.stamps = (unsigned long long*)stamps;
-  g_split_variant = variant;
-  const int rc = launch_wide_max(a, geoa3_stream(stream));
-  g_split_variant = 0;
-  return rc;
+  a.variant = variant;
+  return launch_wide_max(a, geoa3_stream(stream));
 }

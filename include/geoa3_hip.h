@@ -11,7 +11,9 @@
  *       d = fl(fl(fl(dx*dx)+fl(dy*dy))+fl(dz*dz))   (bit-identical to the CPU oracle);
  *     exact distance ties go to the LOWER index;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every entry
- *     point only enqueues work: no allocation, no host synchronisation, no global state;
+ *     point only enqueues work: no allocation, no host synchronisation, no global state
+ *     (the opt-in diagnostics of geoa3_hip_debug.h -- event timers, single-kernel entry points for the
+ *     tools/ benchmarks -- are declared apart from this ABI and never change results);
  *   - return value: 0 on success, a negative GEOA3_E* code otherwise (geoa3_strerror()).
  *     The reference prints and exit(-1)s on a launch failure
  *     (Model/pointnet2_ops_lib/pointnet2_ops/_ext-src/include/cuda_utils.h:30-39); callers of
@@ -401,29 +403,6 @@ int geoa3_sor_statistic(const float* pc, int B, int N, int K, float* dis, void* 
  * stats [B,2] (optional) = (mean, std). */
 int geoa3_sor_select(const float* dis, int B, int N, int mode, int drop_num, float alpha, int32_t* idx,
                      int32_t* count, float* stats, void* stream);
-
-/* ------------------------------------------------------------------------------------------
- * Diagnostics (bench.py): per-launch durations of selected kernels, taken with HIP events recorded on the
- * launch stream.  Off by default; the only process-global state in the library; never changes results.
- * tag: 0 = conv5+max (wide_max_kernel<3>), 1 = geoa3_nn1_pair ("CD kernel"), 2 = geoa3_knn,
- *      3 = T-Net conv3+max (wide_max_kernel<1>).
- * ------------------------------------------------------------------------------------------ */
-int geoa3_profile_enable(int capacity);                 /* events for `capacity` launches per tag; 0 = off */
-int geoa3_profile_select(unsigned mask);                /* bit t set = tag t is recorded (default: all); an event
-                                                           pair costs ~6 us of stream time around the kernel */
-int geoa3_profile_read(int tag, float* ms_host, int cap); /* waits for the recorded launches; returns count */
-/* One channel-major 1x1 convolution Y[B,Co,N] = act(W[Co,K] X[B,K,N] + bias) (gated by Z > 0 when given) of the
- * PointNet trunk in isolation (K, Co in {64, 128}), for tools/bench_conv.py. */
-/* The sparse arg-max backward of a 1024-wide layer in isolation (tools/bench_widebwd.py): g [B,1024], arg [B,1024],
- * W [1024, taps*128], Z / dX [B,128,N]. */
-int geoa3_debug_wide_bwd(const float* g, const int32_t* arg, const float* W, const float* Z, float* dX, int B, int N,
-                         int taps, void* stream);
-int geoa3_debug_wide_fwd(const float* X, const float* Wp, const void* Wh, float unscale, const float* bias, float* out,
-                         int32_t* arg, void* keys, int B, int N, int taps, int variant, void* stamps, void* stream);
-int geoa3_debug_fc(const float* X, const float* W, const float* bias, float* Y, int M, int Nout, int K, int relu,
-                   int ksplit, void* stream);
-int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, int N, int K,
-                        int Co, int relu, int split /* 1: split-fp16 operands */, void* stream);
 
 #ifdef __cplusplus
 }

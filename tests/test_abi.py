@@ -1,6 +1,10 @@
-"""CPU-only: the C-ABI library builds, loads and exports every symbol include/geoa3_hip.h declares."""
+"""CPU-only: the C-ABI library builds, loads and exports every symbol include/geoa3_hip.h (product ABI) and
+include/geoa3_hip_debug.h (diagnostics) declare; the product header holds no diagnostics and the library exports no
+mutable global."""
 import os
 import re
+import shutil
+import subprocess
 
 from geoa3_amd import _lib
 
@@ -12,13 +16,31 @@ def test_library_exports_every_declared_symbol():
     __graft_entry__.build()
     lib = _lib.load()
     hdr = open(os.path.join(REPO, "include", "geoa3_hip.h")).read()
-    declared = set(re.findall(r"\b(geoa3_[a-z0-9_]+)\s*\(", hdr))
-    assert declared, "no declarations parsed"
+    dbg = open(os.path.join(REPO, "include", "geoa3_hip_debug.h")).read()
+    decls = lambda text: set(re.findall(r"\b(geoa3_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
+    product, diagnostics = decls(hdr), decls(dbg)
+    assert product and diagnostics, "no declarations parsed"
+    # the product ABI promises "no global state": timers and single-kernel hooks live in the debug header only
+    assert not [n for n in product if "debug" in n or "profile" in n]
+    assert all("debug" in n or "profile" in n for n in diagnostics), diagnostics
+    declared = product | diagnostics
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.geoa3_version() >= 100
     assert lib.geoa3_strerror(-1) == b"invalid argument"
+
+
+def test_library_exports_no_mutable_global():
+    """`no global state`: the dynamic symbol table holds functions only (no B/D/C data objects such as a tuning
+    variable another caller could flip under a running loop)."""
+    import __graft_entry__
+    __graft_entry__.build()
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    data = [ln for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "BbDdCcGgSs"
+            and not ln.split()[-1].startswith(("__hip", "_edata", "_end", "__bss_start"))]
+    assert not data, data
 
 
 def test_struct_layouts_match_header():
