@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""Benchmark of the GeoA3 inner attack loop on MI355X (BASELINE.json metric: attack-iterations/sec).
+"""Benchmark of the GeoA3 inner attack loop on MI355X (BASELINE.json metric: attack-iterations/sec at B=250).
 
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE inner iteration of the attack (Attacker/geoA3_attack.py:238-352) applied to the whole batch of
-victim instances that lives on a GPU: success check + PointNet forward + CE/CD/HD/curvature objective + input
-gradient + Adam step.  Workload = BASELINE.json configs[1]: PointNet, N=1024 points, 250 instances per GPU, full
-GeoA3 (CD 1.0 + HD 0.1 + curvature 1.0 with k=16), untargeted CE.  Instances are independent, so N GPUs hold N
-independent 250-instance shards (weak scaling, no data-path collective; the global-batch loss divisor and the
-one-int last-label broadcast per binary step are what the sharded attack() adds, geoa3_amd/distributed.py).
+A "step" is ONE inner iteration of the attack (Attacker/geoA3_attack.py:238-352) applied to every victim instance
+held by a GPU: success check + victim forward + CE/CD/HD/curvature objective + input gradient + Adam step.
 
-value = (instances advanced per second over all ranks) / 250 = iterations/sec of a 250-instance batch.
-Inputs are synthetic (seeded ellipsoid clouds, calibrated random-init PointNet), resident in HBM before timing.
+Workloads (BASELINE.json `configs`):
+  default                         configs[1]: PointNet, 1024 points, 250 instances, full GeoA3 (CD 1.0 + HD 0.1 + curvature
+                                  1.0 with k=16), untargeted CE -- the configuration the metric is quoted on
+  --gpus N (N > 1)                configs[2]: the SAME 250-instance batch sharded over N GPUs (`--scaling strong`, the
+                                  default: rank r holds shard_bounds(250, N)[r] instances, loss divisor 1/250, no
+                                  collective in the iteration); `--scaling weak` holds 250 instances on EVERY GPU
+  --instances 32                  1-GPU proxy of configs[2]: one rank's shard of the 8-way split (global divisor 250)
+  --arch PointNetPP               configs[3]: PointNet++ SSG victim
+  --npoint 4096 --knn 32          configs[4]
+
+value = (instances advanced per second over all ranks) / 250 = iterations/sec of the 250-instance batch.
+Inputs are synthetic (seeded ellipsoid clouds, calibrated random-init victim), resident in HBM before timing; the timed
+window starts from a steady-state iterate (`--presteps` untimed iterations after the initial offsets, default 150: the
+data-dependent searches cost more once the offsets span several grid cells than in the first iterations).
 """
 from __future__ import annotations
 
@@ -26,85 +34,106 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-INSTANCES = 250
+BATCH = 250                # the batch the metric is quoted on
 NPOINT = 1024
 KNN = 16
 CLASSES = 40
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: dense fp32 matrix peak (spec)
-PEAK_F16_MFMA = 2.5e15    # dense f16 / bf16 matrix peak (spec, without 2:1 sparsity)
+PEAK_F16_MFMA = 2.5e15     # dense f16 / bf16 matrix peak (spec, without 2:1 sparsity)
 PEAK_HBM = 8.0e12
+PEAK_F32_VALU = 157.3e12
+
+# event-timer tags (include/geoa3_hip_debug.h)
+TAG_CONV5, TAG_NN1, TAG_KNN, TAG_TNET, TAG_SA1_BWD, TAG_SA1_FWD = 0, 1, 2, 3, 4, 5
 
 
-def cfg_config2(steps):
+def cfg_full_geoa3(steps, npoint=NPOINT, knn=KNN):
     """The reference flags of BASELINE.json configs[1] (main_attack.py:317-384 defaults + Untarget)."""
     return argparse.Namespace(attack_label="Untarget", binary_max_steps=1, iter_max_steps=steps, lr=0.01,
                               initial_const=10.0, optim="adam", cls_loss_type="CE", confidence=0.0,
                               dis_loss_type="CD", dis_loss_weight=1.0, is_cd_single_side=False, hd_loss_weight=0.1,
-                              curv_loss_weight=1.0, curv_loss_knn=KNN, uniform_loss_weight=0.0,
+                              curv_loss_weight=1.0, curv_loss_knn=knn, uniform_loss_weight=0.0,
                               is_use_lr_scheduler=False, cc_linf=0.0, is_pro_grad=False, is_real_offset=False,
-                              npoint=NPOINT, classes=CLASSES)
+                              npoint=npoint, classes=CLASSES)
 
 
-def cpu_baseline(sample_b=8, budget_s=20.0):
-    """The CPU port (oracle, reference semantics incl. the b batch-1 success-check forwards and the six dense
-    K-NN queries per iteration) timed on a bounded sample of the same workload: one warm-up iteration sizes
-    the timed run so that it stays within ~budget_s."""
+def cpu_baseline(arch, npoint, knn, budget_s=20.0, threads=0):
+    """The CPU port (oracle: reference semantics incl. the b batch-1 success-check forwards and the six dense K-NN
+    queries per iteration, Attacker/geoA3_attack.py:238-352) timed on the host cores of this box on a BOUNDED sample of
+    the same workload: a 4-instance warm-up iteration sizes the sample (instances x iterations) to ~budget_s."""
     import torch
     from oracle import geoa3_oracle as O
-    threads = min(os.cpu_count() or 1, 32)   # more intra-op threads than this only adds contention on this path
+    host_cores = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling on this path well below the core count of the GPU box (measured there: the same
+    # 4-instance iteration takes 73 s on 256 threads and ~4 s on 32): 32 threads unless --cpu-threads says otherwise
+    threads = threads or min(host_cores, 32)
     torch.set_num_threads(threads)
-    sd = O.make_pointnet_state_dict(CLASSES, seed=0)
-    net = lambda x: O.pointnet_forward(sd, x)
-    ori, nrm = O.make_synthetic_clouds(sample_b, NPOINT, seed=0)
-    with torch.no_grad():
-        gt = net(ori).argmax(1)
-    g = torch.Generator().manual_seed(1)
-    init = [torch.randn(sample_b, 3, NPOINT, generator=g) * 1e-3]
-    t0 = time.perf_counter()
-    O.attack(net, ori, nrm, gt, None, cfg_config2(1), init, faithful_success_check=True)  # warm-up, sizes the run
-    warm = time.perf_counter() - t0
-    iters = max(1, min(10, int(budget_s / max(warm, 1e-3))))
-    t0 = time.perf_counter()
-    O.attack(net, ori, nrm, gt, None, cfg_config2(iters), init, faithful_success_check=True)
-    dt = time.perf_counter() - t0
-    inst_it_per_s = sample_b * iters / dt
-    return {"value": inst_it_per_s / INSTANCES, "unit": "attack-iterations/sec (250-instance batch)",
-            "cores": threads, "kind": "port",
-            "sample": "oracle attack(), %d instances x %d iterations of config 2 (N=1024, CE+CD+HD+curv k=16), "
-                      "%.1f s, rate scaled to 250 instances" % (sample_b, iters, dt)}
+    if arch == "PointNet":
+        sd = O.make_pointnet_state_dict(CLASSES, seed=0)
+        net = lambda x: O.pointnet_forward(sd, x)
+    else:
+        from oracle import pointnet2_oracle as P2
+        sd2 = P2.make_pn2_state_dict(seed=0)
+        net = lambda x: P2.pointnet2_ssg_forward(sd2, x)
+
+    def run(b, iters):
+        ori, nrm = O.make_synthetic_clouds(b, npoint, seed=0)
+        with torch.no_grad():
+            gt = net(ori).argmax(1)
+        g = torch.Generator().manual_seed(1)
+        init = [torch.randn(b, 3, npoint, generator=g) * 1e-3]
+        t0 = time.perf_counter()
+        O.attack(net, ori, nrm, gt, None, cfg_full_geoa3(iters, npoint, knn), init, faithful_success_check=True)
+        return time.perf_counter() - t0
+
+    run(2, 1)                                   # first-touch costs (thread pool, allocator) stay out of the sizing run
+    per_inst_it = run(4, 1) / 4.0
+    b = int(max(4, min(BATCH, budget_s / max(per_inst_it, 1e-6))))
+    iters = int(max(1, min(20, budget_s / max(per_inst_it * b, 1e-6))))
+    dt = run(b, iters)
+    return {"value": b * iters / dt / BATCH, "unit": "attack-iterations/sec (250-instance batch)",
+            "cores": threads, "host_cores": host_cores, "kind": "port",
+            "sample": "oracle attack() (%s victim, N=%d, CE + CD + HD + curvature k=%d, reference success check = b "
+                      "batch-1 forwards): %d instances x %d iterations in %.1f s on %d threads; instance-iterations/s "
+                      "/ 250" % (arch, npoint, knn, b, iters, dt, threads)}
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc.csv:
-    separate FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md).  None when no summary is present."""
+def pmc_traffic(kernel_substr, prefer):
+    """HBM bytes per launch of a kernel from a committed rocprofv3 PMC summary (profiles/*_pmc.csv: separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  `prefer`: substring of the summary to look at (newest match).  None when absent."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.csv")), key=os.path.getmtime)
-    if not files:
-        return None, None
-    for r in csv.DictReader(open(files[-1])):
-        if kernel_substr in r["Kernel"]:
-            return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, os.path.basename(files[-1])
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*%s*_pmc.csv" % prefer)), key=os.path.getmtime)
+    for f in reversed(files):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel"]:
+                return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, os.path.basename(f)
     return None, None
 
 
 def main():
-    global NPOINT, KNN
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--presteps", type=int, default=150,
+                    help="untimed iterations before the warm-up so the timed window starts from a steady-state iterate")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the 250-instance batch sharded over the GPUs (configs[2]); weak = 250 per GPU")
+    ap.add_argument("--global-batch", type=int, default=BATCH, help="instances of the whole job (strong scaling)")
+    ap.add_argument("--instances", type=int, default=0,
+                    help="instances held by EACH GPU (overrides the split): 32 = one rank's shard of the 8-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(host cores, 32), see cpu_baseline)")
     ap.add_argument("--single-mode", action="store_true",
-                    help="skip the second, shorter measurement in the other arithmetic mode of the 1024-wide layers")
-    ap.add_argument("--instances", type=int, default=INSTANCES, help="instances per GPU (default 250)")
+                    help="skip the second, shorter measurement in the strict fp32-MFMA mode of the convolutions")
     ap.add_argument("--npoint", type=int, default=NPOINT, help="points per cloud (configs[4]: 4096)")
     ap.add_argument("--knn", type=int, default=KNN, help="curv_loss_knn (configs[4]: 32)")
     ap.add_argument("--arch", default="PointNet", choices=["PointNet", "PointNetPP"],
-                    help="victim (PointNetPP = configs[3]: SSG classifier on the HIP set-abstraction operators)")
+                    help="victim (PointNetPP = configs[3]: SSG classifier)")
     a = ap.parse_args()
-    NPOINT, KNN = a.npoint, a.knn
+    npoint, knn = a.npoint, a.knn
 
     import torch
     import torch.distributed as dist
@@ -128,10 +157,23 @@ def main():
         __graft_entry__.build()
     from geoa3_amd import _lib
     from geoa3_amd.attack import AttackRunner
-    from geoa3_amd.pointnet import PointNet
     from geoa3_amd.data import synthetic_clouds, synthetic_state_dict
+    from geoa3_amd.distributed import shard_bounds
+    from geoa3_amd.pointnet import PointNet
 
-    B = a.instances
+    # which instances this rank holds, and the divisor of the loss mean (geoA3_attack.py:178 -> 1 / GLOBAL batch)
+    if a.instances > 0:            # explicit per-GPU shard (1-GPU proxy of a sharded run, or a custom weak run)
+        B, lo = a.instances, 0
+        global_batch = max(a.global_batch, B * world) if a.scaling == "strong" else B * world
+        mode = "shard-proxy" if world == 1 and B != BATCH else a.scaling
+    elif a.scaling == "strong":
+        global_batch = a.global_batch
+        lo, hi = shard_bounds(global_batch, world)[rank]
+        B, mode = hi - lo, "strong"
+    else:
+        B, lo, global_batch, mode = BATCH, 0, BATCH * world, "weak"
+    total_instances = B * world if (a.instances > 0 or mode == "weak") else global_batch
+
     if a.arch == "PointNet":
         net = PointNet(CLASSES)
         net.load_state_dict(synthetic_state_dict(CLASSES, seed=0, device=dev))
@@ -140,10 +182,14 @@ def main():
         torch.manual_seed(0)
         net = PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     net = net.to(dev).eval()
-    ori, nrm = synthetic_clouds(B, NPOINT, seed=100 + rank)
+    if mode == "strong":           # every rank cuts ITS rows out of the same seeded global batch
+        ori, nrm = synthetic_clouds(global_batch, npoint, seed=100)
+        ori, nrm = ori[lo:lo + B].contiguous(), nrm[lo:lo + B].contiguous()
+    else:
+        ori, nrm = synthetic_clouds(B, npoint, seed=100 + rank)
     ori, nrm = ori.to(dev), nrm.to(dev)
     with torch.no_grad():
-        gt = net(ori).argmax(1)
+        gt = net(ori).argmax(1) if B > 0 else torch.zeros(0, dtype=torch.long, device=dev)
     lib = _lib.load()
 
     def barrier():
@@ -152,27 +198,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(wide_mode, steps, warmup):
-        """`warmup` untimed + exactly `steps` timed inner iterations with the 1024-wide layers in `wide_mode`;
-        returns (seconds, max over ranks; per-kernel average ms of conv5 / nn1 / knn / T-Net wide)."""
-        total = warmup + steps
-        cfg = cfg_config2(total + 16)
+    dominant_tag = TAG_CONV5 if a.arch == "PointNet" and not (npoint >= 4096) else (
+        TAG_KNN if a.arch == "PointNet" else TAG_SA1_BWD)
+
+    def measure(wide_mode, steps, warmup, presteps, b=B, pts=None):
+        """`presteps` + `warmup` untimed, then exactly `steps` timed inner iterations; -> (seconds, max over ranks;
+        per-kernel average ms by event-timer tag)."""
+        o, nm, g_ = (ori, nrm, gt) if pts is None else pts
+        total = presteps + warmup + steps
+        cfg = cfg_full_geoa3(total + 16, npoint, knn)
         if a.arch == "PointNet":
             net.wide_mode = wide_mode
-        runner = AttackRunner(net, B, NPOINT, cfg, dev, global_batch=B * world)
-        runner.setup(ori, nrm, gt, gt)
+        runner = AttackRunner(net, b, npoint, cfg, dev, global_batch=global_batch if pts is None else BATCH)
+        runner.setup(o, nm, g_, g_)
         g = torch.Generator(device="cpu").manual_seed(7 + rank)
-        init = (torch.randn(B, 3, NPOINT, generator=g) * 1e-3).to(dev)
+        init = (torch.randn(b, 3, npoint, generator=g) * 1e-3).to(dev)
         runner.begin_search_step(init)
-        for s in range(warmup):
+        for s in range(presteps + warmup):
             runner.step(s, 0)
         barrier()
         # HIP events around the DOMINANT kernel only inside the timed region (an event pair costs ~6 us of stream
         # time); the other kernels' durations come from a few extra, untimed iterations afterwards
         lib.geoa3_profile_enable(steps)
-        lib.geoa3_profile_select(1)
+        lib.geoa3_profile_select(1 << dominant_tag)
         t0 = time.perf_counter()
-        for s in range(warmup, total):
+        for s in range(presteps + warmup, total):
             runner.step(s, 0)
         barrier()
         dt = time.perf_counter() - t0
@@ -186,102 +236,171 @@ def main():
             n = lib.geoa3_profile_read(tag, buf, steps)
             return (sum(buf[:n]) / n) if n > 0 else None
 
-        conv5_ms = kernel_ms(0)
+        ms = {dominant_tag: kernel_ms(dominant_tag)}
         extra = min(steps, 10)
-        lib.geoa3_profile_select(0xE)
+        lib.geoa3_profile_select(0xFF & ~(1 << dominant_tag))
         geo_stream, runner.geo_stream = runner.geo_stream, None   # one stream: durations of the kernels on their own
         for s in range(total, total + extra):
             runner.step(s, 0)
         torch.cuda.synchronize()
         runner.geo_stream = geo_stream
-        nn1_ms, knn_ms, tnet_ms = (kernel_ms(t) for t in (1, 2, 3))
+        for tag in range(6):
+            if tag != dominant_tag:
+                ms[tag] = kernel_ms(tag)
         lib.geoa3_profile_select(0xFFFFFFFF)
         lib.geoa3_profile_enable(0)
-        return dt, conv5_ms, nn1_ms, knn_ms, tnet_ms, extra
+        return dt, ms, extra
 
     from geoa3_amd.pointnet import default_wide_mode
-    mode = default_wide_mode() if a.arch == "PointNet" else None
-    dt, conv5_ms, nn1_ms, knn_ms, tnet_ms, extra = measure(mode, a.steps, a.warmup)
+    wmode = default_wide_mode() if a.arch == "PointNet" else None
+    dt, kms, extra = measure(wmode, a.steps, a.warmup, a.presteps)
     other = None
-    if a.arch == "PointNet" and not a.single_mode:
-        # the same loop with the 1024-wide layers in the other arithmetic mode, shorter, reported beside the headline
-        omode = "f32" if mode == "f16x2" else "f16x2"
+    if a.arch == "PointNet" and not a.single_mode and mode != "shard-proxy":
+        # the same loop with every convolution on the fp32 MFMA (strict fp32 products), shorter, beside the headline
+        omode = "f32" if wmode == "f16x2" else "f16x2"
         osteps = max(10, min(a.steps, 40))
-        odt, oconv5, _, _, otnet, _ = measure(omode, osteps, min(a.warmup, 5))
-        other = (omode, osteps, odt, oconv5, otnet)
+        odt, okms, _ = measure(omode, osteps, min(a.warmup, 5), min(a.presteps, 60))
+        other = (omode, osteps, odt, okms)
+    proxy = None
+    if mode == "shard-proxy" and a.arch == "PointNet":
+        # the full 250-instance batch on this GPU in the same process: what linear scaling is measured against
+        fo, fn = synthetic_clouds(BATCH, npoint, seed=100)
+        fo, fn = fo.to(dev), fn.to(dev)
+        with torch.no_grad():
+            fg = net(fo).argmax(1)
+        fsteps = max(10, min(a.steps, 60))
+        fdt, _, _ = measure(wmode, fsteps, 5, a.presteps, b=BATCH, pts=(fo, fn, fg))
+        proxy = (fsteps, fdt)
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
-        value = (B * world * a.steps / dt) / INSTANCES
-        conv5_flops = 2.0 * B * NPOINT * 1024 * 384          # algorithmic: 1024 outputs x (3 taps x 128) MACs / point
+        value = (total_instances * a.steps / dt) / BATCH
+        conv5_flops = 2.0 * B * npoint * 1024 * 384          # algorithmic: 1024 outputs x (3 taps x 128) MACs / point
 
-        def roofline(m, ms):
-            """conv5 + max: fp32 MFMA against the fp32 matrix peak; split mode against the dense f16 peak with the
-            flops the scheme EXECUTES (3 f16 MFMA products per fp32 product)."""
+        def conv5_roofline(m, ms):
+            """conv5 + bn5 + relu + max.  `achieved` = ALGORITHMIC flops (2 * B * N * 1024 * 384 per launch)
+            / the kernel's measured duration; `peak` = the dense peak of the matrix pipe the kernel runs on.  The
+            split mode executes 3 f16 products per fp32 product: `executed_frac` prices those against the same
+            peak (how busy the pipe is), `frac` prices the useful work."""
             if not ms:
                 return None
+            ach = conv5_flops / (ms * 1e-3)
             if m == "f16x2":
-                ach = 3.0 * conv5_flops / (ms * 1e-3)
-                return {"bound": "mfma", "kernel": "wide_split_kernel<3> (conv5+bn5+relu+max; split-fp16 operands, "
-                                                   "3 f16 MFMA products per fp32 product, fp32 accumulate)",
+                return {"bound": "mfma", "kernel": "wide_split_kernel<3> (conv5+bn5+relu+max; fp32 operands carried as "
+                                                   "two fp16 values on the f16 matrix pipe, fp32 accumulate)",
                         "achieved": round(ach / 1e12, 1), "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F16_MFMA, 4), "avg_launch_ms": round(ms, 4),
-                        "algorithmic_flops_per_launch": conv5_flops, "executed_mfma_flops_per_launch": 3.0 * conv5_flops,
-                        "fp32_equivalent_TFLOPs": round(conv5_flops / (ms * 1e-3) / 1e12, 1),
+                        "algorithmic_flops_per_launch": conv5_flops,
+                        "executed_mfma_flops_per_launch": 3.0 * conv5_flops,
+                        "executed_frac": round(3.0 * ach / PEAK_F16_MFMA, 4),
+                        "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MFMA, 3),
                         "note": "MI355X_MICROARCH.md: a tuned 8192^3 bf16 GEMM sustains 1247 TFLOP/s on random data "
-                                "(the chip lowers its clock under 16-bit MFMA load)", "traffic": None}
-            ach = conv5_flops / (ms * 1e-3)
+                                "(the chip lowers its clock under 16-bit MFMA load), i.e. executed_frac ~0.5 is the "
+                                "practical ceiling of this pipe", "traffic": None}
             return {"bound": "mfma", "kernel": "wide_max2_kernel<3> (conv5+bn5+relu+max, fp32 MFMA)",
                     "achieved": round(ach / 1e12, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA, 4), "avg_launch_ms": round(ms, 4),
                     "algorithmic_flops_per_launch": conv5_flops, "traffic": None}
 
+        cfg_idx = 3 if a.arch != "PointNet" else (4 if npoint >= 4096 else (2 if (world > 1 or mode == "shard-proxy") else 1))
+        victim = "PointNet" if a.arch == "PointNet" else "PointNet++ SSG"
         out = {
-            "metric": "attack-iterations/sec (B=250, N=%d)" % NPOINT, "value": round(value, 3),
+            "metric": "attack-iterations/sec (B=250, N=%d)" % npoint, "value": round(value, 3),
             "unit": "iterations/s of a 250-instance batch", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak" if mode == "weak" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "arithmetic": "fp32 MFMA throughout" if mode != "f16x2" else
+            "arithmetic": "fp32 MFMA throughout" if wmode != "f16x2" else
                           "fp32 values and fp32 accumulation everywhere; the convolutions (1024-wide layers, 64/128-wide "
                           "layers, Gram product) carry each fp32 operand as two fp16 values on the f16 MFMA (3 products "
                           "per fp32 product) -- error against float64 no larger than the fp32 MFMA kernels', "
                           "tools/wide_accuracy.py, DESIGN.md 4a; GEOA3_WIDE_MODE=f32 selects fp32 MFMA (other_wide_mode)",
             "data": "synthetic",
-            "config": {"workload": "configs[%d]: PointNet %d-pt, %d instances per GPU, full GeoA3 (CE + CD 1.0 + HD 0.1 + "
-                                   "curvature 1.0 k=%d), untargeted" % (1 if NPOINT == 1024 else 4, NPOINT, B, KNN),
-                       "instances_per_gpu": B, "npoint": NPOINT, "knn": KNN, "classes": CLASSES,
-                       "wide_mode": mode, "parallelism": "instance-sharded x%d" % world},
-            "roofline": roofline(mode, conv5_ms),
+            "config": {"workload": "configs[%d]: %s %d-pt, %s, full GeoA3 (CE + CD 1.0 + HD 0.1 + curvature 1.0 k=%d), "
+                                   "untargeted" % (cfg_idx, victim, npoint,
+                                                   {"strong": "%d instances sharded over %d GPU(s) (%d on rank 0)"
+                                                              % (global_batch, world, B),
+                                                    "weak": "%d instances on each of %d GPU(s)" % (B, world),
+                                                    "shard-proxy": "ONE rank's %d-instance shard of the %d-instance batch "
+                                                                   "on 1 GPU (loss divisor 1/%d)" % (B, global_batch,
+                                                                                                      global_batch)}[mode],
+                                                   knn),
+                       "instances_per_gpu": B, "global_batch": global_batch, "npoint": npoint, "knn": knn,
+                       "classes": CLASSES, "wide_mode": wmode, "presteps": a.presteps,
+                       "parallelism": "instance-sharded x%d" % world},
         }
+        if a.arch == "PointNet" and npoint < 4096:
+            out["roofline"] = conv5_roofline(wmode, kms.get(TAG_CONV5))
+            tr, src = pmc_traffic("wide_split_kernel<3" if wmode == "f16x2" else "wide_max2_kernel<3", "")
+            if tr is not None and B == BATCH and npoint == 1024 and out["roofline"]:
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % src
+        elif a.arch == "PointNet":
+            # configs[4]: the self top-(k+1) search is the largest kernel of the iteration.  Its algorithmic HBM bytes
+            # (SURVEY 8d): read B*N*12, write B*N*(k+1)*8 (distances + indices); it is VALU/LDS bound (8*B*N^2 flops
+            # all-pairs), so the HBM fraction is small by construction and valu_frac is given beside it
+            ms = kms.get(TAG_KNN)
+            bytes_ = B * npoint * (12.0 + (knn + 1) * 8.0)
+            out["roofline"] = None if not ms else {
+                "bound": "hbm", "kernel": "knn_slab_kernel (self top-%d, slab-pruned)" % (knn + 1),
+                "achieved": round(bytes_ / (ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                "frac": round(bytes_ / (ms * 1e-3) / PEAK_HBM, 5), "avg_launch_ms": round(ms, 4),
+                "algorithmic_bytes_per_launch": bytes_,
+                "valu_frac_vs_all_pairs_flops": round(8.0 * B * npoint * npoint / (ms * 1e-3) / PEAK_F32_VALU, 4),
+                "traffic": None}
+            tr, src = pmc_traffic("knn_slab_kernel", "config5")
+            if tr is not None and out["roofline"] and B == BATCH:
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, "profiles/" + src
+        else:
+            # configs[3]: level 1's backward (recompute 3->64->64, then the input gradient through 128->64->64->3) is the
+            # largest kernel.  Algorithmic flops (input gradient only, no recompute): 2*(128*64 + 64*64 + 64*3) per
+            # grouped sample, B*512*64 samples; executed on the f16 pipe with split operands (3 products per product)
+            ms = kms.get(TAG_SA1_BWD)
+            flops = 2.0 * (128 * 64 + 64 * 64 + 64 * 3) * B * 512 * 64
+            out["roofline"] = None if not ms else {
+                "bound": "mfma", "kernel": "sa1_bwd_kernel (PointNet++ level 1 input gradient, split-fp16 operands)",
+                "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
+                "frac": round(flops / (ms * 1e-3) / PEAK_F16_MFMA, 4), "avg_launch_ms": round(ms, 4),
+                "algorithmic_flops_per_launch": flops, "traffic": None}
+            tr, src = pmc_traffic("sa1_bwd_kernel", "config4")
+            if tr is not None and out["roofline"] and B == BATCH:
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, "profiles/" + src
         if other is not None:
-            omode, osteps, odt, oconv5, otnet = other
-            out["other_wide_mode"] = {"wide_mode": omode, "value": round((B * world * osteps / odt) / INSTANCES, 3),
+            omode, osteps, odt, okms = other
+            out["other_wide_mode"] = {"wide_mode": omode, "value": round((total_instances * osteps / odt) / BATCH, 3),
                                       "ms_per_step": round(odt / osteps * 1e3, 4), "steps": osteps,
-                                      "roofline": roofline(omode, oconv5),
-                                      "kernels_ms": {"conv5_wide_max": oconv5, "tnet_wide_max(x2)": otnet}}
-        tr, src = pmc_traffic("wide_split_kernel<3" if mode == "f16x2" else "wide_max2_kernel<3")
-        if tr is not None and NPOINT == 1024 and B == INSTANCES and out["roofline"]:
-            out["roofline"]["traffic"] = tr
-            out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % src
-        if a.arch != "PointNet":   # configs[3]: the MLPs are MIOpen/hipBLASLt kernels, no single hand-written dominant kernel
-            out["config"]["workload"] = out["config"]["workload"].replace("PointNet ", "PointNet++ SSG ").replace(
-                "configs[1]", "configs[3]")
-            out["roofline"] = None
+                                      "roofline": conv5_roofline(omode, okms.get(TAG_CONV5)),
+                                      "kernels_ms": {"conv5_wide_max": okms.get(TAG_CONV5),
+                                                     "tnet_wide_max(x2)": okms.get(TAG_TNET)}}
+        if proxy is not None:
+            fsteps, fdt = proxy
+            full_ms = fdt / fsteps * 1e3
+            ranks = float(global_batch) / B
+            out["strong_scaling_proxy"] = {
+                "full_batch_ms_per_step": round(full_ms, 4), "shard_ms_per_step": round(ms_per_step, 4),
+                "ranks_emulated": round(ranks, 2), "linear_shard_ms": round(full_ms / ranks, 4),
+                "fraction_of_linear": round(full_ms / ranks / ms_per_step, 4),
+                "note": "1-GPU proxy: the %d-instance shard a rank of the %.1f-way split holds vs the whole %d-instance "
+                        "batch on the same GPU, same process (no collective runs in the iteration)" % (B, ranks,
+                                                                                                        global_batch)}
+        nn1_ms = kms.get(TAG_NN1)
         if nn1_ms:
-            cd_bytes = 40.0 * B * NPOINT
+            cd_bytes = 40.0 * B * npoint
             out["cd_kernel"] = {"kernel": "grid_nn1_kernel (1-NN both directions, uniform-grid search; all-pairs "
                                           "nn1_pair_kernel beyond 4096 points)", "avg_launch_us": round(nn1_ms * 1e3, 2),
                                 "hbm_GBps_algorithmic": round(cd_bytes / (nn1_ms * 1e-3) / 1e9, 2),
                                 "hbm_frac": round(cd_bytes / (nn1_ms * 1e-3) / PEAK_HBM, 5),
-                                "valu_frac": round(8.0 * B * NPOINT * NPOINT / (nn1_ms * 1e-3) / 157.3e12, 4)}
-        out["kernels_ms"] = {"conv5_wide_max": conv5_ms, "tnet_wide_max(x2)": tnet_ms, "nn1_pair": nn1_ms, "knn": knn_ms,
-                             "note": "conv5: HIP events inside the timed region; the others: %d untimed iterations "
-                                     "right after it, on ONE stream (in the timed loop the geometry kernels run on a "
-                                     "second stream beside the victim's forward)" % extra}
+                                "valu_frac": round(8.0 * B * npoint * npoint / (nn1_ms * 1e-3) / PEAK_F32_VALU, 4)}
+        out["kernels_ms"] = {"conv5_wide_max": kms.get(TAG_CONV5), "tnet_wide_max(x2)": kms.get(TAG_TNET),
+                             "nn1_pair": nn1_ms, "knn": kms.get(TAG_KNN), "sa1_bwd": kms.get(TAG_SA1_BWD),
+                             "sa1_fwd": kms.get(TAG_SA1_FWD),
+                             "note": "the roofline kernel: HIP events inside the timed region; the others: %d untimed "
+                                     "iterations right after it, on ONE stream (in the timed loop the geometry kernels "
+                                     "run on a second stream beside the victim's forward)" % extra}
         if not a.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(a.arch, npoint, knn, threads=a.cpu_threads)
             except Exception as e:  # the baseline never blocks the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))

@@ -45,6 +45,14 @@ class Sa1Weights(C.Structure):
     _fields_ = [(n, vp) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
 
 
+class Pn2SsgWeights(C.Structure):
+    """struct geoa3_pn2ssg_weights"""
+    _fields_ = [("classes", C.c_int32), ("sa1", Sa1Weights)] + [(n, vp) for n in (
+        "sa2_wx", "sa2_wf", "sa2_b0", "sa2_wft", "sa2_w1", "sa2_b1", "sa2_w1t", "sa2_w2", "sa2_b2", "sa2_w2t",
+        "sa3_wx", "sa3_wf", "sa3_b0", "sa3_wft", "sa3_w1", "sa3_b1", "sa3_w1t", "sa3_w2", "sa3_b2", "sa3_w2t",
+        "f1", "fb1", "f1t", "f2", "fb2", "f2t", "f3", "fb3", "f3t")]
+
+
 class AttackState(C.Structure):
     """struct geoa3_attack_state"""
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("classes", C.c_int32), ("targeted", C.c_int32),
@@ -94,6 +102,9 @@ SIGNATURES = {
     "geoa3_pn2_sa1_forward": (C.c_int, [vp, vp, vp, C.POINTER(Sa1Weights), C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_pn2_sa1_backward": (C.c_int, [vp, vp, vp, C.POINTER(Sa1Weights), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                          vp, vp]),
+    "geoa3_pn2ssg_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "geoa3_pn2ssg_forward": (C.c_int, [C.POINTER(Pn2SsgWeights), vp, C.c_int, C.c_int, vp, vp, vp]),
+    "geoa3_pn2ssg_backward": (C.c_int, [C.POINTER(Pn2SsgWeights), vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_fps_sample": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "geoa3_knn_normal": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_local_frames": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),

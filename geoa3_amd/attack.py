@@ -51,15 +51,21 @@ class AttackRunner:
         # Native victim: the PointNet whose forward / input-gradient live in the HIP library.  Any other eval-mode
         # nn.Module (PointNet++ SSG on the HIP set-abstraction operators, geoa3_amd/pointnet2.py) is driven through
         # torch autograd: logits = net(x); logits.backward(dlogits) -- still no host synchronisation.
-        self.native = isinstance(net, PointNet)
+        # ... and the PointNet++ SSG classifier of geoa3_amd/pointnet2.py (eval mode, xyz only) is native too:
+        # geoa3_pn2ssg_forward / _backward (csrc/pointnet2_net.hip)
+        from .pointnet2 import PointNet2ClassificationSSG
+        self.ssg = (isinstance(net, PointNet2ClassificationSSG) and net.native and not net.training and
+                    not net.use_normal and min(n, int(_cfg(cfg, "npoint", n))) >= 512)
+        self.native = isinstance(net, PointNet) or self.ssg
         if self.native:
             self.packed = net.packed(device)
             self.classes = self.packed.classes
         else:
             self.packed = None
             self.classes = int(_cfg(cfg, "classes", 40))
-            for prm in net.parameters():   # only d/d input is needed; the reference also forms the unused weight
-                prm.requires_grad_(False)  # gradients (its parameters keep requires_grad=True)
+            # only d/d input is needed (the reference also forms the unused weight gradients: its parameters keep
+            # requires_grad=True): the flags are cleared for the duration of run() and restored after it
+            self._grad_flags = None
         self.global_batch = global_batch or b
         self.targeted = cfg.attack_label != "Untarget"
         self.k = int(cfg.curv_loss_knn)
@@ -146,7 +152,9 @@ class AttackRunner:
             self.knn_slab = os.environ.get("GEOA3_KNN_SLAB", "1") != "0"
             t["knn_scratch"] = ops.knn_self_scratch(b, ne, device)
         if self.native:
-            nbytes = self.lib.geoa3_pointnet_workspace_bytes(b * self.eval_num if self.sub else b, ne, self.classes)
+            bw = b * self.eval_num if self.sub else b
+            nbytes = (self.lib.geoa3_pn2ssg_workspace_bytes(bw, ne) if self.ssg
+                      else self.lib.geoa3_pointnet_workspace_bytes(bw, ne, self.classes))
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.state: Optional[AttackState] = None
 
@@ -154,8 +162,22 @@ class AttackRunner:
     def _p(self, x: Optional[Tensor]):
         return None if x is None else x.data_ptr()
 
+    def _freeze(self):
+        if not self.native and self._grad_flags is None:
+            self._grad_flags = [(prm, prm.requires_grad) for prm in self.net.parameters()]
+            for prm, _ in self._grad_flags:
+                prm.requires_grad_(False)
+
+    def _unfreeze(self):
+        if not self.native and self._grad_flags is not None:
+            for prm, flag in self._grad_flags:
+                prm.requires_grad_(flag)
+            self._grad_flags = None
+
     def setup(self, pc_ori: Tensor, normal_ori: Tensor, gt: Tensor, target: Tensor):
         cfg, t = self.cfg, self.t
+        if self.native:   # re-read the folded weights: a cached runner must see a victim whose weights were reloaded
+            self.packed = self.net.packed(self.dev)
         self.ori = pc_ori.to(self.dev, torch.float32).contiguous()
         self.nrm = normal_ori.to(self.dev, torch.float32).contiguous()
         self.gt = gt.to(self.dev, torch.int32).contiguous()
@@ -199,23 +221,41 @@ class AttackRunner:
         if self.partial:   # the offset is drawn inside the loop (every 50 steps): start from the clean cloud
             init_offset = torch.zeros(self.b, 3, self.n, device=self.dev)
         init = init_offset.to(self.dev, torch.float32).contiguous()
+        self._freeze()   # callers that drive step() themselves (bench.py, tests): undone by end_search_step()
         s = torch.cuda.current_stream().cuda_stream
         check(self.lib.geoa3_attack_begin_search_step(C.byref(self.state), self._p(self.ori), self._p(init),
                                                       self._p(t["offset"]), self._p(t["m"]), self._p(t["v"]),
                                                       self._p(t["x"]), s), "begin_search_step")
 
+    def _native_forward(self, pts: Tensor, out: Tensor, s: int):
+        fn = self.lib.geoa3_pn2ssg_forward if self.ssg else self.lib.geoa3_pointnet_forward
+        check(fn(C.byref(self.packed.struct), pts.data_ptr(), pts.shape[0], pts.shape[2], out.data_ptr(),
+                 self.ws.data_ptr(), s), "victim forward")
+
+    def _native_backward(self, pts: Tensor, dlogits: Tensor, dx: Tensor, s: int):
+        fn = self.lib.geoa3_pn2ssg_backward if self.ssg else self.lib.geoa3_pointnet_backward
+        check(fn(C.byref(self.packed.struct), pts.data_ptr(), dlogits.data_ptr(), pts.shape[0], pts.shape[2],
+                 dx.data_ptr(), self.ws.data_ptr(), s), "victim backward")
+
     def _victim_labels_logits(self, pts: Tensor, out: Tensor):
         """logits of the victim on pts [B',3,m] (no gradient kept) -> out [B',classes]."""
         if self.native:
-            check(self.lib.geoa3_pointnet_forward(C.byref(self.packed.struct), pts.data_ptr(), pts.shape[0],
-                                                  pts.shape[2], out.data_ptr(), self.ws.data_ptr(),
-                                                  torch.cuda.current_stream().cuda_stream), "pointnet_forward")
+            self._native_forward(pts, out, torch.cuda.current_stream().cuda_stream)
         else:
             with torch.no_grad():
                 out.copy_(self.net(pts))
 
     def step(self, step: int, search_step: int):
         """One inner iteration (geoA3_attack.py:238-352) for all b instances; only enqueues."""
+        g = self.objective(step, search_step)
+        if g is not None:
+            self.optimiser_step(step, g[0], g[1])
+
+    def objective(self, step: int, search_step: int):
+        """Success check + `_forward_step` + backward of one iteration (geoA3_attack.py:238-326) on the current
+        iterate t["x"]: fills logits / cls_loss / loss_n / the distance losses and returns the two gradient parts
+        (g_cls [b,3,n] already scaled by 1/b, g_geo [b,3,n] = d constrain / dx un-scaled; either may be None), or None
+        when the step is complete (--is_partial_var keeps its own optimiser)."""
         from . import utility as U
         cfg, t, lib = self.cfg, self.t, self.lib
         s = torch.cuda.current_stream().cuda_stream
@@ -277,8 +317,7 @@ class AttackRunner:
             self.geo_stream.wait_event(self.ev_x)
             sg = self.geo_stream.cuda_stream
         if self.native:
-            check(lib.geoa3_pointnet_forward(C.byref(self.packed.struct), xe.data_ptr(), self.b, ne,
-                                             t["logits"].data_ptr(), self.ws.data_ptr(), s), "pointnet_forward")
+            self._native_forward(xe, t["logits"], s)
         else:
             x_leaf = xe.detach().clone().requires_grad_()
             with torch.enable_grad():
@@ -341,9 +380,7 @@ class AttackRunner:
         g_cls = None
         if cfg.cls_loss_type != "None":
             if self.native:
-                check(lib.geoa3_pointnet_backward(C.byref(self.packed.struct), xe.data_ptr(), t["dlogits"].data_ptr(),
-                                                  self.b, ne, t["g_cls"].data_ptr(), self.ws.data_ptr(), s),
-                      "pointnet_backward")
+                self._native_backward(xe, t["dlogits"], t["g_cls"], s)
             else:
                 logits_ag.backward(t["dlogits"])
                 t["g_cls"].copy_(x_leaf.grad)
@@ -368,7 +405,16 @@ class AttackRunner:
                                                     t["periodical"].data_ptr(), t["part"].data_ptr(),
                                                     t["pm"].data_ptr(), t["pv"].data_ptr(), x.data_ptr(), *args, s),
                       "attack_partial_step")
-            return   # the projections / lp_clip act on a padded copy in the reference: no effect (:341-352)
+            return None  # the projections / lp_clip act on a padded copy in the reference: no effect (:341-352)
+        return g_cls, g_geo
+
+    def optimiser_step(self, step: int, g_cls: Optional[Tensor], g_geo: Optional[Tensor]):
+        """Adam / SGD on the offset with g = g_cls + (scale_const / b) g_geo, then the flag-gated projections
+        (geoA3_attack.py:326-352)."""
+        cfg, t, lib = self.cfg, self.t, self.lib
+        s = torch.cuda.current_stream().cuda_stream
+        st = C.byref(self.state)
+        x = t["x"]
         pro_grad = bool(_cfg(cfg, "is_pro_grad", False))
         # optimiser scalars in double, as torch.optim.Adam forms them
         lr = cfg.lr * (0.9990 ** step if _cfg(cfg, "is_use_lr_scheduler", False) else 1.0)
@@ -400,6 +446,7 @@ class AttackRunner:
             sync_last_label(self.t["last_label"])
         s = torch.cuda.current_stream().cuda_stream
         check(self.lib.geoa3_attack_binary_update(C.byref(self.state), s), "binary_update")
+        self._unfreeze()
 
     def info_line(self, search_step, step, i, loader_len) -> str:
         """The reference's progress line (geoA3_attack.py:129,138,154,163,365); the ONLY host sync in the loop."""
@@ -430,6 +477,14 @@ class AttackRunner:
         [b,3,knn_range] (nn.init.normal_) for --is_partial_var."""
         cfg = self.cfg
         self.hooks = dict(hooks or {})
+        self._freeze()
+        try:
+            self._run(init_offsets, i, loader_len, verbose, sync_last_label, on_step)
+        finally:
+            self._unfreeze()
+
+    def _run(self, init_offsets, i, loader_len, verbose, sync_last_label, on_step):
+        cfg = self.cfg
         for search_step in range(int(cfg.binary_max_steps)):
             if self.partial:
                 init = None
@@ -452,7 +507,16 @@ class AttackRunner:
         success = (t["best_loss"].cpu().numpy() < 1e10)
         best_step = t["best_step"].cpu().tolist()
         all_loss = t["loss_hist"].cpu().tolist()
-        return t["best_attack"], self.target.long(), success, best_step, all_loss
+        # a fresh tensor per call, as the reference allocates one (geoA3_attack.py:226): a cached runner refills its
+        # own buffer at the next setup()
+        return t["best_attack"].clone(), self.target.long(), success, best_step, all_loss
+
+
+# cfg fields that shape an AttackRunner's buffers / kernel choices at construction
+RUNNER_CFG_FIELDS = ("attack_label", "iter_max_steps", "curv_loss_knn", "curv_loss_weight", "dis_loss_type",
+                     "hd_loss_weight", "cls_loss_type", "optim", "uniform_loss_weight", "npoint", "is_partial_var",
+                     "knn_range", "is_subsample_opt", "eval_num", "is_pre_jitter_input", "is_pro_grad", "graph_search",
+                     "brute_force_nn1", "classes", "deterministic")
 
 
 def unpack_input(input_data, targeted: bool):
@@ -484,7 +548,9 @@ def attack(net, input_data, cfg, i, loader_len, saved_dir=None, *, init_offsets=
     device = next(net.parameters()).device
     if device.type != "cuda":
         raise _lib.Geoa3Error("attack() needs the victim network on the GPU")
-    key = (b, n, id(net), global_batch)
+    # everything AttackRunner.__init__ derives from cfg is part of the key: a changed flag builds a new runner
+    key = (b, n, id(net), global_batch) + tuple(
+        (name, repr(getattr(cfg, name, None))) for name in RUNNER_CFG_FIELDS)
     runner = runner_cache.get(key) if runner_cache is not None else None
     if runner is None:
         runner = AttackRunner(net, b, n, cfg, device, global_batch)

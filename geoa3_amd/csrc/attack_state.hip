@@ -162,8 +162,10 @@ __global__ __launch_bounds__(256) void attack_update_kernel(int B, int N, const 
     if (g_geo) g += cg * g_geo[e];
     float w = offset[e];
     if (optim == 0) {  // torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8
-      const float m = am[e] * 0.9f + g * (1.0f - 0.9f);
-      const float v = av[e] * 0.999f + (g * g) * (1.0f - 0.999f);
+      // torch forms 1 - beta in DOUBLE and rounds once: 0.1f and 0.001f (1.0f - 0.999f in float is 0.00099998713:
+      // 1.3e-5 off in v, 6.5e-6 in the step -- found by the adam/* reference trace, tests/test_gpu_forward_step.py)
+      const float m = am[e] * 0.9f + g * 0.1f;
+      const float v = av[e] * 0.999f + (g * g) * 0.001f;
       am[e] = m;
       av[e] = v;
       const float denom = sqrtf(v) / sqrt_bc2 + 1e-8f;
@@ -299,8 +301,8 @@ __global__ __launch_bounds__(256) void attack_partial_kernel(int B, int N, int k
       float g = g_cls ? g_cls[e] : 0.f;
       if (g_geo) g += cg * g_geo[e];
       if (optim == 0) {   // torch.optim.Adam defaults
-        const float m = pm[pe] * 0.9f + g * (1.0f - 0.9f);
-        const float v = pv[pe] * 0.999f + (g * g) * (1.0f - 0.999f);
+        const float m = pm[pe] * 0.9f + g * 0.1f;            // 1 - beta rounded from double, as torch (see above)
+        const float v = pv[pe] * 0.999f + (g * g) * 0.001f;
         pm[pe] = m;
         pv[pe] = v;
         w = w - step_size * (m / (sqrtf(v) / sqrt_bc2 + 1e-8f));

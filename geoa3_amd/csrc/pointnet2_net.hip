@@ -1,0 +1,379 @@
+// PointNet++ SSG classifier (eval mode) as ONE native forward and ONE native input-gradient entry point: the launch
+// sequence over the set-abstraction kernels of pointnet2_ops.hip / pointnet2_sa.hip / pointnet2_mlp.hip, the split-fp16
+// 1x1 convolutions of pointnet_conv_split.hip and the FC kernel of pointnet_gemm.hip.  No torch operator, no library
+// GEMM, no host synchronisation in between.
+//
+// Reference: Model/PointNetPP_ssg.py:51-124 (PointNet2ClassificationSSG: SA(512, 0.2, 64, [3,64,64,128]) ->
+// SA(128, 0.4, 64, [128+3,128,128,256]) -> SA(GroupAll, [256+3,256,512,1024]) -> FC 1024-512-256-classes),
+// Model/pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py:29-74 (_PointnetSAModuleBase.forward),
+// pointnet2_utils.py:296-333 (QueryAndGroup), :349-379 (GroupAll); the backward is the hand-derived input gradient of
+// that graph (the attack never needs weight gradients; the reference's autograd forms them anyway,
+// Attacker/geoA3_attack.py:326).
+//
+// Algebra used (eval mode, BatchNorm folded into W / shift on the host, geoa3_amd/pointnet2.py pack_ssg):
+//   * a level's first layer is linear in the grouped input: W [xyz_j - c_m ; f_j] = (W_x xyz + W_f f)_j - (W_x c)_m, so it
+//     is applied to the UN-grouped points and the result is gathered (level 2); GroupAll (level 3) has no centre:
+//     layer 1 = relu(W_f f + W_x xyz + b);
+//   * level 3's 512 -> 1024 layer runs as two K = 256 products accumulated before the bias / relu / max tail.
+#include "pointnet_kernels.h"
+
+namespace {
+
+constexpr int M1 = 512, M2 = 128, S = 64;          // PointNetPP_ssg.py:58-76
+constexpr float R1 = 0.2f, R2 = 0.4f;
+constexpr int C1 = 128, C2 = 256, C3 = 1024;       // output widths of the three levels
+
+#define TRY(expr)               \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+struct Ws {
+  float *xyz, *nx1, *out1, *f1, *nx2, *r, *shift, *a0, *a1, *out2, *h1, *h2, *z3, *p3, *q1, *q2;
+  int32_t *idx1, *gidx1, *idx2, *gidx2, *arg2, *arg3;
+  uint8_t* arg1;
+  // backward
+  float *g256, *g512, *g1024, *dh2, *dh1, *dout2, *dnx2, *gz, *d1, *df1, *dnx1, *g1, *gxyz, *gnx1;
+  int32_t* argt;
+  size_t total;
+};
+
+Ws carve(void* base, int B, int N) {
+  Ws w{};
+  size_t off = 0;
+  char* p = static_cast<char*>(base);
+  auto take = [&](size_t bytes) {
+    void* r = p ? p + off : nullptr;
+    off += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  const size_t b = (size_t)B, f = sizeof(float);
+  w.xyz = (float*)take(b * N * 3 * f);
+  w.idx1 = (int32_t*)take(b * M1 * 4);
+  w.nx1 = (float*)take(b * M1 * 3 * f);
+  w.gidx1 = (int32_t*)take(b * M1 * S * 4);
+  w.out1 = (float*)take(b * M1 * C1 * f);
+  w.arg1 = (uint8_t*)take(b * M1 * C1);
+  w.f1 = (float*)take(b * C1 * M1 * f);
+  w.idx2 = (int32_t*)take(b * M2 * 4);
+  w.nx2 = (float*)take(b * M2 * 3 * f);
+  w.gidx2 = (int32_t*)take(b * M2 * S * 4);
+  w.r = (float*)take(b * 128 * M1 * f);
+  w.shift = (float*)take(b * 128 * M2 * f);
+  w.a0 = (float*)take(b * 128 * M2 * S * f);
+  w.a1 = (float*)take(b * 128 * M2 * S * f);
+  w.out2 = (float*)take(b * C2 * M2 * f);
+  w.arg2 = (int32_t*)take(b * C2 * M2 * 4);
+  w.h1 = (float*)take(b * 256 * M2 * f);
+  w.h2 = (float*)take(b * 512 * M2 * f);
+  w.z3 = (float*)take(b * C3 * M2 * f);
+  w.p3 = (float*)take(b * C3 * f);
+  w.arg3 = (int32_t*)take(b * C3 * 4);
+  w.q1 = (float*)take(b * 512 * f);
+  w.q2 = (float*)take(b * 256 * f);
+  w.g256 = (float*)take(b * 256 * f);
+  w.g512 = (float*)take(b * 512 * f);
+  w.g1024 = (float*)take(b * C3 * f);
+  w.dh2 = (float*)take(b * 512 * M2 * f);
+  w.dh1 = (float*)take(b * 256 * M2 * f);
+  w.dout2 = (float*)take(b * C2 * M2 * f);
+  w.dnx2 = (float*)take(b * M2 * 3 * f);
+  w.gz = (float*)take(b * M2 * C2 * f);
+  w.argt = (int32_t*)take(b * M2 * C2 * 4);
+  w.d1 = (float*)take(b * 128 * M2 * S * f);
+  w.df1 = (float*)take(b * C1 * M1 * f);
+  w.dnx1 = (float*)take(b * M1 * 3 * f);
+  w.g1 = (float*)take(b * M1 * C1 * f);
+  w.gxyz = (float*)take(b * N * 3 * f);
+  w.gnx1 = (float*)take(b * M1 * 3 * f);
+  w.total = off;
+  return w;
+}
+
+// ---- layout helpers -------------------------------------------------------------------------------------------------
+// planar [B,3,N] <-> point-major [B,N,3]
+__global__ __launch_bounds__(256) void planar_to_points_kernel(const float* __restrict__ x, float* __restrict__ xyz, int N,
+                                                               long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long b = e / N;
+  const int n = (int)(e - b * N);
+  const float* p = x + b * 3 * N + n;
+  float* q = xyz + e * 3;
+  q[0] = p[0];
+  q[1] = p[N];
+  q[2] = p[2 * (size_t)N];
+}
+__global__ __launch_bounds__(256) void points_to_planar_kernel(const float* __restrict__ xyz, float* __restrict__ x, int N,
+                                                               long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long b = e / N;
+  const int n = (int)(e - b * N);
+  const float* q = xyz + e * 3;
+  float* p = x + b * 3 * N + n;
+  p[0] = q[0];
+  p[N] = q[1];
+  p[2 * (size_t)N] = q[2];
+}
+
+// out[b][m][:] = in[b][idx[b][m]][:]   (rows of 3 floats)
+__global__ __launch_bounds__(256) void gather_rows3_kernel(const float* __restrict__ in, const int32_t* __restrict__ idx,
+                                                           float* __restrict__ out, int N, int M, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long b = e / M;
+  const float* p = in + (b * N + idx[e]) * 3;
+  float* q = out + e * 3;
+  q[0] = p[0];
+  q[1] = p[1];
+  q[2] = p[2];
+}
+
+// dst[b][n][:] (+)= sum over m with idx[b][m] == n of src[b][m][:], in ascending m: the gradient of gather_rows3 as an
+// OWNER-side scan (every destination row sums its own sources in a fixed order: deterministic, no atomics; FPS indices
+// are distinct except for degenerate clouds, where duplicates simply add up)
+__global__ __launch_bounds__(256) void scatter_rows3_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                            float* __restrict__ dst, int N, int M, int accumulate) {
+  extern __shared__ int32_t s_idx[];
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  for (int m = threadIdx.x; m < M; m += 256) s_idx[m] = idx[(size_t)b * M + m];
+  __syncthreads();
+  if (n >= N) return;
+  float* q = dst + ((size_t)b * N + n) * 3;
+  float a0 = accumulate ? q[0] : 0.f, a1 = accumulate ? q[1] : 0.f, a2 = accumulate ? q[2] : 0.f;
+  const float* sp = src + (size_t)b * M * 3;
+  for (int m = 0; m < M; ++m)
+    if (s_idx[m] == n) {
+      a0 += sp[3 * m];
+      a1 += sp[3 * m + 1];
+      a2 += sp[3 * m + 2];
+    }
+  q[0] = a0;
+  q[1] = a1;
+  q[2] = a2;
+}
+
+// [B][R][C] -> [B][C][R] through a 32 x 33 LDS tile.  GATE: the value is zeroed where gate[b][r][c] <= 0 (the pooled
+// output's relu folded into the transpose that produces the centre-major gradient of geoa3_conv1x1_onehot64).
+template <typename T, bool GATE>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, const float* __restrict__ gate,
+                                                        T* __restrict__ out, int R, int C) {
+  __shared__ T tile[32][33];
+  const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t base = (size_t)b * R * C;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    if (r < R && c < C) {
+      T v = in[base + (size_t)r * C + c];
+      if (GATE) v = gate[base + (size_t)r * C + c] > 0.f ? v : (T)0;
+      tile[ty + 8 * j][tx] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (r < R && c < C) out[base + (size_t)c * R + r] = tile[tx][ty + 8 * j];
+  }
+}
+
+// ---- the 3-channel (xyz) part of a level's first layer -------------------------------------------------------------
+// out[b][co][m] = bias[co] + sign * <Wx[co], p[b][m]>        (shift of the pre-transformed level: b0 - Wx c_m)
+__global__ __launch_bounds__(256) void affine3_kernel(const float* __restrict__ Wx, const float* __restrict__ bias,
+                                                      const float* __restrict__ p, float sign, float* __restrict__ out,
+                                                      int Co, int M, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int m = (int)(e % M);
+  const long t = e / M;
+  const int co = (int)(t % Co);
+  const long b = t / Co;
+  const float* q = p + (b * M + m) * 3;
+  const float d = Wx[3 * co] * q[0] + Wx[3 * co + 1] * q[1] + Wx[3 * co + 2] * q[2];
+  out[e] = (bias ? bias[co] : 0.f) + sign * d;
+}
+// Y[b][co][n] = act(Y[b][co][n] + <Wx[co], p[b][n]> + bias[co])   in place (p point-major [B,N,3])
+__global__ __launch_bounds__(256) void affine3_add_kernel(float* __restrict__ Y, const float* __restrict__ Wx,
+                                                          const float* __restrict__ bias, const float* __restrict__ p,
+                                                          int Co, int N, int relu, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int n = (int)(e % N);
+  const long t = e / N;
+  const int co = (int)(t % Co);
+  const long b = t / Co;
+  const float* q = p + (b * N + n) * 3;
+  float v = Y[e] + (Wx[3 * co] * q[0] + Wx[3 * co + 1] * q[1] + Wx[3 * co + 2] * q[2]);
+  if (bias) v += bias[co];
+  if (relu) v = fmaxf(v, 0.f);
+  Y[e] = v;
+}
+// dp[b][n][c] (+)= sign * sum_co Wx[co][c] dY[b][co][n]   (one thread per point, co ascending: fixed order)
+__global__ __launch_bounds__(256) void affine3_grad_kernel(const float* __restrict__ dY, const float* __restrict__ Wx,
+                                                           float sign, float* __restrict__ dp, int Co, int N,
+                                                           int accumulate, long total) {
+  extern __shared__ float s_wx[];   // [Co][3]
+  for (int i = threadIdx.x; i < 3 * Co; i += 256) s_wx[i] = Wx[i];
+  __syncthreads();
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long b = e / N;
+  const int n = (int)(e - b * N);
+  const float* g = dY + b * Co * N + n;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int co = 0; co < Co; ++co) {
+    const float v = g[(size_t)co * N];
+    a0 += s_wx[3 * co] * v;
+    a1 += s_wx[3 * co + 1] * v;
+    a2 += s_wx[3 * co + 2] * v;
+  }
+  float* q = dp + e * 3;
+  if (accumulate) {
+    q[0] += sign * a0;
+    q[1] += sign * a1;
+    q[2] += sign * a2;
+  } else {
+    q[0] = sign * a0;
+    q[1] = sign * a1;
+    q[2] = sign * a2;
+  }
+}
+// a[i] += b[i]
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < total) a[e] += b[e];
+}
+
+inline dim3 g1d(long total) { return dim3((unsigned)((total + 255) / 256)); }
+
+template <typename T, bool GATE>
+int transpose(const T* in, const float* gate, T* out, int B, int R, int C, hipStream_t s) {
+  hipLaunchKernelGGL((transpose_kernel<T, GATE>), dim3((C + 31) / 32, (R + 31) / 32, B), dim3(256), 0, s, in, gate, out, R, C);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+// Y[b][co][n] = epi(sum_{k < K} W[co][k0 + k] X[b][k0 + k][n]) over a K-slice of a [Co][Kfull] weight / [B][Kfull][N] input
+int conv_slice(const float* X, int Kfull, int k0, int K, const float* W, const float* bias, const float* Z, float* Y, int Co,
+               int B, int N, bool relu, bool accumulate, hipStream_t s) {
+  ConvArgs a{};
+  a.split = 1;
+  a.X = X + (size_t)k0 * N; a.sXb = (long)Kfull * N; a.ldX = N;
+  a.W = W + k0; a.sWb = 0; a.sWco = Kfull; a.sWk = 1;
+  a.bias = bias;
+  a.Z = Z; a.sZb = (long)Co * N; a.ldZ = N;
+  a.Y = Y; a.sYb = (long)Co * N; a.ldY = N;
+  a.Co = Co; a.K = K; a.N = N; a.B = B;
+  a.relu = relu; a.accumulate = accumulate;
+  return launch_conv_cm(a, s);
+}
+
+int fc(const float* X, int K, const float* W, const float* bias, float* Y, int Nout, int M, bool relu, const float* Z,
+       hipStream_t s) {
+  FcArgs a{};
+  a.X = X; a.ldX = K;
+  a.W = W; a.ldW = K;
+  a.bias = bias;
+  a.Z = Z; a.ldZ = Nout;
+  a.Y = Y; a.ldY = Nout;
+  a.M = M; a.Nout = Nout; a.K = K; a.relu = relu;
+  return launch_fc(a, s);
+}
+
+}  // namespace
+
+extern "C" int64_t geoa3_pn2ssg_workspace_bytes(int B, int N) {
+  if (B <= 0 || N < M1) return -1;
+  return (int64_t)carve(nullptr, B, N).total;
+}
+
+extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float* x, int B, int N, float* logits,
+                                    void* workspace, void* stream) {
+  if (!pw || !x || !logits || !workspace || B <= 0 || N < M1 || pw->classes <= 0) return GEOA3_EINVAL;
+  if (((uintptr_t)workspace & 255) != 0) return GEOA3_EINVAL;
+  hipStream_t s = geoa3_stream(stream);
+  const geoa3_pn2ssg_weights& p = *pw;
+  Ws w = carve(workspace, B, N);
+  // ---- level 1 (PointNetPP_ssg.py:58-66): FPS 512, ball 0.2 x 64, MLP 3 -> 64 -> 64 -> 128, max
+  hipLaunchKernelGGL(planar_to_points_kernel, g1d((long)B * N), dim3(256), 0, s, x, w.xyz, N, (long)B * N);
+  TRY(geoa3_pn2_furthest_point_sampling(w.xyz, B, N, M1, nullptr, w.idx1, stream));
+  hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M1), dim3(256), 0, s, w.xyz, w.idx1, w.nx1, N, M1, (long)B * M1);
+  TRY(geoa3_pn2_ball_query(w.nx1, w.xyz, B, N, M1, R1, S, w.gidx1, stream));
+  TRY(geoa3_pn2_sa1_forward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, stream));
+  TRY((transpose<float, false>(w.out1, nullptr, w.f1, B, M1, C1, s)));            // [B,512,128] -> [B,128,512]
+  // ---- level 2 (:68-76): FPS 128, ball 0.4 x 64, MLP (128 + 3) -> 128 -> 128 -> 256, max
+  TRY(geoa3_pn2_furthest_point_sampling(w.nx1, B, M1, M2, nullptr, w.idx2, stream));
+  hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M2), dim3(256), 0, s, w.nx1, w.idx2, w.nx2, M1, M2, (long)B * M2);
+  TRY(geoa3_pn2_ball_query(w.nx2, w.nx1, B, M1, M2, R2, S, w.gidx2, stream));
+  TRY(conv_slice(w.f1, 128, 0, 128, p.sa2_wf, nullptr, nullptr, w.r, 128, B, M1, false, false, s));   // W_f f
+  hipLaunchKernelGGL(affine3_add_kernel, g1d((long)B * 128 * M1), dim3(256), 0, s, w.r, p.sa2_wx, (const float*)nullptr,
+                     w.nx1, 128, M1, 0, (long)B * 128 * M1);                                               // + W_x xyz
+  hipLaunchKernelGGL(affine3_kernel, g1d((long)B * 128 * M2), dim3(256), 0, s, p.sa2_wx, p.sa2_b0, w.nx2, -1.f, w.shift,
+                     128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
+  TRY(geoa3_pn2_group_shift_relu(w.r, w.gidx2, w.shift, B, 128, M1, M2, S, w.a0, stream));
+  TRY(geoa3_conv1x1(w.a0, p.sa2_w1, p.sa2_b1, nullptr, w.a1, B, (long)M2 * S, 128, 128, 1, stream));
+  TRY(geoa3_conv1x1_max64(w.a1, p.sa2_w2, p.sa2_b2, w.out2, w.arg2, B, (long)M2 * S, 128, C2, stream));
+  // ---- level 3 (:78-82, GroupAll): MLP (256 + 3) -> 256 -> 512 -> 1024 on the 128 points, max over them
+  TRY(conv_slice(w.out2, 256, 0, 256, p.sa3_wf, nullptr, nullptr, w.h1, 256, B, M2, false, false, s));
+  hipLaunchKernelGGL(affine3_add_kernel, g1d((long)B * 256 * M2), dim3(256), 0, s, w.h1, p.sa3_wx, p.sa3_b0, w.nx2, 256, M2,
+                     1, (long)B * 256 * M2);
+  TRY(conv_slice(w.h1, 256, 0, 256, p.sa3_w1, p.sa3_b1, nullptr, w.h2, 512, B, M2, true, false, s));
+  TRY(conv_slice(w.h2, 512, 0, 256, p.sa3_w2, nullptr, nullptr, w.z3, C3, B, M2, false, false, s));
+  TRY(conv_slice(w.h2, 512, 256, 256, p.sa3_w2, nullptr, nullptr, w.z3, C3, B, M2, false, true, s));
+  TRY(geoa3_pn2_bias_relu_max(w.z3, p.sa3_b2, B, C3, 1, M2, w.p3, w.arg3, stream));
+  // ---- FC head (:84-98): Linear (no bias) + BatchNorm1d (folded) + ReLU twice, Dropout = identity, Linear
+  TRY(fc(w.p3, C3, p.f1, p.fb1, w.q1, 512, B, true, nullptr, s));
+  TRY(fc(w.q1, 512, p.f2, p.fb2, w.q2, 256, B, true, nullptr, s));
+  TRY(fc(w.q2, 256, p.f3, p.fb3, logits, p.classes, B, false, nullptr, s));
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float* x, const float* dlogits, int B, int N,
+                                     float* dx, void* workspace, void* stream) {
+  if (!pw || !x || !dlogits || !dx || !workspace || B <= 0 || N < M1) return GEOA3_EINVAL;
+  hipStream_t s = geoa3_stream(stream);
+  const geoa3_pn2ssg_weights& p = *pw;
+  Ws w = carve(workspace, B, N);
+  // ---- FC head
+  TRY(fc(dlogits, p.classes, p.f3t, nullptr, w.g256, 256, B, false, w.q2, s));
+  TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.q1, s));
+  TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, C3, B, false, nullptr, s));
+  // ---- level 3: max + relu gate, then W2^T (four K = 256 slices), W1^T (two), Wf^T / Wx^T
+  float* dz3 = w.z3;   // the pre-activation is not needed any more
+  TRY(geoa3_pn2_bias_relu_max_grad(w.g1024, w.p3, w.arg3, B, C3, 1, M2, dz3, stream));
+  for (int k0 = 0; k0 < C3; k0 += 256)
+    TRY(conv_slice(dz3, C3, k0, 256, p.sa3_w2t, nullptr, w.h2, w.dh2, 512, B, M2, false, k0 > 0, s));
+  for (int k0 = 0; k0 < 512; k0 += 256)
+    TRY(conv_slice(w.dh2, 512, k0, 256, p.sa3_w1t, nullptr, w.h1, w.dh1, 256, B, M2, false, k0 > 0, s));
+  TRY(conv_slice(w.dh1, 256, 0, 256, p.sa3_wft, nullptr, nullptr, w.dout2, C2, B, M2, false, false, s));
+  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 256 * sizeof(float), s, w.dh1, p.sa3_wx, 1.f,
+                     w.dnx2, 256, M2, 0, (long)B * M2);
+  // ---- level 2: pooled layer's sparse gradient (centre-major, relu-gated) -> W2^T -> W1^T -> scatter of the gather
+  TRY((transpose<float, true>(w.dout2, w.out2, w.gz, B, C2, M2, s)));              // [B,256,128] -> [B,128,256], gated
+  TRY((transpose<int32_t, false>(w.arg2, nullptr, w.argt, B, C2, M2, s)));
+  TRY(geoa3_conv1x1_onehot64(w.gz, w.argt, p.sa2_w2t, w.a1, w.d1, B, (long)M2 * S, C2, 128, stream));
+  float* da0 = w.a1;   // a1 has served as the gate above
+  TRY(geoa3_conv1x1(w.d1, p.sa2_w1t, nullptr, w.a0, da0, B, (long)M2 * S, 128, 128, 0, stream));
+  float *dr = w.r, *dshift = w.shift;
+  TRY(geoa3_pn2_group_points_grad_sums(da0, w.gidx2, B, 128, M1, M2, S, dr, dshift, stream));
+  TRY(conv_slice(dr, 128, 0, 128, p.sa2_wft, nullptr, nullptr, w.df1, C1, B, M1, false, false, s));   // d f1 = W_f^T dr
+  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M1), dim3(256), 3 * 128 * sizeof(float), s, dr, p.sa2_wx, 1.f, w.dnx1,
+                     128, M1, 0, (long)B * M1);                                                        // d xyz1 = W_x^T dr
+  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 128 * sizeof(float), s, dshift, p.sa2_wx, -1.f,
+                     w.dnx2, 128, M2, 1, (long)B * M2);                                                // d c -= W_x^T dshift
+  hipLaunchKernelGGL(scatter_rows3_kernel, dim3((M1 + 255) / 256, B), dim3(256), M2 * sizeof(int32_t), s, w.dnx2, w.idx2,
+                     w.dnx1, M1, M2, 1);                                                               // gather(new_xyz1, idx2)
+  // ---- level 1
+  TRY((transpose<float, false>(w.df1, nullptr, w.g1, B, C1, M1, s)));              // [B,128,512] -> centroid-major
+  TRY(geoa3_pn2_sa1_backward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, w.g1, w.gxyz, w.gnx1, stream));
+  hipLaunchKernelGGL(add_inplace_kernel, g1d((long)B * M1 * 3), dim3(256), 0, s, w.dnx1, w.gnx1, (long)B * M1 * 3);
+  hipLaunchKernelGGL(scatter_rows3_kernel, dim3((N + 255) / 256, B), dim3(256), M1 * sizeof(int32_t), s, w.dnx1, w.idx1,
+                     w.gxyz, N, M1, 1);                                                                // gather(xyz, idx1)
+  hipLaunchKernelGGL(points_to_planar_kernel, g1d((long)B * N), dim3(256), 0, s, w.gxyz, dx, N, (long)B * N);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}

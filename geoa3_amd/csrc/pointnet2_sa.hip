@@ -20,6 +20,7 @@
 // row-order trick), and finishes with the K = 3 contraction and the scatter to the points.
 // The fp32-MFMA form of this file ran 1.67 ms forward / 2.61 ms backward at B = 250 (MFMA floors 1.4 / 1.9 ms).
 #include "pointnet_kernels.h"
+#include "profile.h"
 
 namespace {
 
@@ -491,8 +492,10 @@ extern "C" int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, con
   const size_t lds = (size_t)sa1_lds_bytes(SA_TF, false);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
+  geoa3_prof_begin(GEOA3_PROF_SA1_FWD, geoa3_stream(stream));
   hipLaunchKernelGGL(sa1_fwd_kernel, dim3(sa1_grid(B, M, SA_TF / 64)), dim3(SA_TF), lds, geoa3_stream(stream), xyz, new_xyz, idx, *w,
                      B, N, M, out, arg);
+  geoa3_prof_end(GEOA3_PROF_SA1_FWD, geoa3_stream(stream));
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
@@ -509,8 +512,10 @@ extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, co
   const size_t lds = (size_t)sa1_lds_bytes(SA_TB, true);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
+  geoa3_prof_begin(GEOA3_PROF_SA1_BWD, s);
   hipLaunchKernelGGL(sa1_bwd_kernel, dim3(sa1_grid(B, M, SA_TB / 64)), dim3(SA_TB), lds, s, xyz, new_xyz, idx, *w, B, N, M, out, arg,
                      grad_out, grad_xyz, grad_new_xyz);
+  geoa3_prof_end(GEOA3_PROF_SA1_BWD, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

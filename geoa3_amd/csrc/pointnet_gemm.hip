@@ -4,6 +4,7 @@
 // chain, so results differ from the CPU reference only by summation order.
 #include "pointnet_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -235,11 +236,20 @@ __global__ __launch_bounds__(256) void reduce_dT_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// fc: Y[m][o] = epi(sum_k X[m][k] W[o][k] + bias[o]).  Tile = 32 rows x 32 outputs per workgroup; the
-// S wavefronts of the workgroup split K and are summed through LDS.  Both operands are k-contiguous,
-// so each lane pulls 4 consecutive k with one 16-byte load straight into MFMA operand registers
-// (k is consumed in the permuted order 8j + 4*(lane>>5) + i, identical for A and B).
+// fc: Y[m][o] = epi(sum_k X[m][k] W[o][k] + bias[o]) -- the fully connected heads in both directions and the small
+// per-instance products.  These layers are LATENCY bound (~1 GFLOP per chain, operands from L2): the time of a launch
+// is one dependent chain load -> MFMA -> reduce -> store, so the kernel is shaped to make that chain short:
+//   * tile T x T outputs per workgroup, T = 16 (v_mfma_f32_16x16x4_f32) for small M so that a 32-row batch still
+//     spreads over >= 64 workgroups, T = 32 (v_mfma_f32_32x32x2_f32) otherwise (half the operand re-reads);
+//   * K is split over up to 16 wavefronts so that a wave's share is ONE batch of loads (64 k: every load of the wave is
+//     issued before its first MFMA; longer K loops double-buffer batches);
+//   * both operands are k-contiguous: a lane pulls 4 consecutive k with one 16-byte load straight into MFMA operand
+//     registers (k is consumed in a permuted order, identical for A and B);
+//   * the S partial tiles meet in LDS and are summed in wave order (fixed order: results do not depend on timing or on
+//     the batch size), each wave finishing one accumulator register (a row group) incl. bias / relu / gate and its store.
 // ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void load4(const float* p, int k, int kend, bool vec, float v[4]) {
   if (vec && k + 3 < kend) {
     const float4 t = *reinterpret_cast<const float4*>(p + k);
@@ -250,33 +260,34 @@ __device__ __forceinline__ void load4(const float* p, int k, int kend, bool vec,
   }
 }
 
-template <int S>
+template <int T, int S>
 __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
-  __shared__ float s_red[S > 1 ? (S - 1) * 16 * 64 : 1];
+  constexpr int R = T == 32 ? 16 : 4;        // accumulator registers per lane
+  constexpr int G = 64 / T;                  // lane groups along k inside one MFMA (2 or 4)
+  constexpr int KQ = 4 * G;                  // k consumed per 16-byte load of every lane (8 or 16)
+  constexpr int U = 64 / KQ;                 // loads per batch: one batch = 64 k
+  __shared__ float s_red[S > 1 ? S * R * 64 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int o0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-  const int r = lane & 31, h = lane >> 5;
+  const int o0 = blockIdx.x * T, m0 = blockIdx.y * T, bz = blockIdx.z;
+  const int r = lane & (T - 1), g = lane / T;
   const int m = min(m0 + r, a.M - 1), o = min(o0 + r, a.Nout - 1);
-  const int bz = blockIdx.z;
   const float* xp = a.X + (size_t)bz * a.sXb + (size_t)m * a.ldX;
   const float* wp = a.W + (size_t)bz * a.sWb + (size_t)o * a.ldW;
   const bool xvec = ((a.ldX | a.sXb) & 3) == 0 && ((uintptr_t)a.X & 15) == 0;
   const bool wvec = ((a.ldW | a.sWb) & 3) == 0 && ((uintptr_t)a.W & 15) == 0;
-  // this wave's K range, in units of 8
-  const int k8 = (a.K + 7) / 8;
-  const int per = (k8 + S - 1) / S;
-  const int kb = wave * per * 8, ke = min(a.K, (wave + 1) * per * 8);
+  // this wave's K range, in units of KQ
+  const int kq = (a.K + KQ - 1) / KQ;
+  const int per = (kq + S - 1) / S;
+  const int kb = wave * per * KQ, ke = min(a.K, (wave + 1) * per * KQ);
 
-  f32x16 acc;
+  typename std::conditional<T == 32, f32x16, f32x4>::type acc;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  // two register buffers of U k-groups: the loads of batch i+1 are in flight under the MFMAs of batch i
-  constexpr int U = 4;
+  for (int i = 0; i < R; ++i) acc[i] = 0.f;
   float xa[2][U][4], wb[2][U][4];
   auto load_batch = [&](int k0, float (&xd)[U][4], float (&wd)[U][4]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = k0 + 8 * u + 4 * h;
+      const int k = k0 + KQ * u + 4 * g;
       load4(xp, k, ke, xvec, xd[u]);
       load4(wp, k, ke, wvec, wd[u]);
     }
@@ -285,40 +296,43 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = mfma32(xd[u][i], wd[u][i], acc);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (T == 32) acc = mfma32(xd[u][i], wd[u][i], acc);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xd[u][i], wd[u][i], acc, 0, 0, 0);
+      }
   };
   if (kb < ke) load_batch(kb, xa[0], wb[0]);
-  for (int k0 = kb; k0 < ke; k0 += 16 * U) {
-    if (k0 + 8 * U < ke) load_batch(k0 + 8 * U, xa[1], wb[1]);
+  for (int k0 = kb; k0 < ke; k0 += 128) {
+    if (k0 + 64 < ke) load_batch(k0 + 64, xa[1], wb[1]);
     mma_batch(xa[0], wb[0]);
-    if (k0 + 8 * U < ke) {
-      if (k0 + 16 * U < ke) load_batch(k0 + 16 * U, xa[0], wb[0]);
+    if (k0 + 64 < ke) {
+      if (k0 + 128 < ke) load_batch(k0 + 128, xa[0], wb[0]);
       mma_batch(xa[1], wb[1]);
     }
   }
-  if (S > 1) {
-    if (wave > 0) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s_red[((wave - 1) * 16 + i) * 64 + lane] = acc[i];
-    }
-    __syncthreads();
-    if (wave > 0) return;
-#pragma unroll
-    for (int w = 0; w < S - 1; ++w)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] += s_red[(w * 16 + i) * 64 + lane];
-  }
   const int oc = o0 + r;
-  if (oc >= a.Nout) return;
-  const float bias = a.bias ? a.bias[oc] : 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int mr = m0 + mfma_row(i, lane);
-    if (mr < a.M) {
-      float v = acc[i] + bias;
+  const float bias = (a.bias && oc < a.Nout) ? a.bias[oc] : 0.f;
+  auto finish = [&](int i, float v) {   // accumulator register i of this lane -> Y
+    const int mr = m0 + (T == 32 ? mfma_row(i, lane) : 4 * g + i);
+    if (oc < a.Nout && mr < a.M) {
+      v += bias;
       if (a.relu) v = fmaxf(v, 0.f);
       if (a.Z) v = a.Z[(size_t)mr * a.ldZ + oc] > 0.f ? v : 0.f;
       a.Y[(size_t)bz * a.sYb + (size_t)mr * a.ldY + oc] = v;
+    }
+  };
+  if constexpr (S == 1) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) finish(i, acc[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i) s_red[(wave * R + i) * 64 + lane] = acc[i];
+    __syncthreads();
+    for (int i = wave; i < R; i += S) {     // register i of every wave, summed in wave order
+      float v = s_red[i * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < S; ++w) v += s_red[(w * R + i) * 64 + lane];
+      finish(i, v);
     }
   }
 }
@@ -371,14 +385,27 @@ int launch_reduce_dT(const float* part, int nparts, float* dT, int B, hipStream_
   return GEOA3_OK;
 }
 
+template <int T>
+static void launch_fc_tile(const FcArgs& a, int waves, hipStream_t s) {
+  dim3 grid((a.Nout + T - 1) / T, (a.M + T - 1) / T, a.batch > 1 ? a.batch : 1);
+  switch (waves) {
+    case 1: hipLaunchKernelGGL((fc_kernel<T, 1>), grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((fc_kernel<T, 2>), grid, dim3(128), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((fc_kernel<T, 4>), grid, dim3(256), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((fc_kernel<T, 8>), grid, dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL((fc_kernel<T, 16>), grid, dim3(1024), 0, s, a);
+  }
+}
+
 int launch_fc(const FcArgs& a, hipStream_t s) {
-  dim3 grid((a.Nout + 31) / 32, (a.M + 31) / 32, a.batch > 1 ? a.batch : 1);
-  if (a.ksplit == 8 || (a.ksplit == 0 && a.K >= 2048))
-    hipLaunchKernelGGL(fc_kernel<8>, grid, dim3(512), 0, s, a);
-  else if (a.K >= 256)
-    hipLaunchKernelGGL(fc_kernel<4>, grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(fc_kernel<1>, grid, dim3(64), 0, s, a);
+  // waves splitting K: one 64-k batch per wave up to 16 waves; a function of K only (or fixed by the call site), so the
+  // summation order never depends on the batch size
+  int waves = a.ksplit > 0 ? a.ksplit : (a.K + 63) / 64;
+  waves = waves >= 16 ? 16 : waves > 4 ? 8 : waves > 2 ? 4 : waves > 1 ? 2 : 1;
+  // 16 x 16 tiles while a 32 x 32 tiling would leave most CUs without a workgroup
+  const long tiles32 = (long)((a.Nout + 31) / 32) * ((a.M + 31) / 32) * (a.batch > 1 ? a.batch : 1);
+  if (a.tile == 16 || (a.tile == 0 && tiles32 < 256)) launch_fc_tile<16>(a, waves, s);
+  else launch_fc_tile<32>(a, waves, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
@@ -391,7 +418,8 @@ extern "C" int geoa3_debug_fc(const float* X, const float* W, const float* bias,
   a.W = W; a.ldW = K;
   a.bias = bias;
   a.Y = Y; a.ldY = Nout;
-  a.M = M; a.Nout = Nout; a.K = K; a.relu = relu; a.ksplit = ksplit;
+  a.M = M; a.Nout = Nout; a.K = K; a.relu = relu;
+  a.ksplit = ksplit & 0xff; a.tile = ksplit >> 8;   // tools/bench_fc.py: (tile << 8) | waves, 0 = the shipped choice
   return launch_fc(a, geoa3_stream(stream));
 }
 

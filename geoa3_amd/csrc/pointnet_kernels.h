@@ -56,8 +56,9 @@ struct FcArgs {
   const float* X; int ldX;
   const float* W; int ldW;
   long sXb, sWb, sYb; int batch;              // optional batch (blockIdx.z): per-instance X, W, Y (0 / 1 = none)
-  int ksplit;                                 // waves splitting K (0 = by K); fixed per call site so that the
-                                              // summation order never depends on the batch size
+  int ksplit;                                 // waves splitting K (0 = by K: one 64-k batch per wave, at most 16); never
+                                              // a function of the batch size, so the summation order is fixed
+  int tile;                                   // 16 / 32: output tile (0 = by the number of tiles)
   const float* bias;
   const float* Z; int ldZ;                    // relu mask source or null
   float* Y; int ldY;

@@ -42,20 +42,34 @@ def make_last_label_sync(b_global: int, group=None) -> Callable[[torch.Tensor], 
     src = owner_of_last_instance(b_global, world)
 
     def sync(t: torch.Tensor) -> None:
-        dist.broadcast(t, src=src, group=group)
+        if t.is_cuda and _host_staged(group):
+            h = t.cpu()
+            dist.broadcast(h, src=src, group=group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src, group=group)
 
     return sync
+
+
+def _host_staged(group=None) -> bool:
+    """gloo carries device tensors only for broadcast / all_reduce: under it (functional runs of the N > 1 path on one
+    GPU, CPU tests) the few KB-MB of per-batch results are staged through the host; RCCL moves device buffers."""
+    return dist.get_backend(group) == "gloo"
 
 
 def _gather_rows(x: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
     """all_gather of row blocks with different row counts (pads to the largest block)."""
     world = len(counts)
     mx = max(counts)
+    dev = x.device
+    if x.is_cuda and _host_staged(group):
+        x = x.cpu()
     pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     pad[: x.shape[0]] = x
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
-    return torch.cat([bufs[r][: counts[r]] for r in range(world)], dim=0)
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)], dim=0).to(dev)
 
 
 def sharded_attack(run_shard: Callable, pc: torch.Tensor, normal: torch.Tensor, gt: torch.Tensor,

@@ -9,12 +9,18 @@ Mirrors, for the classifier path only, the three layers of the reference's vendo
     (Model/PointNetPP_ssg.py:51-124) with the reference's state_dict keys (SA_modules.{0,1,2}.mlps.0.{0..8}.*,
     fc_layer.{0,1,3,4,7}.*), so `load_state_dict(torch.load(...)['state_dict'])` works (main_attack.py:139-145).
 
-As in the reference, the shared MLPs (1x1 Conv2d + BatchNorm2d + ReLU), the max-pool and the FC head are torch.nn
-modules (MIOpen / hipBLASLt on ROCm); the native part -- FPS, ball query, grouping, gathering and their
-scatter-add gradients -- is this library's HIP code.  GPU tensors only.
+Two execution paths:
+  * NATIVE (eval mode, frozen weights, xyz-only input of >= 512 points -- the attack's victim): the whole classifier,
+    forward and input gradient, is one call each into libgeoa3_hip.so (`geoa3_pn2ssg_forward / _backward`,
+    csrc/pointnet2_net.hip): FPS, ball query, the fused level 1, the split-fp16 1x1 convolutions, the pooled layers
+    and the FC head are hand-written HIP kernels; no torch operator and no library GEMM runs in between;
+  * MODULE (everything else: training-mode statistics, weight gradients, extra feature channels): the layer-by-layer
+    composition below on the same HIP operators, with torch.nn modules for the MLPs.
+GPU tensors only.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import List, Optional
 
 import torch
@@ -39,6 +45,13 @@ def _chk(t: Tensor, dtype) -> Tensor:
     if not t.is_contiguous():
         raise _lib.Geoa3Error("tensor must be contiguous")  # utils.h:5-25 CHECK_CONTIGUOUS
     return t
+
+
+def _frozen(mlp) -> bool:
+    """True when no weight gradient can be asked of `mlp` in this call (its parameters are frozen, or autograd is off):
+    the fused HIP paths only form the input gradient.  Under torch.no_grad() the answer does not depend on the
+    parameters' flags, so evaluation before and after an attack runs the same kernels."""
+    return not torch.is_grad_enabled() or not any(p.requires_grad for p in mlp.parameters())
 
 
 class _Ext:
@@ -393,7 +406,7 @@ def run_shared_mlp(mlp: nn.Sequential, x: Tensor, fuse_max: bool = False) -> Ten
     h = x.reshape(B, x.shape[1], M * S)
     # frozen weights (the attack's victim) + the max at the end: the first layer (K = Ci + 3, not a multiple of 64)
     # stays a GEMM + tail pass, the remaining layers run on the fused HIP operator
-    if (fuse_max and fuse_tail and len(triples) >= 2 and not any(p.requires_grad for p in mlp.parameters())):
+    if (fuse_max and fuse_tail and len(triples) >= 2 and _frozen(mlp)):
         folded = _fold_triples(mlp)
         if folded is not None and _tail_eligible(folded, 1):
             (w0, b0) = folded[0]
@@ -504,7 +517,7 @@ class PointnetSAModuleMSG(nn.Module):
         the fused convolution operator (_SharedTail).  None when the level has another shape."""
         if not (self.pretransform and fuse_tail and features is not None and isinstance(grouper, QueryAndGroup) and
                 grouper.use_xyz and xyz.is_cuda and not mlp.training and
-                not any(p.requires_grad for p in mlp.parameters())):
+                _frozen(mlp)):
             return None
         folded = _fold_triples(mlp)
         if folded is None or len(folded) < 2 or not _tail_eligible(folded, 1):
@@ -521,7 +534,7 @@ class PointnetSAModuleMSG(nn.Module):
         """The xyz-only 3->64->64->128 level with 64 samples per ball (SA_modules[0] of the SSG classifier) as ONE
         kernel per direction; None when this level has another shape, is training, or keeps weight gradients."""
         if not (self.fuse_level1 and features is None and isinstance(grouper, QueryAndGroup) and grouper.use_xyz and
-                grouper.nsample == 64 and xyz.is_cuda and not any(p.requires_grad for p in mlp.parameters())):
+                grouper.nsample == 64 and xyz.is_cuda and _frozen(mlp)):
             return None
         folded = _fold_triples(mlp)
         if folded is None or [tuple(w.shape) for w, _ in folded] != [(64, 3), (64, 64), (128, 64)]:
@@ -534,6 +547,90 @@ class PointnetSAModuleMSG(nn.Module):
 class PointnetSAModule(PointnetSAModuleMSG):
     def __init__(self, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True):
         super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz)
+
+
+def _fold_linear_bn(lin: nn.Linear, bn: Optional[nn.BatchNorm1d]):
+    """Linear (+ eval BatchNorm1d) -> (W', shift) in float64 -> float32."""
+    w = lin.weight.detach().double()
+    b = lin.bias.detach().double() if lin.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64,
+                                                                              device=w.device)
+    if bn is not None:
+        scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        w = w * scale.view(-1, 1)
+        b = (b - bn.running_mean.detach().double()) * scale + bn.bias.detach().double()
+    return w.float().contiguous(), b.float().contiguous()
+
+
+class PackedSSG:
+    """Folded device weights of the SSG classifier + the ctypes struct of geoa3_pn2ssg_forward / _backward."""
+
+    def __init__(self, net: "PointNet2ClassificationSSG", device):
+        self._keep = []
+
+        def dev(t: Tensor) -> int:
+            d = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            self._keep.append(d)
+            return d.data_ptr()
+
+        folded = [_fold_triples(m.mlps[0]) for m in net.SA_modules]
+        if any(f is None for f in folded):
+            raise _lib.Geoa3Error("the native SSG path needs eval-mode Conv2d 1x1 (no bias) + BatchNorm2d + ReLU stacks")
+        shapes = [[tuple(w.shape) for w, _ in f] for f in folded]
+        if shapes != [[(64, 3), (64, 64), (128, 64)], [(128, 131), (128, 128), (256, 128)],
+                      [(256, 259), (512, 256), (1024, 512)]]:
+            raise _lib.Geoa3Error("the native SSG path is built for the classifier of Model/PointNetPP_ssg.py:58-82, "
+                                  "got layer shapes %s" % (shapes,))
+        (w11, b11), (w12, b12), (w13, b13) = folded[0]
+        f = {}
+        for lvl, fl in ((2, folded[1]), (3, folded[2])):
+            (w0, b0), (w1, b1), (w2, b2) = fl
+            f["sa%d_wx" % lvl], f["sa%d_wf" % lvl], f["sa%d_b0" % lvl] = w0[:, :3], w0[:, 3:], b0
+            f["sa%d_wft" % lvl] = w0[:, 3:].t()
+            f["sa%d_w1" % lvl], f["sa%d_b1" % lvl], f["sa%d_w1t" % lvl] = w1, b1, w1.t()
+            f["sa%d_w2" % lvl], f["sa%d_b2" % lvl], f["sa%d_w2t" % lvl] = w2, b2, w2.t()
+        fc = net.fc_layer
+        for i, (lin, bn) in enumerate(((fc[0], fc[1]), (fc[3], fc[4]), (fc[7], None)), start=1):
+            w, b = _fold_linear_bn(lin, bn)
+            f["f%d" % i], f["fb%d" % i], f["f%dt" % i] = w, b, w.t()
+        self.classes = int(fc[7].out_features)
+        sa1 = _lib.Sa1Weights(*[dev(t) for t in (w11, b11, w12, b12, w13, b13)])
+        self.struct = _lib.Pn2SsgWeights(classes=self.classes, sa1=sa1, **{k: dev(v) for k, v in f.items()})
+
+
+class _SSGFn(torch.autograd.Function):
+    """logits = geoa3_pn2ssg_forward(x); d logits -> d x = geoa3_pn2ssg_backward (same workspace)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, packed: PackedSSG, ws_cache: dict):
+        x = x.contiguous().float()
+        B, _, N = x.shape
+        lib = _lib.load()
+        nbytes = lib.geoa3_pn2ssg_workspace_bytes(B, N)
+        if nbytes < 0:
+            raise _lib.Geoa3Error("geoa3_pn2ssg: needs at least 512 points per cloud")
+        ws = ws_cache.get("ws")
+        if ws is None or ws.numel() < nbytes or ws.device != x.device:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            ws_cache["ws"] = ws
+        logits = torch.empty(B, packed.classes, device=x.device, dtype=torch.float32)
+        check(lib.geoa3_pn2ssg_forward(C.byref(packed.struct), x.data_ptr(), B, N, logits.data_ptr(), ws.data_ptr(), _s()),
+              "geoa3_pn2ssg_forward")
+        ctx.packed, ctx.ws, ctx.ws_cache = packed, ws, ws_cache
+        ctx.ws_version = ws_cache["version"] = ws_cache.get("version", 0) + 1
+        ctx.save_for_backward(x)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (x,) = ctx.saved_tensors
+        if ctx.ws_cache.get("version") != ctx.ws_version:
+            raise _lib.Geoa3Error("the SSG workspace was overwritten by a later forward before backward ran")
+        B, _, N = x.shape
+        dx = torch.empty_like(x)
+        check(_lib.load().geoa3_pn2ssg_backward(C.byref(ctx.packed.struct), x.data_ptr(),
+                                                g.contiguous().float().data_ptr(), B, N, dx.data_ptr(),
+                                                ctx.ws.data_ptr(), _s()), "geoa3_pn2ssg_backward")
+        return dx, None, None
 
 
 class PointNet2ClassificationSSG(nn.Module):
@@ -553,8 +650,28 @@ class PointNet2ClassificationSSG(nn.Module):
             nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(True),
             nn.Dropout(0.5), nn.Linear(256, 40))
 
+    native = True    # class-wide switch (tests compare the native path with the module path)
+
+    def _weights_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def packed(self, device) -> PackedSSG:
+        key = self._weights_key(device)
+        if getattr(self, "_packed", None) is None or key != self._packed_key:
+            self._packed, self._packed_key = PackedSSG(self, device), key
+        return self._packed
+
+    def native_eligible(self, pointcloud: Tensor) -> bool:
+        """The native kernels form the input gradient only and fold eval-mode BatchNorm statistics."""
+        return (self.native and pointcloud.is_cuda and not self.training and pointcloud.size(1) == 3 and
+                pointcloud.size(2) >= 512 and not self.use_normal and _frozen(self))
+
     def forward(self, pointcloud: Tensor) -> Tensor:
         """pointcloud [B, 3(+C), N] (the attack's layout) -> logits [B, 40]"""
+        if self.native_eligible(pointcloud):
+            if not hasattr(self, "_ws_cache"):
+                self._ws_cache = {}
+            return _SSGFn.apply(pointcloud, self.packed(pointcloud.device), self._ws_cache)
         pc = pointcloud.transpose(2, 1)
         xyz = pc[..., 0:3].contiguous()
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None

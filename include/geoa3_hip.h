@@ -369,6 +369,38 @@ int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, const int32_t
                            float* grad_new_xyz, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The whole PointNet++ SSG classifier (eval mode) as a native victim: forward and input gradient, the counterpart of
+ * geoa3_pointnet_forward / _backward for BASELINE configs[3].  Replaces `PointNet2ClassificationSSG.forward`
+ * (Model/PointNetPP_ssg.py:106-124: SA(512, r 0.2, 64 samples, [3,64,64,128]) -> SA(128, r 0.4, 64, [131,128,128,256])
+ * -> SA(GroupAll, [259,256,512,1024]) -> Linear/BN/ReLU 1024-512-256 -> Linear classes; modules
+ * pointnet2_modules.py:29-74, groupers pointnet2_utils.py:296-379) and torch autograd's backward through it.
+ * Every Conv2d 1x1 / Linear (no bias) + eval BatchNorm is passed FOLDED: W' = diag(bn.weight / sqrt(var + eps)) W,
+ * shift = bn.bias - mean * scale.  The first layer of levels 2 and 3 is split into its xyz columns (w?_wx [Co,3], the
+ * first three input channels: QueryAndGroup / GroupAll cat xyz first) and its feature columns (w?_wf); *t = the
+ * transposed matrix ([K,Co] row-major) used by the input gradient.
+ * x, dx: planar [B,3,N] (the attack's layout), N >= 512; workspace: geoa3_pn2ssg_workspace_bytes(B, N) bytes, 256-byte
+ * aligned, the SAME buffer for forward and the backward that follows it (backward reads the forward's activations).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct geoa3_pn2ssg_weights {
+  int classes;
+  geoa3_sa1_weights sa1;
+  const float *sa2_wx, *sa2_wf, *sa2_b0, *sa2_wft;   /* [128,3], [128,128], [128], [128,128] */
+  const float *sa2_w1, *sa2_b1, *sa2_w1t;            /* [128,128], [128], [128,128] */
+  const float *sa2_w2, *sa2_b2, *sa2_w2t;            /* [256,128], [256], [128,256] */
+  const float *sa3_wx, *sa3_wf, *sa3_b0, *sa3_wft;   /* [256,3], [256,256], [256], [256,256] */
+  const float *sa3_w1, *sa3_b1, *sa3_w1t;            /* [512,256], [512], [256,512] */
+  const float *sa3_w2, *sa3_b2, *sa3_w2t;            /* [1024,512], [1024], [512,1024] */
+  const float *f1, *fb1, *f1t;                       /* [512,1024], [512], [1024,512] */
+  const float *f2, *fb2, *f2t;                       /* [256,512], [256], [512,256] */
+  const float *f3, *fb3, *f3t;                       /* [classes,256], [classes], [256,classes] */
+} geoa3_pn2ssg_weights;
+int64_t geoa3_pn2ssg_workspace_bytes(int B, int N);
+int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* w, const float* x, int B, int N, float* logits, void* workspace,
+                         void* stream);
+int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* w, const float* x, const float* dlogits, int B, int N, float* dx,
+                          void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense-cloud attack path, point-removal defence and smoothness measurement.
  * ------------------------------------------------------------------------------------------ */
 /* farthest_points_sample, Lib/utility.py:175-187: m-1 rounds of dists = min(dists, |p - p_last|), next = first

@@ -132,6 +132,78 @@ def _write_outputs(saved_dir, name, cloud, gt, pred, est_normal=None):
             f.write("v %f %f %f 0 0 0\n" % (cloud[0, m], cloud[1, m], cloud[2, m]))
 
 
+class CountConvergeIter:
+    """Count_converge_iter of the reference (Lib/utility.py:654-677): the best attack step of every instance, saved as
+    Records/converge_iter.mat (+ a histogram when matplotlib is importable; the reference draws it with seaborn)."""
+
+    def __init__(self, fsave):
+        self.fsave = fsave
+        os.makedirs(fsave, exist_ok=True)
+        self.attack_step_list = []
+
+    def record_converge_iter(self, attack_step_list):
+        attack_step_list = list(attack_step_list)
+        if -1 in attack_step_list:            # Lib/utility.py:662-663 drops the FIRST -1 only; kept as is
+            attack_step_list.remove(-1)
+        self.attack_step_list += attack_step_list
+
+    def save_converge_iter(self):
+        sio.savemat(os.path.join(self.fsave, "converge_iter.mat"), {"attack_step_list": self.attack_step_list})
+
+    def plot_converge_iter_hist(self):
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except Exception:
+            return
+        if not self.attack_step_list:
+            return
+        fig = plt.figure()
+        ax = fig.gca()
+        ax.hist(self.attack_step_list, bins=np.histogram(np.hstack(self.attack_step_list), bins=50)[1])
+        ax.set_xlabel("Converged iteration")
+        ax.set_ylabel("Number of Samples")
+        fig.savefig(os.path.join(self.fsave, "converge_iter.png"))
+        plt.close(fig)
+
+
+class CountLossIter:
+    """Count_loss_iter of the reference (Lib/utility.py:680-714): the [steps, instances] loss history of the last
+    binary step of every batch, saved as Records/loss_iter.mat (+ mean / std curve)."""
+
+    def __init__(self, fsave):
+        self.fsave = fsave
+        os.makedirs(fsave, exist_ok=True)
+        self.loss_numpy = None
+
+    def record_loss_iter(self, loss_list):
+        a = np.array(loss_list)
+        self.loss_numpy = a if self.loss_numpy is None else np.concatenate((self.loss_numpy, a), axis=1)
+
+    def save_loss_iter(self):
+        sio.savemat(os.path.join(self.fsave, "loss_iter.mat"), {"loss": self.loss_numpy})
+
+    def plot_loss_iter_hist(self):
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except Exception:
+            return
+        if self.loss_numpy is None:
+            return
+        x = np.arange(1, self.loss_numpy.shape[0] + 1)
+        mean, std = self.loss_numpy.mean(1), self.loss_numpy.std(1)
+        fig, ax = plt.subplots(1, 1)
+        ax.plot(x, mean)
+        ax.fill_between(x, mean - std, mean + std, alpha=0.2)
+        ax.set_xlabel("Number of iteration")
+        ax.set_ylabel("Magnitude of loss")
+        fig.savefig(os.path.join(self.fsave, "loss_iter.png"))
+        plt.close(fig)
+
+
 def main(cfg):
     import torch.distributed as dist
 
@@ -215,10 +287,20 @@ def main(cfg):
 
     if cfg.synthetic and not os.path.isfile(model_path):
         # the reference data file only holds correctly classified shapes (gen_data_mat.py:255-260): mirror that
+        # ... for the targeted modes among the ten ModelNet10 ids the data file can hold
+        # (Provider/modelnet10_instance250.py:10): the `All` / class-name expansion builds "the other nine" from them
         with torch.no_grad():
-            pred = net(dataset.data.to(device)).argmax(1).cpu().numpy()
+            logits = net(dataset.data.to(device))
+            if cfg.attack_label in ("Untarget", "Random"):
+                pred = logits.argmax(1).cpu().numpy()
+            else:
+                ten = torch.as_tensor(TEN_LABEL_INDEXES, device=device)
+                pred = ten[logits[:, ten].argmax(1)].cpu().numpy()
         dataset.label = pred.reshape(-1, 1).astype(np.int64)
 
+    cci = CountConvergeIter(os.path.join(saved_dir, "Records")) if cfg.is_record_converged_steps else None
+    cli = CountLossIter(os.path.join(saved_dir, "Records")) if cfg.is_record_loss else None
+    acc_sum, acc_cnt = 0.0, 0                                # Average_meter of main_attack.py:155,222-224
     num_attack_classes = 9 if cfg.attack_label not in ("Untarget", "Random") else 1
     num_attack_success, cnt_ins, cnt_all = 0, dataset.start_index, 0
     runner_cache = {}
@@ -231,8 +313,9 @@ def main(cfg):
         if cfg.attack is None:                               # clean accuracy only (main_attack.py:213-225)
             with torch.no_grad():
                 x = pc.permute(0, 1, 3, 2).reshape(b, 3, -1).to(device).contiguous()
-                acc = (net(x).argmax(1) == gt_target).float().mean().item() * 100.0
-            say("Prec@1 {:.3f}".format(acc))
+                acc_sum += (net(x).argmax(1) == gt_target).float().sum().item() * 100.0
+                acc_cnt += b
+            say("Prec@1 {:.3f}".format(acc_sum / acc_cnt))   # running average over the batches so far, as the reference
             continue
         if cfg.attack != "GeoA3":
             raise AssertionError("Wrong type of attack.")
@@ -245,6 +328,10 @@ def main(cfg):
         adv_pc, targeted_label, success, best_attack_step, loss = out
         torch.cuda.synchronize()
         t_attack += time.perf_counter() - t0
+        if cci is not None:                                  # main_attack.py:236-239
+            cci.record_converge_iter(best_attack_step)
+        if cli is not None:
+            cli.record_loss_iter(loss)
         saved_normal = None
         if dense_iter is not None:                           # main_attack.py:196-210, 241-247
             from geoa3_amd.attack import unpack_input
@@ -269,6 +356,13 @@ def main(cfg):
         cnt_ins += bs
         cnt_all += b
 
+    if rank == 0:                                            # main_attack.py:298-303
+        if cci is not None:
+            cci.save_converge_iter()
+            cci.plot_converge_iter_hist()
+        if cli is not None and cli.loss_numpy is not None:
+            cli.save_loss_iter()
+            cli.plot_loss_iter_hist()
     if cfg.attack == "GeoA3" and rank == 0:
         line = "attack success: {0:.2f}\n".format(num_attack_success / float(max(cnt_all, 1)) * 100)
         say(line)

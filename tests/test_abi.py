@@ -63,3 +63,5 @@ def test_struct_layouts_match_header():
     assert members("geoa3_tnet_weights") == [f[0] for f in _lib.TnetWeights._fields_]
     assert members("geoa3_pointnet_weights") == [f[0] for f in _lib.PointNetWeights._fields_]
     assert members("geoa3_attack_state") == [f[0] for f in _lib.AttackState._fields_]
+    assert members("geoa3_pn2ssg_weights") == [f[0] for f in _lib.Pn2SsgWeights._fields_]
+    assert members("geoa3_sa1_weights") == [f[0] for f in _lib.Sa1Weights._fields_]

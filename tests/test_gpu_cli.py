@@ -127,3 +127,57 @@ def test_smoothness_cli_matches_oracle(tmp_path, monkeypatch):
     np.testing.assert_array_equal(saved, vals)
     txt = open(os.path.join(saved_dir, "metric", "result.txt")).read()
     assert txt == "k: 8, avg: {0:.4f}, min: {1:.4f}, max: {2:.4f}\n".format(vals.mean(), vals.min(), vals.max())
+
+
+def test_main_attack_targeted_all_with_records(tmp_path, monkeypatch, capsys):
+    """`--attack_label All` (the CLI default): 9 targets per instance from the other ModelNet10 labels
+    (Provider/modelnet10_instance250.py:66-72), file names numbered `cnt_ins + k // 9` (main_attack.py:262-263), and
+    the two recorders of main_attack.py:150-153,236-239,298-303."""
+    import main_attack
+    from geoa3_amd.data import TEN_LABEL_INDEXES
+    monkeypatch.chdir(tmp_path)
+    args = ["--attack", "GeoA3", "--attack_label", "All", "-b", "5", "--npoint", "128", "--synthetic",
+            "--data_dir_file", str(tmp_path / "Data" / "syn128.mat"), "--binary_max_steps", "2", "--iter_max_steps",
+            "8", "--lr", "0.01", "--curv_loss_knn", "8", "--quiet", "--is_record_converged_steps", "--is_record_loss"]
+    cfg = main_attack.build_parser().parse_args(args)
+    # 250 instances x 9 targets is a long run for a test: keep the first 10 instances of the data file
+    from geoa3_amd import data as D
+    orig_init = D.ModelNet40.__init__
+
+    def short_init(self, *a, **k):
+        orig_init(self, *a, **k)
+        self.data, self.normal, self.label = self.data[:10], self.normal[:10], self.label[:10]
+
+    monkeypatch.setattr(D.ModelNet40, "__init__", short_init)
+    saved_dir = main_attack.main(cfg)
+    assert os.path.join("PointNet_npoint128", "All", "GeoA3_0_BiStep2_IterStep8") in saved_dir
+    mats = sorted(glob.glob(os.path.join(saved_dir, "Mat", "adv_*.mat")))
+    res = float(open(os.path.join(saved_dir, "attack_result.txt")).read().split(":")[1])
+    assert len(mats) == round(res * 90 / 100.0)
+    seen = set()
+    for f in mats:
+        name = os.path.basename(f)[:-4].split("_")
+        ins, gt, exp = int(name[1]), int(name[2][2:]), int(name[4][6:])
+        assert 0 <= ins < 10 and gt in TEN_LABEL_INDEXES and exp in TEN_LABEL_INDEXES and exp != gt
+        assert (ins, exp) not in seen      # one file per (instance, target)
+        seen.add((ins, exp))
+    conv = loadmat(os.path.join(saved_dir, "Records", "converge_iter.mat"))["attack_step_list"].reshape(-1)
+    loss = loadmat(os.path.join(saved_dir, "Records", "loss_iter.mat"))["loss"]
+    assert loss.shape == (8, 90) and np.isfinite(loss).all()
+    # every batch of 45 attacks contributes its best steps minus the first -1 (Lib/utility.py:662-663)
+    assert 90 - 2 <= conv.size <= 90 and conv.max() < 8
+
+
+def test_clean_accuracy_is_a_running_average(tmp_path, monkeypatch, capsys):
+    """`--attack None`-style evaluation (main_attack.py:213-225): the printed Prec@1 is the Average_meter over the
+    batches so far, so the LAST line is the dataset accuracy (100 on the synthetic file, whose labels are the
+    net's own predictions)."""
+    import main_attack
+    monkeypatch.chdir(tmp_path)
+    args = ["--attack_label", "Untarget", "-b", "100", "--npoint", "128", "--synthetic",
+            "--data_dir_file", str(tmp_path / "Data" / "syn128.mat")]
+    cfg = main_attack.build_parser().parse_args(args)
+    assert cfg.attack is None
+    main_attack.main(cfg)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("Prec@1")]
+    assert len(lines) == 3 and lines[-1] == "Prec@1 100.000"

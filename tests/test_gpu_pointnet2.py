@@ -119,6 +119,7 @@ def test_fused_first_level_matches_layerwise_path_and_reference(pn2, golden, tag
     net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     net.load_state_dict(sd)
     net = net.cuda().eval()
+    net.native = False                    # the layer-by-layer module path (the native path has its own test below)
     for p in net.parameters():
         p.requires_grad_(False)           # as the attack driver does: only d/d input is needed
     pre = "pn2/%s/" % tag
@@ -183,6 +184,7 @@ def test_fused_shared_mlp_tail_matches_gemm_path_and_reference(pn2, golden, tag)
     net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     net.load_state_dict(sd)
     net = net.cuda().eval()
+    net.native = False
     for p in net.parameters():
         p.requires_grad_(False)
     pre = "pn2/%s/" % tag
@@ -216,6 +218,7 @@ def test_pretransformed_level_matches_grouped_path_and_reference(pn2, golden, ta
     net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     net.load_state_dict(sd)
     net = net.cuda().eval()
+    net.native = False
     for p in net.parameters():
         p.requires_grad_(False)
     pre = "pn2/%s/" % tag
@@ -239,3 +242,66 @@ def test_pretransformed_level_matches_grouped_path_and_reference(pn2, golden, ta
             a[:, :, 9] = 0
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=5e-3, atol=5e-4 * np.abs(ref).max())
     np.testing.assert_allclose(res[True][1], ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag", ["n1024", "n700"])
+def test_native_ssg_matches_reference_and_module_path(pn2, golden, tag):
+    """The whole classifier as geoa3_pn2ssg_forward / _backward (csrc/pointnet2_net.hip: every GEMM a hand-written HIP
+    kernel, no torch operator in between) against the reference's own logits / input gradient -- at the PointNet
+    path's tolerance (logits rtol 1e-4 / atol 3e-4) -- and against the module path on the same weights."""
+    sd = P2.make_pn2_state_dict(0)
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    pre = "pn2/%s/" % tag
+    w = T(golden[pre + "w"]).cuda()
+    res = {}
+    for native in (True, False):
+        net.native = native
+        x = T(golden[pre + "pc"]).cuda().requires_grad_()
+        assert net.native_eligible(x) == native
+        logits = net(x)
+        assert (type(logits.grad_fn).__name__ == "_SSGFnBackward") == native
+        (logits * w).sum().backward()
+        res[native] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
+    np.testing.assert_allclose(res[True][0], golden[pre + "logits"], rtol=1e-4, atol=3e-4)
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-3, atol=2e-3)     # the module path's own bar
+    ref = golden[pre + "g_pc"].copy()
+    for got in (res[True][1], res[False][1]):
+        for a in (ref, got):
+            a[:, :, 8] += a[:, :, 9]       # points 8 / 9 are exact duplicates: which twin wins a pooling tie is free
+            a[:, :, 9] = 0
+    np.testing.assert_allclose(res[True][1], ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=5e-3, atol=5e-4 * np.abs(ref).max())
+
+
+def test_native_ssg_batch_independence_and_no_grad(pn2):
+    """Rows of a batched native forward / backward are bit-identical to batch-1 runs (what lets one batched forward
+    stand for the reference's b batch-1 success-check forwards, geoA3_attack.py:297), and evaluation under
+    torch.no_grad() takes the same kernels whatever the parameters' requires_grad flags say."""
+    sd = P2.make_pn2_state_dict(0)
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    pc, _ = O.make_synthetic_clouds(5, 1024, seed=9)
+    pc = pc.cuda()
+    with torch.no_grad():
+        assert net.native_eligible(pc)
+        full = net(pc)
+        for b in range(5):
+            assert torch.equal(net(pc[b:b + 1].contiguous()), full[b:b + 1])
+    for p in net.parameters():
+        p.requires_grad_(False)
+    x = pc.clone().requires_grad_()
+    g = torch.randn(5, 40, device="cuda")
+    lg = net(x)
+    assert torch.equal(lg.detach(), full)
+    lg.backward(g)
+    for b in (0, 4):
+        xb = pc[b:b + 1].clone().requires_grad_()
+        net(xb).backward(g[b:b + 1])
+        # level 1's scatter-add of the grouping gradient uses float atomics (order free): equal up to rounding
+        np.testing.assert_allclose(xb.grad.cpu().numpy(), x.grad[b:b + 1].cpu().numpy(), rtol=1e-4,
+                                   atol=1e-6 * float(x.grad.abs().max()))
