@@ -77,6 +77,9 @@ class AttackRunner:
         # synthetic workload (offsets of several spacings) it is 2 % SLOWER than brute force, hence off by default.
         self.graph_search = bool(_cfg(cfg, "graph_search", False)) and self.need_nn
         self.iters = int(cfg.iter_max_steps)
+        # the objective's gradient summed in a fixed order (geoa3_geo_args.deterministic): iterates are reproducible bit
+        # for bit and shard rows equal the full batch's; cfg.deterministic / GEOA3_DETERMINISTIC=0 select the atomics
+        self.deterministic = bool(_cfg(cfg, "deterministic", os.environ.get("GEOA3_DETERMINISTIC", "1") != "0"))
         # Dense-cloud path (geoA3_attack.py:283-296): the offset lives on all n points, the objective sees the
         # farthest-point sample of cfg.npoint of them, success is a vote over eval_num resamplings.
         self.npoint = int(_cfg(cfg, "npoint", n))
@@ -368,7 +371,8 @@ class AttackRunner:
                                   i_oa=t["i_oa"] if self.dis_type == 1 and not cfg.is_cd_single_side else None,
                                   knn_adv=knn_adv, k=self.k if self.use_curv else 0, dis_type=self.dis_type,
                                   single_side=bool(cfg.is_cd_single_side), w_dis=float(cfg.dis_loss_weight),
-                                  w_hd=float(cfg.hd_loss_weight), w_curv=float(cfg.curv_loss_weight), out=self.geo_out)
+                                  w_hd=float(cfg.hd_loss_weight), w_curv=float(cfg.curv_loss_weight), out=self.geo_out,
+                                  deterministic=self.deterministic)
                 constrain = self.geo_out["constrain"]
         if self.geo_stream is not None:     # join: the head needs the constrain loss, the update the gradient
             self.ev_geo.record(self.geo_stream)

@@ -245,6 +245,8 @@ __global__ __launch_bounds__(256) void reduce_dT_kernel(const float* __restrict_
 //     issued before its first MFMA; longer K loops double-buffer batches);
 //   * both operands are k-contiguous: a lane pulls 4 consecutive k with one 16-byte load straight into MFMA operand
 //     registers (k is consumed in a permuted order, identical for A and B);
+//   * the order in which the products of one output are added depends on K alone -- not on the tile shape, hence not on
+//     the batch size: rows of a batched run are bit-identical to batch-1 runs (tests/test_gpu_fullsize.py);
 //   * the S partial tiles meet in LDS and are summed in wave order (fixed order: results do not depend on timing or on
 //     the batch size), each wave finishing one accumulator register (a row group) incl. bias / relu / gate and its store.
 // ------------------------------------------------------------------------------------------
@@ -275,10 +277,10 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
   const float* wp = a.W + (size_t)bz * a.sWb + (size_t)o * a.ldW;
   const bool xvec = ((a.ldX | a.sXb) & 3) == 0 && ((uintptr_t)a.X & 15) == 0;
   const bool wvec = ((a.ldW | a.sWb) & 3) == 0 && ((uintptr_t)a.W & 15) == 0;
-  // this wave's K range, in units of KQ
-  const int kq = (a.K + KQ - 1) / KQ;
+  // this wave's K range, in units of 16 for both tile shapes
+  const int kq = (a.K + 15) / 16;
   const int per = (kq + S - 1) / S;
-  const int kb = wave * per * KQ, ke = min(a.K, (wave + 1) * per * KQ);
+  const int kb = wave * per * 16, ke = min(a.K, (wave + 1) * per * 16);
 
   typename std::conditional<T == 32, f32x16, f32x4>::type acc;
 #pragma unroll
@@ -292,14 +294,25 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
       load4(wp, k, ke, wvec, wd[u]);
     }
   };
+  // Both tile shapes add the products of an output element in the SAME order -- within every 16 k: k = i, 4 + i, 8 + i,
+  // 12 + i for i = 0..3 (an fp32 MFMA is a k-ordered fmaf chain) -- so the choice of the tile, which follows the batch
+  // size, never changes a bit of the result: the 16x16x4 form covers the four k of a step in one instruction (lane
+  // group g holds k = 4 g + i), the 32x32x2 form in two (lanes h = 0 / 1 hold 4 h + i, then 8 + 4 h + i).
   auto mma_batch = [&](float (&xd)[U][4], float (&wd)[U][4]) {
+    if constexpr (T == 32) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; u += 2)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (T == 32) acc = mfma32(xd[u][i], wd[u][i], acc);
-        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xd[u][i], wd[u][i], acc, 0, 0, 0);
-      }
+        for (int i = 0; i < 4; ++i) {
+          acc = mfma32(xd[u][i], wd[u][i], acc);
+          acc = mfma32(xd[u + 1][i], wd[u + 1][i], acc);
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xd[u][i], wd[u][i], acc, 0, 0, 0);
+    }
   };
   if (kb < ke) load_batch(kb, xa[0], wb[0]);
   for (int k0 = kb; k0 < ke; k0 += 128) {

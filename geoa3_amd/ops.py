@@ -147,8 +147,10 @@ def kappa(pc: Tensor, normal: Tensor, knn_idx: Tensor, nn_idx: Optional[Tensor] 
 def geo_loss_grad(adv: Tensor, ori: Tensor, *, normal_ori=None, kappa_ori=None, d_ao=None, i_ao=None, d_oa=None,
                   i_oa=None, knn_adv=None, dkappa=None, k: int = 0, dis_type: int = 1, single_side: bool = False,
                   w_dis: float = 1.0, w_hd: float = 0.0, w_curv: float = 0.0, want_grad: bool = True,
-                  want_kappa: bool = False, out: Optional[dict] = None) -> dict:
-    """The fused geometric objective (Attacker/geoA3_attack.py:131-166) and d constrain / d adv."""
+                  want_kappa: bool = False, out: Optional[dict] = None, deterministic: bool = True) -> dict:
+    """The fused geometric objective (Attacker/geoA3_attack.py:131-166) and d constrain / d adv.
+    deterministic (default): every point's gradient is summed by its owner in a fixed order -- bit-for-bit reproducible
+    and independent of the rest of the batch; False: LDS float atomics (free summation order)."""
     B, _, N = adv.shape
     dev = adv.device
     o = out if out is not None else {}
@@ -166,7 +168,7 @@ def geo_loss_grad(adv: Tensor, ori: Tensor, *, normal_ori=None, kappa_ori=None, 
                 B=B, N=N, k=k, Nr=int(ori.shape[2]), dis_type=dis_type, single_side=int(single_side), w_dis=w_dis, w_hd=w_hd,
                 w_curv=w_curv, dis_loss=_p(o["dis_loss"]), hd_loss=_p(o["hd_loss"]), curv_loss=_p(o["curv_loss"]),
                 constrain=_p(o["constrain"]), kappa_adv=_p(o.get("kappa_adv")) if want_kappa else None,
-                grad=_p(o["grad"]) if want_grad else None)
+                grad=_p(o["grad"]) if want_grad else None, deterministic=int(bool(deterministic)))
     check(_lib.load().geoa3_geo_loss_grad(C.byref(a), _stream()), "geoa3_geo_loss_grad")
     return o
 

@@ -132,6 +132,10 @@ typedef struct geoa3_geo_args {
   float* constrain;        /* [B] w_dis*dis + w_hd*hd + w_curv*curv (geoA3_attack.py:137,153,162) */
   float* kappa_adv;        /* [B,N] _get_kappa_adv, Lib/loss_utils.py:64-82            */
   float* grad;             /* [B,3,N] d constrain[b] / d adv[b]                        */
+  /* deterministic != 0: every point's gradient is summed by its owner in a fixed order (own terms, then the pulls it
+   * receives sorted by source) instead of with LDS float atomics: bit-for-bit reproducible and independent of the rest
+   * of the batch (what the reference's scatter-adds -- knn_gather / index backward -- do not promise either). */
+  int32_t deterministic;
 } geoa3_geo_args;
 int geoa3_geo_loss_grad(const geoa3_geo_args* args, void* stream);
 

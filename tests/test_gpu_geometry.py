@@ -104,11 +104,17 @@ def _geo(ops, golden, tag, **kw):
                              knn_adv=knn_adv, k=k, want_kappa=True, **kw), pre
 
 
+@pytest.mark.parametrize("det", [True, False])
 @pytest.mark.parametrize("tag", CASES)
-def test_geo_losses_and_grads_golden(ops, golden, tag):
-    # fp32 tolerance: 2e-5 relative on values, 1e-4 relative (+1e-7 abs) on gradients
+def test_geo_losses_and_grads_golden(ops, golden, tag, det):
+    # fp32 tolerance: 2e-5 relative on values, 1e-4 relative (+1e-7 abs) on gradients; the curvature gradient (sums of
+    # k = 2..32 cancelling terms per point): 1e-4 with the owner-ordered accumulation, 2e-3 with the LDS float atomics
     def close(a, b, rtol, atol):
         np.testing.assert_allclose(a.cpu().numpy(), b, rtol=rtol, atol=atol)
+
+    import functools
+    _geo = functools.partial(globals()["_geo"], deterministic=det)
+    curv_rtol = CURV_RTOL_DET if det else 2e-3
 
     o, pre = _geo(ops, golden, tag, dis_type=1, w_dis=1.0)
     close(o["dis_loss"], golden[pre + "cd"], 2e-5, 1e-7)
@@ -126,14 +132,43 @@ def test_geo_losses_and_grads_golden(ops, golden, tag):
     o, _ = _geo(ops, golden, tag, dis_type=0, w_curv=1.0)
     close(o["kappa_adv"], golden[pre + "kappa_adv"], 2e-5, 2e-6)
     close(o["curv_loss"], golden[pre + "curv"], 1e-4, 1e-8)
-    close(o["grad"], golden[pre + "g_curv"], 2e-3, 2e-6)
+    close(o["grad"], golden[pre + "g_curv"], curv_rtol, 2e-6)
     # the combined objective: constrain and its gradient
     o, _ = _geo(ops, golden, tag, dis_type=1, w_dis=1.0, w_hd=0.1, w_curv=1.0)
     con = golden[pre + "cd"] + 0.1 * golden[pre + "hd"] + golden[pre + "curv"]
     close(o["constrain"], con, 5e-5, 1e-7)
     g = golden[pre + "g_cd"] + 0.1 * golden[pre + "g_hd"] + golden[pre + "g_curv"]
     if tag != "zero":
-        close(o["grad"], g, 2e-3, 2e-6)
+        close(o["grad"], g, curv_rtol, 2e-6)
+
+
+CURV_RTOL_DET = 1e-4
+
+
+@pytest.mark.parametrize("tag", ["n256k16", "n128k32", "dup"])
+def test_deterministic_gradient_is_reproducible_and_batch_independent(ops, golden, tag):
+    """geoa3_geo_args.deterministic: ten launches give the same bits, and an instance's gradient does not depend on
+    which other instances share the batch (the reference's scatter-adds -- knn_gather / index backward,
+    sampling_gpu.cu:42, group_points_gpu.cu:60 -- promise neither)."""
+    kw = dict(dis_type=1, w_dis=1.0, w_hd=0.1, w_curv=1.0, deterministic=True)
+    first, pre = _geo(ops, golden, tag, **kw)
+    g0 = first["grad"].clone()
+    for _ in range(9):
+        o, _ = _geo(ops, golden, tag, **kw)
+        assert torch.equal(o["grad"], g0)
+    # the same clouds as rows 1.. of a larger batch whose row 0 is another cloud
+    adv, ori, nrm = (dev(T(golden[pre + n])) for n in ("adv", "ori", "nrm"))
+    k = int(golden[pre + "k"])
+    adv2 = torch.cat([adv[-1:].flip(2), adv]).contiguous()
+    ori2 = torch.cat([ori[-1:].flip(2), ori]).contiguous()
+    nrm2 = torch.cat([nrm[-1:].flip(2), nrm]).contiguous()
+    d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(adv2, ori2)
+    _, knn_ori = ops.knn_planar(ori2, ori2, k + 1)
+    kap_ori = ops.kappa(ori2, nrm2, knn_ori)
+    _, knn_adv = ops.knn_planar(adv2, adv2, k + 1, knn_ori)
+    o2 = ops.geo_loss_grad(adv2, ori2, normal_ori=nrm2, kappa_ori=kap_ori, d_ao=d_ao, i_ao=i_ao, d_oa=d_oa, i_oa=i_oa,
+                           knn_adv=knn_adv, k=k, **kw)
+    assert torch.equal(o2["grad"][1:], g0)
 
 
 def test_knn_points_operator_autograd(ops, golden):

@@ -60,9 +60,10 @@ def main():
     d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(adv, ori)
     _, knn_adv = ops.knn_planar(adv, adv, k + 1, knn_ori)
     out = {}
-    res["geo_loss_grad_us"] = timeit(lambda: ops.geo_loss_grad(
-        adv, ori, normal_ori=nrm, kappa_ori=kap, d_ao=d_ao, i_ao=i_ao, d_oa=d_oa, i_oa=i_oa, knn_adv=knn_adv, k=k,
-        w_dis=1.0, w_hd=0.1, w_curv=1.0, out=out), a.iters)
+    for det in (True, False):
+        res["geo_loss_grad_%s_us" % ("det" if det else "atomic")] = timeit(lambda: ops.geo_loss_grad(
+            adv, ori, normal_ori=nrm, kappa_ori=kap, d_ao=d_ao, i_ao=i_ao, d_oa=d_oa, i_oa=i_oa, knn_adv=knn_adv, k=k,
+            w_dis=1.0, w_hd=0.1, w_curv=1.0, out=out, deterministic=det), a.iters)
     print(json.dumps({"B": B, "N": N, "k": k, **{kk: round(v, 3) for kk, v in res.items()}}))
 
 
