@@ -101,7 +101,8 @@ SIGNATURES = {
     "geoa3_pn2_bias_relu_max_grad": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_long, C.c_int, vp, vp]),
     "geoa3_pn2_sa1_forward": (C.c_int, [vp, vp, vp, C.POINTER(Sa1Weights), C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_pn2_sa1_backward": (C.c_int, [vp, vp, vp, C.POINTER(Sa1Weights), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
-                                         vp, vp]),
+                                         vp, vp, vp]),
+    "geoa3_pn2_sa1_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "geoa3_pn2ssg_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "geoa3_pn2ssg_forward": (C.c_int, [C.POINTER(Pn2SsgWeights), vp, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_pn2ssg_backward": (C.c_int, [C.POINTER(Pn2SsgWeights), vp, vp, C.c_int, C.c_int, vp, vp, vp]),

@@ -369,7 +369,8 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
                      w.dnx1, M1, M2, 1);                                                               // gather(new_xyz1, idx2)
   // ---- level 1
   TRY((transpose<float, false>(w.df1, nullptr, w.g1, B, C1, M1, s)));              // [B,128,512] -> centroid-major
-  TRY(geoa3_pn2_sa1_backward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, w.g1, w.gxyz, w.gnx1, stream));
+  // (the [B,512,64,3] contributions go through the level-2 buffer d1, free by now)
+  TRY(geoa3_pn2_sa1_backward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, w.g1, w.gxyz, w.gnx1, w.d1, stream));
   hipLaunchKernelGGL(add_inplace_kernel, g1d((long)B * M1 * 3), dim3(256), 0, s, w.dnx1, w.gnx1, (long)B * M1 * 3);
   hipLaunchKernelGGL(scatter_rows3_kernel, dim3((N + 255) / 256, B), dim3(256), M1 * sizeof(int32_t), s, w.dnx1, w.idx1,
                      w.gxyz, N, M1, 1);                                                                // gather(xyz, idx1)

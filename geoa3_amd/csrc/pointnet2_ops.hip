@@ -183,14 +183,19 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __r
 // summed with wave shuffles first and leave as ONE add.  (Valid for any index table: only entries equal to the
 // row's first one are merged.)  Measured at [250,128,128,64] -> [250,128,512]: 4.5 ms with global atomics.
 constexpr int GPG_CT = 8;
+// PRIV: every wavefront accumulates into its OWN copy of the accumulators ([4][GPG_CT][N]) -- its rows in a fixed order,
+// no other wave touching the copy -- and the four copies are added in wave order at the end: the sum no longer depends
+// on how the waves' atomics interleave (deterministic; the reference's scatter-add, group_points_gpu.cu:60, is not).
+template <bool PRIV>
 __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* __restrict__ grad_out,
                                                                   const int32_t* __restrict__ idx,
                                                                   float* __restrict__ grad_points, int C, int N, int M,
                                                                   float* __restrict__ rowsum) {
-  extern __shared__ __attribute__((aligned(16))) float s_acc[];   // [GPG_CT][N]
+  extern __shared__ __attribute__((aligned(16))) float s_all[];   // [PRIV ? 4 : 1][GPG_CT][N]
   const int b = blockIdx.y, c0 = blockIdx.x * GPG_CT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = min(GPG_CT, C - c0);
-  for (int e = tid; e < GPG_CT * N; e += 256) s_acc[e] = 0.f;
+  for (int e = tid; e < (PRIV ? 4 : 1) * GPG_CT * N; e += 256) s_all[e] = 0.f;
+  float* s_acc = s_all + (PRIV ? wave * GPG_CT * N : 0);
   __syncthreads();
   const float* G = grad_out + ((size_t)b * C + c0) * M * 64;
   for (int j = wave; j < M; j += 4) {
@@ -214,7 +219,9 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
   }
   __syncthreads();
   float* dst = grad_points + ((size_t)b * C + c0) * N;
-  for (int e = tid; e < nc * N; e += 256) dst[e] = s_acc[e];
+  const int P = GPG_CT * N;
+  for (int e = tid; e < nc * N; e += 256)
+    dst[e] = PRIV ? ((s_all[e] + s_all[P + e]) + s_all[2 * P + e]) + s_all[3 * P + e] : s_all[e];
 }
 
 }  // namespace
@@ -306,11 +313,16 @@ static int group_points_grad_impl(const float* grad_out, const int32_t* idx, int
   if (!grad_out || !idx || !grad_points || B <= 0 || C <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
   const int MS = M * nsample;
   const size_t lds = (size_t)GPG_CT * N * sizeof(float);
-  if (nsample == 64 && lds <= 128 * 1024) {
+  if (nsample == 64 && 4 * lds <= 128 * 1024) {          // per-wave accumulators: deterministic
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_points_grad64_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds));
+    hipLaunchKernelGGL(group_points_grad64_kernel<true>, dim3((C + GPG_CT - 1) / GPG_CT, B), dim3(256), 4 * lds,
+                       geoa3_stream(stream), grad_out, idx, grad_points, C, N, M, rowsum);
+  } else if (nsample == 64 && lds <= 128 * 1024) {
     if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_points_grad64_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_points_grad64_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(group_points_grad64_kernel, dim3((C + GPG_CT - 1) / GPG_CT, B), dim3(256), lds,
+    hipLaunchKernelGGL(group_points_grad64_kernel<false>, dim3((C + GPG_CT - 1) / GPG_CT, B), dim3(256), lds,
                        geoa3_stream(stream), grad_out, idx, grad_points, C, N, M, rowsum);
   } else {
     if (hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), geoa3_stream(stream)) != hipSuccess)

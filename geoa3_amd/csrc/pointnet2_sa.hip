@@ -302,7 +302,8 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                                                        const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
                                                        int M, const float* __restrict__ out,
                                                        const uint8_t* __restrict__ arg, const float* __restrict__ g,
-                                                       float* __restrict__ dxyz, float* __restrict__ dnew) {
+                                                       float* __restrict__ dxyz, float* __restrict__ dnew,
+                                                       float* __restrict__ dpbuf) {
   extern __shared__ __attribute__((aligned(16))) float sa_sm[];
   const Sa1Lds L = sa1_carve(sa_sm, true);
   sa1_stage<SA_TB, true>(w, L);
@@ -459,15 +460,22 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int i0 = __shfl(i, 0, 64);
     const bool dup = lane > 0 && i == i0;
     const float ex = wave_sum(dup ? dpx : 0.f), ey = wave_sum(dup ? dpy : 0.f), ez = wave_sum(dup ? dpz : 0.f);
-    float* dq = dxyz + ((size_t)b * N + i) * 3;
-    if (lane == 0) {
-      atomicAdd(dq + 0, dpx + ex);
-      atomicAdd(dq + 1, dpy + ey);
-      atomicAdd(dq + 2, dpz + ez);
-    } else if (!dup) {
-      atomicAdd(dq + 0, dpx);
-      atomicAdd(dq + 1, dpy);
-      atomicAdd(dq + 2, dpz);
+    if (dpbuf) {   // deterministic mode: the (centroid, sample) contributions are summed by sa1_scatter_kernel
+      float* dq = dpbuf + ((size_t)c * SA_S + lane) * 3;
+      dq[0] = lane == 0 ? dpx + ex : (dup ? 0.f : dpx);
+      dq[1] = lane == 0 ? dpy + ey : (dup ? 0.f : dpy);
+      dq[2] = lane == 0 ? dpz + ez : (dup ? 0.f : dpz);
+    } else {
+      float* dq = dxyz + ((size_t)b * N + i) * 3;
+      if (lane == 0) {
+        atomicAdd(dq + 0, dpx + ex);
+        atomicAdd(dq + 1, dpy + ey);
+        atomicAdd(dq + 2, dpz + ez);
+      } else if (!dup) {
+        atomicAdd(dq + 0, dpx);
+        atomicAdd(dq + 1, dpy);
+        atomicAdd(dq + 2, dpz);
+      }
     }
     const float tx = wave_sum(dpx), ty = wave_sum(dpy), tz = wave_sum(dpz);
     if (lane == 0) {
@@ -476,6 +484,108 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       dnew[(size_t)c * 3 + 2] = -tz;
     }
   }
+}
+
+// dxyz[b][n] = sum over the (centroid m, sample s) with idx[b][m][s] == n of dp[b][m][s], in ascending (m, s): the
+// scatter-add of the grouping gradient (group_points_gpu.cu:60 behind pointnet2_utils.py:318) as an OWNER-side sum over
+// reverse lists built per launch in LDS (histogram, scan, unordered fill, per-owner sort), chunked over the centroids so
+// that a chunk's lists fit.  Padded entries (repeats of a ball's first index) were merged into sample 0 by the producer
+// and are skipped.  One workgroup per instance.  Deterministic, no atomics on floats.
+constexpr int SCAT_BLOCK = 512;
+__global__ __launch_bounds__(SCAT_BLOCK) void sa1_scatter_kernel(const float* __restrict__ dp, const int32_t* __restrict__ idx,
+                                                                float* __restrict__ dxyz, int N, int M, int rcap) {
+  extern __shared__ __attribute__((aligned(16))) int sc_sm[];
+  int* s_cnt = sc_sm;                                         // [N + 1]
+  float* s_g = reinterpret_cast<float*>(sc_sm + N + 1);       // [3 N]
+  int* rlist = reinterpret_cast<int*>(s_g + 3 * N);           // [rcap]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int32_t* I = idx + (size_t)b * M * SA_S;
+  const float* D = dp + (size_t)b * M * SA_S * 3;
+  for (int i = tid; i < 3 * N; i += SCAT_BLOCK) s_g[i] = 0.f;
+  const int cm = max(1, rcap / SA_S);                         // centroids per chunk
+  for (int m0 = 0; m0 < M; m0 += cm) {
+    const int nent = (min(M, m0 + cm) - m0) * SA_S, e0 = m0 * SA_S;
+    for (int i = tid; i <= N; i += SCAT_BLOCK) s_cnt[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < nent; e += SCAT_BLOCK) {
+      const int ge = e0 + e, q = I[ge];
+      if ((ge & (SA_S - 1)) == 0 || q != I[ge & ~(SA_S - 1)]) atomicAdd(&s_cnt[q], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int per = (N + 1 + 63) / 64, a0 = tid * per, a1 = min(a0 + per, N + 1);
+      int sum = 0;
+      for (int i = a0; i < a1; ++i) sum += s_cnt[i];
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += v;
+      }
+      int run = incl - sum;
+      for (int i = a0; i < a1; ++i) {
+        const int c = s_cnt[i];
+        s_cnt[i] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < nent; e += SCAT_BLOCK) {
+      const int ge = e0 + e, q = I[ge];
+      if ((ge & (SA_S - 1)) == 0 || q != I[ge & ~(SA_S - 1)]) rlist[atomicAdd(&s_cnt[q], 1)] = ge;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += SCAT_BLOCK) {
+      const int st = i ? s_cnt[i - 1] : 0, n = s_cnt[i] - st;
+      if (n == 0) continue;
+      int* L = rlist + st;
+      if (n <= 24) {
+        for (int a = 1; a < n; ++a) {
+          const int v = L[a];
+          int c = a - 1;
+          while (c >= 0 && L[c] > v) {
+            L[c + 1] = L[c];
+            --c;
+          }
+          L[c + 1] = v;
+        }
+      } else {
+        auto sift = [&](int start, int end) {
+          int root = start;
+          for (;;) {
+            int child = 2 * root + 1;
+            if (child > end) break;
+            if (child + 1 <= end && L[child] < L[child + 1]) ++child;
+            if (L[root] >= L[child]) break;
+            const int tmp = L[root];
+            L[root] = L[child];
+            L[child] = tmp;
+            root = child;
+          }
+        };
+        for (int h0 = (n - 2) / 2; h0 >= 0; --h0) sift(h0, n - 1);
+        for (int end = n - 1; end > 0; --end) {
+          const int tmp = L[0];
+          L[0] = L[end];
+          L[end] = tmp;
+          sift(0, end - 1);
+        }
+      }
+      float gx = s_g[3 * i], gy = s_g[3 * i + 1], gz = s_g[3 * i + 2];
+      for (int e = 0; e < n; ++e) {
+        const float* d = D + (size_t)L[e] * 3;
+        gx += d[0];
+        gy += d[1];
+        gz += d[2];
+      }
+      s_g[3 * i] = gx;
+      s_g[3 * i + 1] = gy;
+      s_g[3 * i + 2] = gz;
+    }
+    __syncthreads();
+  }
+  float* G = dxyz + (size_t)b * N * 3;
+  for (int i = tid; i < 3 * N; i += SCAT_BLOCK) G[i] = s_g[i];
 }
 
 int sa1_grid(int B, int M, int waves) {
@@ -500,22 +610,38 @@ extern "C" int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, con
   return GEOA3_OK;
 }
 
+extern "C" int64_t geoa3_pn2_sa1_scratch_bytes(int B, int M) {
+  if (B <= 0 || M <= 0) return -1;
+  return (int64_t)B * M * SA_S * 3 * (int64_t)sizeof(float);
+}
+
 extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx,
                                       const geoa3_sa1_weights* w, int B, int N, int M, const float* out,
                                       const uint8_t* arg, const float* grad_out, float* grad_xyz, float* grad_new_xyz,
-                                      void* stream) {
+                                      float* scratch, void* stream) {
   if (!xyz || !new_xyz || !idx || !w || !out || !arg || !grad_out || !grad_xyz || !grad_new_xyz || B <= 0 || N <= 0 ||
       M <= 0)
     return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
-  if (hipMemsetAsync(grad_xyz, 0, (size_t)B * N * 3 * sizeof(float), s) != hipSuccess) return GEOA3_ELAUNCH;
+  // deterministic scatter (scratch given and the owner's accumulators + at least one centroid's lists fit LDS)
+  const size_t fixed = ((size_t)N + 1) * sizeof(int) + (size_t)3 * N * sizeof(float), cap = 160 * 1024 - 512;
+  const bool det = scratch && fixed + SA_S * sizeof(int) <= cap;
+  if (!det && hipMemsetAsync(grad_xyz, 0, (size_t)B * N * 3 * sizeof(float), s) != hipSuccess) return GEOA3_ELAUNCH;
   const size_t lds = (size_t)sa1_lds_bytes(SA_TB, true);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   geoa3_prof_begin(GEOA3_PROF_SA1_BWD, s);
   hipLaunchKernelGGL(sa1_bwd_kernel, dim3(sa1_grid(B, M, SA_TB / 64)), dim3(SA_TB), lds, s, xyz, new_xyz, idx, *w, B, N, M, out, arg,
-                     grad_out, grad_xyz, grad_new_xyz);
+                     grad_out, grad_xyz, grad_new_xyz, det ? scratch : nullptr);
   geoa3_prof_end(GEOA3_PROF_SA1_BWD, s);
+  if (det) {
+    size_t rcap = (cap - fixed) / sizeof(int);
+    if (rcap > (size_t)M * SA_S) rcap = (size_t)M * SA_S;
+    const size_t l2 = fixed + rcap * sizeof(int);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)l2);
+    hipLaunchKernelGGL(sa1_scatter_kernel, dim3(B), dim3(SCAT_BLOCK), l2, s, scratch, idx, grad_xyz, N, M, (int)rcap);
+  }
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

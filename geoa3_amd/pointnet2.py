@@ -468,10 +468,11 @@ class _SA1Fused(torch.autograd.Function):
         gx = torch.empty_like(xyz)
         gn = torch.empty_like(new_xyz)
         ws = _lib.Sa1Weights(*[t.data_ptr() for t in (w1, b1, w2, b2, w3, b3)])
+        scratch = torch.empty(B, M, 64, 3, device=xyz.device, dtype=torch.float32)   # owner-ordered scatter (deterministic)
         check(_lib.load().geoa3_pn2_sa1_backward(xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), ws, B, N, M,
                                                  out.data_ptr(), arg.data_ptr(),
                                                  g.transpose(1, 2).contiguous().data_ptr(),
-                                                 gx.data_ptr(), gn.data_ptr(), _s()), "sa1_backward")
+                                                 gx.data_ptr(), gn.data_ptr(), scratch.data_ptr(), _s()), "sa1_backward")
         return gx, gn, None, None, None, None, None, None, None
 
 

@@ -366,11 +366,14 @@ typedef struct geoa3_sa1_weights {
 } geoa3_sa1_weights;
 int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B,
                           int N, int M, float* out, uint8_t* arg, void* stream);
-/* grad_xyz [B,N,3] (zeroed here, scatter-add over idx) and grad_new_xyz [B,M,3] (= minus the per-centroid sum) from
- * grad_out [B,M,128] (same layout as out); the hidden activations are recomputed, not stored. */
+/* grad_xyz [B,N,3] (the scatter-add over idx) and grad_new_xyz [B,M,3] (= minus the per-centroid sum) from
+ * grad_out [B,M,128] (same layout as out); the hidden activations are recomputed, not stored.
+ * scratch: geoa3_pn2_sa1_scratch_bytes(B, M) bytes -> the scatter-add is an owner-side sum in ascending (centroid,
+ * sample) order (deterministic); NULL -> global float atomics as the reference (group_points_gpu.cu:60). */
+int64_t geoa3_pn2_sa1_scratch_bytes(int B, int M);
 int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B,
                            int N, int M, const float* out, const uint8_t* arg, const float* grad_out, float* grad_xyz,
-                           float* grad_new_xyz, void* stream);
+                           float* grad_new_xyz, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The whole PointNet++ SSG classifier (eval mode) as a native victim: forward and input gradient, the counterpart of
