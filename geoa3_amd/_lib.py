@@ -113,7 +113,7 @@ SIGNATURES = {
     "geoa3_smoothness": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_sor_statistic": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_sor_select": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]),
-    "geoa3_debug_wide_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "geoa3_debug_wide_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_debug_wide_fwd": (C.c_int, [vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_pn2_group_points_grad_sums": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_pn2_group_shift_relu": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -80,3 +80,40 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
   return ((unsigned long long)hi << 32) | lo;
 }
+
+// ascending in-place sort of a short int list owned by ONE thread (reverse lists of the deterministic scatter-adds):
+// insertion sort, heap sort beyond 24 entries (bounded work for degenerate inputs whose lists are long)
+__device__ __forceinline__ void geoa3_sort_ints(int* L, int n) {
+  if (n <= 24) {
+    for (int a = 1; a < n; ++a) {
+      const int v = L[a];
+      int c = a - 1;
+      while (c >= 0 && L[c] > v) {
+        L[c + 1] = L[c];
+        --c;
+      }
+      L[c + 1] = v;
+    }
+    return;
+  }
+  auto sift = [&](int start, int end) {
+    int root = start;
+    for (;;) {
+      int child = 2 * root + 1;
+      if (child > end) break;
+      if (child + 1 <= end && L[child] < L[child + 1]) ++child;
+      if (L[root] >= L[child]) break;
+      const int tmp = L[root];
+      L[root] = L[child];
+      L[child] = tmp;
+      root = child;
+    }
+  };
+  for (int h0 = (n - 2) / 2; h0 >= 0; --h0) sift(h0, n - 1);
+  for (int end = n - 1; end > 0; --end) {
+    const int tmp = L[0];
+    L[0] = L[end];
+    L[end] = tmp;
+    sift(0, end - 1);
+  }
+}

@@ -101,6 +101,8 @@ struct WideBwdArgs {
   const unsigned long long* Zmask;            // its bit mask [B][ceil(N/64)][128] (ConvArgs::Ymask)
   float* dX; long sXb; int ldX;               // [B][128][N]
   int Co, N, B, taps;
+  int form;                                   // 0 = register accumulation over per-column lists (default), 1 = the first
+                                              // form (LDS accumulation); same sums in the same order
 };
 int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s);
 

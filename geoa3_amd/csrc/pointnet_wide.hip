@@ -284,6 +284,237 @@ __global__ __launch_bounds__(128 * NP) void wide_max_bwd_kernel(WideBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sparse backward, second form (the default): the same sums in the same order, accumulated in REGISTERS.
+// One workgroup per (instance, 64-point tile), 8 wavefronts.  (1) the (channel, tap) pairs whose arg-max lands in the
+// tile are compacted into a flat list in a fixed order (ballot + popcount); (2) a stable placement groups them by
+// column (wave w owns 8 columns and passes over the flat list in order: no sort, no order left to chance); (3) the
+// grouped list is cut into equal shares, one per wave: eight weight rows (512 B each, lane = two input channels) are in
+// flight per step, the running column's sum lives in two registers and is stored to the LDS tile when the column
+// changes -- no read-modify-write chain through LDS, which is what bounded the first form (97 / 151 us for 64 / 192
+// hits per tile); (4) the tile is written out with the relu gate of the layer input as before.
+// ------------------------------------------------------------------------------------------
+constexpr int BW2_WAVES = 8, BW2_THREADS = 64 * BW2_WAVES;
+template <int TAPS>
+__global__ __launch_bounds__(BW2_THREADS) void wide_max_bwd2_kernel(WideBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int COLS = 64, PITCH = COLS + 1;
+  float* s_acc = smem;                                                  // [128 ci][65]; before the walk: the flat list
+  int* s_flat = reinterpret_cast<int*>(smem);                           // [Co * TAPS] hits in (channel chunk, tap, channel) order
+  float* s_fg = smem + a.Co * TAPS;                                     // [Co * TAPS] their upstream gradients
+  const int region = max(WM_CI * PITCH, 2 * a.Co * TAPS);
+  int* s_list = reinterpret_cast<int*>(smem + region);                  // [Co * TAPS] (co * TAPS + tap) | (column << 16), by column
+  float* s_gl = reinterpret_cast<float*>(s_list + a.Co * TAPS);         // [Co * TAPS] upstream gradient of the hit
+  int* s_off = reinterpret_cast<int*>(s_gl + a.Co * TAPS);              // [COLS + 1] column counts -> start offsets
+  int* s_wcnt = s_off + COLS + 1;                                       // [BW2_WAVES + 1] hits found by each wave -> offsets
+  int* s_sidecol = s_wcnt + BW2_WAVES + 1;                              // [BW2_WAVES]
+  float* s_side = reinterpret_cast<float*>(s_sidecol + BW2_WAVES);      // [BW2_WAVES][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, m0 = blockIdx.x * COLS;
+  const float* gb = a.g + (size_t)b * a.Co;
+  const int* argb = a.arg + (size_t)b * a.Co;
+  if (tid <= COLS) s_off[tid] = 0;
+  __syncthreads();
+  // (1) ordered compaction.  Wave w looks at channels [w Co/8, (w+1) Co/8) in chunks of 64; a hit's place in the flat
+  // list follows (chunk, tap, channel): ballot + popcount, no ordering left to chance.
+  const int cpw = (a.Co + BW2_WAVES - 1) / BW2_WAVES, c_lo = wave * cpw, c_hi = min(a.Co, c_lo + cpw);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  {
+    int cnt = 0;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+      const int co = c0 + lane;
+      const bool in = co < c_hi;
+      const float g = in ? gb[co] : 0.f;
+      const int base = (in ? argb[co] : 0) - TAPS / 2 - m0;
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int c = base + tap;
+        const bool hit = g != 0.f && c >= 0 && c < COLS && m0 + c < a.N;
+        cnt += __popcll(__ballot(hit));
+        if (hit) atomicAdd(&s_off[c], 1);
+      }
+    }
+    if (lane == 0) s_wcnt[wave] = cnt;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < BW2_WAVES; ++w) {
+      const int c = s_wcnt[w];
+      s_wcnt[w] = run;
+      run += c;
+    }
+    s_wcnt[BW2_WAVES] = run;
+  }
+  if (tid >= 64 && tid < 128) {   // exclusive scan of the 64 column counts (wave 1)
+    const int cnt = s_off[lane];
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    s_off[lane] = incl - cnt;
+    if (lane == 63) s_off[COLS] = incl;
+  }
+  __syncthreads();
+  {
+    int pos = s_wcnt[wave];
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+      const int co = c0 + lane;
+      const bool in = co < c_hi;
+      const float g = in ? gb[co] : 0.f;
+      const int base = (in ? argb[co] : 0) - TAPS / 2 - m0;
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int c = base + tap;
+        const bool hit = g != 0.f && c >= 0 && c < COLS && m0 + c < a.N;
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+          const int slot = pos + __popcll(mask & lt);
+          s_flat[slot] = (co * TAPS + tap) | (c << 16);
+          s_fg[slot] = g;
+        }
+        pos += __popcll(mask);
+      }
+    }
+  }
+  __syncthreads();
+  // (2) stable placement by column: wave w owns columns 8 w .. 8 w + 7 and passes over the flat list in order, so
+  // every column's list keeps the flat order
+  const int total = s_off[COLS];
+  {
+    int basec[COLS / BW2_WAVES];
+#pragma unroll
+    for (int j = 0; j < COLS / BW2_WAVES; ++j) basec[j] = s_off[(COLS / BW2_WAVES) * wave + j];
+    for (int i0 = 0; i0 < total; i0 += 64) {
+      const int i = i0 + lane;
+      const int e = i < total ? s_flat[i] : -1;
+      const float g = i < total ? s_fg[i] : 0.f;
+      const int col = e >> 16;     // -1 for the padding lanes
+#pragma unroll
+      for (int j = 0; j < COLS / BW2_WAVES; ++j) {
+        const bool mine = col == (COLS / BW2_WAVES) * wave + j;
+        const unsigned long long mask = __ballot(mine);
+        if (mine) {
+          const int slot = basec[j] + __popcll(mask & lt);
+          s_list[slot] = e;
+          s_gl[slot] = g;
+        }
+        basec[j] += __popcll(mask);
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < WM_CI * PITCH; e += BW2_THREADS) s_acc[e] = 0.f;   // the flat list is done with: the tile
+  __syncthreads();
+  // (3) walk: the flat list is cut into equal shares, one per wave -- arg-max columns cluster on a few "critical" points,
+  // so a split by columns leaves most waves idle.  A column that continues from the previous wave's share is summed
+  // into the wave's side row and added to the tile afterwards, in wave order (fixed order: deterministic).
+  {
+    const int per = (total + BW2_WAVES - 1) / BW2_WAVES;
+    const int lo = min(total, wave * per), hi = min(total, lo + per);
+    constexpr int U = 8;
+    int cur = -1;
+    float acc0 = 0.f, acc1 = 0.f;
+    // the column of hit lo started in an earlier share <=> lo is not the first entry of that column's list
+    int side_col = -1;
+    if (lo < hi) {
+      const int c0 = s_list[lo] >> 16;
+      if (lo > s_off[c0]) side_col = c0;
+    }
+    bool in_side = side_col >= 0;
+    auto flush = [&]() {
+      if (cur < 0) return;
+      if (in_side) {
+        s_side[wave * WM_CI + 2 * lane] = acc0;
+        s_side[wave * WM_CI + 2 * lane + 1] = acc1;
+        in_side = false;
+      } else {
+        s_acc[(2 * lane) * PITCH + cur] = acc0;
+        s_acc[(2 * lane + 1) * PITCH + cur] = acc1;
+      }
+    };
+    for (int h0 = lo; h0 < hi; h0 += U) {
+      float2 w[U];
+      float gg[U];
+      int cc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = h0 + u < hi;
+        const int e = s_list[ok ? h0 + u : hi - 1];
+        w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)(e & 0xffff) * WM_CI + 2 * lane);
+        gg[u] = ok ? s_gl[h0 + u] : 0.f;
+        cc[u] = ok ? e >> 16 : -2;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (cc[u] == -2) break;
+        if (cc[u] != cur) {
+          flush();
+          cur = cc[u];
+          acc0 = 0.f;
+          acc1 = 0.f;
+        }
+        acc0 += w[u].x * gg[u];
+        acc1 += w[u].y * gg[u];
+      }
+    }
+    flush();
+    if (lane == 0) s_sidecol[wave] = side_col;
+  }
+  __syncthreads();
+  if (tid < WM_CI) {
+    for (int w = 1; w < BW2_WAVES; ++w) {
+      const int c = s_sidecol[w];
+      if (c >= 0) s_acc[tid * PITCH + c] += s_side[w * WM_CI + tid];
+    }
+  }
+  __syncthreads();
+  // (4) write out with the relu gate of the layer input: 4 consecutive points per thread (16-byte stores)
+  float* dX = a.dX + (size_t)b * a.sXb;
+  const bool vecx = (a.ldX & 3) == 0;
+  if (a.Zmask) {
+    const unsigned long long* mk = a.Zmask + ((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * WM_CI;   // [B][tile][ci]
+#pragma unroll 4
+    for (int e = tid; e < WM_CI * (COLS / 4); e += BW2_THREADS) {
+      const int c = e / (COLS / 4), j = (e - c * (COLS / 4)) * 4, m = m0 + j;
+      const float* sa = s_acc + c * PITCH + j;
+      const unsigned bits = (unsigned)(mk[c] >> j) & 15u;
+      if (vecx && m + 3 < a.N) {
+        float4 v;
+        v.x = bits & 1u ? sa[0] : 0.f;
+        v.y = bits & 2u ? sa[1] : 0.f;
+        v.z = bits & 4u ? sa[2] : 0.f;
+        v.w = bits & 8u ? sa[3] : 0.f;
+        *reinterpret_cast<float4*>(dX + (size_t)c * a.ldX + m) = v;
+      } else {
+        for (int i = 0; i < 4; ++i)
+          if (m + i < a.N) dX[(size_t)c * a.ldX + m + i] = (bits >> i) & 1u ? sa[i] : 0.f;
+      }
+    }
+    return;
+  }
+  const float* Z = a.Z + (size_t)b * a.sZb;
+  const bool vec = vecx && (a.ldZ & 3) == 0;
+#pragma unroll 4
+  for (int e = tid; e < WM_CI * (COLS / 4); e += BW2_THREADS) {
+    const int c = e / (COLS / 4), j = (e - c * (COLS / 4)) * 4, m = m0 + j;
+    const float* sa = s_acc + c * PITCH + j;
+    if (vec && m + 3 < a.N) {
+      const float4 z = *reinterpret_cast<const float4*>(Z + (size_t)c * a.ldZ + m);
+      float4 v;
+      v.x = z.x > 0.f ? sa[0] : 0.f;
+      v.y = z.y > 0.f ? sa[1] : 0.f;
+      v.z = z.z > 0.f ? sa[2] : 0.f;
+      v.w = z.w > 0.f ? sa[3] : 0.f;
+      *reinterpret_cast<float4*>(dX + (size_t)c * a.ldX + m) = v;
+    } else {
+      for (int i = 0; i < 4; ++i)
+        if (m + i < a.N) dX[(size_t)c * a.ldX + m + i] = Z[(size_t)c * a.ldZ + m + i] > 0.f ? sa[i] : 0.f;
+    }
+  }
+}
+
 }  // namespace
 
 void launch_wide_finalize(const WideArgs& a, hipStream_t s) {
@@ -324,15 +555,32 @@ int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s) {
   if (a.taps != 1 && a.taps != 3) return GEOA3_ENOSUPPORT;
   // tile width / parts / compaction block picked on hardware (tools/bench_widebwd.py): 64-column tiles leave room for
   // three workgroups per CU, so one workgroup's write-out overlaps its neighbours' hit walks (95 / 150 us)
-  if (a.taps == 1) launch_wide_bwd_variant<1, 2, 256, 64>(a, s);
-  else launch_wide_bwd_variant<3, 2, 128, 64>(a, s);
+  if (a.form == 1) {   // the first form (LDS accumulation), kept for tools/bench_widebwd.py and the cross-check test
+    if (a.taps == 1) launch_wide_bwd_variant<1, 2, 256, 64>(a, s);
+    else launch_wide_bwd_variant<3, 2, 128, 64>(a, s);
+  } else {
+    if (a.Co * a.taps > 0xffff) return GEOA3_ENOSUPPORT;
+    dim3 grid((a.N + 63) / 64, a.B);
+    const size_t region = (size_t)WM_CI * 65 > 2 * (size_t)a.Co * a.taps ? (size_t)WM_CI * 65 : 2 * (size_t)a.Co * a.taps;
+    const size_t lds = (region + 2 * (size_t)a.Co * a.taps + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 3) * sizeof(float);
+    if (a.taps == 1) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_max_bwd2_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(wide_max_bwd2_kernel<1>, grid, dim3(BW2_THREADS), lds, s, a);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_max_bwd2_kernel<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(wide_max_bwd2_kernel<3>, grid, dim3(BW2_THREADS), lds, s, a);
+    }
+  }
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
 
 extern "C" int geoa3_debug_wide_bwd(const float* g, const int32_t* arg, const float* W, const float* Z, float* dX, int B,
-                                    int N, int taps, void* stream) {
+                                    int N, int taps, int form, void* stream) {
   WideBwdArgs a{};
+  a.form = form;
   a.g = g; a.arg = arg; a.W = W;
   a.Z = Z; a.sZb = (long)128 * N; a.ldZ = N;
   a.dX = dX; a.sXb = (long)128 * N; a.ldX = N;

@@ -33,7 +33,7 @@ int geoa3_profile_read(int tag, float* ms_host, int cap); /* waits for the recor
 /* The sparse arg-max backward of a 1024-wide layer (tools/bench_widebwd.py): g [B,1024], arg [B,1024],
  * W [1024, taps*128], Z / dX [B,128,N]. */
 int geoa3_debug_wide_bwd(const float* g, const int32_t* arg, const float* W, const float* Z, float* dX, int B, int N,
-                         int taps, void* stream);
+                         int taps, int form /* 0: shipped (register accumulation), 1: LDS accumulation */, void* stream);
 /* One 1024-wide layer + max (tools/bench_wide.py): Wp = fp32 MFMA fragments, Wh = split-fp16 fragments or NULL;
  * variant selects a tuning variant of the split kernel for THIS call (0 = the shipped configuration). */
 int geoa3_debug_wide_fwd(const float* X, const float* Wp, const void* Wh, float unscale, const float* bias, float* out,

@@ -10,9 +10,9 @@ from tools.bench_conv import timeit  # noqa: E402
 
 def main():
     lib = _lib.load()
-    B, N = 250, 1024
+    N = 1024
     s = torch.cuda.current_stream().cuda_stream
-    for taps in (1, 3):
+    for B, taps in ((250, 1), (250, 3), (32, 1), (32, 3)):
         g = torch.randn(B, 1024, device="cuda")
         # arg-max columns concentrated on ~35 % of the points, like a trained max-pool
         pool = torch.randint(0, N, (B, 360), device="cuda")
@@ -20,10 +20,14 @@ def main():
         W = torch.randn(1024, taps * 128, device="cuda") * 0.05
         Z = torch.randn(B, 128, N, device="cuda")
         dX = torch.empty(B, 128, N, device="cuda")
-        fn = lambda: lib.geoa3_debug_wide_bwd(g.data_ptr(), arg.data_ptr(), W.data_ptr(), Z.data_ptr(),
-                                              dX.data_ptr(), B, N, taps, s)
-        us = timeit(fn)
-        print("taps=%d: %6.1f us  %5.2f TB/s (262 MB)" % (taps, us, 262.1 / us))
+        res = {}
+        for form in (1, 0):
+            fn = lambda: lib.geoa3_debug_wide_bwd(g.data_ptr(), arg.data_ptr(), W.data_ptr(), Z.data_ptr(),
+                                                  dX.data_ptr(), B, N, taps, form, s)
+            us = timeit(fn)
+            res[form] = dX.clone()
+            print("B=%d taps=%d form=%d: %6.1f us  %5.2f TB/s (write + gate read)" % (B, taps, form, us, 2 * B * 128 * N * 4e-6 / us))
+        print("   forms bit-identical:", bool(torch.equal(res[0], res[1])))
 
 
 if __name__ == "__main__":
