@@ -149,9 +149,22 @@ int fc(const float* X, int K, const float* W, const float* bias, float* Y, int N
   return launch_fc(a, s);
 }
 
+// fused: the 64 -> 128 layer in front (weights w2 / fragments w2h / bias b2) is evaluated in the wide kernel's staging pass
+// from h64 [B][64][N] (or, with x3, from relu(w1 x3 + b1)); its relu gate goes to m128, its activation nowhere
+struct FrontLayer {
+  const void* w2h; float w2_unscale; const float* w2; const float* b2;
+  const float* h64; const float* x3; const float* w1; const float* b1;
+  unsigned long long* m128;
+};
 int wide(const float* X, const float* W, const void* Wh, float unscale, const float* bias, float* out, int* arg,
-         unsigned long long* keys, int taps, int B, int N, hipStream_t s) {
+         unsigned long long* keys, int taps, int B, int N, hipStream_t s, const FrontLayer* f = nullptr) {
   WideArgs a{};
+  if (f) {
+    a.W2h = f->w2h; a.w2_unscale = f->w2_unscale; a.W2f = f->w2; a.b2 = f->b2;
+    a.Xin = f->h64; a.sXinb = (long)64 * N; a.ldXin = N;
+    a.x3 = f->x3; a.w1 = f->w1; a.b1 = f->b1;
+    a.Ymask = f->m128;
+  }
   a.keys = keys;
   a.keys_clean = 1;   // zeroed once per forward; every finalize leaves them zero
   a.Wh = Wh; a.unscale = unscale;
@@ -177,9 +190,14 @@ int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, con
 int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* x3, float* act128,
                   unsigned long long* m128, float* pooled,
                   int* arg, float* f4, float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s) {
-  if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s, m128));
-  else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s, m128));
-  TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s));
+  if (tl_split && t.w2h) {   // conv2 (behind conv1 for the 3-channel T-Net) inside the wide kernel: act128 is never written
+    FrontLayer f{t.w2h, t.w2h_unscale, t.w2, t.b2, act64, act64 ? nullptr : x3, t.w1, t.b1, m128};
+    TRY(wide(nullptr, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, &f));
+  } else {
+    if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s, m128));
+    else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s, m128));
+    TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s));
+  }
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
   TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
   TRY(fc(f5, 256, t.f3, t.fb3, T, t.K * t.K, B, false, nullptr, s));
@@ -244,8 +262,13 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
     TRY(launch_conv_cm(a, s));
   }
   // conv4, conv5 + max (:145-147)
-  TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s, w.m_h4));
-  TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s));
+  if (tl_split && p.w4h) {   // conv4 inside conv5's staging pass: h4 is never written
+    FrontLayer f{p.w4h, p.w4h_unscale, p.w4, p.b4, w.h3, nullptr, nullptr, nullptr, w.m_h4};
+    TRY(wide(nullptr, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, &f));
+  } else {
+    TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s, w.m_h4));
+    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s));
+  }
   // classifier head (:150-152), dropout is the identity in eval mode
   TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));
   TRY(fc(w.f6, 512, p.f2, p.fb2, w.f7, 256, B, true, nullptr, s));

@@ -80,6 +80,15 @@ struct WideArgs {
   float unscale;                              // 1 / (power-of-two scale of Wh)
   int keys_clean;                             // 1: keys are already zero (wide_finalize_kernel leaves them zero): no memset
   int variant;                                // tuning variant of the split kernel (geoa3_debug_wide_fwd; 0 = shipped)
+  // split kernel only: the layer in front of the wide one folded into its staging pass -- X[b][c][n] =
+  // relu(W2 h + b2)[c][n] is computed per tile (X unused, never written) from the 64-channel activation h = Xin, or,
+  // with x3, from h = relu(w1 x3 + b1); Ymask receives the relu gate of X as bits ([B][ceil(N/64)][128] 64-bit words)
+  const void* W2h; float w2_unscale;          // pack_wide_split fragments of W2 [128][64] and 1 / their scale
+  const float* W2f;                           // the same weights [128][64] fp32 (conv5's two halo points per tile)
+  const float* b2;                            // [128]
+  const float* Xin; long sXinb; int ldXin;    // [B][64][N]
+  const float* x3; const float* w1; const float* b1;   // [B][3][N], [64][3], [64]
+  unsigned long long* Ymask;
   unsigned long long* stamps;                 // diagnostics (tools/bench_wide.py --stamps): s_memtime trace of workgroup 0
 };
 int launch_wide_max(const WideArgs& a, hipStream_t s);          // dispatches on a.Wh

@@ -41,7 +41,16 @@ __device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
 }
 
 // CB: channel tiles of 32 per wave (1: a workgroup covers 128 channels per group step, 2: 256)
-template <int TAPS, int OCC, int GROUPS, int CB, int PIPE, bool DESYNC>
+// FUSE: the 128-channel input tile is COMPUTED while it is staged instead of being read (WideArgs::Xin etc.):
+//   1: tile = relu(W2 h + b2) from the 64-channel activation h = Xin [B][64][N]   (T-Net(64) conv2, trunk conv4)
+//   2: the same with h = relu(w1 x + b1) evaluated from the 3-channel cloud x3    (T-Net(3) conv1 + conv2)
+// Wave w owns the tile's points 32 w .. 32 w + 31: its B operands are the wave's own 64 x 32 block of h (split with a
+// per-wave power-of-two scale), the A operands the pre-split fragments of W2 (host: pack_wide_split, K = 64) streamed
+// from L2 tile by tile; 48 MFMAs per wave against 1152 (conv5) / 768 (T-Net) of the layer itself.  The relu gate of
+// the tile goes out as the bit mask the backward reads (32 bits per (channel, wave)); the [B][128][N] activation is
+// never written.  conv5's two halo points are evaluated on the VALU (fp32): they differ from the neighbouring tile's
+// MFMA values in the last bit at most, like any two fp32 evaluations.
+template <int TAPS, int OCC, int GROUPS, int CB, int PIPE, bool DESYNC, int FUSE>
 __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a, int slots_per_xcd) {
   constexpr int KS = TAPS * 8;               // k-steps of 16 per channel tile
   constexpr int PF = CB == 1 ? 4 : 2;        // k-steps of weight fragments in flight; 8 % PF == 0
@@ -49,6 +58,7 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
   constexpr int GSTEPS = GROUPS / CB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ float s_max[4];
+  __shared__ float4 s_w1[FUSE == 2 ? 64 : 1];      // (w1 row, b1) of the 3-channel first layer
   // packed maxima of the current unit, published (atomicMax) while the NEXT unit is being staged: keeps the atomics
   // out of the in-order vmcnt queue in front of the weight stream (on its own within run-to-run noise)
   __shared__ unsigned long long s_keys[4][GROUPS][32];
@@ -71,6 +81,10 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
     if (tid == 0) s_max[0] = __int_as_float(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1);   // HW_REG_HW_ID[3:0]
     __syncthreads();
     late = __float_as_int(s_max[0]) != 0;
+  }
+  if (FUSE == 2) {
+    if (tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
+    __syncthreads();
   }
   const int nmine = units > slot ? (units - slot + slots_per_xcd - 1) / slots_per_xcd : 0;
   late = late && nmine > 0 && GSTEPS > 1;
@@ -99,6 +113,104 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
     // n0 .. n0+127): 8 coalesced row reads per octet.  conv5's two halo rows (points n0-1, n0+128): one value per
     // thread.
     float xv[2][4][8], xhalo = 0.f;
+    float yt[FUSE ? 4 : 1][16];          // FUSE: channel 32 t + (r & 3) + 8 (r >> 2) + 4 kh of point 32 wave + l31
+    float m = 0.f;
+    if constexpr (FUSE != 0) {
+      const int n = n0 + 32 * wave + l31;
+      const bool in = n < N;
+      float hv[4][8];                    // [k-step][i]: channel 16 s + 8 kh + i of the wave's point l31
+      if (FUSE == 1) {
+        int ldi = a.ldXin;
+        asm volatile("" : "+s"(ldi));
+        const float* ph = a.Xin + (size_t)b * a.sXinb + (in ? n : 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float v = ph[(size_t)((16 * s4 + 8 * kh + i) * ldi)];
+            hv[s4][i] = in ? v : 0.f;
+          }
+      } else {
+        const float* px = a.x3 + (size_t)b * 3 * N + (in ? n : 0);
+        const float x0 = px[0], x1 = px[N], x2 = px[2 * (size_t)N];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float4 w = s_w1[16 * s4 + 8 * kh + i];
+            const float v = fmaxf(w.x * x0 + w.y * x1 + w.z * x2 + w.w, 0.f);   // first_layer of pointnet_conv_split.hip
+            hv[s4][i] = in ? v : 0.f;
+          }
+      }
+      if (TAPS == 3) {   // halo points n0 - 1 (threads 0..127) and n0 + 128 (128..255): channel tid & 127, on the VALU
+        const int nh = tid < 128 ? n0 - 1 : n0 + SP_PTS;
+        if (nh >= 0 && nh < N) {
+          const int c = tid & 127;
+          const float* wr = a.W2f + (size_t)c * 64;
+          const float* ph = a.Xin + (size_t)b * a.sXinb + nh;
+          float acc = a.b2[c];
+#pragma unroll 8
+          for (int k = 0; k < 64; ++k) acc += wr[k] * ph[(size_t)k * a.ldXin];
+          xhalo = fmaxf(acc, 0.f);
+        }
+      }
+      float hm = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hm = fmaxf(hm, __builtin_fabsf(hv[s4][i]));
+      hm = wave_max(hm);
+      unsigned Eh = (__float_as_uint(hm) >> 23) & 0xffu;
+      Eh = Eh < 14u ? 14u : (Eh > 254u ? 254u : Eh);
+      const float hscale = __uint_as_float((267u - Eh) << 23);
+      const float hun = a.w2_unscale * __uint_as_float((Eh - 13u) << 23);
+      half8 bh[4], bl[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          _Float16 h, l;
+          split16(hv[s4][i] * hscale, h, l);
+          bh[s4][i] = h;
+          bl[s4][i] = l;
+        }
+      const half8* W2 = reinterpret_cast<const half8*>(a.W2h) + lane;   // [t][s][piece][lane]
+      unsigned mk0 = 0u, mk1 = 0u;       // lane L collects the 32-bit gate words of channels L and 64 + L
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const half8 wh = W2[(size_t)((t * 4 + s4) * 2) * 64], wl = W2[(size_t)((t * 4 + s4) * 2 + 1) * 64];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[s4], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[s4], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[s4], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          float v = fmaxf(acc[r] * hun + a.b2[ch], 0.f);
+          v = in ? v : 0.f;
+          yt[t][r] = v;
+          m = fmaxf(m, v);
+          if (a.Ymask) {
+            const unsigned long long bal = __ballot(v > 0.f);
+            const int rowA = (32 * t + (r & 3) + 8 * (r >> 2)) & 63;     // the channel of the kh = 0 half, mod 64
+            if (lane == rowA) (t < 2 ? mk0 : mk1) = (unsigned)bal;
+            if (lane == rowA + 4) (t < 2 ? mk0 : mk1) = (unsigned)(bal >> 32);
+          }
+        }
+      }
+      if (a.Ymask && (TAPS == 1 || half == 0) && n0 + 32 * wave < N) {
+        unsigned* mk = reinterpret_cast<unsigned*>(a.Ymask) +
+                       (((size_t)b * ((N + 63) >> 6) + (size_t)((n0 >> 6) + (wave >> 1))) * 128) * 2 + (wave & 1);
+        mk[2 * lane] = mk0;
+        mk[2 * (64 + lane)] = mk1;
+      }
+      m = fmaxf(m, __builtin_fabsf(xhalo));
+    } else {
     {
       int ldx = a.ldX;
       asm volatile("" : "+s"(ldx));              // opaque: keeps the row offsets from being hoisted out of the unit
@@ -121,13 +233,14 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
         if (n >= 0 && n < N) xhalo = X[(size_t)((tid & 127) * ldx) + n];
       }
     }
-    float m = __builtin_fabsf(xhalo);
+    m = __builtin_fabsf(xhalo);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
       for (int oc = 0; oc < 4; ++oc)
 #pragma unroll
         for (int i = 0; i < 8; ++i) m = fmaxf(m, __builtin_fabsf(xv[pass][oc][i]));   // NaN is caught through xs below
+    }
     m = wave_max(m);
     stamp();
     flush();           // the previous unit's maxima, behind this unit's loads
@@ -140,6 +253,28 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
     bool bad = E == 255u;    // inf (a NaN does not survive fmaxf: caught below)
     E = E < 14u ? 14u : (E > 254u ? 254u : E);
     const float scale = __uint_as_float((267u - E) << 23), unscale = a.unscale * __uint_as_float((E - 13u) << 23);
+    if constexpr (FUSE != 0) {
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      const int p = 1 + 32 * wave + l31;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          half4 hi, lo;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float xs = yt[t][4 * j + i] * scale;
+            bad |= xs != xs;
+            _Float16 h, l;
+            split16(xs, h, l);
+            hi[i] = h;
+            lo[i] = l;
+          }
+          unsigned char* dst = smem_raw + p * SP_ROWB + (32 * t + 8 * j + 4 * kh) * 2;
+          *reinterpret_cast<half4*>(dst) = hi;
+          *reinterpret_cast<half4*>(dst + SP_PIECEB) = lo;
+        }
+    } else {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int p = 1 + pass * 64 + lane;
@@ -159,6 +294,7 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
         *reinterpret_cast<half8*>(dst) = hi;
         *reinterpret_cast<half8*>(dst + SP_PIECEB) = lo;
       }
+    }
     }
     if (TAPS == 3) {
       const float xs = xhalo * scale;
@@ -341,9 +477,9 @@ __global__ __launch_bounds__(SP_THREADS, OCC) void wide_split_kernel(WideArgs a,
   if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[0] = nstamp;
 }
 
-template <int TAPS, int OCC, int GROUPS, int CB, int PIPE, bool DESYNC>
+template <int TAPS, int OCC, int GROUPS, int CB, int PIPE, bool DESYNC, int FUSE = 0>
 void launch_variant(const WideArgs& a, hipStream_t s) {
-  auto kern = wide_split_kernel<TAPS, OCC, GROUPS, CB, PIPE, DESYNC>;
+  auto kern = wide_split_kernel<TAPS, OCC, GROUPS, CB, PIPE, DESYNC, FUSE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
   constexpr int SLOTS = 32 * OCC;
   hipLaunchKernelGGL(kern, dim3(SLOTS * 8), dim3(SP_THREADS), SP_LDS, s, a, SLOTS);
@@ -359,7 +495,12 @@ int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
       hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess)
     return GEOA3_ELAUNCH;
   // variants measured on hardware (tools/bench_wide.py 0 1 2): within +-5 % of each other and of run-to-run noise
-  if (a.taps == 1) {
+  if (a.W2h) {   // the 64 -> 128 layer in front is computed while the tile is staged
+    if (!a.b2 || (a.x3 ? (!a.w1 || !a.b1 || a.taps != 1) : !a.Xin) || (a.taps == 3 && !a.W2f)) return GEOA3_EINVAL;
+    if (a.taps == 1 && a.x3) launch_variant<1, 2, 8, 1, 0, true, 2>(a, s);
+    else if (a.taps == 1) launch_variant<1, 2, 8, 1, 0, true, 1>(a, s);
+    else launch_variant<3, 2, 4, 1, 2, true, 1>(a, s);
+  } else if (a.taps == 1) {
     switch (a.variant) {
       case 1: launch_variant<1, 2, 8, 1, 2, true>(a, s); break;
       case 2: launch_variant<1, 2, 8, 1, 0, false>(a, s); break;

@@ -77,6 +77,7 @@ def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
         out[n + "t"] = out[n].t()
     out = {k: v.float().contiguous() for k, v in out.items()}
     out["w3h"], out["w3h_unscale"] = pack_wide_split(out["w3"], 1)
+    out["w2h"], out["w2h_unscale"] = pack_wide_split(out["w2"], 1)
     return out
 
 
@@ -100,6 +101,7 @@ def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
         t[n + "t"] = t[n].t()
     out.update({k: v.float().contiguous() for k, v in t.items()})
     out["w5h"], out["w5h_unscale"] = pack_wide_split(out["w5"], 3)
+    out["w4h"], out["w4h_unscale"] = pack_wide_split(out["w4"], 1)
     return out
 
 
@@ -116,6 +118,16 @@ def default_wide_mode() -> str:
     if mode not in WIDE_MODES:
         raise ValueError("GEOA3_WIDE_MODE must be one of %s" % (WIDE_MODES,))
     return mode
+
+
+def fuse_front() -> bool:
+    """GEOA3_FUSE_FRONT=1 (opt-in): the 64 -> 128 layers in front of the three 1024-wide layers (T-Net conv2, trunk conv4)
+    are evaluated inside the wide kernels' staging pass (split mode only) and their [B,128,N] activations never
+    written.  Same results to rounding, all tests pass -- but measured SLOWER on MI355X (conv5 0.50 -> 0.71 ms, T-Net
+    conv3 0.186 -> 0.238 ms against 52-60 us per convolution saved: 2.26 -> 2.45 ms/iteration): the staging pass of a
+    unit grows from two dependent phases to six (loads, split, four rounds of weight-fragment loads + MFMAs +
+    epilogue) and the co-resident workgroup's MFMAs no longer cover it.  Off by default; DESIGN.md."""
+    return os.environ.get("GEOA3_FUSE_FRONT", "0") == "1"
 
 
 class PackedPointNet:
@@ -136,7 +148,7 @@ class PackedPointNet:
             return d.data_ptr()
 
         def pick(p: Dict[str, object], name: str):
-            if name in ("w3h", "w5h") and not split:
+            if name in ("w3h", "w5h", "w2h", "w4h") and (not split or (name in ("w2h", "w4h") and not fuse_front())):
                 return None
             return dev(p[name])
 
@@ -231,7 +243,7 @@ class PointNet(nn.Module):
         self.wide_mode: Optional[str] = None       # None = GEOA3_WIDE_MODE / 'f16x2'; see default_wide_mode()
 
     def _weights_key(self, device):
-        return (str(device), self.wide_mode or default_wide_mode()) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (str(device), self.wide_mode or default_wide_mode(), fuse_front()) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def packed(self, device) -> PackedPointNet:
         key = self._weights_key(device)

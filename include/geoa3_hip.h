@@ -157,6 +157,10 @@ typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 
   const float *f1t, *f2t, *f3t; /* transposes: [1024,512], [512,256], [256,K*K] */
   const void *w3h;          /* optional (NULL = fp32 MFMA): w3 as split-fp16 fragments, see w5h */
   float w3h_unscale;
+  const void *w2h;          /* optional, with w3h: w2 as split-fp16 fragments (same packing, K = 64).  Given, conv2 (and
+                               conv1 of the 3-channel T-Net) is evaluated inside conv3's staging pass: its [B,128,N]
+                               activation is never written, only its relu gate bits */
+  float w2h_unscale;
 } geoa3_tnet_weights;
 
 typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 */
@@ -183,6 +187,8 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
                                Gram product of the backward use the same arithmetic (they split their fp32 weights
                                themselves: csrc/pointnet_conv_split.hip, pointnet_gram.hip); NULL = fp32 MFMA throughout. */
   float w5h_unscale;        /* 2^-e */
+  const void *w4h;          /* optional, with w5h: w4 as split-fp16 fragments (K = 64): conv4 inside conv5's staging pass */
+  float w4h_unscale;
 } geoa3_pointnet_weights;
 
 /* bytes of scratch the forward+backward pair needs for a batch of B clouds of N points */
