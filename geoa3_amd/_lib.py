@@ -72,7 +72,7 @@ SIGNATURES = {
     "geoa3_grid_nn1_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "geoa3_knn": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "geoa3_knn_self_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
-    "geoa3_knn_self": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "geoa3_knn_self": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "geoa3_graph_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "geoa3_graph_nn1_pair": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "geoa3_graph_knn": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

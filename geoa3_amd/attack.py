@@ -153,6 +153,7 @@ class AttackRunner:
             t["knn"] = [torch.zeros(b, ne, self.k + 1, **i32) for _ in range(2)]
             t["knn_d"] = z(b, ne, self.k + 1)
             self.knn_slab = os.environ.get("GEOA3_KNN_SLAB", "1") != "0"
+            self.knn_method = int(os.environ.get("GEOA3_KNN_METHOD", "0"))   # 0 = by (K, N), 1 = slab, 2 = cell grid
             t["knn_scratch"] = ops.knn_self_scratch(b, ne, device)
         if self.native:
             bw = b * self.eval_num if self.sub else b
@@ -358,7 +359,8 @@ class AttackRunner:
                 else:
                     check(lib.geoa3_knn_self(xe.data_ptr(), self.b, ne, self.k + 1,
                                              prior.data_ptr() if self.knn_seeded else None, t["knn_d"].data_ptr(),
-                                             out.data_ptr(), t["knn_scratch"].data_ptr() if self.knn_slab else None, sg),
+                                             out.data_ptr(), t["knn_scratch"].data_ptr() if self.knn_slab else None,
+                                             self.knn_method, sg),
                           "knn_self")
                 self.knn_seeded = True
                 self.knn_cur = 1 - self.knn_cur

@@ -290,6 +290,282 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Cell-grid search, one WAVEFRONT per query (the K = 33 / N = 4096 regime, where the per-thread lists of the slab kernel
+// leave room for one wave per SIMD and a 1-D slab still holds 10-15 % of the cloud).
+// The cloud is counting-sorted into a 16^3 grid over its bounding box (cell index x fastest, so the cells x0..x1 of a
+// (y, z) row are ONE contiguous run of the sorted array).  A query's radius tau is the largest distance to last
+// iteration's K neighbours (K distinct points: an upper bound of the true K-th distance), so every true neighbour lies in
+// the box of cells that [q - sqrt(tau), q + sqrt(tau)] touches (the cell function is monotone in the coordinate).
+// The wave gives every (y, z) row of that box to a lane; the lanes walk their runs in lockstep, candidates with d <= tau
+// are appended to the wave's list by ballot + popcount (64 at a time), and the K smallest by (distance, index) are
+// picked by rank counting over the list -- every lane ranks its own candidates against all of them.  Distances are the
+// un-fused bits of geoa3_sqdist and the order is the lexicographic one of the other kernels: BIT-IDENTICAL results.
+// No per-thread lists, ~2.5 KB of LDS per wave: eight waves per SIMD hide the dependent loads of the walk.
+// ------------------------------------------------------------------------------------------
+constexpr int KG_G = 16, KG_CELLS = KG_G * KG_G * KG_G;
+constexpr int KG_T = 1024, KG_PPT = 8;       // cell sort: up to 8192 points
+constexpr int KG_CAP = 256;                  // entries of a wave's candidate list
+constexpr int KG_QPW = 8;                    // queries per wave (sequential)
+
+struct GridGeo {
+  float lox, loy, loz, inv_h;
+};
+
+__device__ __forceinline__ int kg_cell(float v, float lo, float inv_h) {
+  const int c = (int)floorf((v - lo) * inv_h);
+  return c < 0 ? 0 : (c > KG_G - 1 ? KG_G - 1 : c);
+}
+
+// sorted [B][3][N] coordinates in cell order, sidx [B][N] original indices, cstart [B][KG_CELLS + 1], geo [B]
+__global__ __launch_bounds__(KG_T) void knn_cellsort_kernel(const float* __restrict__ pc, int N, float* __restrict__ sorted,
+                                                            int32_t* __restrict__ sidx, int32_t* __restrict__ cstart,
+                                                            GridGeo* __restrict__ geo) {
+  __shared__ float s_red[16][6];
+  __shared__ int s_cnt[KG_CELLS], s_wsum[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* P = pc + (size_t)b * 3 * N;
+  float px[KG_PPT], py[KG_PPT], pz[KG_PPT];
+  float lo[3] = {S_INF, S_INF, S_INF}, hi[3] = {-S_INF, -S_INF, -S_INF};
+#pragma unroll
+  for (int p = 0; p < KG_PPT; ++p) {
+    const int i = tid + p * KG_T;
+    if (i < N) {
+      px[p] = P[i];
+      py[p] = P[N + i];
+      pz[p] = P[2 * N + i];
+      lo[0] = fminf(lo[0], px[p]); hi[0] = fmaxf(hi[0], px[p]);
+      lo[1] = fminf(lo[1], py[p]); hi[1] = fmaxf(hi[1], py[p]);
+      lo[2] = fminf(lo[2], pz[p]); hi[2] = fmaxf(hi[2], pz[p]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = -wave_max(-lo[c]);
+    hi[c] = wave_max(hi[c]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      s_red[wave][c] = lo[c];
+      s_red[wave][3 + c] = hi[c];
+    }
+  }
+  for (int e = tid; e < KG_CELLS; e += KG_T) s_cnt[e] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 16; ++w)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = fminf(lo[c], s_red[w][c]);
+      hi[c] = fmaxf(hi[c], s_red[w][3 + c]);
+    }
+  const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+  const float inv_h = ext > 1e-30f ? (float)KG_G / (ext * 1.00001f) : 0.f;
+  int cell[KG_PPT];
+#pragma unroll
+  for (int p = 0; p < KG_PPT; ++p) {
+    const int i = tid + p * KG_T;
+    if (i < N) {
+      cell[p] = (kg_cell(pz[p], lo[2], inv_h) * KG_G + kg_cell(py[p], lo[1], inv_h)) * KG_G + kg_cell(px[p], lo[0], inv_h);
+      atomicAdd(&s_cnt[cell[p]], 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the 4096 counters: four consecutive entries per thread
+  int c4[4], sum = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    c4[u] = s_cnt[4 * tid + u];
+    sum += c4[u];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  int run = incl - sum;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) run += (w < wave) ? s_wsum[w] : 0;
+  int32_t* cs = cstart + (size_t)b * (KG_CELLS + 1);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    s_cnt[4 * tid + u] = run;     // from here on: the fill cursor of the cell
+    cs[4 * tid + u] = run;
+    run += c4[u];
+  }
+  if (tid == KG_T - 1) cs[KG_CELLS] = run;
+  __syncthreads();
+  float* S = sorted + (size_t)b * 3 * N;
+#pragma unroll
+  for (int p = 0; p < KG_PPT; ++p) {
+    const int i = tid + p * KG_T;
+    if (i < N) {
+      const int pos = atomicAdd(&s_cnt[cell[p]], 1);   // the order inside a cell is free: the selection does not depend on it
+      S[pos] = px[p];
+      S[N + pos] = py[p];
+      S[2 * N + pos] = pz[p];
+      sidx[(size_t)b * N + pos] = i;
+    }
+  }
+  if (tid == 0) geo[b] = GridGeo{lo[0], lo[1], lo[2], inv_h};
+}
+
+__device__ __forceinline__ unsigned long long kg_key(float d, int i) {   // d >= 0: its bits order like the value
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__ R, int N, int K,
+                                                       const int32_t* __restrict__ prior,
+                                                       const float* __restrict__ sorted, const int32_t* __restrict__ sidx,
+                                                       const int32_t* __restrict__ cstart, const GridGeo* __restrict__ geo,
+                                                       float* __restrict__ dists, int32_t* __restrict__ idx) {
+  __shared__ unsigned long long s_key[4][KG_CAP];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* Rb = R + (size_t)b * 3 * N;
+  const float* Sb = sorted + (size_t)b * 3 * N;
+  const int32_t* Ib = sidx + (size_t)b * N;
+  const int32_t* cs = cstart + (size_t)b * (KG_CELLS + 1);
+  const GridGeo g = geo[b];
+  unsigned long long* L = s_key[wave];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int q0 = (blockIdx.x * 4 + wave) * KG_QPW;
+  for (int qi = 0; qi < KG_QPW; ++qi) {
+    const int pos = q0 + qi;
+    if (pos >= N) break;                       // wave-uniform
+    const float qx = Sb[pos], qy = Sb[N + pos], qz = Sb[2 * N + pos];
+    const int qo = Ib[pos];
+    // radius: the largest distance to last iteration's K neighbours
+    float t = 0.f;
+    bool ok = true;
+    for (int m = lane; m < K; m += 64) {
+      const int j = prior[((size_t)b * N + qo) * K + m];
+      if (j < 0 || j >= N) ok = false;
+      else t = fmaxf(t, geoa3_sqdist(qx, qy, qz, Rb[j], Rb[N + j], Rb[2 * N + j]));
+    }
+    float tau = wave_max(t);
+    if (__any(!ok)) tau = S_INF;               // no usable radius: the whole grid
+    int cnt = 0;                                // wave-uniform
+    // second pass only when a degenerate prior (repeated indices) left fewer than K candidates within its radius
+    for (int pass = 0; pass < 2; ++pass) {
+    int x0 = 0, x1 = KG_G - 1, y0 = 0, y1 = KG_G - 1, z0 = 0, z1 = KG_G - 1;
+    if (tau < S_INF) {
+      const float r = sqrtf(tau) * 1.00001f + 1e-30f;
+      x0 = kg_cell(qx - r, g.lox, g.inv_h); x1 = kg_cell(qx + r, g.lox, g.inv_h);
+      y0 = kg_cell(qy - r, g.loy, g.inv_h); y1 = kg_cell(qy + r, g.loy, g.inv_h);
+      z0 = kg_cell(qz - r, g.loz, g.inv_h); z1 = kg_cell(qz + r, g.loz, g.inv_h);
+    }
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    cnt = 0;
+    for (int rb = 0; rb < nrows; rb += 64) {
+      const int row = rb + lane;
+      int s = 0, len = 0;
+      if (row < nrows) {
+        const int zz = z0 + row / ny, yy = y0 + row - (row / ny) * ny;
+        const int c0 = (zz * KG_G + yy) * KG_G;
+        s = cs[c0 + x0];
+        len = cs[c0 + x1 + 1] - s;
+      }
+      int maxlen = len;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+      for (int i = 0; i < maxlen; ++i) {
+        float d = S_INF;
+        int oi = 0;
+        if (i < len) {
+          const int j = s + i;
+          d = geoa3_sqdist(qx, qy, qz, Sb[j], Sb[N + j], Sb[2 * N + j]);
+          oi = Ib[j];
+        }
+        const bool pass = i < len && d <= tau;
+        const unsigned long long mask = __ballot(pass);
+        if (pass) L[cnt + __popcll(mask & lt)] = kg_key(d, oi);
+        cnt += __popcll(mask);
+        if (cnt > KG_CAP - 64) {                // wave-uniform, rare: keep the K best, tighten the radius
+          // rank counting over the list; the K smallest move to the front (through registers: 4 entries per lane)
+          unsigned long long mine[KG_CAP / 64];
+          int rk[KG_CAP / 64];
+#pragma unroll
+          for (int u = 0; u < KG_CAP / 64; ++u) {
+            const int c = lane + 64 * u;
+            mine[u] = c < cnt ? L[c] : ~0ull;
+            rk[u] = 0;
+          }
+          for (int j2 = 0; j2 < cnt; ++j2) {
+            const unsigned long long kj = L[j2];
+#pragma unroll
+            for (int u = 0; u < KG_CAP / 64; ++u) rk[u] += kj < mine[u] ? 1 : 0;
+          }
+          const int keep = cnt < K ? cnt : K;
+#pragma unroll
+          for (int u = 0; u < KG_CAP / 64; ++u)
+            if (lane + 64 * u < cnt && rk[u] < keep) L[rk[u]] = mine[u];
+          cnt = keep;
+          if (keep == K) tau = __uint_as_float((unsigned)(L[K - 1] >> 32));
+        }
+      }
+    }
+    if (cnt >= K || K > N || !(tau < S_INF)) break;
+    tau = S_INF;
+    }
+    // the K smallest of the list by (distance, index): every lane ranks its own entries
+    {
+      unsigned long long mine[KG_CAP / 64];
+      int rk[KG_CAP / 64];
+#pragma unroll
+      for (int u = 0; u < KG_CAP / 64; ++u) {
+        const int c = lane + 64 * u;
+        mine[u] = c < cnt ? L[c] : ~0ull;
+        rk[u] = 0;
+      }
+      for (int j2 = 0; j2 < cnt; ++j2) {
+        const unsigned long long kj = L[j2];
+#pragma unroll
+        for (int u = 0; u < KG_CAP / 64; ++u) rk[u] += kj < mine[u] ? 1 : 0;
+      }
+      float* od = dists + ((size_t)b * N + qo) * K;
+      int32_t* oi = idx + ((size_t)b * N + qo) * K;
+#pragma unroll
+      for (int u = 0; u < KG_CAP / 64; ++u)
+        if (lane + 64 * u < cnt && rk[u] < K) {
+          od[rk[u]] = __uint_as_float((unsigned)(mine[u] >> 32));
+          oi[rk[u]] = (int32_t)(unsigned)(mine[u] & 0xffffffffull);
+        }
+      for (int m = cnt + lane; m < K; m += 64) {   // fewer than K candidates (K > N): the all-pairs kernel's padding
+        od[m] = S_INF;
+        oi[m] = -1;
+      }
+    }
+  }
+}
+
+struct GridScratch {
+  float* sorted;
+  int32_t* sidx;
+  int32_t* cstart;
+  GridGeo* geo;
+  size_t total;
+};
+GridScratch grid_carve(void* base, int B, int N) {
+  GridScratch s{};
+  size_t off = 0;
+  char* p = static_cast<char*>(base);
+  auto take = [&](size_t bytes) {
+    void* r = p ? p + off : nullptr;
+    off += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  s.sorted = (float*)take((size_t)B * 3 * N * 4);
+  s.sidx = (int32_t*)take((size_t)B * N * 4);
+  s.cstart = (int32_t*)take((size_t)B * (KG_CELLS + 1) * 4);
+  s.geo = (GridGeo*)take((size_t)B * sizeof(GridGeo));
+  s.total = off;
+  return s;
+}
+
 struct SlabScratch {
   float* sorted;
   int32_t* sidx;
@@ -318,17 +594,27 @@ SlabScratch slab_carve(void* base, int B, int N) {
 
 extern "C" int64_t geoa3_knn_self_scratch_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return -1;
-  return (int64_t)slab_carve(nullptr, B, N).total;
+  const size_t a = slab_carve(nullptr, B, N).total, g = grid_carve(nullptr, B, N).total;
+  return (int64_t)(a > g ? a : g);
 }
 
 extern "C" int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_t* prior, float* dists, int32_t* idx,
-                              void* scratch, void* stream) {
+                              void* scratch, int method, void* stream) {
   if (!pc || !dists || !idx || B <= 0 || N <= 0 || K <= 0 || K > GEOA3_KNN_MAX_K) return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
   geoa3_prof_begin(GEOA3_PROF_KNN, s);
   int rc = GEOA3_OK;
+  // method 0: the cell grid (one wave per query) for large lists / large clouds, the slab kernel otherwise
+  const bool grid = method == 2 || (method == 0 && (K > 20 || N >= 2048));
   if (!prior || !scratch || N > SB_T * SB_PPT || K > N || ((uintptr_t)scratch & 255) != 0) {
     rc = geoa3_launch_knn(pc, pc, B, N, N, K, prior, dists, idx, nullptr, s);   // nothing to prune with
+  } else if (grid && K <= KG_CAP - 64) {
+    const GridScratch gs = grid_carve(scratch, B, N);
+    hipLaunchKernelGGL(knn_cellsort_kernel, dim3(B), dim3(KG_T), 0, s, pc, N, gs.sorted, gs.sidx, gs.cstart, gs.geo);
+    dim3 ggrid((N + 4 * KG_QPW - 1) / (4 * KG_QPW), B);
+    hipLaunchKernelGGL(knn_grid_kernel, ggrid, dim3(256), 0, s, pc, N, K, prior, gs.sorted, gs.sidx, gs.cstart, gs.geo,
+                       dists, idx);
+    if (hipGetLastError() != hipSuccess) rc = GEOA3_ELAUNCH;
   } else {
     const SlabScratch sc = slab_carve(scratch, B, N);
     hipLaunchKernelGGL(slab_bin_kernel, dim3(B), dim3(SB_T), 0, s, pc, N, sc.sorted, sc.sidx, sc.bstart, sc.geo);

@@ -76,8 +76,9 @@ def knn_self_scratch(B: int, N: int, device) -> Tensor:
 
 
 def knn_self_planar(pc: Tensor, K: int, prior: Optional[Tensor] = None, scratch: Optional[Tensor] = None,
-                    out=None) -> Tuple[Tensor, Tensor]:
-    """== knn_planar(pc, pc, K, prior) bit for bit; slab-pruned when prior and scratch are given."""
+                    out=None, method: int = 0) -> Tuple[Tensor, Tensor]:
+    """== knn_planar(pc, pc, K, prior) bit for bit; pruned when prior and scratch are given (method 1: slab along the
+    longest axis, 2: cell grid with one wavefront per query, 0: by (K, N))."""
     B, _, N = pc.shape
     if out is None:
         d = torch.empty(B, N, K, device=pc.device, dtype=torch.float32)
@@ -85,7 +86,7 @@ def knn_self_planar(pc: Tensor, K: int, prior: Optional[Tensor] = None, scratch:
     else:
         d, i = out
     check(_lib.load().geoa3_knn_self(_p(pc, torch.float32), B, N, K, _p(prior, torch.int32), _p(d), _p(i),
-                                     _p(scratch), _stream()), "geoa3_knn_self")
+                                     _p(scratch), int(method), _stream()), "geoa3_knn_self")
     return d, i
 
 

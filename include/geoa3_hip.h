@@ -69,15 +69,20 @@ int geoa3_grid_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, c
 int geoa3_knn(const float* q, const float* r, int B, int Nq, int Nr, int K,
               const int32_t* prior, float* dists, int32_t* idx, void* stream);
 
-/* Self K-NN of one cloud (q == r == pc, [B,3,N]) == geoa3_knn(pc, pc, B, N, N, K, prior, ...) bit for bit, with slab
- * pruning: the cloud is counting-sorted along its longest axis and each workgroup of queries scans only the
- * contiguous run of sorted points whose coordinate can lie within the queries' radius (the K-th distance among
- * `prior`).  Without `prior` or `scratch`, or for N > 8192, it runs the all-pairs kernel.  scratch:
+/* Self K-NN of one cloud (q == r == pc, [B,3,N]) == geoa3_knn(pc, pc, B, N, N, K, prior, ...) bit for bit, pruned by
+ * the radius `prior` gives (the K-th distance among last iteration's neighbours), with one of two searches:
+ *   method 1 (slab): the cloud is counting-sorted along its longest axis and each workgroup of queries scans only the
+ *            contiguous run of sorted points whose coordinate can lie within the queries' radius;
+ *   method 2 (grid): the cloud is counting-sorted into a 16^3 grid and ONE WAVEFRONT per query walks the cell rows its
+ *            ball touches, collects candidates by ballot and picks the K smallest by rank counting (no per-thread
+ *            lists: the form for K > 20 or N >= 2048);
+ *   method 0: picks by (K, N).
+ * Without `prior` or `scratch`, or for N > 8192, it runs the all-pairs kernel.  scratch:
  * geoa3_knn_self_scratch_bytes(B, N) bytes, 256-byte aligned, contents irrelevant.
  * Replaces knn_points(adv, adv, K=k+1) at Lib/loss_utils.py:77. */
 int64_t geoa3_knn_self_scratch_bytes(int B, int N);
 int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_t* prior, float* dists, int32_t* idx,
-                   void* scratch, void* stream);
+                   void* scratch, int method, void* stream);
 
 /* Graph-pruned forms of the two searches for the attack loop, where the searched cloud is adv = ori + offset and
  * `ori` is fixed for the whole batch (Attacker/geoA3_attack.py:281).  (gidx, gdist): ori's own neighbour table,

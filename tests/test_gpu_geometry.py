@@ -289,9 +289,10 @@ def test_slab_pruned_self_knn_is_bit_identical_to_brute_force(ops, N, K, scale):
     bad = clean.clone()
     bad[:, ::3, 1] = bad[:, ::3, 0]                  # duplicates: fewer than K distinct candidates within the radius
     bad[:, 1::7, 2] = N + 5                          # out of range: no radius
-    for prior in (clean, stale, bad, None):
-        d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch)
-        assert torch.equal(i, bi) and torch.equal(d, bd)
+    for method in (1, 2, 0):                         # slab, cell grid (one wavefront per query), the library's choice
+        for prior in (clean, stale, bad, None):
+            d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch, method=method)
+            assert torch.equal(i, bi) and torch.equal(d, bd), (method, prior is None)
     d, i = ops.knn_self_planar(advD, kk, prior=clean, scratch=None)
     assert torch.equal(i, bi) and torch.equal(d, bd)
     # in place over the prior (the loop's double buffer may alias)

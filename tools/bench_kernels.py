@@ -51,10 +51,15 @@ def main():
     res["knn_noprior_us"] = timeit(lambda: ops.knn_planar(adv, adv, k + 1), a.iters)
     res["knn_prior_us"] = timeit(lambda: ops.knn_planar(adv, adv, k + 1, knn_ori), a.iters)
     scratch = ops.knn_self_scratch(B, N, adv.device)
-    res["knn_slab_us"] = timeit(lambda: ops.knn_self_planar(adv, k + 1, knn_ori, scratch), a.iters)
+    res["knn_slab_us"] = timeit(lambda: ops.knn_self_planar(adv, k + 1, knn_ori, scratch, method=1), a.iters)
+    res["knn_grid_us"] = timeit(lambda: ops.knn_self_planar(adv, k + 1, knn_ori, scratch, method=2), a.iters)
     _, knn_far = ops.knn_planar(far, far, k + 1)
     res["knn_prior_far_us"] = timeit(lambda: ops.knn_planar(far, far, k + 1, knn_far), a.iters)
-    res["knn_slab_far_us"] = timeit(lambda: ops.knn_self_planar(far, k + 1, knn_far, scratch), a.iters)
+    res["knn_slab_far_us"] = timeit(lambda: ops.knn_self_planar(far, k + 1, knn_far, scratch, method=1), a.iters)
+    res["knn_grid_far_us"] = timeit(lambda: ops.knn_self_planar(far, k + 1, knn_far, scratch, method=2), a.iters)
+    # the attack's regime: a stale table (last iteration's, here the clean cloud's) as the radius
+    res["knn_grid_stale_us"] = timeit(lambda: ops.knn_self_planar(far, k + 1, knn_ori, scratch, method=2), a.iters)
+    res["knn_slab_stale_us"] = timeit(lambda: ops.knn_self_planar(far, k + 1, knn_ori, scratch, method=1), a.iters)
     kap = ops.kappa(ori, nrm, knn_ori)
     res["kappa_us"] = timeit(lambda: ops.kappa(ori, nrm, knn_ori), a.iters)
     d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(adv, ori)
