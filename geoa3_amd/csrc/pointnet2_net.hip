@@ -268,6 +268,7 @@ int conv_slice(const float* X, int Kfull, int k0, int K, const float* W, const f
   a.Y = Y; a.sYb = (long)Co * N; a.ldY = N;
   a.Co = Co; a.K = K; a.N = N; a.B = B;
   a.relu = relu; a.accumulate = accumulate;
+  a.pack2 = N <= 128;   // level 3's [B][C][128] tensors: two instances per workgroup
   return launch_conv_cm(a, s);
 }
 

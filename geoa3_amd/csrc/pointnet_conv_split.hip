@@ -51,9 +51,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
   // grid (row blocks, column blocks, instances): the row blocks of one column tile are dispatched back to back, so
   // the tile is read from HBM once and from L2 by the others (with the row block as grid.z a 256-channel layer read
   // its input four times)
-  const int rb = blockIdx.x, cblk = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = cblk * 256 + wave * 64 + lane;
-  const bool live = col < a.N;
+  // a.pack2 (N <= 128, shared weights): two instances per workgroup, waves 0-1 the columns of instance 2 z, waves 2-3
+  // those of 2 z + 1 -- a [B][C][128] tensor (PointNet++ level 3) keeps all four waves busy
+  const int rb = blockIdx.x, cblk = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bz = a.pack2 ? 2 * blockIdx.z + (wave >> 1) : blockIdx.z;
+  const bool b_ok = bz < a.B;
+  const int b = b_ok ? bz : a.B - 1;
+  const int col = a.pack2 ? (wave & 1) * 64 + lane : cblk * 256 + wave * 64 + lane;
+  const bool live = b_ok && col < a.N;
   const float* X = (FIRST || PN2 == 2) ? nullptr : a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
   // PN2: this wave's centre (its 64 columns are the centre's samples)
   const int centres = a.N >> 6, centre = cblk * 4 + wave;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
   const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
   const int n64 = (a.N + 63) >> 6;
   const size_t mword = ((size_t)b * n64 + (size_t)(cblk * 4 + wave)) * a.Co;   // bit masks [B][column block][row]
-  const bool wave_live = cblk * 256 + wave * 64 < a.N;
+  const bool wave_live = b_ok && (a.pack2 ? (wave & 1) * 64 : cblk * 256 + wave * 64) < a.N;
   unsigned long long mymask = 0ull;
   float q0 = 0.f, q1 = 0.f, q2 = 0.f;   // BWD3: d/d(T^T x) of this lane's point, summed over the 64 rows
 #pragma unroll
@@ -360,7 +365,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
 int launch_conv_cm_split(const ConvArgs& a, hipStream_t s) {
   if ((a.K != 64 && a.K != 128 && a.K != 256) || a.Co <= 0 || a.Co % 64 != 0) return GEOA3_ENOSUPPORT;
   const size_t lds = (size_t)2 * 64 * (a.K * 2 + 16) + 64 * 16 + 44 * 4;
-  dim3 grid(a.Co / 64, (a.N + 255) / 256, a.B);
+  if (a.pack2 && (a.N > 128 || a.sWb != 0 || a.Ymask || a.Zmask || a.pool_out || a.oh_g || a.produce_first || a.gate_first))
+    return GEOA3_EINVAL;
+  dim3 grid(a.Co / 64, a.pack2 ? 1 : (a.N + 255) / 256, a.pack2 ? (a.B + 1) / 2 : a.B);
   if (a.pool_out || a.oh_g) {   // PointNet++ forms: a wave = one centre
     if (a.N % 64 != 0 || a.produce_first || a.gate_first) return GEOA3_ENOSUPPORT;
     if (a.pool_out && (!a.pool_arg || !a.pool_bias || a.K != 128 || a.oh_g)) return GEOA3_ENOSUPPORT;

@@ -40,6 +40,7 @@ struct ConvArgs {
   float* dx3;                                 // [B][3][N] or null (= write Y as usual)
   float* dTpart;
   int split;                                  // 1: split-fp16 operands on the f16 matrix pipe (pointnet_conv_split.hip)
+  int pack2;                                  // split kernel, N <= 128, shared weights: two instances per workgroup
   // PointNet++ shared-MLP forms (split kernel only; a wave's 64 columns = the 64 samples of ONE centre, N % 64 == 0):
   // pool_out: the output is max-pooled over each centre's samples in the epilogue instead of being written,
   //           pool_out[b][co][m] = relu(max_s y + pool_bias[co]), pool_arg = first maximal sample (Y unused);
