@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--instances", type=int, default=0,
                     help="instances held by EACH GPU (overrides the split): 32 = one rank's shard of the 8-GPU run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-proxy-full", action="store_true",
+                    help="shard proxy (--instances): skip the full 250-instance comparison run (profiling)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(host cores, 32), see cpu_baseline)")
     ap.add_argument("--single-mode", action="store_true",
                     help="skip the second, shorter measurement in the strict fp32-MFMA mode of the convolutions")
@@ -262,7 +264,7 @@ def main():
         odt, okms, _ = measure(omode, osteps, min(a.warmup, 5), min(a.presteps, 60))
         other = (omode, osteps, odt, okms)
     proxy = None
-    if mode == "shard-proxy" and a.arch == "PointNet":
+    if mode == "shard-proxy" and a.arch == "PointNet" and not a.no_proxy_full:
         # the full 250-instance batch on this GPU in the same process: what linear scaling is measured against
         fo, fn = synthetic_clouds(BATCH, npoint, seed=100)
         fo, fn = fo.to(dev), fn.to(dev)

@@ -83,6 +83,8 @@ SIGNATURES = {
     "geoa3_pointnet_backward": (C.c_int, [C.POINTER(PointNetWeights), vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_attack_head": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "geoa3_attack_head_vote": (C.c_int, [C.POINTER(AttackState), vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "geoa3_attack_head_classify": (C.c_int, [C.POINTER(AttackState), vp, vp, C.c_int, vp, vp, vp]),
+    "geoa3_attack_head_finish": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, C.c_int, C.c_int, vp]),
     "geoa3_attack_update": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float,
                                       C.c_float, C.c_float, vp]),
     "geoa3_attack_partial_step": (C.c_int, [C.POINTER(AttackState), vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,

@@ -107,6 +107,12 @@ class AttackRunner:
                            else None)
         self.ev_x, self.ev_geo = ((torch.cuda.Event(), torch.cuda.Event()) if self.geo_stream is not None
                                   else (None, None))
+        # Small shards (the 32-instance regime of an 8-GPU split) are latency bound: there the geometry chain is as long
+        # as the forward, so the head is split (geoa3_attack_head_classify / _finish) and the geometry stream is joined
+        # only AFTER the victim's backward.  At 250 instances the kernels are throughput bound and the late join gains
+        # nothing (measured), so it is taken for b <= 96 unless GEOA3_LATE_JOIN says otherwise.  Same results.
+        lj = os.environ.get("GEOA3_LATE_JOIN", "auto")
+        self.late_join = (b <= 96) if lj == "auto" else lj == "1"
         # the 1-NN tables through the uniform-grid search (geom_grid.hip; same bits as the all-pairs kernel, which
         # stays the path for clouds beyond 4096 points or when cfg.brute_force_nn1 is set)
         self.grid_nn1 = max(n, self.ne) <= 4096 and not _cfg(cfg, "brute_force_nn1", False)
@@ -139,6 +145,7 @@ class AttackRunner:
         for name in ("best_step", "best_bs", "iter_best_score", "label"):
             t[name] = torch.zeros(b, **i32)
         t["last_label"] = torch.zeros(1, **i32)
+        t["ok"] = torch.zeros(b, **i32)
         t["loss_hist"] = z(self.iters, b)
         t["logits"], t["dlogits"] = z(b, self.classes), z(b, self.classes)
         t["d_ao"], t["d_oa"] = z(b, ne), z(b, n)
@@ -376,13 +383,20 @@ class AttackRunner:
                                   w_hd=float(cfg.hd_loss_weight), w_curv=float(cfg.curv_loss_weight), out=self.geo_out,
                                   deterministic=self.deterministic)
                 constrain = self.geo_out["constrain"]
-        if self.geo_stream is not None:     # join: the head needs the constrain loss, the update the gradient
+        late = self.late_join and self.geo_stream is not None
+        if self.geo_stream is not None:     # join: the bookkeeping needs the constrain loss, the update the gradient
             self.ev_geo.record(self.geo_stream)
-            main.wait_event(self.ev_geo)
-        check(lib.geoa3_attack_head_vote(st, t["logits"].data_ptr(), self._p(vote_logits),
-                                         self.eval_num if self.sub else 1,
-                                         self._p(constrain), x.data_ptr(), step, search_step,
-                                         t["dlogits"].data_ptr(), s), "attack_head")
+            if not late:
+                main.wait_event(self.ev_geo)
+        if late:   # the classification half of the head now, the victim's backward beside the geometry kernels
+            check(lib.geoa3_attack_head_classify(st, t["logits"].data_ptr(), self._p(vote_logits),
+                                                 self.eval_num if self.sub else 1, t["dlogits"].data_ptr(),
+                                                 t["ok"].data_ptr(), s), "attack_head_classify")
+        else:
+            check(lib.geoa3_attack_head_vote(st, t["logits"].data_ptr(), self._p(vote_logits),
+                                             self.eval_num if self.sub else 1,
+                                             self._p(constrain), x.data_ptr(), step, search_step,
+                                             t["dlogits"].data_ptr(), s), "attack_head")
         g_cls = None
         if cfg.cls_loss_type != "None":
             if self.native:
@@ -391,6 +405,10 @@ class AttackRunner:
                 logits_ag.backward(t["dlogits"])
                 t["g_cls"].copy_(x_leaf.grad)
             g_cls = t["g_cls"]
+        if late:
+            main.wait_event(self.ev_geo)
+            check(lib.geoa3_attack_head_finish(st, t["ok"].data_ptr(), self._p(constrain), x.data_ptr(), step,
+                                               search_step, s), "attack_head_finish")
         g_geo = t["g_geo"] if constrain is not None else None
         if self.sub:   # torch.gather's backward (Lib/utility.py:185): scatter the sample's gradient to the full cloud
             for src, dst in ((g_cls, "g_cls_full"), (g_geo, "g_geo_full")):

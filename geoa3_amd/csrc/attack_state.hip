@@ -16,12 +16,40 @@ __global__ __launch_bounds__(HEAD_BLOCK) void attack_head_kernel(geoa3_attack_st
                                                                  const float* __restrict__ vote_logits, int eval_num,
                                                                  const float* __restrict__ constrain,
                                                                  const float* __restrict__ x, int step,
-                                                                 int search_step, float* __restrict__ dlogits) {
+                                                                 int search_step, float* __restrict__ dlogits,
+                                                                 int phase, int32_t* __restrict__ okbuf) {
+  // phase 0: everything.  phase 1: the classification part only (loss, d loss / d logits, label, success flag ->
+  // okbuf) -- it does not need the constrain loss, so the victim's backward can start while the geometry kernels still
+  // run; phase 2: the bookkeeping of geoA3_attack.py:297-310 from what phase 1 stored, once the constrain loss is there.
   __shared__ int s_copy;
   __shared__ int s_vote[GEOA3_WAVE];
   const int b = blockIdx.x, tid = threadIdx.x, C = st.classes;
   const float* lg = logits + (size_t)b * C;
-  if (tid < GEOA3_WAVE) {
+  if (phase == 2) {
+    if (tid == 0) {
+      const float cls = st.cls_loss[b];
+      const int am = st.label[b];
+      const bool ok = okbuf[b] != 0;
+      const float con = constrain ? constrain[b] : 0.f;
+      const float ln = cls + st.scale_const[b] * con;
+      st.loss_n[b] = ln;
+      if (st.loss_hist) st.loss_hist[(size_t)step * st.B + b] = ln;
+      const float metric = st.prev_constrain[b];
+      int copy = 0;
+      if (ok && metric < st.best_loss[b]) {
+        st.best_loss[b] = metric;
+        st.best_step[b] = step;
+        st.best_bs[b] = search_step;
+        copy = 1;
+      }
+      if (ok && metric < st.iter_best_loss[b]) {
+        st.iter_best_loss[b] = metric;
+        st.iter_best_score[b] = am;
+      }
+      st.prev_constrain[b] = con;
+      s_copy = copy;
+    }
+  } else if (tid < GEOA3_WAVE) {
     const int lane = tid;
     const int tgt = st.target[b];
     // arg-max (first maximal index, as torch.argmax) and max over c != target
@@ -108,7 +136,13 @@ __global__ __launch_bounds__(HEAD_BLOCK) void attack_head_kernel(geoa3_attack_st
       am = lab;
       ok = (float)n_ok > 0.5f * (float)eval_num;
     }
-    if (lane == 0) {
+    if (lane == 0 && phase == 1) {
+      st.cls_loss[b] = cls;
+      st.label[b] = am;
+      if (b == st.B - 1) *st.last_label = am;
+      okbuf[b] = ok ? 1 : 0;
+      s_copy = 0;
+    } else if (lane == 0) {
       const float con = constrain ? constrain[b] : 0.f;
       const float ln = cls + st.scale_const[b] * con;
       st.cls_loss[b] = cls;
@@ -344,7 +378,27 @@ extern "C" int geoa3_attack_head_vote(const geoa3_attack_state* st, const float*
   if (!st || !logits || !x || !dlogits || st->B <= 0 || st->classes <= 0) return GEOA3_EINVAL;
   if (vote_logits && (eval_num <= 0 || eval_num > GEOA3_WAVE)) return GEOA3_EINVAL;
   hipLaunchKernelGGL(attack_head_kernel, dim3(st->B), dim3(HEAD_BLOCK), 0, geoa3_stream(stream), *st, logits,
-                     vote_logits, eval_num, constrain, x, step, search_step, dlogits);
+                     vote_logits, eval_num, constrain, x, step, search_step, dlogits, 0, (int32_t*)nullptr);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_attack_head_classify(const geoa3_attack_state* st, const float* logits, const float* vote_logits,
+                                          int eval_num, float* dlogits, int32_t* ok, void* stream) {
+  if (!st || !logits || !dlogits || !ok || st->B <= 0 || st->classes <= 0) return GEOA3_EINVAL;
+  if (vote_logits && (eval_num <= 0 || eval_num > GEOA3_WAVE)) return GEOA3_EINVAL;
+  hipLaunchKernelGGL(attack_head_kernel, dim3(st->B), dim3(HEAD_BLOCK), 0, geoa3_stream(stream), *st, logits,
+                     vote_logits, eval_num, (const float*)nullptr, (const float*)nullptr, 0, 0, dlogits, 1, ok);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+extern "C" int geoa3_attack_head_finish(const geoa3_attack_state* st, const int32_t* ok, const float* constrain,
+                                        const float* x, int step, int search_step, void* stream) {
+  if (!st || !ok || !x || st->B <= 0) return GEOA3_EINVAL;
+  hipLaunchKernelGGL(attack_head_kernel, dim3(st->B), dim3(HEAD_BLOCK), 0, geoa3_stream(stream), *st,
+                     (const float*)nullptr, (const float*)nullptr, 0, constrain, x, step, search_step, (float*)nullptr, 2,
+                     const_cast<int32_t*>(ok));
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

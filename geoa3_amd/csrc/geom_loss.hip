@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void kappa_kernel(const float* __restrict__ pc
 // ------------------------------------------------------------------------------------------
 // Fused objective: one workgroup per instance.
 // ------------------------------------------------------------------------------------------
-constexpr int GEO_BLOCK = 512;
+constexpr int GEO_BLOCK = 1024;
 constexpr int GEO_WAVES = GEO_BLOCK / GEOA3_WAVE;
 
 struct MaxIdx {

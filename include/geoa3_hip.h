@@ -253,6 +253,14 @@ int geoa3_attack_head(const geoa3_attack_state* st, const float* logits, const f
 int geoa3_attack_head_vote(const geoa3_attack_state* st, const float* logits, const float* vote_logits, int eval_num,
                            const float* constrain, const float* x, int step, int search_step, float* dlogits,
                            void* stream);
+/* The same step in two launches, for callers that overlap the geometry kernels with the victim's backward:
+ * _classify = the part that needs only the logits (cls_loss, label, last_label, d loss / d logits, the success flag of
+ * geoA3_attack.py:297-300 -> ok [B] int32); _finish = loss_n / loss history and the best-so-far bookkeeping of
+ * :301-310 once the constrain loss is known.  _classify + _finish == geoa3_attack_head_vote bit for bit. */
+int geoa3_attack_head_classify(const geoa3_attack_state* st, const float* logits, const float* vote_logits, int eval_num,
+                               float* dlogits, int32_t* ok, void* stream);
+int geoa3_attack_head_finish(const geoa3_attack_state* st, const int32_t* ok, const float* constrain, const float* x,
+                             int step, int search_step, void* stream);
 
 /* Per step, after both backward passes: g = g_cls + scale_const[b]*inv_global_batch*g_geo, then the
  * optimiser update of `offset` (torch.optim.Adam defaults or plain SGD, geoA3_attack.py:269-272,

@@ -223,3 +223,22 @@ def test_pointnetpp_attack_matches_oracle():
     np.testing.assert_allclose(np.asarray(all_loss, dtype=np.float32), np.asarray(oloss, dtype=np.float32),
                                rtol=5e-3, atol=2e-3)
     assert (np.asarray(succ) == osucc).mean() >= 0.66
+
+
+def test_late_join_equals_early_join(net, golden, monkeypatch):
+    """The split head (geoa3_attack_head_classify + _finish, geometry joined after the victim's backward: the small-shard
+    schedule) and the single head (geometry joined before it) give the same bits."""
+    kw, targeted, _, _ = ATK_CASES["target_full"]
+    cfg = O.AttackCfg(**kw)
+    pre = "atk/target_full/"
+    ori, nrm, gt, tgt = (T(golden[pre + n]) for n in ("ori", "nrm", "gt", "tgt"))
+    inits = [T(a) for a in golden[pre + "inits"]]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GEOA3_LATE_JOIN", mode)
+        r, out, xs, labels = _run(net, cfg, ori, nrm, gt, tgt, targeted, inits)
+        assert r.late_join == (mode == "1")
+        res[mode] = (out, xs, labels, r.t["loss_hist"].cpu().clone())
+    assert np.array_equal(res["1"][1], res["0"][1]) and np.array_equal(res["1"][2], res["0"][2])
+    assert torch.equal(res["1"][0][0], res["0"][0][0]) and torch.equal(res["1"][3], res["0"][3])
+    assert (res["1"][0][2] == res["0"][0][2]).all() and list(res["1"][0][3]) == list(res["0"][0][3])
