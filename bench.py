@@ -98,13 +98,20 @@ def cpu_baseline(arch, npoint, knn, budget_s=20.0, threads=0):
                       "/ 250" % (arch, npoint, knn, b, iters, dt, threads)}
 
 
-def pmc_traffic(kernel_substr, prefer):
-    """HBM bytes per launch of a kernel from a committed rocprofv3 PMC summary (profiles/*_pmc.csv: separate
-    FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md).  `prefer`: substring of the summary to look at (newest match).  None when absent."""
+def pmc_traffic(kernel_substr, cfg_tag):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary of this configuration
+    (profiles/round*_<cfg_tag>_pmc.csv, the newest round/version by name: separate FETCH_SIZE / WRITE_SIZE passes of this
+    same command, tools/gpu_profiles.sh; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  None when
+    absent."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*%s*_pmc.csv" % prefer)), key=os.path.getmtime)
+    import re
+
+    def version(f):
+        m = re.search(r"round(\d+)_v(\d+)", os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "round*_%s_pmc.csv" % cfg_tag)), key=version)
     for f in reversed(files):
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel"]:
@@ -334,7 +341,7 @@ def main():
         }
         if a.arch == "PointNet" and npoint < 4096:
             out["roofline"] = conv5_roofline(wmode, kms.get(TAG_CONV5))
-            tr, src = pmc_traffic("wide_split_kernel<3" if wmode == "f16x2" else "wide_max2_kernel<3", "")
+            tr, src = pmc_traffic("wide_split_kernel<3" if wmode == "f16x2" else "wide_max2_kernel<3", "c2")
             if tr is not None and B == BATCH and npoint == 1024 and out["roofline"]:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % src
@@ -345,13 +352,13 @@ def main():
             ms = kms.get(TAG_KNN)
             bytes_ = B * npoint * (12.0 + (knn + 1) * 8.0)
             out["roofline"] = None if not ms else {
-                "bound": "hbm", "kernel": "knn_slab_kernel (self top-%d, slab-pruned)" % (knn + 1),
+                "bound": "hbm", "kernel": "knn_grid_kernel (self top-%d on a 16^3 cell grid, one wavefront per query)" % (knn + 1),
                 "achieved": round(bytes_ / (ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                 "frac": round(bytes_ / (ms * 1e-3) / PEAK_HBM, 5), "avg_launch_ms": round(ms, 4),
                 "algorithmic_bytes_per_launch": bytes_,
                 "valu_frac_vs_all_pairs_flops": round(8.0 * B * npoint * npoint / (ms * 1e-3) / PEAK_F32_VALU, 4),
                 "traffic": None}
-            tr, src = pmc_traffic("knn_slab_kernel", "config5")
+            tr, src = pmc_traffic("knn_grid_kernel", "c5")
             if tr is not None and out["roofline"] and B == BATCH:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, "profiles/" + src
         else:
@@ -365,7 +372,7 @@ def main():
                 "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                 "frac": round(flops / (ms * 1e-3) / PEAK_F16_MFMA, 4), "avg_launch_ms": round(ms, 4),
                 "algorithmic_flops_per_launch": flops, "traffic": None}
-            tr, src = pmc_traffic("sa1_bwd_kernel", "config4")
+            tr, src = pmc_traffic("sa1_bwd_kernel", "c4")
             if tr is not None and out["roofline"] and B == BATCH:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, "profiles/" + src
         if other is not None:
