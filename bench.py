@@ -295,8 +295,11 @@ def main():
                 return None
             ach = conv5_flops / (ms * 1e-3)
             if m == "f16x2":
-                return {"bound": "mfma", "kernel": "wide_split_kernel<3> (conv5+bn5+relu+max; fp32 operands carried as "
-                                                   "two fp16 values on the f16 matrix pipe, fp32 accumulate)",
+                from geoa3_amd.pointnet import wide_shape
+                kname = ("wide16_kernel<3> (v_mfma_f32_16x16x32_f16)" if wide_shape("conv5") == 16
+                         else "wide_split_kernel<3> (v_mfma_f32_32x32x16_f16)")
+                return {"bound": "mfma", "kernel": kname + ": conv5+bn5+relu+max; fp32 operands carried as two fp16 "
+                                                           "values on the f16 matrix pipe, fp32 accumulate",
                         "achieved": round(ach / 1e12, 1), "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F16_MFMA, 4), "avg_launch_ms": round(ms, 4),
                         "algorithmic_flops_per_launch": conv5_flops,
@@ -341,7 +344,9 @@ def main():
         }
         if a.arch == "PointNet" and npoint < 4096:
             out["roofline"] = conv5_roofline(wmode, kms.get(TAG_CONV5))
-            tr, src = pmc_traffic("wide_split_kernel<3" if wmode == "f16x2" else "wide_max2_kernel<3", "c2")
+            from geoa3_amd.pointnet import wide_shape
+            tr, src = pmc_traffic(("wide16_kernel<3" if wide_shape("conv5") == 16 else "wide_split_kernel<3")
+                                  if wmode == "f16x2" else "wide_max2_kernel<3", "c2")
             if tr is not None and B == BATCH and npoint == 1024 and out["roofline"]:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % src

@@ -157,8 +157,10 @@ struct FrontLayer {
   unsigned long long* m128;
 };
 int wide(const float* X, const float* W, const void* Wh, float unscale, const float* bias, float* out, int* arg,
-         unsigned long long* keys, int taps, int B, int N, hipStream_t s, const FrontLayer* f = nullptr) {
+         unsigned long long* keys, int taps, int B, int N, hipStream_t s, const FrontLayer* f = nullptr,
+         const void* Wh16 = nullptr) {
   WideArgs a{};
+  a.Wh16 = Wh16;
   if (f) {
     a.W2h = f->w2h; a.w2_unscale = f->w2_unscale; a.W2f = f->w2; a.b2 = f->b2;
     a.Xin = f->h64; a.sXinb = (long)64 * N; a.ldXin = N;
@@ -196,7 +198,7 @@ int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* 
   } else {
     if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s, m128));
     else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s, m128));
-    TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s));
+    TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, nullptr, t.w3h16));
   }
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
   TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
@@ -267,7 +269,7 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
     TRY(wide(nullptr, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, &f));
   } else {
     TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s, w.m_h4));
-    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s));
+    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16));
   }
   // classifier head (:150-152), dropout is the identity in eval mode
   TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));

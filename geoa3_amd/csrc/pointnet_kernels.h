@@ -78,6 +78,7 @@ struct WideArgs {
   unsigned long long* keys;                   // [B][Co] scratch of the column-major kernel (packed running maxima)
   int Co, N, B, taps;
   const void* Wh;                             // split-fp16 fragments (pointnet_wide_split.hip) or null = fp32 MFMA
+  const void* Wh16;                           // the same weights as 16x16x32 fragments (pointnet_wide16.hip); takes precedence
   float unscale;                              // 1 / (power-of-two scale of Wh)
   int keys_clean;                             // 1: keys are already zero (wide_finalize_kernel leaves them zero): no memset
   int variant;                                // tuning variant of the split kernel (geoa3_debug_wide_fwd; 0 = shipped)
@@ -94,6 +95,7 @@ struct WideArgs {
 };
 int launch_wide_max(const WideArgs& a, hipStream_t s);          // dispatches on a.Wh
 int launch_wide_max_split(const WideArgs& a, hipStream_t s);    // pointnet_wide_split.hip
+int launch_wide_max_split16(const WideArgs& a, hipStream_t s);  // pointnet_wide16.hip
 void launch_wide_finalize(const WideArgs& a, hipStream_t s);    // keys -> out (bias + relu), arg
 
 // packed running maximum of the 1024-wide layers: (order-preserving value bits, ~point index) under a 64-bit atomicMax

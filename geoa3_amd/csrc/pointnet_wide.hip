@@ -524,6 +524,7 @@ void launch_wide_finalize(const WideArgs& a, hipStream_t s) {
 }
 
 int launch_wide_max(const WideArgs& a, hipStream_t s) {
+  if (a.Wh16 && !a.W2h) return launch_wide_max_split16(a, s);
   if (a.Wh) return launch_wide_max_split(a, s);
   if (a.Co != 8 * WM_CO || (a.taps != 1 && a.taps != 3) || !a.keys) return GEOA3_ENOSUPPORT;
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;

@@ -60,6 +60,30 @@ def pack_wide_split(w: Tensor, taps: int):
     return frag, float(2.0 ** -e)
 
 
+def pack_wide_split16(w: Tensor):
+    """pack_wide_split for the 16x16x32 MFMA shape (csrc/pointnet_wide16.hip): the same scaled hi / lo pieces as
+    [T = Co/16][s = K/32][piece][lane = 16q + r][j] = piece(w[16T + r][32s + 8q + j])."""
+    w = w.float()
+    co, K = w.shape
+    amax = float(w.abs().max())
+    e = 13 - int(torch.frexp(torch.tensor(amax)).exponent) + 1 if amax > 0 else 0
+    v = torch.ldexp(w, torch.tensor(e))
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    frag = torch.stack((hi, lo), 0).reshape(2, co // 16, 16, K // 32, 4, 8)       # p, T, r, s, q, j
+    return frag.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1, 8), float(2.0 ** -e)   # T, s, p, (q, r), j
+
+
+def wide_shape(layer: str = "conv5") -> int:
+    """MFMA shape of a split 1024-wide layer: 16 = v_mfma_f32_16x16x32_f16 (pointnet_wide16.hip), 32 =
+    v_mfma_f32_32x32x16_f16 (pointnet_wide_split.hip).  Measured on MI355X: conv5 (K = 384 per group) 0.495 -> 0.444 ms on
+    the 16x16x32 shape, the T-Nets' conv3 (K = 128 per group: a third of the MFMAs between two epilogues) 0.182 -> 0.292 ms
+    -- so conv5 defaults to 16, the T-Nets to 32.  GEOA3_WIDE_SHAPE / GEOA3_WIDE_SHAPE_TNET override."""
+    if layer == "conv5":
+        return int(os.environ.get("GEOA3_WIDE_SHAPE", "16"))
+    return int(os.environ.get("GEOA3_WIDE_SHAPE_TNET", "32"))
+
+
 def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     eps = 1e-3  # transform_net.eps, Model/PointNet.py:59
     sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
@@ -78,6 +102,7 @@ def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     out = {k: v.float().contiguous() for k, v in out.items()}
     out["w3h"], out["w3h_unscale"] = pack_wide_split(out["w3"], 1)
     out["w2h"], out["w2h_unscale"] = pack_wide_split(out["w2"], 1)
+    out["w3h16"], _ = pack_wide_split16(out["w3"])
     return out
 
 
@@ -102,6 +127,7 @@ def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
     out.update({k: v.float().contiguous() for k, v in t.items()})
     out["w5h"], out["w5h_unscale"] = pack_wide_split(out["w5"], 3)
     out["w4h"], out["w4h_unscale"] = pack_wide_split(out["w4"], 1)
+    out["w5h16"], _ = pack_wide_split16(out["w5"])
     return out
 
 
@@ -149,6 +175,10 @@ class PackedPointNet:
 
         def pick(p: Dict[str, object], name: str):
             if name in ("w3h", "w5h", "w2h", "w4h") and (not split or (name in ("w2h", "w4h") and not fuse_front())):
+                return None
+            if name == "w5h16" and (not split or wide_shape("conv5") != 16):
+                return None
+            if name == "w3h16" and (not split or wide_shape("tnet") != 16):
                 return None
             return dev(p[name])
 
@@ -243,7 +273,7 @@ class PointNet(nn.Module):
         self.wide_mode: Optional[str] = None       # None = GEOA3_WIDE_MODE / 'f16x2'; see default_wide_mode()
 
     def _weights_key(self, device):
-        return (str(device), self.wide_mode or default_wide_mode(), fuse_front()) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (str(device), self.wide_mode or default_wide_mode(), fuse_front(), wide_shape("conv5"), wide_shape("tnet")) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def packed(self, device) -> PackedPointNet:
         key = self._weights_key(device)

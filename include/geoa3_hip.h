@@ -166,6 +166,10 @@ typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 
                                conv1 of the 3-channel T-Net) is evaluated inside conv3's staging pass: its [B,128,N]
                                activation is never written, only its relu gate bits */
   float w2h_unscale;
+  const void *w3h16;        /* optional, with w3h: the same split weights in 16x16x32 fragment order
+                               [T = co/16][s = k/32][piece][lane][j] = piece(w3[16T + (lane&15)][32s + 8(lane>>4) + j])
+                               (same scale: w3h_unscale): the layer then runs on `v_mfma_f32_16x16x32_f16`
+                               (csrc/pointnet_wide16.hip) -- same arithmetic, higher sustained clock */
 } geoa3_tnet_weights;
 
 typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 */
@@ -194,6 +198,7 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
   float w5h_unscale;        /* 2^-e */
   const void *w4h;          /* optional, with w5h: w4 as split-fp16 fragments (K = 64): conv4 inside conv5's staging pass */
   float w4h_unscale;
+  const void *w5h16;        /* optional, with w5h: w5 in 16x16x32 fragment order (see t3.w3h16) */
 } geoa3_pointnet_weights;
 
 /* bytes of scratch the forward+backward pair needs for a batch of B clouds of N points */
