@@ -241,6 +241,34 @@ __global__ __launch_bounds__(256) void affine3_grad_kernel(const float* __restri
     q[2] = sign * a2;
   }
 }
+// out[b][c][m][s] = relu(PT[b][idx[b][m][s]][c] + shift[b][c][m]), C = 128, S = 64: geoa3_pn2_group_shift_relu with the
+// source POINT-major, so a lane gathers its sample's 128 channels as 32 16-byte loads of one 512-byte row instead of
+// 128 4-byte loads from 128 rows (the channel-major form is bound by the texture addresser: one lane per cycle per CU,
+// 0.46 ms for [250,128,128,64]).  One wavefront per (instance, centre); stores are 256-byte rows as before.
+__global__ __launch_bounds__(256) void group_shift_relu_t_kernel(const float* __restrict__ PT, const int32_t* __restrict__ idx,
+                                                                 const float* __restrict__ shift, float* __restrict__ out,
+                                                                 int N, int M) {
+  const int b = blockIdx.y, j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= M) return;
+  const int i = idx[((size_t)b * M + j) * 64 + lane];
+  const float4* src = reinterpret_cast<const float4*>(PT + ((size_t)b * N + i) * 128);
+  const float sh0 = shift[((size_t)b * 128 + lane) * M + j], sh1 = shift[((size_t)b * 128 + 64 + lane) * M + j];
+  float* O = out + ((size_t)b * 128 * M + j) * 64 + lane;
+  const size_t cs = (size_t)M * 64;
+#pragma unroll
+  for (int c4 = 0; c4 < 32; ++c4) {
+    const float4 g = src[c4];
+    const int sv = __float_as_int(c4 < 16 ? sh0 : sh1), l0 = (4 * c4) & 63;
+    const float s0 = __int_as_float(__builtin_amdgcn_readlane(sv, l0));
+    const float s1 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 1));
+    const float s2 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 2));
+    const float s3 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 3));
+    O[(4 * c4 + 0) * cs] = fmaxf(g.x + s0, 0.f);
+    O[(4 * c4 + 1) * cs] = fmaxf(g.y + s1, 0.f);
+    O[(4 * c4 + 2) * cs] = fmaxf(g.z + s2, 0.f);
+    O[(4 * c4 + 3) * cs] = fmaxf(g.w + s3, 0.f);
+  }
+}
 // a[i] += b[i]
 __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -314,7 +342,9 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
                      w.nx1, 128, M1, 0, (long)B * 128 * M1);                                               // + W_x xyz
   hipLaunchKernelGGL(affine3_kernel, g1d((long)B * 128 * M2), dim3(256), 0, s, p.sa2_wx, p.sa2_b0, w.nx2, -1.f, w.shift,
                      128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
-  TRY(geoa3_pn2_group_shift_relu(w.r, w.gidx2, w.shift, B, 128, M1, M2, S, w.a0, stream));
+  float* rt = w.df1;   // [B,512,128]: r point-major (a backward buffer, free in forward)
+  TRY((transpose<float, false>(w.r, nullptr, rt, B, 128, M1, s)));
+  hipLaunchKernelGGL(group_shift_relu_t_kernel, dim3((M2 + 3) / 4, B), dim3(256), 0, s, rt, w.gidx2, w.shift, w.a0, M1, M2);
   TRY(geoa3_conv1x1(w.a0, p.sa2_w1, p.sa2_b1, nullptr, w.a1, B, (long)M2 * S, 128, 128, 1, stream));
   TRY(geoa3_conv1x1_max64(w.a1, p.sa2_w2, p.sa2_b2, w.out2, w.arg2, B, (long)M2 * S, 128, C2, stream));
   // ---- level 3 (:78-82, GroupAll): MLP (256 + 3) -> 256 -> 512 -> 1024 on the 128 points, max over them

@@ -142,6 +142,47 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
   }
 }
 
+// nsample <= 64 and the cloud in LDS: one WAVEFRONT per centre, lane = point of a 64-point chunk.  The hits of a chunk
+// are a ballot; a hit's slot is the running count + the number of hits below its lane (index order kept), the row of
+// `nsample` indices is assembled in LDS and leaves as one coalesced store (no memset, no per-hit global writes; the
+// thread-per-centre form above ran 250 us for 512 centres x 1024 points x 250 instances).
+constexpr int BQW_CPW = 8;   // centres per wavefront
+__global__ __launch_bounds__(256) void ball_query_wave_kernel(const float* __restrict__ new_xyz,
+                                                              const float* __restrict__ xyz, int N, int M, float radius2,
+                                                              int nsample, int32_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float s_bq[];   // x[N], y[N], z[N], rows [4][64]
+  float *s_x = s_bq, *s_y = s_bq + N, *s_z = s_bq + 2 * N;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* row = reinterpret_cast<int*>(s_bq + 3 * N) + wave * 64;
+  for (int e = tid; e < N; e += 256) {
+    const float* p = xyz + ((size_t)b * N + e) * 3;
+    s_x[e] = p[0];
+    s_y[e] = p[1];
+    s_z[e] = p[2];
+  }
+  __syncthreads();
+  const int j0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * BQW_CPW);
+  for (int c = 0; c < BQW_CPW; ++c) {
+    const int j = j0 + c;
+    if (j >= M) break;
+    const float* C = new_xyz + ((size_t)b * M + j) * 3;
+    const float cx = C[0], cy = C[1], cz = C[2];
+    int cnt = 0;
+    for (int k0 = 0; k0 < N && cnt < nsample; k0 += 64) {
+      const int k = k0 + lane;
+      bool hit = false;
+      if (k < N) hit = sq3(cx - s_x[k], cy - s_y[k], cz - s_z[k]) < radius2;
+      const unsigned long long mask = __ballot(hit);
+      if (mask == 0ull) continue;
+      if (cnt == 0) row[lane] = k0 + (int)__builtin_ctzll(mask);     // the first hit pre-fills every slot
+      const int slot = cnt + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      if (hit && slot < nsample) row[slot] = k;
+      cnt += (int)__builtin_popcountll(mask);
+    }
+    if (lane < nsample) idx[((size_t)b * M + j) * nsample + lane] = cnt ? row[lane] : 0;
+  }
+}
+
 // out[b][c][j][k] = points[b][c][idx[b][j][k]]
 __global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ points,
                                                            const int32_t* __restrict__ idx, float* __restrict__ out,
@@ -186,7 +227,28 @@ constexpr int GPG_CT = 8;
 // PRIV: every wavefront accumulates into its OWN copy of the accumulators ([4][GPG_CT][N]) -- its rows in a fixed order,
 // no other wave touching the copy -- and the four copies are added in wave order at the end: the sum no longer depends
 // on how the waves' atomics interleave (deterministic; the reference's scatter-add, group_points_gpu.cu:60, is not).
-template <bool PRIV>
+// The loads are software-pipelined GPG_PF rows deep (a wave that loads one row and waits keeps 2 KB in flight: 1.25 TB/s
+// at two workgroups per CU), and the 2 x GPG_CT row reductions (totals, padded entries) are done TRANSPOSED: two
+// half-swaps leave every lane with a quarter of the values, four DPP steps finish them -- 40 instructions instead of 16
+// full wave reductions.
+__device__ __forceinline__ void gpg_swap32(float& a, float& b) {   // a[32..63] <-> b[0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void gpg_swap16(float& a, float& b) {   // a's odd rows of 16 <-> b's even rows
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float gpg_row_sum(float v) {            // sum over the 16 lanes of a DPP row, in every lane
+  v += dpp_f32<0xB1, 0xF>(v, 0.f);
+  v += dpp_f32<0x4E, 0xF>(v, 0.f);
+  v += dpp_f32<0x141, 0xF>(v, 0.f);
+  v += dpp_f32<0x140, 0xF>(v, 0.f);
+  return v;
+}
+template <bool PRIV, int MODE = 0, int GPG_PF = 8>   // MODE != 0, GPG_PF: variants for tools/ub/gpg_ub.hip
 __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* __restrict__ grad_out,
                                                                   const int32_t* __restrict__ idx,
                                                                   float* __restrict__ grad_points, int C, int N, int M,
@@ -194,27 +256,81 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
   extern __shared__ __attribute__((aligned(16))) float s_all[];   // [PRIV ? 4 : 1][GPG_CT][N]
   const int b = blockIdx.y, c0 = blockIdx.x * GPG_CT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = min(GPG_CT, C - c0);
-  for (int e = tid; e < (PRIV ? 4 : 1) * GPG_CT * N; e += 256) s_all[e] = 0.f;
   float* s_acc = s_all + (PRIV ? wave * GPG_CT * N : 0);
-  __syncthreads();
   const float* G = grad_out + ((size_t)b * C + c0) * M * 64;
-  for (int j = wave; j < M; j += 4) {
-    const int i = idx[((size_t)b * M + j) * 64 + lane];
-    const int i0 = __shfl(i, 0, 64);
-    const bool dup = lane > 0 && i == i0;
-    float v[GPG_CT];
+  const int32_t* I = idx + (size_t)b * M * 64;
+  float v[GPG_PF][GPG_CT];
+  int iv[GPG_PF];
+  auto load_row = [&](int j, float (&d)[GPG_CT], int& i) {
+    const int jj = j < M ? j : M - 1;
+    i = I[(size_t)jj * 64 + lane];
 #pragma unroll
-    for (int c = 0; c < GPG_CT; ++c) v[c] = c < nc ? G[((size_t)c * M + j) * 64 + lane] : 0.f;
+    for (int c = 0; c < GPG_CT; ++c) d[c] = c < nc ? G[((size_t)c * M + jj) * 64 + lane] : 0.f;
+  };
 #pragma unroll
-    for (int c = 0; c < GPG_CT; ++c) {
-      if (c >= nc) break;
-      const float s = wave_sum(dup ? v[c] : 0.f);
-      if (lane == 0) atomicAdd(&s_acc[c * N + i], v[c] + s);
-      else if (!dup) atomicAdd(&s_acc[c * N + i], v[c]);
-      if (rowsum) {   // sum over the row's 64 samples (d shift of the pre-transformed first layer), same pass
-        const float tot = wave_sum(v[c]);
-        if (lane == 0) rowsum[((size_t)b * C + c0 + c) * M + j] = tot;
+  for (int p = 0; p < GPG_PF; ++p) load_row(wave + 4 * p, v[p], iv[p]);   // in flight while the accumulators are cleared
+  for (int e = tid; e < (PRIV ? 4 : 1) * GPG_CT * N; e += 256) s_all[e] = 0.f;
+  __syncthreads();
+  for (int j0 = wave; j0 < M; j0 += 4 * GPG_PF) {
+#pragma unroll
+    for (int p = 0; p < GPG_PF; ++p) {
+      const int j = j0 + 4 * p;
+      if (j < M) {   // wave-uniform
+        const int i = iv[p];
+        const int i0 = __builtin_amdgcn_readfirstlane(i);
+        const bool dup = lane > 0 && i == i0;
+        // A ball query's row -- indices ascending, then repeats of the first -- has distinct live entries: plain
+        // read-modify-writes then (ds_add_f32 runs at a fraction of the plain LDS rate: 905 us against 401 us for this
+        // kernel at [250,128,128,64]); any other table takes the atomics.  Same sums either way.
+        const int iprev = __shfl_up(i, 1, 64);
+        const bool dprev = __shfl_up((int)dup, 1, 64) != 0;
+        const bool distinct = __all(lane == 0 || dup || (i > iprev && !dprev)) != 0;
+        // r[0..7]: the row totals, r[8..15]: the sums over the padded entries -- reduced transposed
+        float r[2 * GPG_CT];
+#pragma unroll
+        for (int c = 0; c < GPG_CT; ++c) {
+          r[c] = v[p][c];
+          r[GPG_CT + c] = dup ? v[p][c] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < GPG_CT; ++c) {      // lanes 0-31 keep value c, lanes 32-63 value 8 + c
+          gpg_swap32(r[c], r[GPG_CT + c]);
+          r[c] += r[GPG_CT + c];
+        }
+#pragma unroll
+        for (int c = 0; c < GPG_CT / 2; ++c) {  // even rows keep value c, odd rows value 4 + c (of their half's eight)
+          gpg_swap16(r[c], r[GPG_CT / 2 + c]);
+          r[c] += r[GPG_CT / 2 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < GPG_CT / 2; ++c) r[c] = gpg_row_sum(r[c]);
+        // row 0 (lane 0): totals 0-3, row 1 (lane 16): totals 4-7, row 2 (lane 32): padded sums 0-3, row 3 (lane 48): 4-7
+        float dsum[GPG_CT];
+#pragma unroll
+        for (int c = 0; c < GPG_CT / 2; ++c) {
+          dsum[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[c]), 32));
+          dsum[GPG_CT / 2 + c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[c]), 48));
+        }
+#pragma unroll
+        for (int c = 0; c < GPG_CT; ++c) {
+          if (c >= nc) break;
+          if (MODE == 1 || (MODE == 0 && distinct)) {
+            if (!dup) s_acc[c * N + i] += lane == 0 ? v[p][c] + dsum[c] : v[p][c];
+          } else if (MODE == 2) {
+            if (v[p][c] + dsum[c] == 123.456f) s_acc[c * N + i] = 1.f;
+          } else {
+            if (lane == 0) atomicAdd(&s_acc[c * N + i], v[p][c] + dsum[c]);
+            else if (!dup) atomicAdd(&s_acc[c * N + i], v[p][c]);
+          }
+        }
+        if (rowsum && (lane == 0 || lane == 16)) {   // d shift of the pre-transformed first layer: the row totals
+          const int cb = lane ? GPG_CT / 2 : 0;
+#pragma unroll
+          for (int c = 0; c < GPG_CT / 2; ++c)
+            if (cb + c < nc) rowsum[((size_t)b * C + c0 + cb + c) * M + j] = r[c];
+        }
       }
+      load_row(j + 4 * GPG_PF, v[p], iv[p]);   // (clamped past the end)
     }
   }
   __syncthreads();
@@ -264,6 +380,16 @@ extern "C" int geoa3_pn2_gather_points_grad(const float* grad_out, const int32_t
 extern "C" int geoa3_pn2_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
                                     int nsample, int32_t* idx, void* stream) {
   if (!new_xyz || !xyz || !idx || B <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
+  const size_t lds = (size_t)N * 3 * sizeof(float) + 4 * 64 * sizeof(int);
+  if (nsample <= 64 && lds <= 128 * 1024) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_wave_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ball_query_wave_kernel, dim3((M + 4 * BQW_CPW - 1) / (4 * BQW_CPW), B), dim3(256), lds,
+                       geoa3_stream(stream), new_xyz, xyz, N, M, radius * radius, nsample, idx);
+    GEOA3_CHECK_LAUNCH();
+    return GEOA3_OK;
+  }
   if (hipMemsetAsync(idx, 0, (size_t)B * M * nsample * sizeof(int32_t), geoa3_stream(stream)) != hipSuccess)
     return GEOA3_ELAUNCH;
   hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, geoa3_stream(stream), new_xyz, xyz, N, M,

@@ -48,13 +48,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
   float4* s_w1 = reinterpret_cast<float4*>(cs_smem + 2 * 64 * PITCH);   // [64] (w1 row, b1) of the folded first layer
   float* s_part = reinterpret_cast<float*>(s_w1 + 64);   // [4 waves][9]
   float* s_red = s_part + 40;                            // [4]
-  // grid (row blocks, column blocks, instances): the row blocks of one column tile are dispatched back to back, so
-  // the tile is read from HBM once and from L2 by the others (with the row block as grid.z a 256-channel layer read
-  // its input four times)
+  // grid (row blocks, column blocks, instances); the row blocks of one column tile read the same input
   // a.pack2 (N <= 128, shared weights): two instances per workgroup, waves 0-1 the columns of instance 2 z, waves 2-3
   // those of 2 z + 1 -- a [B][C][128] tensor (PointNet++ level 3) keeps all four waves busy
-  const int rb = blockIdx.x, cblk = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bz = a.pack2 ? 2 * blockIdx.z + (wave >> 1) : blockIdx.z;
+  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so neighbours in dispatch order do NOT share
+  // an L2: the R row blocks of a column tile are therefore given the linear ids base + xcd + 8 rb -- one XCD, a few
+  // dispatch slots apart -- instead of base + rb (speed only; any placement computes the same values).
+  int rb, cblk, zblk;
+  {
+    const unsigned R = gridDim.x, tiles = gridDim.y * gridDim.z;
+    const unsigned L = blockIdx.x + R * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned grp = L / (8 * R), rem = L - grp * 8 * R;
+    unsigned tile;
+    if ((grp + 1) * 8 <= tiles) {
+      tile = grp * 8 + (rem & 7);
+      rb = (int)(rem >> 3);
+    } else {   // the last, partial group of tiles: dispatch order
+      tile = L / R;
+      rb = (int)(L - tile * R);
+    }
+    zblk = (int)(tile / gridDim.y);
+    cblk = (int)(tile - zblk * gridDim.y);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bz = a.pack2 ? 2 * zblk + (wave >> 1) : zblk;
   const bool b_ok = bz < a.B;
   const int b = b_ok ? bz : a.B - 1;
   const int col = a.pack2 ? (wave & 1) * 64 + lane : cblk * 256 + wave * 64 + lane;

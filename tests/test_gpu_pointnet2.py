@@ -42,7 +42,7 @@ def test_fps_all_points_skipped(pn2):
 
 
 @pytest.mark.parametrize("B,N,M,r,ns", [(2, 1024, 512, 0.2, 64), (2, 512, 128, 0.4, 64), (1, 300, 77, 0.05, 8),
-                                        (1, 1500, 260, 0.3, 16)])
+                                        (1, 1500, 260, 0.3, 16), (1, 900, 70, 0.5, 80), (2, 64, 64, 0.6, 64)])
 def test_ball_query_exact(pn2, B, N, M, r, ns):
     xyz = _cloud(B, N, 200 + N)
     centres = xyz[:, :M].clone()
