@@ -36,6 +36,8 @@ struct Ws {
   // backward
   float *g256, *g512, *g1024, *dh2, *dh1, *dout2, *dnx2, *gz, *d1, *df1, *dnx1, *g1, *gxyz, *gnx1;
   int32_t* argt;
+  unsigned long long *m0, *m1;   // relu gates of the level-2 activations a0, a1 as bits [B * M2][128]
+  void* sa2_scratch;             // launch_sa2_bwd: 64 KB + 256 B
   size_t total;
 };
 
@@ -87,6 +89,9 @@ Ws carve(void* base, int B, int N) {
   w.g1 = (float*)take(b * M1 * C1 * f);
   w.gxyz = (float*)take(b * N * 3 * f);
   w.gnx1 = (float*)take(b * M1 * 3 * f);
+  w.m0 = (unsigned long long*)take(b * M2 * 128 * 8);
+  w.m1 = (unsigned long long*)take(b * M2 * 128 * 8);
+  w.sa2_scratch = take(65536 + 256);
   w.total = off;
   return w;
 }
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void affine3_grad_kernel(const float* __restri
 // 0.46 ms for [250,128,128,64]).  One wavefront per (instance, centre); stores are 256-byte rows as before.
 __global__ __launch_bounds__(256) void group_shift_relu_t_kernel(const float* __restrict__ PT, const int32_t* __restrict__ idx,
                                                                  const float* __restrict__ shift, float* __restrict__ out,
-                                                                 int N, int M) {
+                                                                 unsigned long long* __restrict__ gate, int N, int M) {
   const int b = blockIdx.y, j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (j >= M) return;
   const int i = idx[((size_t)b * M + j) * 64 + lane];
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(256) void group_shift_relu_t_kernel(const float* __
   const float sh0 = shift[((size_t)b * 128 + lane) * M + j], sh1 = shift[((size_t)b * 128 + 64 + lane) * M + j];
   float* O = out + ((size_t)b * 128 * M + j) * 64 + lane;
   const size_t cs = (size_t)M * 64;
+  unsigned long long gw0 = 0ull, gw1 = 0ull;
 #pragma unroll
   for (int c4 = 0; c4 < 32; ++c4) {
     const float4 g = src[c4];
@@ -263,11 +269,19 @@ __global__ __launch_bounds__(256) void group_shift_relu_t_kernel(const float* __
     const float s1 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 1));
     const float s2 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 2));
     const float s3 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 3));
-    O[(4 * c4 + 0) * cs] = fmaxf(g.x + s0, 0.f);
-    O[(4 * c4 + 1) * cs] = fmaxf(g.y + s1, 0.f);
-    O[(4 * c4 + 2) * cs] = fmaxf(g.z + s2, 0.f);
-    O[(4 * c4 + 3) * cs] = fmaxf(g.w + s3, 0.f);
+    const float o0 = fmaxf(g.x + s0, 0.f), o1 = fmaxf(g.y + s1, 0.f), o2 = fmaxf(g.z + s2, 0.f), o3 = fmaxf(g.w + s3, 0.f);
+    O[(4 * c4 + 0) * cs] = o0;
+    O[(4 * c4 + 1) * cs] = o1;
+    O[(4 * c4 + 2) * cs] = o2;
+    O[(4 * c4 + 3) * cs] = o3;
+    // relu gate bits (bit = sample) of channel c land in lane c & 63 of word c >> 6
+    const unsigned long long k0 = __ballot(o0 > 0.f), k1 = __ballot(o1 > 0.f), k2 = __ballot(o2 > 0.f), k3 = __ballot(o3 > 0.f);
+    unsigned long long& gw = c4 < 16 ? gw0 : gw1;
+    gw = lane == l0 ? k0 : (lane == l0 + 1 ? k1 : (lane == l0 + 2 ? k2 : (lane == l0 + 3 ? k3 : gw)));
   }
+  unsigned long long* G = gate + ((size_t)b * M + j) * 128;
+  G[lane] = gw0;
+  G[64 + lane] = gw1;
 }
 // a[i] += b[i]
 __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long total) {
@@ -344,8 +358,21 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
                      128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
   float* rt = w.df1;   // [B,512,128]: r point-major (a backward buffer, free in forward)
   TRY((transpose<float, false>(w.r, nullptr, rt, B, 128, M1, s)));
-  hipLaunchKernelGGL(group_shift_relu_t_kernel, dim3((M2 + 3) / 4, B), dim3(256), 0, s, rt, w.gidx2, w.shift, w.a0, M1, M2);
-  TRY(geoa3_conv1x1(w.a0, p.sa2_w1, p.sa2_b1, nullptr, w.a1, B, (long)M2 * S, 128, 128, 1, stream));
+  hipLaunchKernelGGL(group_shift_relu_t_kernel, dim3((M2 + 3) / 4, B), dim3(256), 0, s, rt, w.gidx2, w.shift, w.a0, w.m0, M1,
+                     M2);
+  {   // a1 = relu(W1 a0 + b1), its gate as bits for the backward
+    ConvArgs a{};
+    a.split = 1;
+    const int n = M2 * S;
+    a.X = w.a0; a.sXb = (long)128 * n; a.ldX = n;
+    a.W = p.sa2_w1; a.sWb = 0; a.sWco = 128; a.sWk = 1;
+    a.bias = p.sa2_b1;
+    a.Y = w.a1; a.sYb = (long)128 * n; a.ldY = n;
+    a.Ymask = w.m1;
+    a.Co = 128; a.K = 128; a.N = n; a.B = B;
+    a.relu = 1;
+    TRY(launch_conv_cm(a, s));
+  }
   TRY(geoa3_conv1x1_max64(w.a1, p.sa2_w2, p.sa2_b2, w.out2, w.arg2, B, (long)M2 * S, 128, C2, stream));
   // ---- level 3 (:78-82, GroupAll): MLP (256 + 3) -> 256 -> 512 -> 1024 on the 128 points, max over them
   TRY(conv_slice(w.out2, 256, 0, 256, p.sa3_wf, nullptr, nullptr, w.h1, 256, B, M2, false, false, s));
@@ -386,9 +413,11 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   // ---- level 2: pooled layer's sparse gradient (centre-major, relu-gated) -> W2^T -> W1^T -> scatter of the gather
   TRY((transpose<float, true>(w.dout2, w.out2, w.gz, B, C2, M2, s)));              // [B,256,128] -> [B,128,256], gated
   TRY((transpose<int32_t, false>(w.arg2, nullptr, w.argt, B, C2, M2, s)));
-  TRY(geoa3_conv1x1_onehot64(w.gz, w.argt, p.sa2_w2t, w.a1, w.d1, B, (long)M2 * S, C2, 128, stream));
-  float* da0 = w.a1;   // a1 has served as the gate above
-  TRY(geoa3_conv1x1(w.d1, p.sa2_w1t, nullptr, w.a0, da0, B, (long)M2 * S, 128, 128, 0, stream));
+  float* ent_g = w.d1;   // the level-1 scratch, free until sa1_backward
+  int32_t* ent_c = reinterpret_cast<int32_t*>(w.d1 + (size_t)B * M2 * C2);
+  TRY(launch_sa2_sort(w.gz, w.argt, ent_g, ent_c, (long)B * M2, s));
+  float* da0 = w.a1;     // the activations are not read in backward (bit gates m0 / m1)
+  TRY(launch_sa2_bwd(ent_g, ent_c, p.sa2_w2, p.sa2_w1t, w.m1, w.m0, da0, B, M2, w.sa2_scratch, s));
   float *dr = w.r, *dshift = w.shift;
   TRY(geoa3_pn2_group_points_grad_sums(da0, w.gidx2, B, 128, M1, M2, S, dr, dshift, stream));
   TRY(conv_slice(dr, 128, 0, 128, p.sa2_wft, nullptr, nullptr, w.df1, C1, B, M1, false, false, s));   // d f1 = W_f^T dr

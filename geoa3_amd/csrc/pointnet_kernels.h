@@ -125,3 +125,9 @@ int launch_gram64(const float* A, const float* G, int B, int N, float* P, float*
 // dT[b][i] = sum_w part[b][w][i], i < 9, in a fixed order (the partial sums of ConvArgs::dTpart)
 int launch_reduce_dT(const float* part, int nparts, float* dT, int B, hipStream_t s);
 
+
+// PointNet++ level 2 backward, both hidden layers in one kernel (pointnet2_sa2.hip): entries sorted by arg-max sample,
+// then d a0 = gate0 . W1^T (gate1 . sparse(W2, g, arg))
+int launch_sa2_sort(const float* gz, const int32_t* argt, float* ent_g, int32_t* ent_c, long centres, hipStream_t s);
+int launch_sa2_bwd(const float* ent_g, const int32_t* ent_c, const float* W2, const float* W1t, const unsigned long long* m1,
+                   const unsigned long long* m0, float* da0, int B, int M, void* scratch, hipStream_t s);
