@@ -29,6 +29,35 @@ constexpr int C1 = 128, C2 = 256, C3 = 1024;       // output widths of the three
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// ---- fragment images of the level-2 / level-3 matrices (launch_frag_image), one buffer: image i at img_off(i), its
+// 1 / scale in the 256 bytes behind it
+enum ImgId { IM_SA2_WF, IM_SA2_W1, IM_SA2_W2, IM_SA2_W1T, IM_SA2_WFT, IM_SA3_WF, IM_SA3_W1, IM_SA3_W2, IM_SA3_W2T, IM_SA3_W1T,
+             IM_SA3_WFT, IM_COUNT };
+constexpr int IMG_R[IM_COUNT] = {128, 128, 256, 128, 128, 256, 512, 1024, 512, 256, 256};
+constexpr int IMG_K[IM_COUNT] = {128, 128, 128, 128, 128, 256, 256, 512, 1024, 512, 256};
+constexpr size_t img_off(int i) {
+  size_t o = 0;
+  for (int j = 0; j < i; ++j) o += (size_t)IMG_R[j] * IMG_K[j] * 4 + 256;
+  return o;
+}
+struct Img {
+  const void* p;
+  const float* un;
+};
+inline Img img_of(const void* base, int i) {
+  const char* b = static_cast<const char*>(base) + img_off(i);
+  return Img{b, reinterpret_cast<const float*>(b + (size_t)IMG_R[i] * IMG_K[i] * 4)};
+}
+int pack_images(const geoa3_pn2ssg_weights& p, void* base, hipStream_t s) {
+  const float* W[IM_COUNT] = {p.sa2_wf, p.sa2_w1, p.sa2_w2, p.sa2_w1t, p.sa2_wft, p.sa3_wf, p.sa3_w1, p.sa3_w2, p.sa3_w2t,
+                              p.sa3_w1t, p.sa3_wft};
+  for (int i = 0; i < IM_COUNT; ++i) {
+    const Img im = img_of(base, i);
+    TRY(launch_frag_image(W[i], IMG_R[i], IMG_K[i], const_cast<void*>(im.p), const_cast<float*>(im.un), s));
+  }
+  return GEOA3_OK;
+}
+
 struct Ws {
   float *xyz, *nx1, *out1, *f1, *nx2, *r, *shift, *a0, *a1, *out2, *h1, *h2, *z3, *p3, *q1, *q2;
   int32_t *idx1, *gidx1, *idx2, *gidx2, *arg2, *arg3;
@@ -37,7 +66,7 @@ struct Ws {
   float *g256, *g512, *g1024, *dh2, *dh1, *dout2, *dnx2, *gz, *d1, *df1, *dnx1, *g1, *gxyz, *gnx1;
   int32_t* argt;
   unsigned long long *m0, *m1;   // relu gates of the level-2 activations a0, a1 as bits [B * M2][128]
-  void* sa2_scratch;             // launch_sa2_bwd: 64 KB + 256 B
+  void* images;   // fragment images, when the caller passes none (geoa3_pn2ssg_weights::images == NULL)
   size_t total;
 };
 
@@ -91,7 +120,7 @@ Ws carve(void* base, int B, int N) {
   w.gnx1 = (float*)take(b * M1 * 3 * f);
   w.m0 = (unsigned long long*)take(b * M2 * 128 * 8);
   w.m1 = (unsigned long long*)take(b * M2 * 128 * 8);
-  w.sa2_scratch = take(65536 + 256);
+  w.images = take(img_off(IM_COUNT));
   w.total = off;
   return w;
 }
@@ -299,12 +328,12 @@ int transpose(const T* in, const float* gate, T* out, int B, int R, int C, hipSt
 }
 
 // Y[b][co][n] = epi(sum_{k < K} W[co][k0 + k] X[b][k0 + k][n]) over a K-slice of a [Co][Kfull] weight / [B][Kfull][N] input
-int conv_slice(const float* X, int Kfull, int k0, int K, const float* W, const float* bias, const float* Z, float* Y, int Co,
+int conv_slice(const float* X, int Kfull, int k0, int K, const Img& W, const float* bias, const float* Z, float* Y, int Co,
                int B, int N, bool relu, bool accumulate, hipStream_t s) {
   ConvArgs a{};
   a.split = 1;
   a.X = X + (size_t)k0 * N; a.sXb = (long)Kfull * N; a.ldX = N;
-  a.W = W + k0; a.sWb = 0; a.sWco = Kfull; a.sWk = 1;
+  a.Wimg = W.p; a.Wun = W.un; a.img_kc = Kfull / 16; a.img_c0 = k0 / 16;
   a.bias = bias;
   a.Z = Z; a.sZb = (long)Co * N; a.ldZ = N;
   a.Y = Y; a.sYb = (long)Co * N; a.ldY = N;
@@ -333,6 +362,13 @@ extern "C" int64_t geoa3_pn2ssg_workspace_bytes(int B, int N) {
   return (int64_t)carve(nullptr, B, N).total;
 }
 
+extern "C" int64_t geoa3_pn2ssg_images_bytes(void) { return (int64_t)img_off(IM_COUNT); }
+
+extern "C" int geoa3_pn2ssg_pack_images(const geoa3_pn2ssg_weights* pw, void* images, void* stream) {
+  if (!pw || !images || ((uintptr_t)images & 255) != 0) return GEOA3_EINVAL;
+  return pack_images(*pw, images, geoa3_stream(stream));
+}
+
 extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float* x, int B, int N, float* logits,
                                     void* workspace, void* stream) {
   if (!pw || !x || !logits || !workspace || B <= 0 || N < M1 || pw->classes <= 0) return GEOA3_EINVAL;
@@ -340,6 +376,11 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   hipStream_t s = geoa3_stream(stream);
   const geoa3_pn2ssg_weights& p = *pw;
   Ws w = carve(workspace, B, N);
+  const void* im = p.images;
+  if (!im) {   // no packed images: build them into the workspace (eleven one-workgroup launches per call)
+    TRY(pack_images(p, w.images, s));
+    im = w.images;
+  }
   // ---- level 1 (PointNetPP_ssg.py:58-66): FPS 512, ball 0.2 x 64, MLP 3 -> 64 -> 64 -> 128, max
   hipLaunchKernelGGL(planar_to_points_kernel, g1d((long)B * N), dim3(256), 0, s, x, w.xyz, N, (long)B * N);
   TRY(geoa3_pn2_furthest_point_sampling(w.xyz, B, N, M1, nullptr, w.idx1, stream));
@@ -351,36 +392,26 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   TRY(geoa3_pn2_furthest_point_sampling(w.nx1, B, M1, M2, nullptr, w.idx2, stream));
   hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M2), dim3(256), 0, s, w.nx1, w.idx2, w.nx2, M1, M2, (long)B * M2);
   TRY(geoa3_pn2_ball_query(w.nx2, w.nx1, B, M1, M2, R2, S, w.gidx2, stream));
-  TRY(conv_slice(w.f1, 128, 0, 128, p.sa2_wf, nullptr, nullptr, w.r, 128, B, M1, false, false, s));   // W_f f
+  TRY(conv_slice(w.f1, 128, 0, 128, img_of(im, IM_SA2_WF), nullptr, nullptr, w.r, 128, B, M1, false, false, s));   // W_f f
   hipLaunchKernelGGL(affine3_add_kernel, g1d((long)B * 128 * M1), dim3(256), 0, s, w.r, p.sa2_wx, (const float*)nullptr,
                      w.nx1, 128, M1, 0, (long)B * 128 * M1);                                               // + W_x xyz
   hipLaunchKernelGGL(affine3_kernel, g1d((long)B * 128 * M2), dim3(256), 0, s, p.sa2_wx, p.sa2_b0, w.nx2, -1.f, w.shift,
                      128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
   float* rt = w.df1;   // [B,512,128]: r point-major (a backward buffer, free in forward)
   TRY((transpose<float, false>(w.r, nullptr, rt, B, 128, M1, s)));
-  hipLaunchKernelGGL(group_shift_relu_t_kernel, dim3((M2 + 3) / 4, B), dim3(256), 0, s, rt, w.gidx2, w.shift, w.a0, w.m0, M1,
-                     M2);
-  {   // a1 = relu(W1 a0 + b1), its gate as bits for the backward
-    ConvArgs a{};
-    a.split = 1;
-    const int n = M2 * S;
-    a.X = w.a0; a.sXb = (long)128 * n; a.ldX = n;
-    a.W = p.sa2_w1; a.sWb = 0; a.sWco = 128; a.sWk = 1;
-    a.bias = p.sa2_b1;
-    a.Y = w.a1; a.sYb = (long)128 * n; a.ldY = n;
-    a.Ymask = w.m1;
-    a.Co = 128; a.K = 128; a.N = n; a.B = B;
-    a.relu = 1;
-    TRY(launch_conv_cm(a, s));
+  // gather + shift + relu, W1, W2 + max in one kernel; the activations a0 / a1 exist only as gate bits (m0 / m1)
+  {
+    const Img i1 = img_of(im, IM_SA2_W1), i2 = img_of(im, IM_SA2_W2);
+    TRY(launch_sa2_fwd(rt, w.gidx2, w.shift, i1.p, i1.un, p.sa2_b1, i2.p, i2.un, p.sa2_b2, w.out2, w.arg2, w.m0, w.m1, B, M1,
+                       M2, s));
   }
-  TRY(geoa3_conv1x1_max64(w.a1, p.sa2_w2, p.sa2_b2, w.out2, w.arg2, B, (long)M2 * S, 128, C2, stream));
   // ---- level 3 (:78-82, GroupAll): MLP (256 + 3) -> 256 -> 512 -> 1024 on the 128 points, max over them
-  TRY(conv_slice(w.out2, 256, 0, 256, p.sa3_wf, nullptr, nullptr, w.h1, 256, B, M2, false, false, s));
+  TRY(conv_slice(w.out2, 256, 0, 256, img_of(im, IM_SA3_WF), nullptr, nullptr, w.h1, 256, B, M2, false, false, s));
   hipLaunchKernelGGL(affine3_add_kernel, g1d((long)B * 256 * M2), dim3(256), 0, s, w.h1, p.sa3_wx, p.sa3_b0, w.nx2, 256, M2,
                      1, (long)B * 256 * M2);
-  TRY(conv_slice(w.h1, 256, 0, 256, p.sa3_w1, p.sa3_b1, nullptr, w.h2, 512, B, M2, true, false, s));
-  TRY(conv_slice(w.h2, 512, 0, 256, p.sa3_w2, nullptr, nullptr, w.z3, C3, B, M2, false, false, s));
-  TRY(conv_slice(w.h2, 512, 256, 256, p.sa3_w2, nullptr, nullptr, w.z3, C3, B, M2, false, true, s));
+  TRY(conv_slice(w.h1, 256, 0, 256, img_of(im, IM_SA3_W1), p.sa3_b1, nullptr, w.h2, 512, B, M2, true, false, s));
+  TRY(conv_slice(w.h2, 512, 0, 256, img_of(im, IM_SA3_W2), nullptr, nullptr, w.z3, C3, B, M2, false, false, s));
+  TRY(conv_slice(w.h2, 512, 256, 256, img_of(im, IM_SA3_W2), nullptr, nullptr, w.z3, C3, B, M2, false, true, s));
   TRY(geoa3_pn2_bias_relu_max(w.z3, p.sa3_b2, B, C3, 1, M2, w.p3, w.arg3, stream));
   // ---- FC head (:84-98): Linear (no bias) + BatchNorm1d (folded) + ReLU twice, Dropout = identity, Linear
   TRY(fc(w.p3, C3, p.f1, p.fb1, w.q1, 512, B, true, nullptr, s));
@@ -396,6 +427,7 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   hipStream_t s = geoa3_stream(stream);
   const geoa3_pn2ssg_weights& p = *pw;
   Ws w = carve(workspace, B, N);
+  const void* im = p.images ? p.images : w.images;   // the forward of this workspace built them
   // ---- FC head
   TRY(fc(dlogits, p.classes, p.f3t, nullptr, w.g256, 256, B, false, w.q2, s));
   TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.q1, s));
@@ -404,10 +436,10 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   float* dz3 = w.z3;   // the pre-activation is not needed any more
   TRY(geoa3_pn2_bias_relu_max_grad(w.g1024, w.p3, w.arg3, B, C3, 1, M2, dz3, stream));
   for (int k0 = 0; k0 < C3; k0 += 256)
-    TRY(conv_slice(dz3, C3, k0, 256, p.sa3_w2t, nullptr, w.h2, w.dh2, 512, B, M2, false, k0 > 0, s));
+    TRY(conv_slice(dz3, C3, k0, 256, img_of(im, IM_SA3_W2T), nullptr, w.h2, w.dh2, 512, B, M2, false, k0 > 0, s));
   for (int k0 = 0; k0 < 512; k0 += 256)
-    TRY(conv_slice(w.dh2, 512, k0, 256, p.sa3_w1t, nullptr, w.h1, w.dh1, 256, B, M2, false, k0 > 0, s));
-  TRY(conv_slice(w.dh1, 256, 0, 256, p.sa3_wft, nullptr, nullptr, w.dout2, C2, B, M2, false, false, s));
+    TRY(conv_slice(w.dh2, 512, k0, 256, img_of(im, IM_SA3_W1T), nullptr, w.h1, w.dh1, 256, B, M2, false, k0 > 0, s));
+  TRY(conv_slice(w.dh1, 256, 0, 256, img_of(im, IM_SA3_WFT), nullptr, nullptr, w.dout2, C2, B, M2, false, false, s));
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 256 * sizeof(float), s, w.dh1, p.sa3_wx, 1.f,
                      w.dnx2, 256, M2, 0, (long)B * M2);
   // ---- level 2: pooled layer's sparse gradient (centre-major, relu-gated) -> W2^T -> W1^T -> scatter of the gather
@@ -417,10 +449,13 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   int32_t* ent_c = reinterpret_cast<int32_t*>(w.d1 + (size_t)B * M2 * C2);
   TRY(launch_sa2_sort(w.gz, w.argt, ent_g, ent_c, (long)B * M2, s));
   float* da0 = w.a1;     // the activations are not read in backward (bit gates m0 / m1)
-  TRY(launch_sa2_bwd(ent_g, ent_c, p.sa2_w2, p.sa2_w1t, w.m1, w.m0, da0, B, M2, w.sa2_scratch, s));
+  {
+    const Img i1t = img_of(im, IM_SA2_W1T);
+    TRY(launch_sa2_bwd(ent_g, ent_c, p.sa2_w2, i1t.p, i1t.un, w.m1, w.m0, da0, B, M2, s));
+  }
   float *dr = w.r, *dshift = w.shift;
   TRY(geoa3_pn2_group_points_grad_sums(da0, w.gidx2, B, 128, M1, M2, S, dr, dshift, stream));
-  TRY(conv_slice(dr, 128, 0, 128, p.sa2_wft, nullptr, nullptr, w.df1, C1, B, M1, false, false, s));   // d f1 = W_f^T dr
+  TRY(conv_slice(dr, 128, 0, 128, img_of(im, IM_SA2_WFT), nullptr, nullptr, w.df1, C1, B, M1, false, false, s));   // d f1 = W_f^T dr
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M1), dim3(256), 3 * 128 * sizeof(float), s, dr, p.sa2_wx, 1.f, w.dnx1,
                      128, M1, 0, (long)B * M1);                                                        // d xyz1 = W_x^T dr
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 128 * sizeof(float), s, dshift, p.sa2_wx, -1.f,

@@ -89,45 +89,13 @@ struct Sa2BwdArgs {
   const float* ent_g;              // [centres][256]
   const int32_t* ent_c;            // [centres][256]
   const float* W2;                 // [256][128]
-  const _Float16* w1img;           // sa2_prep_kernel: W1^T as A fragments, [hf][c][t][hi / lo][lane][8]
+  const _Float16* w1img;           // W1^T as a fragment image (frag_image_kernel)
   const float* w1un;               // [1]: 1 / the image's power-of-two scale
   const unsigned long long* m1;    // [centres][128]: a1 > 0
   const unsigned long long* m0;    // [centres][128]: a0 > 0
   float* da0;                      // [B][128][M * 64]
   int B, M;                        // M centres per instance (even)
 };
-
-// W1^T [128 i][128 k] -> power-of-two scale from its maximum, split, stored in the order the matrix-core loop reads it:
-// fragment (hf, c, t, piece) = rows 64 hf + 32 t .. + 31, k = 16 c .. + 15, one 16-byte element per lane (row r = lane & 31,
-// k half lane >> 5).  One workgroup; 64 KB, read by every wave of sa2_bwd_kernel from L2.
-__global__ __launch_bounds__(256) void sa2_prep_kernel(const float* __restrict__ W1t, _Float16* __restrict__ img,
-                                                       float* __restrict__ un) {
-  __shared__ float s_m[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float wv[64];
-  float m = 0.f;
-#pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    wv[i] = W1t[tid + 256 * i];
-    m = fmaxf(m, __builtin_fabsf(wv[i]));
-  }
-  m = wave_max(m);
-  if (lane == 0) s_m[wave] = m;
-  __syncthreads();
-  const unsigned Ew = s2_exp(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])));
-  const float sw = s2_scale(Ew);
-  if (tid == 0) un[0] = s2_unscale(Ew);
-#pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    const int e = tid + 256 * i, row = e >> 7, k = e & 127;
-    const int hf = row >> 6, t = (row >> 5) & 1, r = row & 31, c = k >> 4, h = (k >> 3) & 1, j = k & 7;
-    const int frag = (hf * 8 + c) * 2 + t;
-    const float v = wv[i] * sw;
-    const _Float16 hi = (_Float16)v;
-    img[((size_t)(frag * 2 + 0) * 64 + h * 32 + r) * 8 + j] = hi;
-    img[((size_t)(frag * 2 + 1) * 64 + h * 32 + r) * 8 + j] = (_Float16)(v - (float)hi);
-  }
-}
 
 constexpr int sa2_bwd_lds() { return 2 * 64 * S2_PT * 4 + 16 * 4; }
 
@@ -164,10 +132,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   auto w2row = [&](int cw) { return (a.W2 + (size_t)(cw & 0xffff) * S2_K)[k]; };   // uniform row + lane offset
-  const half8* img = reinterpret_cast<const half8*>(a.w1img) + (size_t)hf * 8 * 2 * 2 * 64 + lane;
+  const half8* img = reinterpret_cast<const half8*>(a.w1img) + (size_t)(2 * hf) * 8 * 2 * 64 + lane;   // row tiles 2 hf, 2 hf + 1
   auto load_a = [&](int c, half8 (&f)[4]) {   // fragments (t, piece) of k-step c
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = img[(size_t)(c * 4 + i) * 64];
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) f[2 * t + p] = img[(size_t)((t * 8 + c) * 2 + p) * 64];
   };
 
   PairRegs cur, nxt;
@@ -289,6 +259,325 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward of the same level in one kernel: gather + shift + relu (a0), W1 (+ b1, relu: a1), W2 max-pooled over the 64
+// samples -- pointnet2_modules.py:57-70 behind the pre-transformed first layer (r = W_f f + W_x xyz per POINT, shift =
+// b0 - W_x c per centre: pointnet2_net.hip).  The unfused chain wrote and re-read the [B,128,8192] tensors a0 and a1
+// (0.36 + 0.58 + 0.81 ms at B = 250); here neither exists: a workgroup keeps two centres' activations in LDS as split
+// fp16 images (sample-major, one power-of-two scale per centre from the tile's own maximum) that the matrix-core loops
+// read as ready operands:
+//   A  (2 waves per centre, lane = sample): the sample's 64 channels of its wave's half are one 256-byte gather from the
+//      point-major r; + shift, relu, gate bits (m0), maximum -> scale -> hi / lo images of a0;
+//   B  (wave = 64 output rows x one centre): a1 = relu(W1 a0 + b1) with W1 as A fragments streamed from an L2-resident
+//      image (sa2_img_kernel), gate bits (m1), maximum -> scale -> the images are OVERWRITTEN with a1;
+//   C  the pooled layer TRANSPOSED (activations as A: rows = samples, W2 fragments as B: columns = channels) in two
+//      passes of 64 channels per wave: a lane ends with one channel and 32 of its samples, the max over samples is
+//      lane-local plus one exchange (first maximal sample on ties, as F.max_pool2d).
+// Arithmetic of pointnet_conv_split.hip: a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulation.
+constexpr int S2_PH = S2_K * 2 + 16;     // bytes per sample row of an fp16 image (conflict-free 16-byte reads)
+
+// W[R][K] (R % 32 == 0, K % 16 == 0) -> power-of-two scale from its maximum, split, in fragment order:
+// [tile = row >> 5][cg = k >> 4][piece][lane = 32 (k half) + (row & 31)][8 k]; un[0] = 1 / scale.  One workgroup (runs
+// once per set of weights: geoa3_pn2ssg_pack_images).
+__global__ __launch_bounds__(256) void frag_image_kernel(const float* __restrict__ W, int R, int K, _Float16* __restrict__ img,
+                                                         float* __restrict__ un) {
+  __shared__ float s_m[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = 0.f;
+  for (int e = tid; e < R * K; e += 256) m = fmaxf(m, __builtin_fabsf(W[e]));
+  m = wave_max(m);
+  if (lane == 0) s_m[wave] = m;
+  __syncthreads();
+  const unsigned Ew = s2_exp(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])));
+  const float sw = s2_scale(Ew);
+  if (tid == 0) un[0] = s2_unscale(Ew);
+  const int kc = K >> 4;
+  for (int e = tid; e < R * K; e += 256) {
+    const int row = e / K, k = e - row * K;
+    const int tile = row >> 5, r = row & 31, cg = k >> 4, h = (k >> 3) & 1, j = k & 7;
+    const float v = W[e] * sw;
+    const _Float16 hi = (_Float16)v;
+    const size_t f = ((size_t)tile * kc + cg) * 2;
+    img[((f + 0) * 64 + h * 32 + r) * 8 + j] = hi;
+    img[((f + 1) * 64 + h * 32 + r) * 8 + j] = (_Float16)(v - (float)hi);
+  }
+}
+
+struct Sa2FwdArgs {
+  const float* rT;                 // [B][N1][128]
+  const int32_t* gidx;             // [B][M][64]
+  const float* shift;              // [B][128][M]
+  const float* b1;                 // [128]
+  const float* b2;                 // [256]
+  const _Float16* img1; const float* un1;   // W1 [128][128]
+  const _Float16* img2; const float* un2;   // W2 [256][128]
+  float* out; int32_t* arg;        // [B][256][M]
+  unsigned long long* m0;          // [B * M][128]
+  unsigned long long* m1;
+  int B, N1, M;
+};
+
+constexpr int sa2_fwd_lds() { return 2 * 2 * 64 * S2_PH + (8 + S2_K + S2_C) * 4; }
+
+template <int MODE, int S2_RING = 2>   // MODE 0 = shipped; tools/ub/sa2f_ub.hip: 1 no gather, 2 no W1 MFMAs, 3 no W2 MFMAs,
+                                       // 4 no pooled stores, 5 no gate stores, 6 weight loads hoisted; S2_RING: k-steps in flight
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sa2_fwd_kernel(Sa2FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s2_sm[];
+  float* s_red = reinterpret_cast<float*>(s2_sm + 2 * 2 * 64 * S2_PH);   // [0..3] a0 maxima, [4..7] a1 maxima
+  float* s_b1 = s_red + 8;
+  float* s_b2 = s_b1 + S2_K;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ci = wave >> 1, hf = wave & 1;
+  unsigned char* thi = s2_sm + ci * 2 * 64 * S2_PH;
+  unsigned char* tlo = thi + 64 * S2_PH;
+  for (int e = tid; e < S2_K; e += 256) s_b1[e] = a.b1[e];
+  for (int e = tid; e < S2_C; e += 256) s_b2[e] = a.b2[e];
+  const float un1 = a.un1[0], un2 = a.un2[0];
+  // fragment (tile, c, piece) of an image sits at ((tile * 8 + c) * 2 + piece) * 64 + lane (in 16-byte elements)
+  const half8* A1 = reinterpret_cast<const half8*>(a.img1) + (size_t)(2 * hf) * 8 * 2 * 64 + lane;
+  const half8* B2 = reinterpret_cast<const half8*>(a.img2) + (size_t)(4 * hf) * 8 * 2 * 64 + lane;
+  // The 24 k-steps of a pair -- 8 of W1 (steps 0-7), 2 x 8 of W2 (channel tiles 2 pass + tt) -- take their four weight
+  // fragments from a ring S2_RING steps deep: a step's matrix work (12 MFMAs, ~0.16 us) is far shorter than an L2 round trip.
+  auto load_step = [&](int step, half8 (&f)[4]) {
+    if (step < 8) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          f[2 * t + p] = MODE == 6 ? A1[(t * 2 + p) * 64] * (_Float16)step : A1[(size_t)((t * 8 + step) * 2 + p) * 64];
+    } else {
+      const int pass = (step - 8) >> 3, c = (step - 8) & 7;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          f[2 * tt + p] = MODE == 6 ? B2[(tt * 2 + p) * 64] * (_Float16)step : B2[(size_t)(((2 * pass + tt) * 8 + c) * 2 + p) * 64];
+    }
+  };
+  const long pairs = (long)a.B * a.M / 2;
+  // a pair's sample indices and shifts are requested one iteration ahead (the gather itself waits on the indices; the
+  // other workgroup of the CU covers it)
+  int gi = 0, gi_n = 0;
+  float shv = 0.f, shv_n = 0.f;
+  auto request = [&](long p, int& i, float& sh) {
+    const long centre = 2 * p + ci;
+    const int b = (int)(centre / a.M), m = (int)(centre - (long)b * a.M);
+    i = a.gidx[centre * 64 + lane];
+    sh = a.shift[((size_t)b * S2_K + 64 * hf + lane) * a.M + m];
+  };
+  if ((long)blockIdx.x < pairs) request(blockIdx.x, gi, shv);
+  __syncthreads();
+
+  for (long p = blockIdx.x; p < pairs; p += gridDim.x) {
+    const long centre = 2 * p + ci;
+    const int b = (int)(centre / a.M), m = (int)(centre - (long)b * a.M);
+    float4 gv[16];
+    {
+      const float4* src = reinterpret_cast<const float4*>(a.rT + ((size_t)b * a.N1 + gi) * S2_K + 64 * hf);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) gv[q] = MODE == 1 ? make_float4(0.1f * q, 0.2f, -0.1f, 0.3f) : src[q];
+    }
+    request(p + gridDim.x < pairs ? p + gridDim.x : p, gi_n, shv_n);
+    half8 fr[S2_RING][4];
+#pragma unroll
+    for (int i = 0; i + 1 < S2_RING; ++i) load_step(i, fr[i]);
+    // ---- A: a0 = relu(r[sample] + shift), this wave's 64 channels of its centre
+    float mx = 0.f;
+    {
+      float v[64];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        v[4 * q] = gv[q].x;
+        v[4 * q + 1] = gv[q].y;
+        v[4 * q + 2] = gv[q].z;
+        v[4 * q + 3] = gv[q].w;
+      }
+      unsigned long long gw = 0ull;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) {
+        v[c] = fmaxf(v[c] + s2_rlf(shv, c), 0.f);
+        mx = fmaxf(mx, v[c]);
+        const unsigned long long bal = __ballot(v[c] > 0.f);
+        gw = lane == c ? bal : gw;
+      }
+      if (MODE != 5) a.m0[centre * S2_K + 64 * hf + lane] = gw;
+      mx = wave_max(mx);
+      if (lane == 0) s_red[wave] = mx;
+      __syncthreads();
+      const unsigned Ea = s2_exp(fmaxf(s_red[2 * ci], s_red[2 * ci + 1]));
+      const float sa = s2_scale(Ea);
+#pragma unroll
+      for (int j8 = 0; j8 < 8; ++j8) {
+        half8 hh, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = v[8 * j8 + j] * sa;
+          const _Float16 hi = (_Float16)x;
+          hh[j] = hi;
+          ll[j] = (_Float16)(x - (float)hi);
+        }
+        *reinterpret_cast<half8*>(thi + lane * S2_PH + (64 * hf + 8 * j8) * 2) = hh;
+        *reinterpret_cast<half8*>(tlo + lane * S2_PH + (64 * hf + 8 * j8) * 2) = ll;
+      }
+      mx = s2_unscale(Ea);   // carried to phase B
+    }
+    __syncthreads();
+    // ---- B: a1 rows 64 hf .. 64 hf + 63 of the centre
+    {
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[cb][t][r] = 0.f;
+      const unsigned char* xrow = thi + l31 * S2_PH + h * 16;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        load_step(c + S2_RING - 1, fr[(c + S2_RING - 1) % S2_RING]);
+        half8 xh[2], xl[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          xh[cb] = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32);
+          xl[cb] = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32 + 64 * S2_PH);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const half8 wh = fr[c % S2_RING][2 * t], wl = fr[c % S2_RING][2 * t + 1];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            if (MODE == 2) {
+              acc[cb][t][0] += (float)wh[0] + (float)xh[cb][0] + (float)wl[0] + (float)xl[cb][0];
+              continue;
+            }
+            acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[cb], acc[cb][t], 0, 0, 0);
+            acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[cb], acc[cb][t], 0, 0, 0);
+            acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[cb], acc[cb][t], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one k-step of operands in flight, not eight (256 VGPRs)
+      }
+      // acc[cb][t][r]: row 64 hf + 32 t + (r&3) + 8 (r>>2) + 4 h, sample 32 cb + l31
+      const float un = mx * un1;
+      float mh = 0.f;
+      unsigned long long gw = 0ull;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = 32 * t + (r & 3) + 8 * (r >> 2);   // + 4 h
+          const float bias = s_b1[64 * hf + rr + 4 * h];
+          const float o0 = fmaxf(acc[0][t][r] * un + bias, 0.f), o1 = fmaxf(acc[1][t][r] * un + bias, 0.f);
+          acc[0][t][r] = o0;
+          acc[1][t][r] = o1;
+          mh = fmaxf(mh, fmaxf(o0, o1));
+          const unsigned long long k0 = __ballot(o0 > 0.f), k1 = __ballot(o1 > 0.f);
+          const unsigned long long w0 = (k0 & 0xffffffffull) | (k1 << 32);            // row rr: samples 0-31 | 32-63
+          const unsigned long long w1 = (k0 >> 32) | (k1 & 0xffffffff00000000ull);    // row rr + 4
+          gw = lane == rr ? w0 : (lane == rr + 4 ? w1 : gw);
+        }
+      if (MODE != 5) a.m1[centre * S2_K + 64 * hf + lane] = gw;
+      mh = wave_max(mh);
+      if (lane == 0) s_red[4 + wave] = mh;
+      __syncthreads();   // every wave is done reading a0; the maxima are visible
+      const unsigned Eh = s2_exp(fmaxf(s_red[4 + 2 * ci], s_red[5 + 2 * ci]));
+      const float sh = s2_scale(Eh);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            half4 hh, ll;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float x = acc[cb][t][4 * g4 + i] * sh;
+              const _Float16 hi = (_Float16)x;
+              hh[i] = hi;
+              ll[i] = (_Float16)(x - (float)hi);
+            }
+            const int k0 = 64 * hf + 32 * t + 8 * g4 + 4 * h;
+            *reinterpret_cast<half4*>(thi + (32 * cb + l31) * S2_PH + k0 * 2) = hh;
+            *reinterpret_cast<half4*>(tlo + (32 * cb + l31) * S2_PH + k0 * 2) = ll;
+          }
+      mx = s2_unscale(Eh);
+    }
+    __syncthreads();
+    // ---- C: pooled channels 128 hf + 64 pass .. + 63, transposed
+    {
+      const float un = mx * un2;
+      const unsigned char* xrow = thi + l31 * S2_PH + h * 16;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][tt][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int step = 8 + pass * 8 + c;
+          if (step + S2_RING - 1 < 24) load_step(step + S2_RING - 1, fr[(step + S2_RING - 1) % S2_RING]);
+          half8 xh[2], xl[2];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            xh[cb] = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32);
+            xl[cb] = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32 + 64 * S2_PH);
+          }
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const half8 wh = fr[step % S2_RING][2 * tt], wl = fr[step % S2_RING][2 * tt + 1];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              if (MODE == 3) {
+                acc[cb][tt][0] += (float)wh[0] + (float)xh[cb][0] + (float)wl[0] + (float)xl[cb][0];
+                continue;
+              }
+              acc[cb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[cb], wh, acc[cb][tt], 0, 0, 0);
+              acc[cb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[cb], wh, acc[cb][tt], 0, 0, 0);
+              acc[cb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[cb], wl, acc[cb][tt], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // acc[cb][tt][r]: channel 128 hf + 64 pass + 32 tt + l31, sample 32 cb + (r&3) + 8 (r>>2) + 4 h (ascending)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          float v = -__builtin_inff();
+          int smp = 0;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool gt = acc[cb][tt][r] > v;
+              v = gt ? acc[cb][tt][r] : v;
+              smp = gt ? 32 * cb + mfma_row(r, lane) : smp;
+            }
+          const float ov = __shfl_xor(v, 32, 64);
+          const int os = __shfl_xor(smp, 32, 64);
+          const bool take = ov > v || (ov == v && os < smp);
+          v = take ? ov : v;
+          smp = take ? os : smp;
+          if (lane < 32 && (MODE != 4 || v == 123.f)) {
+            const int ch = 128 * hf + 64 * pass + 32 * tt + lane;
+            const size_t e = ((size_t)b * S2_C + ch) * a.M + m;
+            a.out[e] = fmaxf(v * un + s_b2[ch], 0.f);     // the (positive) scale commutes with the max
+            a.arg[e] = smp;
+          }
+        }
+      }
+    }
+    __syncthreads();   // the images are rewritten by the next pair
+    gi = gi_n;
+    shv = shv_n;
+  }
+}
+
 }  // namespace
 
 int launch_sa2_sort(const float* gz, const int32_t* argt, float* ent_g, int32_t* ent_c, long centres, hipStream_t s) {
@@ -297,19 +586,37 @@ int launch_sa2_sort(const float* gz, const int32_t* argt, float* ent_g, int32_t*
   return GEOA3_OK;
 }
 
-// scratch: 64 KB + 256 B (the W1^T fragment image and its scale)
-int launch_sa2_bwd(const float* ent_g, const int32_t* ent_c, const float* W2, const float* W1t, const unsigned long long* m1,
-                   const unsigned long long* m0, float* da0, int B, int M, void* scratch, hipStream_t s) {
+int launch_frag_image(const float* W, int R, int K, void* img, float* un, hipStream_t s) {
+  if (R % 32 != 0 || K % 16 != 0) return GEOA3_EINVAL;
+  hipLaunchKernelGGL(frag_image_kernel, dim3(1), dim3(256), 0, s, W, R, K, static_cast<_Float16*>(img), un);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+int launch_sa2_bwd(const float* ent_g, const int32_t* ent_c, const float* W2, const void* w1t_img, const float* w1t_un,
+                   const unsigned long long* m1, const unsigned long long* m0, float* da0, int B, int M, hipStream_t s) {
   if (M % 2 != 0) return GEOA3_ENOSUPPORT;
-  _Float16* img = static_cast<_Float16*>(scratch);
-  float* un = reinterpret_cast<float*>(static_cast<char*>(scratch) + 65536);
-  hipLaunchKernelGGL(sa2_prep_kernel, dim3(1), dim3(256), 0, s, W1t, img, un);
-  Sa2BwdArgs a{ent_g, ent_c, W2, img, un, m1, m0, da0, B, M};
+  Sa2BwdArgs a{ent_g, ent_c, W2, static_cast<const _Float16*>(w1t_img), w1t_un, m1, m0, da0, B, M};
   const long pairs = (long)B * M / 2;
   const int lds = sa2_bwd_lds();
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const unsigned grid = (unsigned)(pairs < 512 ? pairs : 512);   // two workgroups per CU, persistent
   hipLaunchKernelGGL(sa2_bwd_kernel<0>, dim3(grid), dim3(256), lds, s, a);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+int launch_sa2_fwd(const float* rT, const int32_t* gidx, const float* shift, const void* w1_img, const float* w1_un,
+                   const float* b1, const void* w2_img, const float* w2_un, const float* b2, float* out, int32_t* arg,
+                   unsigned long long* m0, unsigned long long* m1, int B, int N1, int M, hipStream_t s) {
+  if (M % 2 != 0) return GEOA3_ENOSUPPORT;
+  Sa2FwdArgs a{rT, gidx, shift, b1, b2, static_cast<const _Float16*>(w1_img), w1_un, static_cast<const _Float16*>(w2_img),
+               w2_un, out, arg, m0, m1, B, N1, M};
+  const long pairs = (long)B * M / 2;
+  const int lds = sa2_fwd_lds();
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_fwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const unsigned grid = (unsigned)(pairs < 512 ? pairs : 512);   // two workgroups per CU, persistent
+  hipLaunchKernelGGL(sa2_fwd_kernel<0>, dim3(grid), dim3(256), lds, s, a);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

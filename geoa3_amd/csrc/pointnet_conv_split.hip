@@ -37,15 +37,16 @@ __device__ __forceinline__ unsigned cs_exp(float m) {
 __device__ __forceinline__ float cs_scale(unsigned E) { return __uint_as_float((267u - E) << 23); }
 __device__ __forceinline__ float cs_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
 
-template <int NCH, bool FIRST, bool GFIRST, bool BWD3, int PN2 = 0>  // K = 16 * NCH; BWD3 needs GFIRST;
-                                                                  // PN2: 1 = pooled output, 2 = one-hot input
+template <int NCH, bool FIRST, bool GFIRST, bool BWD3, int PN2 = 0, bool IMG = false>  // K = 16 * NCH; BWD3 needs GFIRST;
+                                                                  // PN2: 1 = pooled output, 2 = one-hot input;
+                                                                  // IMG: weights from a pre-split fragment image
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 4 : 2, NCH <= 8 ? 4 : 2))) void conv_cm64s_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
   constexpr int CH = 16, K = CH * NCH;
   constexpr int PITCH = K * 2 + 16;                      // bytes per weight row and piece
   unsigned char* s_wh = cs_smem;                         // [64][PITCH] hi
   unsigned char* s_wl = cs_smem + 64 * PITCH;            // [64][PITCH] lo
-  float4* s_w1 = reinterpret_cast<float4*>(cs_smem + 2 * 64 * PITCH);   // [64] (w1 row, b1) of the folded first layer
+  float4* s_w1 = reinterpret_cast<float4*>(cs_smem + (IMG ? 0 : 2 * 64 * PITCH));   // [64] (w1 row, b1) of the folded first layer
   float* s_part = reinterpret_cast<float*>(s_w1 + 64);   // [4 waves][9]
   float* s_red = s_part + 40;                            // [4]
   // grid (row blocks, column blocks, instances); the row blocks of one column tile read the same input
@@ -124,54 +125,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
   };
   if (!FIRST) load_rows(0, xb[0]);
 
-  // ---- weights: 64 x K values, K / 4 per thread (element e = tid + 256 i: row e / K, k = e % K), maximum, split.
-  // K <= 128: the values stay in registers between the two passes; K = 256: they are read again (L2)
-  constexpr int WPT = 64 * K / 256;
-  constexpr bool WKEEP = NCH <= 8;
-  float wv[WKEEP ? WPT : 1];
-  const float* W = a.W + (size_t)b * a.sWb + (size_t)rb * 64 * a.sWco;
-  {
-    float m = 0.f;
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = tid + 256 * i;
-      int co, k;
-      if (a.sWk == 1) {     // rows are k-contiguous
-        co = e / K;
-        k = e - co * K;
-      } else {              // transposed storage: co is the contiguous index
-        k = e / 64;
-        co = e - k * 64;
+  // IMG: the 64 x K block is read as ready A fragments (hi / lo pieces, 16 bytes per lane) from an image in fragment
+  // order, [tile = row >> 5][k >> 4][piece][lane][8] (geoa3_pn2ssg_pack_images): nothing to stage, no LDS for weights
+  unsigned Ew = 14u;
+  const half8* wimg = nullptr;
+  if (IMG) {
+    wimg = reinterpret_cast<const half8*>(a.Wimg) + ((size_t)(2 * rb) * a.img_kc + a.img_c0) * 2 * 64 + lane;
+  } else {
+    // ---- weights: 64 x K values, K / 4 per thread (element e = tid + 256 i: row e / K, k = e % K), maximum, split.
+    // K <= 128: the values stay in registers between the two passes; K = 256: they are read again (L2)
+    constexpr int WPT = 64 * K / 256;
+    constexpr bool WKEEP = NCH <= 8;
+    float wv[WKEEP ? WPT : 1];
+    const float* W = a.W + (size_t)b * a.sWb + (size_t)rb * 64 * a.sWco;
+    {
+      float m = 0.f;
+  #pragma unroll
+      for (int i = 0; i < WPT; ++i) {
+        const int e = tid + 256 * i;
+        int co, k;
+        if (a.sWk == 1) {     // rows are k-contiguous
+          co = e / K;
+          k = e - co * K;
+        } else {              // transposed storage: co is the contiguous index
+          k = e / 64;
+          co = e - k * 64;
+        }
+        const float v = W[(size_t)co * a.sWco + (size_t)k * a.sWk];
+        if (WKEEP) wv[i] = v;
+        m = fmaxf(m, __builtin_fabsf(v));
       }
-      const float v = W[(size_t)co * a.sWco + (size_t)k * a.sWk];
-      if (WKEEP) wv[i] = v;
-      m = fmaxf(m, __builtin_fabsf(v));
+      m = wave_max(m);
+      if (lane == 0) s_red[wave] = m;
     }
-    m = wave_max(m);
-    if (lane == 0) s_red[wave] = m;
-  }
-  __syncthreads();
-  const unsigned Ew = cs_exp(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
-  {
-    const float sw = cs_scale(Ew);
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = tid + 256 * i;
-      int co, k;
-      if (a.sWk == 1) {
-        co = e / K;
-        k = e - co * K;
-      } else {
-        k = e / 64;
-        co = e - k * 64;
+    __syncthreads();
+    Ew = cs_exp(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
+    {
+      const float sw = cs_scale(Ew);
+  #pragma unroll
+      for (int i = 0; i < WPT; ++i) {
+        const int e = tid + 256 * i;
+        int co, k;
+        if (a.sWk == 1) {
+          co = e / K;
+          k = e - co * K;
+        } else {
+          k = e / 64;
+          co = e - k * 64;
+        }
+        const float v = (WKEEP ? wv[i] : W[(size_t)co * a.sWco + (size_t)k * a.sWk]) * sw;
+        const _Float16 h = (_Float16)v;
+        *reinterpret_cast<_Float16*>(s_wh + co * PITCH + k * 2) = h;
+        *reinterpret_cast<_Float16*>(s_wl + co * PITCH + k * 2) = (_Float16)(v - (float)h);
       }
-      const float v = (WKEEP ? wv[i] : W[(size_t)co * a.sWco + (size_t)k * a.sWk]) * sw;
-      const _Float16 h = (_Float16)v;
-      *reinterpret_cast<_Float16*>(s_wh + co * PITCH + k * 2) = h;
-      *reinterpret_cast<_Float16*>(s_wl + co * PITCH + k * 2) = (_Float16)(v - (float)h);
     }
+    __syncthreads();
   }
-  __syncthreads();
   const unsigned char* arow = s_wh + (lane & 31) * PITCH + (lane >> 5) * 16;   // A operand: row r, k = 8h + j
 
   f32x16 acc[2][2];   // [column block][row tile]
@@ -223,8 +232,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const half8 wh = *reinterpret_cast<const half8*>(arow + t * 32 * PITCH + c * 32);
-      const half8 wl = *reinterpret_cast<const half8*>(arow + t * 32 * PITCH + c * 32 + 64 * PITCH);
+      const half8 wh = IMG ? wimg[((size_t)t * a.img_kc + c) * 2 * 64]
+                           : *reinterpret_cast<const half8*>(arow + t * 32 * PITCH + c * 32);
+      const half8 wl = IMG ? wimg[(((size_t)t * a.img_kc + c) * 2 + 1) * 64]
+                           : *reinterpret_cast<const half8*>(arow + t * 32 * PITCH + c * 32 + 64 * PITCH);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         if (PN2 == 1) {   // transposed: rows = samples, columns = channels (the max over samples becomes lane-local)
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
       }
     }
   }
-  const float unscale = cs_unscale(Ex) * cs_unscale(Ew);
+  const float unscale = cs_unscale(Ex) * (IMG ? a.Wun[0] : cs_unscale(Ew));
 
   if (PN2 == 1) {
     // acc[cb][t][r]: channel rb*64 + 32t + (lane & 31), sample 32 cb + (r&3) + 8(r>>2) + 4(lane>>5) of the wave's centre:
@@ -396,6 +407,14 @@ int launch_conv_cm_split(const ConvArgs& a, hipStream_t s) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     }
+    GEOA3_CHECK_LAUNCH();
+    return GEOA3_OK;
+  }
+  if (a.Wimg) {   // pre-split weights: plain layers with shared weights only
+    if (a.produce_first || a.gate_first || a.sWb != 0 || (a.K != 128 && a.K != 256) || !a.Wun) return GEOA3_ENOSUPPORT;
+    const size_t l = 64 * 16 + 44 * 4;
+    if (a.K == 128) hipLaunchKernelGGL((conv_cm64s_kernel<8, false, false, false, 0, true>), grid, dim3(256), l, s, a);
+    else hipLaunchKernelGGL((conv_cm64s_kernel<16, false, false, false, 0, true>), grid, dim3(256), l, s, a);
     GEOA3_CHECK_LAUNCH();
     return GEOA3_OK;
   }

@@ -48,6 +48,10 @@ struct ConvArgs {
   //           : 0 (oh_* CENTRE-major [B][centres][K]), formed in registers (X unused)
   float* pool_out; int32_t* pool_arg; const float* pool_bias;
   const float* oh_g; const int32_t* oh_arg;
+  // split kernel, shared weights (sWb == 0), K = 128 / 256: the weights as a pre-split fragment image of the FULL matrix
+  // [Co][16 img_kc] (geoa3_pn2ssg_pack_images: [row >> 5][k >> 4][piece][lane][8 halves]); this launch's K-slice starts
+  // at k-step img_c0; Wun[0] = 1 / the image's power-of-two scale.  W is unused then.
+  const void* Wimg; const float* Wun; int img_kc, img_c0;
 };
 int launch_conv_cm(const ConvArgs& a, hipStream_t s);         // dispatches on a.split
 int launch_conv_cm_split(const ConvArgs& a, hipStream_t s);
@@ -126,8 +130,16 @@ int launch_gram64(const float* A, const float* G, int B, int N, float* P, float*
 int launch_reduce_dT(const float* part, int nparts, float* dT, int B, hipStream_t s);
 
 
-// PointNet++ level 2 backward, both hidden layers in one kernel (pointnet2_sa2.hip): entries sorted by arg-max sample,
-// then d a0 = gate0 . W1^T (gate1 . sparse(W2, g, arg))
+// PointNet++ level 2 (pointnet2_sa2.hip).  Weight matrices as split-fp16 FRAGMENT IMAGES: W[R][K] -> [row >> 5][k >> 4]
+// [hi / lo][lane][8 halves], un[0] = 1 / the image's power-of-two scale (R * K * 4 bytes; one workgroup, run once per
+// set of weights)
+int launch_frag_image(const float* W, int R, int K, void* img, float* un, hipStream_t s);
+// backward of both hidden layers in one kernel: entries sorted by arg-max sample, then
+// d a0 = gate0 . W1^T (gate1 . sparse(W2, g, arg))
 int launch_sa2_sort(const float* gz, const int32_t* argt, float* ent_g, int32_t* ent_c, long centres, hipStream_t s);
-int launch_sa2_bwd(const float* ent_g, const int32_t* ent_c, const float* W2, const float* W1t, const unsigned long long* m1,
-                   const unsigned long long* m0, float* da0, int B, int M, void* scratch, hipStream_t s);
+int launch_sa2_bwd(const float* ent_g, const int32_t* ent_c, const float* W2, const void* w1t_img, const float* w1t_un,
+                   const unsigned long long* m1, const unsigned long long* m0, float* da0, int B, int M, hipStream_t s);
+// the level's forward in one kernel: out = relu(max_s W2 relu(W1 relu(rT[gidx] + shift) + b1) + b2), arg, gate bits m0 / m1
+int launch_sa2_fwd(const float* rT, const int32_t* gidx, const float* shift, const void* w1_img, const float* w1_un,
+                   const float* b1, const void* w2_img, const float* w2_un, const float* b2, float* out, int32_t* arg,
+                   unsigned long long* m0, unsigned long long* m1, int B, int N1, int M, hipStream_t s);

@@ -595,7 +595,13 @@ class PackedSSG:
             f["f%d" % i], f["fb%d" % i], f["f%dt" % i] = w, b, w.t()
         self.classes = int(fc[7].out_features)
         sa1 = _lib.Sa1Weights(*[dev(t) for t in (w11, b11, w12, b12, w13, b13)])
-        self.struct = _lib.Pn2SsgWeights(classes=self.classes, sa1=sa1, **{k: dev(v) for k, v in f.items()})
+        self.struct = _lib.Pn2SsgWeights(classes=self.classes, sa1=sa1, images=None, **{k: dev(v) for k, v in f.items()})
+        # the level-2 / level-3 matrices once more, as the split-fp16 fragment images the matrix-core loops read
+        lib = _lib.load()
+        images = torch.empty(int(lib.geoa3_pn2ssg_images_bytes()), dtype=torch.uint8, device=device)
+        check(lib.geoa3_pn2ssg_pack_images(C.byref(self.struct), images.data_ptr(), _s()), "geoa3_pn2ssg_pack_images")
+        self._keep.append(images)
+        self.struct.images = images.data_ptr()
 
 
 class _SSGFn(torch.autograd.Function):

@@ -424,7 +424,13 @@ typedef struct geoa3_pn2ssg_weights {
   const float *f1, *fb1, *f1t;                       /* [512,1024], [512], [1024,512] */
   const float *f2, *fb2, *f2t;                       /* [256,512], [256], [512,256] */
   const float *f3, *fb3, *f3t;                       /* [classes,256], [classes], [256,classes] */
+  const void* images;   /* geoa3_pn2ssg_pack_images of THESE weights, or NULL (the forward then rebuilds them per call) */
 } geoa3_pn2ssg_weights;
+/* The level-2 / level-3 matrices as split-fp16 fragment images (the order the matrix-core loops read them; one
+ * power-of-two scale per matrix): built once per set of weights into `images` (geoa3_pn2ssg_images_bytes() bytes,
+ * 256-byte aligned; the `images` member of *w is not read). */
+int64_t geoa3_pn2ssg_images_bytes(void);
+int geoa3_pn2ssg_pack_images(const geoa3_pn2ssg_weights* w, void* images, void* stream);
 int64_t geoa3_pn2ssg_workspace_bytes(int B, int N);
 int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* w, const float* x, int B, int N, float* logits, void* workspace,
                          void* stream);

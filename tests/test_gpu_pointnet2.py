@@ -308,3 +308,13 @@ def test_native_ssg_batch_independence_and_no_grad(pn2):
         xr = pc.clone().requires_grad_()
         net(xr).backward(g)
         assert torch.equal(xr.grad, x.grad)
+    # without the packed fragment images (geoa3_pn2ssg_weights::images == NULL) the forward rebuilds them per call
+    packed = net.packed(pc.device)
+    saved, packed.struct.images = packed.struct.images, None
+    try:
+        xr = pc.clone().requires_grad_()
+        lg2 = net(xr)
+        lg2.backward(g)
+        assert torch.equal(lg2.detach(), full) and torch.equal(xr.grad, x.grad)
+    finally:
+        packed.struct.images = saved
