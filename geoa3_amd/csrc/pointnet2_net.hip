@@ -59,7 +59,7 @@ int pack_images(const geoa3_pn2ssg_weights& p, void* base, hipStream_t s) {
 }
 
 struct Ws {
-  float *xyz, *nx1, *out1, *f1, *nx2, *r, *shift, *a0, *a1, *out2, *h1, *h2, *z3, *p3, *q1, *q2;
+  float *xyz, *nx1, *out1, *f1, *nx2, *r, *shift, *da0, *out2, *h1, *h2, *z3, *p3, *q1, *q2;
   int32_t *idx1, *gidx1, *idx2, *gidx2, *arg2, *arg3;
   uint8_t* arg1;
   // backward
@@ -92,8 +92,7 @@ Ws carve(void* base, int B, int N) {
   w.gidx2 = (int32_t*)take(b * M2 * S * 4);
   w.r = (float*)take(b * 128 * M1 * f);
   w.shift = (float*)take(b * 128 * M2 * f);
-  w.a0 = (float*)take(b * 128 * M2 * S * f);
-  w.a1 = (float*)take(b * 128 * M2 * S * f);
+  w.da0 = (float*)take(b * 128 * M2 * S * f);   // the level-2 activations a0 / a1 exist only as gate bits (m0 / m1)
   w.out2 = (float*)take(b * C2 * M2 * f);
   w.arg2 = (int32_t*)take(b * C2 * M2 * 4);
   w.h1 = (float*)take(b * 256 * M2 * f);
@@ -410,9 +409,17 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   hipLaunchKernelGGL(affine3_add_kernel, g1d((long)B * 256 * M2), dim3(256), 0, s, w.h1, p.sa3_wx, p.sa3_b0, w.nx2, 256, M2,
                      1, (long)B * 256 * M2);
   TRY(conv_slice(w.h1, 256, 0, 256, img_of(im, IM_SA3_W1), p.sa3_b1, nullptr, w.h2, 512, B, M2, true, false, s));
-  TRY(conv_slice(w.h2, 512, 0, 256, img_of(im, IM_SA3_W2), nullptr, nullptr, w.z3, C3, B, M2, false, false, s));
-  TRY(conv_slice(w.h2, 512, 256, 256, img_of(im, IM_SA3_W2), nullptr, nullptr, w.z3, C3, B, M2, false, true, s));
-  TRY(geoa3_pn2_bias_relu_max(w.z3, p.sa3_b2, B, C3, 1, M2, w.p3, w.arg3, stream));
+  {   // 512 -> 1024 with the bias / relu / max over the 128 points in the epilogue (the [B,1024,128] tensor never exists)
+    ConvArgs a{};
+    a.split = 1;
+    a.X = w.h2; a.sXb = (long)512 * M2; a.ldX = M2;
+    const Img i2 = img_of(im, IM_SA3_W2);
+    a.Wimg = i2.p; a.Wun = i2.un; a.img_kc = 32; a.img_c0 = 0;
+    a.pool_out = w.p3; a.pool_arg = w.arg3; a.pool_bias = p.sa3_b2;
+    a.Co = C3; a.K = 512; a.N = M2; a.B = B;
+    a.pack2 = 1;
+    TRY(launch_conv_cm(a, s));
+  }
   // ---- FC head (:84-98): Linear (no bias) + BatchNorm1d (folded) + ReLU twice, Dropout = identity, Linear
   TRY(fc(w.p3, C3, p.f1, p.fb1, w.q1, 512, B, true, nullptr, s));
   TRY(fc(w.q1, 512, p.f2, p.fb2, w.q2, 256, B, true, nullptr, s));
@@ -431,12 +438,18 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   // ---- FC head
   TRY(fc(dlogits, p.classes, p.f3t, nullptr, w.g256, 256, B, false, w.q2, s));
   TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.q1, s));
-  TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, C3, B, false, nullptr, s));
-  // ---- level 3: max + relu gate, then W2^T (four K = 256 slices), W1^T (two), Wf^T / Wx^T
-  float* dz3 = w.z3;   // the pre-activation is not needed any more
-  TRY(geoa3_pn2_bias_relu_max_grad(w.g1024, w.p3, w.arg3, B, C3, 1, M2, dz3, stream));
-  for (int k0 = 0; k0 < C3; k0 += 256)
-    TRY(conv_slice(dz3, C3, k0, 256, img_of(im, IM_SA3_W2T), nullptr, w.h2, w.dh2, 512, B, M2, false, k0 > 0, s));
+  TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, C3, B, false, w.p3, s));   // gated by the pooled layer's relu
+  // ---- level 3: the pooled gradient reaches one point per channel: d h2 = relu'(h2) . sum_{ch : arg = point} g W2[ch]
+  // (the sparse walk of the PointNet 1024-wide layers, in four 128-row slices of h2), then W1^T (two), Wf^T / Wx^T
+  for (int k0 = 0; k0 < 512; k0 += 128) {
+    WideBwdArgs a{};
+    a.g = w.g1024; a.arg = w.arg3;
+    a.W = p.sa3_w2 + k0; a.ldW = 512;
+    a.Z = w.h2 + (size_t)k0 * M2; a.sZb = (long)512 * M2; a.ldZ = M2;
+    a.dX = w.dh2 + (size_t)k0 * M2; a.sXb = (long)512 * M2; a.ldX = M2;
+    a.Co = C3; a.N = M2; a.B = B; a.taps = 1;
+    TRY(launch_wide_max_bwd(a, s));
+  }
   for (int k0 = 0; k0 < 512; k0 += 256)
     TRY(conv_slice(w.dh2, 512, k0, 256, img_of(im, IM_SA3_W1T), nullptr, w.h1, w.dh1, 256, B, M2, false, k0 > 0, s));
   TRY(conv_slice(w.dh1, 256, 0, 256, img_of(im, IM_SA3_WFT), nullptr, nullptr, w.dout2, C2, B, M2, false, false, s));
@@ -448,7 +461,7 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   float* ent_g = w.d1;   // the level-1 scratch, free until sa1_backward
   int32_t* ent_c = reinterpret_cast<int32_t*>(w.d1 + (size_t)B * M2 * C2);
   TRY(launch_sa2_sort(w.gz, w.argt, ent_g, ent_c, (long)B * M2, s));
-  float* da0 = w.a1;     // the activations are not read in backward (bit gates m0 / m1)
+  float* da0 = w.da0;
   {
     const Img i1t = img_of(im, IM_SA2_W1T);
     TRY(launch_sa2_bwd(ent_g, ent_c, p.sa2_w2, i1t.p, i1t.un, w.m1, w.m0, da0, B, M2, s));

@@ -38,7 +38,8 @@ __device__ __forceinline__ float cs_scale(unsigned E) { return __uint_as_float((
 __device__ __forceinline__ float cs_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
 
 template <int NCH, bool FIRST, bool GFIRST, bool BWD3, int PN2 = 0, bool IMG = false>  // K = 16 * NCH; BWD3 needs GFIRST;
-                                                                  // PN2: 1 = pooled output, 2 = one-hot input;
+                                                                  // PN2: 1 = pooled output, 2 = one-hot input,
+                                                                  // 3 = output pooled over the instance's 128 columns;
                                                                   // IMG: weights from a pre-split fragment image
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 4 : 2, NCH <= 8 ? 4 : 2))) void conv_cm64s_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
@@ -192,15 +193,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
       for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
 
   unsigned Ex = 14u;   // running exponent of the wave's activation scale
+  constexpr int CU = NCH < 16 ? NCH : 16;   // chunks unrolled together (K = 512: two rounds of sixteen)
+#pragma unroll 1
+  for (int c0 = 0; c0 < NCH; c0 += CU)
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
+  for (int cc = 0; cc < CU; ++cc) {
+    const int c = c0 + cc;
     if (FIRST) {
 #pragma unroll
-      for (int u = 0; u < CH; ++u) xb[c & 1][u] = fmaxf(cs_first_layer(s_w1[CH * c + u], p0, p1, p2), 0.f);
+      for (int u = 0; u < CH; ++u) xb[cc & 1][u] = fmaxf(cs_first_layer(s_w1[CH * c + u], p0, p1, p2), 0.f);
     } else if (c + 1 < NCH) {
-      load_rows(c + 1, xb[(c + 1) & 1]);
+      load_rows(c + 1, xb[(cc + 1) & 1]);
     }
-    float* x = xb[c & 1];
+    float* x = xb[cc & 1];
     float m = 0.f;
 #pragma unroll
     for (int u = 0; u < CH; ++u) m = fmaxf(m, __builtin_fabsf(live ? x[u] : 0.f));
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
                            : *reinterpret_cast<const half8*>(arow + t * 32 * PITCH + c * 32 + 64 * PITCH);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        if (PN2 == 1) {   // transposed: rows = samples, columns = channels (the max over samples becomes lane-local)
+        if (PN2 == 1 || PN2 == 3) {   // transposed: rows = samples, columns = channels (the max over samples becomes lane-local)
           acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[cb], wh, acc[cb][t], 0, 0, 0);
           acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[cb], wh, acc[cb][t], 0, 0, 0);
           acc[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[cb], wl, acc[cb][t], 0, 0, 0);
@@ -252,6 +257,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
   }
   const float unscale = cs_unscale(Ex) * (IMG ? a.Wun[0] : cs_unscale(Ew));
 
+  if (PN2 == 3) {
+    // pack2 layout, N = 128: waves 2 i, 2 i + 1 hold columns 0-63 / 64-127 of instance 2 z + i.  Per wave as PN2 == 1
+    // (lane-local max over 32 registers + one exchange), then the two waves of an instance meet in LDS: the max over
+    // the instance's 128 points (GroupAll + max_pool2d, pointnet2_modules.py:57-70), first maximal point on ties.
+    float* s_pv = s_red + 4;                                  // [4 waves][64 channels]
+    int* s_ps = reinterpret_cast<int*>(s_pv + 256);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v = -__builtin_inff();
+      int smp = 0;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool gt = acc[cb][t][r] > v;
+          v = gt ? acc[cb][t][r] : v;
+          smp = gt ? 32 * cb + mfma_row(r, lane) : smp;
+        }
+      const float ov = __shfl_xor(v, 32, 64);
+      const int os = __shfl_xor(smp, 32, 64);
+      const bool take = ov > v || (ov == v && os < smp);
+      v = take ? ov : v;
+      smp = take ? os : smp;
+      if (lane < 32) {
+        s_pv[wave * 64 + 32 * t + lane] = v * unscale;      // the (positive, per-wave) scale before the waves compare
+        s_ps[wave * 64 + 32 * t + lane] = smp + 64 * (wave & 1);
+      }
+    }
+    __syncthreads();
+    if ((wave & 1) == 0 && b_ok) {
+      const float v0 = s_pv[wave * 64 + lane], v1 = s_pv[(wave + 1) * 64 + lane];
+      const bool take = v1 > v0;                              // ties: the lower point index (this wave's half)
+      const int co = rb * 64 + lane;
+      const size_t e = (size_t)bz * a.Co + co;
+      a.pool_out[e] = fmaxf((take ? v1 : v0) + a.pool_bias[co], 0.f);
+      a.pool_arg[e] = take ? s_ps[(wave + 1) * 64 + lane] : s_ps[wave * 64 + lane];
+    }
+    return;
+  }
   if (PN2 == 1) {
     // acc[cb][t][r]: channel rb*64 + 32t + (lane & 31), sample 32 cb + (r&3) + 8(r>>2) + 4(lane>>5) of the wave's centre:
     // max over the 64 samples = 32 registers + one exchange between the lane halves; first maximal sample on ties
@@ -391,11 +435,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
 }  // namespace
 
 int launch_conv_cm_split(const ConvArgs& a, hipStream_t s) {
-  if ((a.K != 64 && a.K != 128 && a.K != 256) || a.Co <= 0 || a.Co % 64 != 0) return GEOA3_ENOSUPPORT;
+  if ((a.K != 64 && a.K != 128 && a.K != 256 && !(a.K == 512 && a.Wimg)) || a.Co <= 0 || a.Co % 64 != 0) return GEOA3_ENOSUPPORT;
   const size_t lds = (size_t)2 * 64 * (a.K * 2 + 16) + 64 * 16 + 44 * 4;
-  if (a.pack2 && (a.N > 128 || a.sWb != 0 || a.Ymask || a.Zmask || a.pool_out || a.oh_g || a.produce_first || a.gate_first))
+  if (a.pack2 && (a.N > 128 || a.sWb != 0 || a.Ymask || a.Zmask || (a.pool_out && !a.Wimg) || a.oh_g || a.produce_first || a.gate_first))
     return GEOA3_EINVAL;
   dim3 grid(a.Co / 64, a.pack2 ? 1 : (a.N + 255) / 256, a.pack2 ? (a.B + 1) / 2 : a.B);
+  if (a.Wimg && a.pool_out) {   // K = 512, the output pooled over each instance's 128 points (PointNet++ level 3)
+    if (!a.pack2 || a.N != 128 || a.K != 512 || !a.pool_arg || !a.pool_bias || !a.Wun || a.oh_g) return GEOA3_ENOSUPPORT;
+    const size_t l = 64 * 16 + 44 * 4 + 2048;
+    hipLaunchKernelGGL((conv_cm64s_kernel<32, false, false, false, 3, true>), grid, dim3(256), l, s, a);
+    GEOA3_CHECK_LAUNCH();
+    return GEOA3_OK;
+  }
   if (a.pool_out || a.oh_g) {   // PointNet++ forms: a wave = one centre
     if (a.N % 64 != 0 || a.produce_first || a.gate_first) return GEOA3_ENOSUPPORT;
     if (a.pool_out && (!a.pool_arg || !a.pool_bias || a.K != 128 || a.oh_g)) return GEOA3_ENOSUPPORT;

@@ -113,6 +113,8 @@ __device__ __forceinline__ unsigned long long wide_key(float v, int col) {
 struct WideBwdArgs {
   const float* g; const int* arg;             // [B][Co]
   const float* W;                             // [Co][TAPS*128]
+  int ldW;                                    // elements between the 128-channel rows (co * TAPS + tap); 0 = 128.  A
+                                              // [Co][K] matrix is walked in 128-column slices with ldW = K, W + k0
   const float* Z; long sZb; int ldZ;          // activation whose relu gates the result ([B][128][N]), or
   const unsigned long long* Zmask;            // its bit mask [B][ceil(N/64)][128] (ConvArgs::Ymask)
   float* dX; long sXb; int ldX;               // [B][128][N]

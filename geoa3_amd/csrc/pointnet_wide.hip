@@ -414,6 +414,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_max_bwd2_kernel(WideBwdArgs 
     const int per = (total + BW2_WAVES - 1) / BW2_WAVES;
     const int lo = min(total, wave * per), hi = min(total, lo + per);
     constexpr int U = 8;
+    const int ldW = a.ldW ? a.ldW : WM_CI;   // (co * TAPS + tap) -th row of 128 input channels
     int cur = -1;
     float acc0 = 0.f, acc1 = 0.f;
     // the column of hit lo started in an earlier share <=> lo is not the first entry of that column's list
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_max_bwd2_kernel(WideBwdArgs 
       for (int u = 0; u < U; ++u) {
         const bool ok = h0 + u < hi;
         const int e = s_list[ok ? h0 + u : hi - 1];
-        w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)(e & 0xffff) * WM_CI + 2 * lane);
+        w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)(e & 0xffff) * ldW + 2 * lane);
         gg[u] = ok ? s_gl[h0 + u] : 0.f;
         cc[u] = ok ? e >> 16 : -2;
       }
