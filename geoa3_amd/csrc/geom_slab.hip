@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ cstart, const GridGeo* __restrict__ geo,
                                                        float* __restrict__ dists, int32_t* __restrict__ idx) {
   __shared__ unsigned long long s_key[4][KG_CAP];
+  __shared__ int s_rowp[4][64], s_rows[4][64];   // per wave: exclusive prefix of the rows' lengths, their first positions
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* Rb = R + (size_t)b * 3 * N;
   const float* Sb = sorted + (size_t)b * 3 * N;
@@ -431,6 +432,8 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
   const int32_t* cs = cstart + (size_t)b * (KG_CELLS + 1);
   const GridGeo g = geo[b];
   unsigned long long* L = s_key[wave];
+  int* P = s_rowp[wave];
+  int* Sr = s_rows[wave];
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int q0 = (blockIdx.x * 4 + wave) * KG_QPW;
   for (int qi = 0; qi < KG_QPW; ++qi) {
@@ -469,18 +472,31 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
         s = cs[c0 + x0];
         len = cs[c0 + x1 + 1] - s;
       }
-      int maxlen = len;
+      // The rows' point ranges, concatenated, are walked 64 candidates at a time (lane = candidate): a lane per ROW left a
+      // quarter of the lanes busy and made the loop as long as the longest row -- one L2 round trip per iteration.
+      int incl = len;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-      for (int i = 0; i < maxlen; ++i) {
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      const int T = __builtin_amdgcn_readlane(incl, 63);
+      P[lane] = incl - len;      // this wave's own slots: LDS operations of a wave execute in order
+      Sr[lane] = s;
+      for (int t0 = 0; t0 < T; t0 += 64) {
+        const int c = t0 + lane;
         float d = S_INF;
         int oi = 0;
-        if (i < len) {
-          const int j = s + i;
+        if (c < T) {
+          int r = 0;             // the last row whose range starts at or before candidate c
+#pragma unroll
+          for (int st = 32; st > 0; st >>= 1)
+            if (P[r + st] <= c) r += st;
+          const int j = Sr[r] + (c - P[r]);
           d = geoa3_sqdist(qx, qy, qz, Sb[j], Sb[N + j], Sb[2 * N + j]);
           oi = Ib[j];
         }
-        const bool pass = i < len && d <= tau;
+        const bool pass = c < T && d <= tau;
         const unsigned long long mask = __ballot(pass);
         if (pass) L[cnt + __popcll(mask & lt)] = kg_key(d, oi);
         cnt += __popcll(mask);
