@@ -578,6 +578,232 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The forward as ONE 8-wave workgroup per CU (the shipped form; sa2_fwd_kernel above is the first version, kept for
+// tools/ub/sa2f_ub.hip).  What bounded the 4-wave / two-workgroups-per-CU form was weight traffic per wave: both waves of
+// a centre streamed all of W1 and half of W2 through a two-step register ring (a deeper ring spilled at 256 VGPRs), so part
+// of every L2 round trip was exposed.  Here
+//   * W1's fragment image (64 KB) is copied into LDS once per workgroup: layer 1 reads its A fragments from LDS;
+//   * W2 is split eight ways: wave w owns channel tile w (32 channels) for BOTH centres, so every fragment of W2 is
+//     loaded once per pair and CU (16 x 1 KB per wave), through a ring S8_RING k-steps deep;
+//   * layer 1 is split as (centre, 32-row tile) over the eight waves; the gather as (centre, 32-channel quarter).
+// Same arithmetic and the same per-centre scales as the first version: bit-identical results.
+constexpr int S8_RING = 4;
+constexpr int sa2_fwd8_lds() { return S2_K * S2_K * 4 + 2 * 2 * 64 * S2_PH + (16 + S2_K + S2_C) * 4; }
+
+__global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s2_sm[];
+  half8* s_w1 = reinterpret_cast<half8*>(s2_sm);                      // fragment image of W1: [(tile * 8 + c) * 2 + piece][lane]
+  unsigned char* s_img = s2_sm + S2_K * S2_K * 4;                     // [2 centres][hi / lo][64 samples][S2_PH]
+  float* s_red = reinterpret_cast<float*>(s_img + 2 * 2 * 64 * S2_PH);   // [0..7] a0 maxima, [8..15] a1 maxima (per wave)
+  float* s_b1 = s_red + 16;
+  float* s_b2 = s_b1 + S2_K;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ci = wave >> 2, qt = wave & 3;       // phases A / B: this wave's centre and its channel quarter / row tile
+  unsigned char* thi = s_img + ci * 2 * 64 * S2_PH;
+  unsigned char* tlo = thi + 64 * S2_PH;
+  {
+    const half8* src = reinterpret_cast<const half8*>(a.img1);
+    for (int e = tid; e < S2_K * S2_K * 4 / 16; e += 512) s_w1[e] = src[e];
+  }
+  for (int e = tid; e < S2_K; e += 512) s_b1[e] = a.b1[e];
+  for (int e = tid; e < S2_C; e += 512) s_b2[e] = a.b2[e];
+  const float un1 = a.un1[0], un2 = a.un2[0];
+  const half8* B2 = reinterpret_cast<const half8*>(a.img2) + (size_t)wave * 8 * 2 * 64 + lane;   // channel tile `wave`
+  auto load_w2 = [&](int c, half8 (&f)[2]) {
+    f[0] = B2[(size_t)(c * 2 + 0) * 64];
+    f[1] = B2[(size_t)(c * 2 + 1) * 64];
+  };
+  const long pairs = (long)a.B * a.M / 2;
+  int gi = 0;
+  float shv = 0.f;
+  float4 gv[8];
+  auto request = [&](long p) {     // the pair's gather for this wave: sample `lane` of centre ci, channels 32 qt .. + 31
+    const long centre = 2 * p + ci;
+    const int b = (int)(centre / a.M), m = (int)(centre - (long)b * a.M);
+    gi = a.gidx[centre * 64 + lane];
+    shv = a.shift[((size_t)b * S2_K + 32 * qt + l31) * a.M + m];
+    const float4* src = reinterpret_cast<const float4*>(a.rT + ((size_t)b * a.N1 + gi) * S2_K + 32 * qt);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gv[q] = src[q];
+  };
+  if ((long)blockIdx.x < pairs) request(blockIdx.x);
+  __syncthreads();
+
+  for (long p = blockIdx.x; p < pairs; p += gridDim.x) {
+    const long centre = 2 * p + ci;
+    half8 ring[S8_RING][2];
+#pragma unroll
+    for (int i = 0; i + 1 < S8_RING; ++i) load_w2(i, ring[i]);
+    // ---- A: a0 = relu(r[sample] + shift): lane = sample, this wave's 32 channels
+    float carry;
+    {
+      float v[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v[4 * q] = gv[q].x;
+        v[4 * q + 1] = gv[q].y;
+        v[4 * q + 2] = gv[q].z;
+        v[4 * q + 3] = gv[q].w;
+      }
+      unsigned long long gw = 0ull;
+      float mx = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        v[c] = fmaxf(v[c] + s2_rlf(shv, c), 0.f);
+        mx = fmaxf(mx, v[c]);
+        const unsigned long long bal = __ballot(v[c] > 0.f);
+        gw = lane == c ? bal : gw;
+      }
+      if (lane < 32) a.m0[centre * S2_K + 32 * qt + lane] = gw;
+      mx = wave_max(mx);
+      if (lane == 0) s_red[wave] = mx;
+      __syncthreads();
+      const unsigned Ea = s2_exp(fmaxf(fmaxf(s_red[4 * ci], s_red[4 * ci + 1]), fmaxf(s_red[4 * ci + 2], s_red[4 * ci + 3])));
+      const float sa = s2_scale(Ea);
+#pragma unroll
+      for (int j8 = 0; j8 < 4; ++j8) {
+        half8 hh, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = v[8 * j8 + j] * sa;
+          const _Float16 hi = (_Float16)x;
+          hh[j] = hi;
+          ll[j] = (_Float16)(x - (float)hi);
+        }
+        *reinterpret_cast<half8*>(thi + lane * S2_PH + (32 * qt + 8 * j8) * 2) = hh;
+        *reinterpret_cast<half8*>(tlo + lane * S2_PH + (32 * qt + 8 * j8) * 2) = ll;
+      }
+      carry = s2_unscale(Ea);
+    }
+    __syncthreads();
+    // ---- B: a1 rows 32 qt .. 32 qt + 31 of centre ci
+    {
+      f32x16 acc[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+      const unsigned char* xrow = thi + l31 * S2_PH + h * 16;
+      const half8* wf = s_w1 + (size_t)qt * 8 * 2 * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const half8 wh = wf[(c * 2 + 0) * 64], wl = wf[(c * 2 + 1) * 64];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const half8 xh = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32);
+          const half8 xl = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32 + 64 * S2_PH);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[cb], 0, 0, 0);
+        }
+      }
+      // acc[cb][r]: row 32 qt + (r&3) + 8 (r>>2) + 4 h, sample 32 cb + l31
+      const float un = carry * un1;
+      float mh = 0.f;
+      unsigned long long gw = 0ull;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);   // + 4 h
+        const float bias = s_b1[32 * qt + rr + 4 * h];
+        const float o0 = fmaxf(acc[0][r] * un + bias, 0.f), o1 = fmaxf(acc[1][r] * un + bias, 0.f);
+        acc[0][r] = o0;
+        acc[1][r] = o1;
+        mh = fmaxf(mh, fmaxf(o0, o1));
+        const unsigned long long k0 = __ballot(o0 > 0.f), k1 = __ballot(o1 > 0.f);
+        const unsigned long long w0 = (k0 & 0xffffffffull) | (k1 << 32);            // row rr: samples 0-31 | 32-63
+        const unsigned long long w1 = (k0 >> 32) | (k1 & 0xffffffff00000000ull);    // row rr + 4
+        gw = lane == rr ? w0 : (lane == rr + 4 ? w1 : gw);
+      }
+      if (lane < 32) a.m1[centre * S2_K + 32 * qt + lane] = gw;
+      mh = wave_max(mh);
+      if (lane == 0) s_red[8 + wave] = mh;
+      __syncthreads();   // every wave is done reading a0; the maxima are visible
+      const unsigned Eh =
+          s2_exp(fmaxf(fmaxf(s_red[8 + 4 * ci], s_red[9 + 4 * ci]), fmaxf(s_red[10 + 4 * ci], s_red[11 + 4 * ci])));
+      const float sh = s2_scale(Eh);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+          half4 hh, ll;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float x = acc[cb][4 * g4 + i] * sh;
+            const _Float16 hi = (_Float16)x;
+            hh[i] = hi;
+            ll[i] = (_Float16)(x - (float)hi);
+          }
+          const int k0 = 32 * qt + 8 * g4 + 4 * h;
+          *reinterpret_cast<half4*>(thi + (32 * cb + l31) * S2_PH + k0 * 2) = hh;
+          *reinterpret_cast<half4*>(tlo + (32 * cb + l31) * S2_PH + k0 * 2) = ll;
+        }
+      carry = s2_unscale(Eh);     // of this wave's centre ci; phase C needs both centres' (below)
+    }
+    __syncthreads();
+    // the next pair's gather: in flight across phase C
+    if (p + gridDim.x < pairs) request(p + gridDim.x);
+    // ---- C: pooled channels 32 wave .. + 31 for both centres, transposed (rows = samples)
+    {
+      f32x16 acc[4];     // [2 centre + column block]
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+      const unsigned char* xrow = s_img + l31 * S2_PH + h * 16;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c + S8_RING - 1 < 8) load_w2(c + S8_RING - 1, ring[(c + S8_RING - 1) % S8_RING]);
+        const half8 wh = ring[c % S8_RING][0], wl = ring[c % S8_RING][1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned char* xr = xrow + (q >> 1) * 2 * 64 * S2_PH + (q & 1) * 32 * S2_PH + c * 32;
+          const half8 xh = *reinterpret_cast<const half8*>(xr);
+          const half8 xl = *reinterpret_cast<const half8*>(xr + 64 * S2_PH);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[q], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // acc[2 cc + cb][r]: channel 32 wave + l31, sample 32 cb + (r&3) + 8 (r>>2) + 4 h of centre cc (ascending)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const unsigned Eh =
+            s2_exp(fmaxf(fmaxf(s_red[8 + 4 * cc], s_red[9 + 4 * cc]), fmaxf(s_red[10 + 4 * cc], s_red[11 + 4 * cc])));
+        const float un = s2_unscale(Eh) * un2;
+        float v = -__builtin_inff();
+        int smp = 0;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool gt = acc[2 * cc + cb][r] > v;
+            v = gt ? acc[2 * cc + cb][r] : v;
+            smp = gt ? 32 * cb + mfma_row(r, lane) : smp;
+          }
+        const float ov = __shfl_xor(v, 32, 64);
+        const int os = __shfl_xor(smp, 32, 64);
+        const bool take = ov > v || (ov == v && os < smp);
+        v = take ? ov : v;
+        smp = take ? os : smp;
+        if (lane < 32) {
+          const long cen = 2 * p + cc;
+          const int b = (int)(cen / a.M), m = (int)(cen - (long)b * a.M);
+          const int ch = 32 * wave + lane;
+          const size_t e = ((size_t)b * S2_C + ch) * a.M + m;
+          a.out[e] = fmaxf(v * un + s_b2[ch], 0.f);     // the (positive) scale commutes with the max
+          a.arg[e] = smp;
+        }
+      }
+    }
+    __syncthreads();   // the images and s_red are rewritten by the next pair
+  }
+}
+
 }  // namespace
 
 int launch_sa2_sort(const float* gz, const int32_t* argt, float* ent_g, int32_t* ent_c, long centres, hipStream_t s) {
@@ -613,10 +839,10 @@ int launch_sa2_fwd(const float* rT, const int32_t* gidx, const float* shift, con
   Sa2FwdArgs a{rT, gidx, shift, b1, b2, static_cast<const _Float16*>(w1_img), w1_un, static_cast<const _Float16*>(w2_img),
                w2_un, out, arg, m0, m1, B, N1, M};
   const long pairs = (long)B * M / 2;
-  const int lds = sa2_fwd_lds();
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_fwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  const unsigned grid = (unsigned)(pairs < 512 ? pairs : 512);   // two workgroups per CU, persistent
-  hipLaunchKernelGGL(sa2_fwd_kernel<0>, dim3(grid), dim3(256), lds, s, a);
+  const int lds = sa2_fwd8_lds();
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const unsigned grid = (unsigned)(pairs < 256 ? pairs : 256);   // one 8-wave workgroup per CU, persistent
+  hipLaunchKernelGGL(sa2_fwd8_kernel, dim3(grid), dim3(512), lds, s, a);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
