@@ -592,6 +592,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 constexpr int S8_RING = 4;
 constexpr int sa2_fwd8_lds() { return S2_K * S2_K * 4 + 2 * 2 * 64 * S2_PH + (16 + S2_K + S2_C) * 4; }
 
+template <int MODE>   // 0 = shipped; tools/ub/sa2f_ub.hip: 1 no W2 MFMAs, 2 no W1 MFMAs, 3 no pooled stores, 4 no gather, 5 no syncs C
 __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s2_sm[];
   half8* s_w1 = reinterpret_cast<half8*>(s2_sm);                      // fragment image of W1: [(tile * 8 + c) * 2 + piece][lane]
@@ -616,24 +617,24 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
     f[0] = B2[(size_t)(c * 2 + 0) * 64];
     f[1] = B2[(size_t)(c * 2 + 1) * 64];
   };
-  const long pairs = (long)a.B * a.M / 2;
+  const int pairs = a.B * a.M / 2;   // B * M < 2^31 (checked by the launcher); a pair never straddles two instances (M even)
   int gi = 0;
   float shv = 0.f;
   float4 gv[8];
-  auto request = [&](long p) {     // the pair's gather for this wave: sample `lane` of centre ci, channels 32 qt .. + 31
-    const long centre = 2 * p + ci;
-    const int b = (int)(centre / a.M), m = (int)(centre - (long)b * a.M);
-    gi = a.gidx[centre * 64 + lane];
+  auto request = [&](int p) {     // the pair's gather for this wave: sample `lane` of centre ci, channels 32 qt .. + 31
+    const int centre = 2 * p + ci;
+    const int b = (2 * p) / a.M, m = centre - b * a.M;
+    gi = a.gidx[(size_t)centre * 64 + lane];
     shv = a.shift[((size_t)b * S2_K + 32 * qt + l31) * a.M + m];
     const float4* src = reinterpret_cast<const float4*>(a.rT + ((size_t)b * a.N1 + gi) * S2_K + 32 * qt);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) gv[q] = src[q];
+    for (int q = 0; q < 8; ++q) gv[q] = MODE == 4 ? make_float4(0.1f * q, 0.2f, -0.1f, 0.3f) : src[q];
   };
-  if ((long)blockIdx.x < pairs) request(blockIdx.x);
+  if ((int)blockIdx.x < pairs) request(blockIdx.x);
   __syncthreads();
 
-  for (long p = blockIdx.x; p < pairs; p += gridDim.x) {
-    const long centre = 2 * p + ci;
+  for (int p = blockIdx.x; p < pairs; p += gridDim.x) {
+    const size_t centre = (size_t)(2 * p + ci);
     half8 ring[S8_RING][2];
 #pragma unroll
     for (int i = 0; i + 1 < S8_RING; ++i) load_w2(i, ring[i]);
@@ -688,17 +689,34 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
       const unsigned char* xrow = thi + l31 * S2_PH + h * 16;
       const half8* wf = s_w1 + (size_t)qt * 8 * 2 * 64 + lane;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const half8 wh = wf[(c * 2 + 0) * 64], wl = wf[(c * 2 + 1) * 64];
+      // operands of k-step c + 1 are read from LDS while the matrix core works on step c
+      half8 wq[2][2], xq[2][4];
+      auto read_b = [&](int c, half8 (&w)[2], half8 (&x)[4]) {
+        w[0] = wf[(c * 2 + 0) * 64];
+        w[1] = wf[(c * 2 + 1) * 64];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          const half8 xh = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32);
-          const half8 xl = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32 + 64 * S2_PH);
+          x[2 * cb] = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32);
+          x[2 * cb + 1] = *reinterpret_cast<const half8*>(xrow + cb * 32 * S2_PH + c * 32 + 64 * S2_PH);
+        }
+      };
+      read_b(0, wq[0], xq[0]);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c + 1 < 8) read_b(c + 1, wq[(c + 1) & 1], xq[(c + 1) & 1]);
+        const half8 wh = wq[c & 1][0], wl = wq[c & 1][1];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const half8 xh = xq[c & 1][2 * cb], xl = xq[c & 1][2 * cb + 1];
+          if (MODE == 2) {
+            acc[cb][0] += (float)wh[0] + (float)xh[0] + (float)wl[0] + (float)xl[0];
+            continue;
+          }
           acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[cb], 0, 0, 0);
           acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[cb], 0, 0, 0);
           acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[cb], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // acc[cb][r]: row 32 qt + (r&3) + 8 (r>>2) + 4 h, sample 32 cb + l31
       const float un = carry * un1;
@@ -754,15 +772,28 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
       const unsigned char* xrow = s_img + l31 * S2_PH + h * 16;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        if (c + S8_RING - 1 < 8) load_w2(c + S8_RING - 1, ring[(c + S8_RING - 1) % S8_RING]);
-        const half8 wh = ring[c % S8_RING][0], wl = ring[c % S8_RING][1];
+      half8 xc[2][8];
+      auto read_c = [&](int c, half8 (&x)[8]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const unsigned char* xr = xrow + (q >> 1) * 2 * 64 * S2_PH + (q & 1) * 32 * S2_PH + c * 32;
-          const half8 xh = *reinterpret_cast<const half8*>(xr);
-          const half8 xl = *reinterpret_cast<const half8*>(xr + 64 * S2_PH);
+          x[2 * q] = *reinterpret_cast<const half8*>(xr);
+          x[2 * q + 1] = *reinterpret_cast<const half8*>(xr + 64 * S2_PH);
+        }
+      };
+      read_c(0, xc[0]);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c + S8_RING - 1 < 8) load_w2(c + S8_RING - 1, ring[(c + S8_RING - 1) % S8_RING]);
+        if (c + 1 < 8) read_c(c + 1, xc[(c + 1) & 1]);
+        const half8 wh = ring[c % S8_RING][0], wl = ring[c % S8_RING][1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const half8 xh = xc[c & 1][2 * q], xl = xc[c & 1][2 * q + 1];
+          if (MODE == 1) {
+            acc[q][0] += (float)wh[0] + (float)xh[0] + (float)wl[0] + (float)xl[0];
+            continue;
+          }
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[q], 0, 0, 0);
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[q], 0, 0, 0);
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[q], 0, 0, 0);
@@ -790,9 +821,8 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
         const bool take = ov > v || (ov == v && os < smp);
         v = take ? ov : v;
         smp = take ? os : smp;
-        if (lane < 32) {
-          const long cen = 2 * p + cc;
-          const int b = (int)(cen / a.M), m = (int)(cen - (long)b * a.M);
+        if (lane < 32 && (MODE != 3 || v == 123.f)) {
+          const int b = (2 * p) / a.M, m = 2 * p + cc - b * a.M;
           const int ch = 32 * wave + lane;
           const size_t e = ((size_t)b * S2_C + ch) * a.M + m;
           a.out[e] = fmaxf(v * un + s_b2[ch], 0.f);     // the (positive) scale commutes with the max
@@ -835,14 +865,14 @@ int launch_sa2_bwd(const float* ent_g, const int32_t* ent_c, const float* W2, co
 int launch_sa2_fwd(const float* rT, const int32_t* gidx, const float* shift, const void* w1_img, const float* w1_un,
                    const float* b1, const void* w2_img, const float* w2_un, const float* b2, float* out, int32_t* arg,
                    unsigned long long* m0, unsigned long long* m1, int B, int N1, int M, hipStream_t s) {
-  if (M % 2 != 0) return GEOA3_ENOSUPPORT;
+  if (M % 2 != 0 || (long)B * M > 0x3fffffffL) return GEOA3_ENOSUPPORT;
   Sa2FwdArgs a{rT, gidx, shift, b1, b2, static_cast<const _Float16*>(w1_img), w1_un, static_cast<const _Float16*>(w2_img),
                w2_un, out, arg, m0, m1, B, N1, M};
   const long pairs = (long)B * M / 2;
   const int lds = sa2_fwd8_lds();
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_fwd8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const unsigned grid = (unsigned)(pairs < 256 ? pairs : 256);   // one 8-wave workgroup per CU, persistent
-  hipLaunchKernelGGL(sa2_fwd8_kernel, dim3(grid), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(sa2_fwd8_kernel<0>, dim3(grid), dim3(512), lds, s, a);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -19,6 +19,21 @@ float run(const Sa2FwdArgs& a, int iters) {
   float ms; hipEventElapsedTime(&ms, e0, e1);
   return ms * 1000.f / iters;
 }
+template <int MODE>
+float run8(const Sa2FwdArgs& a, int iters) {
+  const int lds = sa2_fwd8_lds();
+  auto k = sa2_fwd8_kernel<MODE>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, 0, a);
+  hipEventRecord(e0, 0);
+  for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, 0, a);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1000.f / iters;
+}
 int main() {
   const int B = 250, M = 128, N1 = 512;
   const long centres = (long)B * M;
@@ -52,9 +67,15 @@ int main() {
   hipMemcpy(db2, b2.data(), 1024, hipMemcpyHostToDevice);
   hipMemcpy(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice);
   _Float16* img1 = (_Float16*)scr; _Float16* img2 = (_Float16*)(scr + 65536); float* un = (float*)(scr + 196608);
-  hipLaunchKernelGGL(sa2_img_kernel, dim3(1), dim3(256), 0, 0, dw1, 128, img1, un);
-  hipLaunchKernelGGL(sa2_img_kernel, dim3(1), dim3(256), 0, 0, dw2, 256, img2, un + 64);
+  launch_frag_image(dw1, 128, 128, img1, un, 0);
+  launch_frag_image(dw2, 256, 128, img2, un + 64, 0);
   Sa2FwdArgs a{drT, didx, dsh, db1, db2, img1, un, img2, un + 64, out, arg, m0, m1, B, N1, M};
+  printf("fwd8 all               %.1f us\n", run8<0>(a, 5));
+  printf("fwd8 no W2 MFMAs       %.1f us\n", run8<1>(a, 5));
+  printf("fwd8 no W1 MFMAs       %.1f us\n", run8<2>(a, 5));
+  printf("fwd8 no pooled stores  %.1f us\n", run8<3>(a, 5));
+  printf("fwd8 no gather         %.1f us\n", run8<4>(a, 5));
+  printf("fwd8 all               %.1f us\n", run8<0>(a, 5));
   printf("mode0 (all)            %.1f us\n", run<0>(a, 5));
   printf("mode1 (no gather)      %.1f us\n", run<1>(a, 5));
   printf("mode2 (no W1 MFMAs)    %.1f us\n", run<2>(a, 5));
