@@ -32,9 +32,11 @@ __device__ __forceinline__ float sq3(float dx, float dy, float dz) {
 // and padding carry key 0), reduced with DPP row operations inside a wavefront (common.h) and through one LDS slot per
 // wave across wavefronts: ONE barrier per round, no global traffic.  0.66 ms -> see DESIGN for 512 of 1024 points.
 // ------------------------------------------------------------------------------------------
-constexpr int FPS_BLOCK = 512;
-constexpr int FPS_PPT = 16;  // up to 8192 points per cloud
+// FPS_BLOCK threads x FPS_PPT points: 512 x 16 (up to 8192 points) or, for clouds of at most 2048 points, 256 x 8 -- one
+// wave per SIMD: a round is a dependent chain (update, DPP reduction, LDS exchange), two waves on a SIMD only take turns
+// issuing the same ~100 instructions
 
+template <int FPS_BLOCK, int FPS_PPT>
 __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict__ xyz, int N, int m, int T,
                                                         float* __restrict__ temp, int32_t* __restrict__ idxs) {
   extern __shared__ __attribute__((aligned(16))) float s_p[];   // [N][3]
@@ -345,14 +347,18 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
 extern "C" int geoa3_pn2_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int32_t* idx,
                                                  void* stream) {
   if (!xyz || !idx || B <= 0 || N <= 0 || m <= 0) return GEOA3_EINVAL;
-  if (N > FPS_BLOCK * FPS_PPT) return GEOA3_ENOSUPPORT;
+  if (N > 512 * 16) return GEOA3_ENOSUPPORT;
   int T = 1;
   while (T * 2 <= N && T * 2 <= 512) T *= 2;  // opt_n_threads(N), cuda_utils.h:13-19
   const size_t lds = (size_t)N * 3 * sizeof(float);
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(FPS_BLOCK), lds, geoa3_stream(stream), xyz, N, m, T, temp, idx);
+  if (N <= 2048) {
+    hipLaunchKernelGGL((fps_kernel<256, 8>), dim3(B), dim3(256), lds, geoa3_stream(stream), xyz, N, m, T, temp, idx);
+  } else {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<512, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+    hipLaunchKernelGGL((fps_kernel<512, 16>), dim3(B), dim3(512), lds, geoa3_stream(stream), xyz, N, m, T, temp, idx);
+  }
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
