@@ -154,7 +154,7 @@ __device__ __forceinline__ void grid_ball(const int* __restrict__ s_start, float
   }
 }
 
-template <int PPT>
+template <int PPT, int MODE = 0>   // MODE (tools/ub/nn1_ub.hip): 1 = build only, 2 = seeds only (no ball walk)
 __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ A, const float* __restrict__ R, int Na,
                                                       int Nr, const int32_t* prior_ar, const int32_t* prior_ra,
                                                       float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra) {
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
   int* s_pi = reinterpret_cast<int*>(s_pz + M);
   const GridGeom g = grid_build<GT, PPT>(P, M, s_start, s_fill, s_px, s_py, s_pz, s_pi, s_red);
 
+  if (MODE == 1) return;
   for (int t = threadIdx.x; t < Nq; t += GT) {
     // equal-sized clouds: walk the queries in the searched cloud's cell order (query i is a perturbation of point i
     // in the attack loop), so that the lanes of a wavefront look at the same few cells
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
     si = si < 0 ? 0 : (si >= M ? M - 1 : si);
     float best = geoa3_sqdist(qx, qy, qz, P[si], P[M + si], P[2 * M + si]);
     int bi = si;
-    grid_ball(s_start, fx, fy, fz, sqrtf(best), g.inv_h, [&](int s, int e) {
+    if (MODE != 2) grid_ball(s_start, fx, fy, fz, sqrtf(best), g.inv_h, [&](int s, int e) {
       for (int j = s; j < e; ++j) {
         const float d = geoa3_sqdist(qx, qy, qz, s_px[j], s_py[j], s_pz[j]);
         const int i = s_pi[j];

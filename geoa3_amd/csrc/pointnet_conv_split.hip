@@ -37,11 +37,13 @@ __device__ __forceinline__ unsigned cs_exp(float m) {
 __device__ __forceinline__ float cs_scale(unsigned E) { return __uint_as_float((267u - E) << 23); }
 __device__ __forceinline__ float cs_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
 
-template <int NCH, bool FIRST, bool GFIRST, bool BWD3, int PN2 = 0, bool IMG = false>  // K = 16 * NCH; BWD3 needs GFIRST;
+template <int NCH, bool FIRST, bool GFIRST, bool BWD3, int PN2 = 0, bool IMG = false, bool DEEP = false>  // K = 16 * NCH; BWD3 needs GFIRST;
                                                                   // PN2: 1 = pooled output, 2 = one-hot input,
                                                                   // 3 = output pooled over the instance's 128 columns;
-                                                                  // IMG: weights from a pre-split fragment image
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 4 : 2, NCH <= 8 ? 4 : 2))) void conv_cm64s_kernel(ConvArgs a) {
+                                                                  // IMG: weights from a pre-split fragment image;
+                                                                  // DEEP: four chunks in flight per wave, two waves per
+                                                                  // SIMD (launches with at most two workgroups per CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 && !DEEP ? 4 : 2, NCH <= 8 && !DEEP ? 4 : 2))) void conv_cm64s_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
   constexpr int CH = 16, K = CH * NCH;
   constexpr int PITCH = K * 2 + 16;                      // bytes per weight row and piece
@@ -107,7 +109,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
     }
     if (tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
   }
-  float xb[2][CH];
+  // chunks in flight: NB - 1 ahead of the one in the matrix core (a chunk = 16 rows of 256 bytes per wave).  One ahead
+  // leaves a launch with few workgroups (small shards: nothing else on the CU) waiting on NCH dependent round trips
+  constexpr int NB = DEEP && !FIRST ? 4 : 2;
+  float xb[NB][CH];
   auto load_rows = [&](int c, float (&d)[CH]) {
     if (PN2 == 2) {
 #pragma unroll
@@ -124,7 +129,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
       for (int u = 0; u < CH; ++u) d[u] = X[(size_t)(CH * c + u) * a.ldX];
     }
   };
-  if (!FIRST) load_rows(0, xb[0]);
+  if (!FIRST) {
+#pragma unroll
+    for (int i = 0; i + 1 < NB; ++i)
+      if (i < NCH) load_rows(i, xb[i]);
+  }
 
   // IMG: the 64 x K block is read as ready A fragments (hi / lo pieces, 16 bytes per lane) from an image in fragment
   // order, [tile = row >> 5][k >> 4][piece][lane][8] (geoa3_pn2ssg_pack_images): nothing to stage, no LDS for weights
@@ -201,11 +210,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 ? 
     const int c = c0 + cc;
     if (FIRST) {
 #pragma unroll
-      for (int u = 0; u < CH; ++u) xb[cc & 1][u] = fmaxf(cs_first_layer(s_w1[CH * c + u], p0, p1, p2), 0.f);
-    } else if (c + 1 < NCH) {
-      load_rows(c + 1, xb[(cc + 1) & 1]);
+      for (int u = 0; u < CH; ++u) xb[cc % NB][u] = fmaxf(cs_first_layer(s_w1[CH * c + u], p0, p1, p2), 0.f);
+    } else if (c + NB - 1 < NCH) {
+      load_rows(c + NB - 1, xb[(cc + NB - 1) % NB]);
     }
-    float* x = xb[cc & 1];
+    float* x = xb[cc % NB];
     float m = 0.f;
 #pragma unroll
     for (int u = 0; u < CH; ++u) m = fmaxf(m, __builtin_fabsf(live ? x[u] : 0.f));
@@ -477,20 +486,27 @@ int launch_conv_cm_split(const ConvArgs& a, hipStream_t s) {
     GEOA3_CHECK_LAUNCH();
     return GEOA3_OK;
   }
+  // few workgroups (at most two per CU: the 32-instance shards of a multi-GPU run): latency-bound, deep prefetch
+  const bool deep = (size_t)grid.x * grid.y * grid.z <= 512;
   if (a.produce_first)
     hipLaunchKernelGGL((conv_cm64s_kernel<4, true, false, false>), grid, dim3(256), lds, s, a);
-  else if (a.gate_first && a.dx3 && a.K == 64)
-    hipLaunchKernelGGL((conv_cm64s_kernel<4, false, true, true>), grid, dim3(256), lds, s, a);
-  else if (a.gate_first && a.dx3)
-    hipLaunchKernelGGL((conv_cm64s_kernel<8, false, true, true>), grid, dim3(256), lds, s, a);
-  else if (a.gate_first && a.K == 64)
+  else if (a.gate_first && a.dx3 && a.K == 64) {
+    if (deep) hipLaunchKernelGGL((conv_cm64s_kernel<4, false, true, true, 0, false, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_cm64s_kernel<4, false, true, true>), grid, dim3(256), lds, s, a);
+  } else if (a.gate_first && a.dx3) {
+    if (deep) hipLaunchKernelGGL((conv_cm64s_kernel<8, false, true, true, 0, false, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_cm64s_kernel<8, false, true, true>), grid, dim3(256), lds, s, a);
+  } else if (a.gate_first && a.K == 64)
     hipLaunchKernelGGL((conv_cm64s_kernel<4, false, true, false>), grid, dim3(256), lds, s, a);
   else if (a.gate_first)
     hipLaunchKernelGGL((conv_cm64s_kernel<8, false, true, false>), grid, dim3(256), lds, s, a);
-  else if (a.K == 64)
-    hipLaunchKernelGGL((conv_cm64s_kernel<4, false, false, false>), grid, dim3(256), lds, s, a);
-  else
-    hipLaunchKernelGGL((conv_cm64s_kernel<8, false, false, false>), grid, dim3(256), lds, s, a);
+  else if (a.K == 64) {
+    if (deep) hipLaunchKernelGGL((conv_cm64s_kernel<4, false, false, false, 0, false, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_cm64s_kernel<4, false, false, false>), grid, dim3(256), lds, s, a);
+  } else {
+    if (deep) hipLaunchKernelGGL((conv_cm64s_kernel<8, false, false, false, 0, false, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_cm64s_kernel<8, false, false, false>), grid, dim3(256), lds, s, a);
+  }
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

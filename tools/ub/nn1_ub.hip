@@ -1,0 +1,53 @@
+// micro-benchmark of grid_nn1_kernel: hipcc --offload-arch=gfx950 -O3 -o nn1_ub nn1_ub.hip
+#include "../../geoa3_amd/csrc/geom_grid.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+bool geoa3_prof_on() { return false; }
+void geoa3_prof_begin(int, hipStream_t) {}
+void geoa3_prof_end(int, hipStream_t) {}
+template <int MODE>
+float run(const float* A, const float* R, int B, int N, int* prior_ar, int* prior_ra, float* d_ar, int* i_ar, float* d_ra, int* i_ra, int iters) {
+  const size_t lds = grid_nn1_lds(N);
+  auto k = grid_nn1_kernel<1, MODE>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, A, R, N, N, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra);
+  hipEventRecord(e0, 0);
+  for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, A, R, N, N, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1000.f / iters;
+}
+int main(int argc, char** argv) {
+  const int B = 250, N = 1024;
+  const float noise = argc > 1 ? atof(argv[1]) : 0.03f;
+  std::vector<float> ori((size_t)B * 3 * N), adv((size_t)B * 3 * N);
+  srand(5);
+  auto rnd = [] { return (rand() % 20001 - 10000) * 1e-4f; };
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < N; ++i) {
+      float x = rnd(), y = rnd(), z = rnd();
+      const float n = sqrtf(x * x + y * y + z * z) + 1e-6f;
+      x /= n; y /= n; z /= n;
+      const size_t o = (size_t)b * 3 * N + i;
+      ori[o] = x; ori[o + N] = y; ori[o + 2 * N] = z;
+      adv[o] = x + noise * rnd(); adv[o + N] = y + noise * rnd(); adv[o + 2 * N] = z + noise * rnd();
+    }
+  float *dA, *dR, *d_ar, *d_ra; int *i_ar, *i_ra;
+  hipMalloc(&dA, adv.size() * 4); hipMalloc(&dR, ori.size() * 4);
+  hipMalloc(&d_ar, (size_t)B * N * 4); hipMalloc(&d_ra, (size_t)B * N * 4); hipMalloc(&i_ar, (size_t)B * N * 4); hipMalloc(&i_ra, (size_t)B * N * 4);
+  hipMemcpy(dA, adv.data(), adv.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dR, ori.data(), ori.size() * 4, hipMemcpyHostToDevice);
+  // first run without priors fills i_*, then they serve as priors (the loop's steady state)
+  run<0>(dA, dR, B, N, nullptr, nullptr, d_ar, i_ar, d_ra, i_ra, 1);
+  printf("noise %.2f\n", noise);
+  printf("full, own-index seed  %.1f us\n", run<0>(dA, dR, B, N, nullptr, nullptr, d_ar, i_ar, d_ra, i_ra, 10));
+  printf("full, prior seed      %.1f us\n", run<0>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
+  printf("build only            %.1f us\n", run<1>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
+  printf("seeds only            %.1f us\n", run<2>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
+  return 0;
+}
