@@ -207,8 +207,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    dominant_tag = TAG_CONV5 if a.arch == "PointNet" and not (npoint >= 4096) else (
-        TAG_KNN if a.arch == "PointNet" else TAG_SA1_BWD)
+    dominant_tag = TAG_CONV5 if a.arch == "PointNet" else TAG_SA1_BWD
 
     submit = [0.0]
 
@@ -347,21 +346,22 @@ def main():
                        "classes": CLASSES, "wide_mode": wmode, "presteps": a.presteps,
                        "parallelism": "instance-sharded x%d" % world},
         }
-        if a.arch == "PointNet" and npoint < 4096:
+        if a.arch == "PointNet":
             out["roofline"] = conv5_roofline(wmode, kms.get(TAG_CONV5))
             from geoa3_amd.pointnet import wide_shape
             tr, src = pmc_traffic(("wide16_kernel<3" if wide_shape("conv5") == 16 else "wide_split_kernel<3")
-                                  if wmode == "f16x2" else "wide_max2_kernel<3", "c2")
-            if tr is not None and B == BATCH and npoint == 1024 and out["roofline"]:
+                                  if wmode == "f16x2" else "wide_max2_kernel<3", "c2" if npoint < 4096 else "c5")
+            if tr is not None and B == BATCH and npoint in (1024, 4096) and out["roofline"]:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % src
-        elif a.arch == "PointNet":
-            # configs[4]: the self top-(k+1) search is the largest kernel of the iteration.  Its algorithmic HBM bytes
-            # (SURVEY 8d): read B*N*12, write B*N*(k+1)*8 (distances + indices); it is VALU/LDS bound (8*B*N^2 flops
-            # all-pairs), so the HBM fraction is small by construction and valu_frac is given beside it
+        if a.arch == "PointNet" and npoint >= 4096:
+            # configs[4]: the self top-(k+1) search was the largest kernel of the iteration until the cell-grid walk took
+            # its candidates 64 at a time (now conv5 is, as at 1024 points); it is reported beside the roofline.  Its
+            # algorithmic HBM bytes: read B*N*12, write B*N*(k+1)*8 (distances + indices); it is VALU/LDS
+            # bound (8*B*N^2 flops all-pairs), so the HBM fraction is small by construction: valu_frac is given beside it
             ms = kms.get(TAG_KNN)
             bytes_ = B * npoint * (12.0 + (knn + 1) * 8.0)
-            out["roofline"] = None if not ms else {
+            out["knn_kernel"] = None if not ms else {
                 "bound": "hbm", "kernel": "knn_grid_kernel (self top-%d on a 16^3 cell grid, one wavefront per query)" % (knn + 1),
                 "achieved": round(bytes_ / (ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                 "frac": round(bytes_ / (ms * 1e-3) / PEAK_HBM, 5), "avg_launch_ms": round(ms, 4),
@@ -369,9 +369,9 @@ def main():
                 "valu_frac_vs_all_pairs_flops": round(8.0 * B * npoint * npoint / (ms * 1e-3) / PEAK_F32_VALU, 4),
                 "traffic": None}
             tr, src = pmc_traffic("knn_grid_kernel", "c5")
-            if tr is not None and out["roofline"] and B == BATCH:
-                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, "profiles/" + src
-        else:
+            if tr is not None and out["knn_kernel"] and B == BATCH:
+                out["knn_kernel"]["traffic"], out["knn_kernel"]["traffic_source"] = tr, "profiles/" + src
+        if a.arch != "PointNet":
             # configs[3]: level 1's backward (recompute 3->64->64, then the input gradient through 128->64->64->3) is the
             # largest kernel.  Algorithmic flops (input gradient only, no recompute): 2*(128*64 + 64*64 + 64*3) per
             # grouped sample, B*512*64 samples; executed on the f16 pipe with split operands (3 products per product)
