@@ -147,7 +147,7 @@ __device__ __forceinline__ void grid_ball(const int* __restrict__ s_start, float
       const float ey = fmaxf(fmaxf((float)y - fy, fy - (float)(y + 1)), 0.f);
       const float rem = rho2 - ex * ex - ey * ey;
       if (rem < 0.f) continue;
-      const float zr = sqrtf(rem) + 1e-4f;
+      const float zr = __builtin_amdgcn_sqrtf(rem) + 1e-4f;   // v_sqrt_f32 (1 ulp): far inside the 1e-4-cell margin
       const int col = (x * GG + y) * GG;
       visit(s_start[col + grid_coord(fz - zr)], s_start[col + grid_coord(fz + zr) + 1]);
     }
@@ -190,7 +190,17 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
     si = si < 0 ? 0 : (si >= M ? M - 1 : si);
     float best = geoa3_sqdist(qx, qy, qz, P[si], P[M + si], P[2 * M + si]);
     int bi = si;
+    if (MODE == 3) {   // statistics: columns iterated per query, by bucket
+      const float rho = sqrtf(best) * g.inv_h * 1.00001f + 1e-4f;
+      const int nx = grid_coord(fx + rho) - grid_coord(fx - rho) + 1, ny = grid_coord(fy + rho) - grid_coord(fy - rho) + 1;
+      const int n = nx * ny;
+      atomicAdd(reinterpret_cast<unsigned long long*>(d_ar) + 2 + (n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 64 ? 2 : 3))), 1ull);
+    }
     if (MODE != 2) grid_ball(s_start, fx, fy, fz, sqrtf(best), g.inv_h, [&](int s, int e) {
+      if (MODE == 3) {   // statistics: columns visited, candidates
+        atomicAdd(reinterpret_cast<unsigned long long*>(d_ar), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(d_ar) + 1, (unsigned long long)(e - s));
+      }
       for (int j = s; j < e; ++j) {
         const float d = geoa3_sqdist(qx, qy, qz, s_px[j], s_py[j], s_pz[j]);
         const int i = s_pi[j];
@@ -199,8 +209,10 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
         bi = take ? i : bi;
       }
     });
-    dout[q] = best;
-    iout[q] = bi;
+    if (MODE != 3) {
+      dout[q] = best;
+      iout[q] = bi;
+    }
   }
 }
 

@@ -49,5 +49,15 @@ int main(int argc, char** argv) {
   printf("full, prior seed      %.1f us\n", run<0>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
   printf("build only            %.1f us\n", run<1>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
   printf("seeds only            %.1f us\n", run<2>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
+  {
+    unsigned long long* cnt; hipMalloc(&cnt, 64); hipMemset(cnt, 0, 64);
+    const size_t lds = grid_nn1_lds(N);
+    auto k = grid_nn1_kernel<1, 3>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, dA, dR, N, N, i_ar, i_ra, (float*)cnt, i_ar, (float*)cnt, i_ra);
+    unsigned long long h[8]; hipMemcpy(h, cnt, 64, hipMemcpyDeviceToHost);
+    printf("columns iterated per query: <=4: %llu  <=16: %llu  <=64: %llu  >64: %llu\n", h[2], h[3], h[4], h[5]);
+    printf("per query: %.1f columns, %.1f candidates\n", h[0] / (2.0 * B * N), h[1] / (2.0 * B * N));
+  }
   return 0;
 }
