@@ -42,6 +42,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
   const bool live = col < a.N;
   const float* X = FIRST ? nullptr : a.X + (size_t)b * a.sXb + (live ? col : a.N - 1);
   float4* s_w1 = reinterpret_cast<float4*>(s_w + 64 * pitch + 4);   // [64] (w1 row, b1) of the folded first layer
+  // per-row operands of the epilogue (bias, gate words): one coalesced load per wave here, read back with v_readlane --
+  // 64 uniform loads inside the epilogue are 64 dependent round trips (pointnet_conv_split.hip)
+  const size_t mword = ((size_t)b * ((a.N + 63) >> 6) + (size_t)(blockIdx.x * 4 + wave)) * a.Co;
+  const bool wave_live = blockIdx.x * 256 + wave * 64 < a.N;
+  const float biasv = a.bias ? a.bias[rb * 64 + lane] : 0.f;
+  const unsigned long long zmv = (a.Zmask && wave_live) ? a.Zmask[mword + rb * 64 + lane] : 0ull;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;                                // T^T x of this lane's point
   float x0 = 0.f, x1 = 0.f, x2 = 0.f;
   if (FIRST || GFIRST) {
@@ -122,9 +128,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
   const float* Z = a.Z ? a.Z + (size_t)b * a.sZb + col : nullptr;
   // bit masks: one 64-bit word per (row, this wave's 64 columns), stored [B][column block][row]: the 64 rows of a
   // wave are one 512-byte run (a store of 8 scattered bytes per row cost more than the row reads it saved)
-  const int n64 = (a.N + 63) >> 6;
-  const size_t mword = ((size_t)b * n64 + (size_t)(blockIdx.x * 4 + wave)) * a.Co;
-  const bool wave_live = blockIdx.x * 256 + wave * 64 < a.N;
   unsigned long long mymask = 0ull;    // Ymask: lane r collects the word of row rb*64 + r
   float q0 = 0.f, q1 = 0.f, q2 = 0.f;   // BWD3: d/d(T^T x) of this lane's point, summed over the 64 rows
 #pragma unroll
@@ -142,8 +145,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
       if (a.Zmask && wave_live) {                  // wave-uniform 8-byte loads: bit `lane` gates this lane's column
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const unsigned long long m = a.Zmask[mword + row0 + i];
-          z[i] = (m >> lane) & 1ull ? 1.f : 0.f;
+          const int rl = t * 32 + 8 * g + i;   // the lane that holds this row's gate word
+          const unsigned mlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)zmv, rl);
+          const unsigned mhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(zmv >> 32), rl);
+          z[i] = ((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u) ? 1.f : 0.f;
         }
       }
       if (live) {
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           float o = v[i];
-          if (a.bias) o += a.bias[row0 + i];
+          if (a.bias) o += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(biasv), t * 32 + 8 * g + i));
           if (a.relu) o = fmaxf(o, 0.f);
           if (a.accumulate) o += y[i];
           if (Z || a.Zmask) o = z[i] > 0.f ? o : 0.f;  // gate AFTER accumulation (sum of branches, then relu')
