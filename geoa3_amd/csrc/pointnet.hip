@@ -138,8 +138,9 @@ int conv_gate_first(const float* X, int K, const float* W, float* Y, const float
 }
 
 int fc(const float* X, int K, const float* W, const float* bias, float* Y, int Nout, int M, bool relu, const float* Z,
-       hipStream_t s) {
+       hipStream_t s, float* kscratch = nullptr) {
   FcArgs a{};
+  a.kscratch = kscratch;
   a.X = X; a.ldX = K;
   a.W = W; a.ldW = K;
   a.bias = bias;
@@ -211,7 +212,10 @@ int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, c
              const float* x3, const float* act128, const unsigned long long* m128,
              const float* pooled, const int* arg, const float* f4, const float* f5, Ws& w, float* G64out, int B, int N,
              hipStream_t s) {
-  TRY(fc(gT, t.K * t.K, t.f3t, nullptr, w.g256, 256, B, false, f5, s));
+  // (K = 4096 for the feature transform: split over four workgroups per tile through G128, which is written only below,
+  //  when its B * 128 * N floats hold the ceil(B / 16) * 16 tiles x 4096 partial values)
+  const bool ks = (size_t)((B + 15) / 16) * 16 * 4096 <= (size_t)B * 128 * N;
+  TRY(fc(gT, t.K * t.K, t.f3t, nullptr, w.g256, 256, B, false, f5, s, ks ? w.G128 : nullptr));
   TRY(fc(w.g256, 256, t.f2t, nullptr, w.g512, 512, B, false, f4, s));
   TRY(fc(w.g512, 512, t.f1t, nullptr, w.g1024, 1024, B, false, pooled, s));
   TRY(wide_bwd(w.g1024, arg, t.w3, act128, m128, w.G128, 1, B, N, s));

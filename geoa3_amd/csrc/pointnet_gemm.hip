@@ -267,15 +267,20 @@ __device__ __forceinline__ void load4(const float* p, int k, int kend, bool vec,
   }
 }
 
-template <int T, int S>
+// Q > 1 (K >= 2048, a.kscratch given): the S * Q waves that split K are spread over Q workgroups (grid.z); every wave
+// writes its partial tile to kscratch and fc_ksplit_reduce_kernel adds the S * Q partials in wave order and finishes --
+// the same partial sums in the same order as ONE workgroup of S * Q waves, so not a bit changes, but a K = 4096 layer with
+// 256 output tiles runs on 1024 workgroups instead of 256 (54 -> ~20 us at 250 instances).
+template <int T, int S, int Q = 1>
 __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
   constexpr int R = T == 32 ? 16 : 4;        // accumulator registers per lane
   constexpr int G = 64 / T;                  // lane groups along k inside one MFMA (2 or 4)
   constexpr int KQ = 4 * G;                  // k consumed per 16-byte load of every lane (8 or 16)
   constexpr int U = 64 / KQ;                 // loads per batch: one batch = 64 k
-  __shared__ float s_red[S > 1 ? S * R * 64 : 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int o0 = blockIdx.x * T, m0 = blockIdx.y * T, bz = blockIdx.z;
+  __shared__ float s_red[S > 1 && Q == 1 ? S * R * 64 : 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) + (Q > 1 ? (int)blockIdx.z * S : 0);   // among the S * Q waves that split K
+  const int o0 = blockIdx.x * T, m0 = blockIdx.y * T, bz = Q > 1 ? 0 : blockIdx.z;
   const int r = lane & (T - 1), g = lane / T;
   const int m = min(m0 + r, a.M - 1), o = min(o0 + r, a.Nout - 1);
   const float* xp = a.X + (size_t)bz * a.sXb + (size_t)m * a.ldX;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
   const bool wvec = ((a.ldW | a.sWb) & 3) == 0 && ((uintptr_t)a.W & 15) == 0;
   // this wave's K range, in units of 16 for both tile shapes
   const int kq = (a.K + 15) / 16;
-  const int per = (kq + S - 1) / S;
+  const int per = (kq + S * Q - 1) / (S * Q);
   const int kb = wave * per * 16, ke = min(a.K, (wave + 1) * per * 16);
 
   typename std::conditional<T == 32, f32x16, f32x4>::type acc;
@@ -328,6 +333,12 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
       mma_batch(xa[1], wb[1]);
     }
   }
+  if constexpr (Q > 1) {   // partial tile of this wave: [tile][wave][register][lane]
+    float* ps = a.kscratch + (((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (S * Q) + wave) * R) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < R; ++i) ps[i * 64] = acc[i];
+    return;
+  }
   const int oc = o0 + r;
   const float bias = (a.bias && oc < a.Nout) ? a.bias[oc] : 0.f;
   auto finish = [&](int i, float v) {   // accumulator register i of this lane -> Y
@@ -351,6 +362,28 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
 #pragma unroll
       for (int w = 1; w < S; ++w) v += s_red[(w * R + i) * 64 + lane];
       finish(i, v);
+    }
+  }
+}
+
+// the S * Q partial tiles of fc_kernel<T, S, Q> summed in wave order, then the layer's tail (one wavefront per tile)
+template <int T>
+__global__ __launch_bounds__(64) void fc_ksplit_reduce_kernel(FcArgs a, int waves) {
+  constexpr int R = T == 32 ? 16 : 4;
+  const int lane = threadIdx.x, o0 = blockIdx.x * T, m0 = blockIdx.y * T;
+  const int r = lane & (T - 1), g = lane / T, oc = o0 + r;
+  const float bias = (a.bias && oc < a.Nout) ? a.bias[oc] : 0.f;
+  const float* ps = a.kscratch + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * waves * R) * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    float v = ps[i * 64];
+    for (int w = 1; w < waves; ++w) v += ps[((size_t)w * R + i) * 64];
+    const int mr = m0 + (T == 32 ? mfma_row(i, lane) : 4 * g + i);
+    if (oc < a.Nout && mr < a.M) {
+      v += bias;
+      if (a.relu) v = fmaxf(v, 0.f);
+      if (a.Z) v = a.Z[(size_t)mr * a.ldZ + oc] > 0.f ? v : 0.f;
+      a.Y[(size_t)mr * a.ldY + oc] = v;
     }
   }
 }
@@ -422,6 +455,14 @@ int launch_fc(const FcArgs& a, hipStream_t s) {
   waves = waves >= 16 ? 16 : waves > 4 ? 8 : waves > 2 ? 4 : waves > 1 ? 2 : 1;
   // 16 x 16 tiles while a 32 x 32 tiling would leave most CUs without a workgroup
   const long tiles32 = (long)((a.Nout + 31) / 32) * ((a.M + 31) / 32) * (a.batch > 1 ? a.batch : 1);
+  if (a.kscratch && waves == 16 && a.K >= 2048 && a.batch <= 1 && (a.tile == 16 || (a.tile == 0 && tiles32 < 256))) {
+    // K spread over four workgroups per tile (same partial sums, same order: see fc_kernel)
+    dim3 grid((a.Nout + 15) / 16, (a.M + 15) / 16, 4);
+    hipLaunchKernelGGL((fc_kernel<16, 4, 4>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((fc_ksplit_reduce_kernel<16>), dim3(grid.x, grid.y), dim3(64), 0, s, a, 16);
+    GEOA3_CHECK_LAUNCH();
+    return GEOA3_OK;
+  }
   if (a.tile == 16 || (a.tile == 0 && tiles32 < 256)) launch_fc_tile<16>(a, waves, s);
   else launch_fc_tile<32>(a, waves, s);
   GEOA3_CHECK_LAUNCH();

@@ -69,6 +69,8 @@ struct FcArgs {
   float* Y; int ldY;
   int M, Nout, K;
   int relu;
+  float* kscratch;                            // optional: ceil(Nout/16) * ceil(M/16) * 4096 floats -- K >= 2048 is then split
+                                              // over four workgroups per tile (same sums, same order)
 };
 int launch_fc(const FcArgs& a, hipStream_t s);
 
