@@ -367,17 +367,23 @@ __global__ __launch_bounds__(64 * S) void fc_kernel(FcArgs a) {
 }
 
 // the S * Q partial tiles of fc_kernel<T, S, Q> summed in wave order, then the layer's tail (one wavefront per tile)
-template <int T>
-__global__ __launch_bounds__(64) void fc_ksplit_reduce_kernel(FcArgs a, int waves) {
+template <int T, int WAVES>
+__global__ __launch_bounds__(64) void fc_ksplit_reduce_kernel(FcArgs a) {
   constexpr int R = T == 32 ? 16 : 4;
   const int lane = threadIdx.x, o0 = blockIdx.x * T, m0 = blockIdx.y * T;
   const int r = lane & (T - 1), g = lane / T, oc = o0 + r;
   const float bias = (a.bias && oc < a.Nout) ? a.bias[oc] : 0.f;
-  const float* ps = a.kscratch + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * waves * R) * 64 + lane;
+  const float* ps = a.kscratch + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES * R) * 64 + lane;
+  float part[R][WAVES];     // every partial value in flight before the first add
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) part[i][w] = ps[((size_t)w * R + i) * 64];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    float v = ps[i * 64];
-    for (int w = 1; w < waves; ++w) v += ps[((size_t)w * R + i) * 64];
+    float v = part[i][0];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) v += part[i][w];
     const int mr = m0 + (T == 32 ? mfma_row(i, lane) : 4 * g + i);
     if (oc < a.Nout && mr < a.M) {
       v += bias;
@@ -459,7 +465,7 @@ int launch_fc(const FcArgs& a, hipStream_t s) {
     // K spread over four workgroups per tile (same partial sums, same order: see fc_kernel)
     dim3 grid((a.Nout + 15) / 16, (a.M + 15) / 16, 4);
     hipLaunchKernelGGL((fc_kernel<16, 4, 4>), grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL((fc_ksplit_reduce_kernel<16>), dim3(grid.x, grid.y), dim3(64), 0, s, a, 16);
+    hipLaunchKernelGGL((fc_ksplit_reduce_kernel<16, 16>), dim3(grid.x, grid.y), dim3(64), 0, s, a);
     GEOA3_CHECK_LAUNCH();
     return GEOA3_OK;
   }
