@@ -2,6 +2,7 @@
 // Reference: Model/PointNet.py:56-94 (transform_net) and :96-160 (PointNet.forward); the backward is the
 // hand-derived input-gradient of that graph (weights never receive gradients; the reference's autograd
 // also forms the unused weight gradients, Attacker/geoA3_attack.py:326).
+#include <cstdlib>
 #include "pointnet_kernels.h"
 
 namespace {
@@ -86,6 +87,12 @@ thread_local int tl_split = 0;
     int rc__ = (expr);        \
     if (rc__ != 0) return rc__; \
   } while (0)
+
+// GEOA3_FUSE_BWD=0: the sparse backward and the 128 -> 64 layer behind it as two kernels (A/B switch)
+bool fuse_bwd() {
+  const char* e = getenv("GEOA3_FUSE_BWD");
+  return !(e && e[0] == '0');
+}
 
 // Y = act(W X + bias) over [B][K][N] -> [B][Co][N]; shared weights [Co][K]
 int conv(const float* X, int K, const float* W, const float* bias, float* Y, int Co, int B, int N, bool relu,
@@ -188,6 +195,18 @@ int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, con
   return launch_wide_max_bwd(a, s);
 }
 
+// sparse backward of a 1024-wide layer + the gated 128 -> 64 layer behind it in one kernel (split mode: bit gates)
+int wide_bwd_conv(const float* g, const int* arg, const float* W, const unsigned long long* Zmask, const float* W2t,
+                  const unsigned long long* Zmask2, float* dY, int taps, int B, int N, hipStream_t s) {
+  WideBwdArgs a{};
+  a.Zmask = Zmask;
+  a.g = g; a.arg = arg; a.W = W;
+  a.W2t = W2t; a.Zmask2 = Zmask2;
+  a.dY = dY; a.sYb = (long)64 * N; a.ldY = N;
+  a.Co = 1024; a.N = N; a.B = B; a.taps = taps;
+  return launch_wide_bwd_conv(a, s);
+}
+
 // transform_net.forward (Model/PointNet.py:78-87) after its first layer
 // act64 == nullptr: the T-Net reads the cloud itself (K = 3) and its first layer is folded into conv2 (x3 given)
 int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* x3, float* act128,
@@ -218,6 +237,10 @@ int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, c
   TRY(fc(gT, t.K * t.K, t.f3t, nullptr, w.g256, 256, B, false, f5, s, ks ? w.G128 : nullptr));
   TRY(fc(w.g256, 256, t.f2t, nullptr, w.g512, 512, B, false, f4, s));
   TRY(fc(w.g512, 512, t.f1t, nullptr, w.g1024, 1024, B, false, pooled, s));
+  if (act64 && tl_split && m128 && m64 && fuse_bwd()) {
+    TRY(wide_bwd_conv(w.g1024, arg, t.w3, m128, t.w2t, m64, G64out, 1, B, N, s));
+    return 0;
+  }
   TRY(wide_bwd(w.g1024, arg, t.w3, act128, m128, w.G128, 1, B, N, s));
   if (act64) TRY(conv(w.G128, 128, t.w2t, nullptr, G64out, 64, B, N, false, nullptr, false, s, nullptr, m64));
   else TRY(conv_gate_first(w.G128, 128, t.w2t, nullptr, x3, nullptr, t.w1, t.b1, B, N, s, G64out /* = dx */, 1));
@@ -294,8 +317,12 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.f6, s));
   TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, 1024, B, false, w.p5, s));
   // max + conv5 (sparse), conv4, conv3
-  TRY(wide_bwd(w.g1024, w.i5, p.w5, w.h4, w.m_h4, w.G128, 3, B, N, s));
-  TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, nullptr, false, s, nullptr, w.m_h3));
+  if (tl_split && fuse_bwd()) {
+    TRY(wide_bwd_conv(w.g1024, w.i5, p.w5, w.m_h4, p.w4t, w.m_h3, w.G64a, 3, B, N, s));
+  } else {
+    TRY(wide_bwd(w.g1024, w.i5, p.w5, w.h4, w.m_h4, w.G128, 3, B, N, s));
+    TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, nullptr, false, s, nullptr, w.m_h3));
+  }
   // conv3 + feature transform, merged as in forward (G64a = d/d(pre-activation of h3)):
   //   dT64[b][i][j] = sum_n h2[i][n] (W3^T G64a)[j][n] = ((h2 G64a^T) W3)[i][j];   dh2 = T64 W3^T G64a = W3eff^T G64a
   {

@@ -121,10 +121,16 @@ struct WideBwdArgs {
   const unsigned long long* Zmask;            // its bit mask [B][ceil(N/64)][128] (ConvArgs::Ymask)
   float* dX; long sXb; int ldX;               // [B][128][N]
   int Co, N, B, taps;
+  // launch_wide_bwd_conv (pointnet_wide_bwdconv.hip): the gated 128 -> 64 layer behind the sparse gradient in the same
+  // kernel: dY[b][o][n] = gate2 . sum_ci W2t[o][ci] dX[b][ci][n] (dX stays in LDS; needs Zmask).  W2t [64][128];
+  // Zmask2: relu bits of the 64-channel activation, [B][ceil(N/64)][64] words (ConvArgs::Ymask layout)
+  const float* W2t; const unsigned long long* Zmask2;
+  float* dY; long sYb; int ldY;
   int form;                                   // 0 = register accumulation over per-column lists (default), 1 = the first
                                               // form (LDS accumulation); same sums in the same order
 };
 int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s);
+int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s);
 
 // P[b][i][o] = sum_n A[b][i][n] G[b][o][n], A and G [B][64][N], split-fp16 operands (pointnet_gram.hip)
 int gram64_parts(int N);

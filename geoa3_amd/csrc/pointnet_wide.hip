@@ -304,8 +304,9 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_max_bwd2_kernel(WideBwdArgs 
   float* s_fg = smem + a.Co * TAPS;                                     // [Co * TAPS] their upstream gradients
   const int region = max(WM_CI * PITCH, 2 * a.Co * TAPS);
   int* s_list = reinterpret_cast<int*>(smem + region);                  // [Co * TAPS] (co * TAPS + tap) | (column << 16), by column
-  float* s_gl = reinterpret_cast<float*>(s_list + a.Co * TAPS);         // [Co * TAPS] upstream gradient of the hit
-  int* s_off = reinterpret_cast<int*>(s_gl + a.Co * TAPS);              // [COLS + 1] column counts -> start offsets
+  // (a hit's upstream gradient is read again from g in the walk -- an L2 hit beside the weight row it multiplies --
+  //  instead of being carried in a second list: one more workgroup per CU)
+  int* s_off = s_list + a.Co * TAPS;                                    // [COLS + 1] column counts -> start offsets
   int* s_wcnt = s_off + COLS + 1;                                       // [BW2_WAVES + 1] hits found by each wave -> offsets
   int* s_sidecol = s_wcnt + BW2_WAVES + 1;                              // [BW2_WAVES]
   float* s_side = reinterpret_cast<float*>(s_sidecol + BW2_WAVES);      // [BW2_WAVES][128]
@@ -398,7 +399,6 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_max_bwd2_kernel(WideBwdArgs 
         if (mine) {
           const int slot = basec[j] + __popcll(mask & lt);
           s_list[slot] = e;
-          s_gl[slot] = g;
         }
         basec[j] += __popcll(mask);
       }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_max_bwd2_kernel(WideBwdArgs 
         const bool ok = h0 + u < hi;
         const int e = s_list[ok ? h0 + u : hi - 1];
         w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)(e & 0xffff) * ldW + 2 * lane);
-        gg[u] = ok ? s_gl[h0 + u] : 0.f;
+        gg[u] = ok ? gb[(e & 0xffff) / TAPS] : 0.f;
         cc[u] = ok ? e >> 16 : -2;
       }
 #pragma unroll
@@ -564,7 +564,7 @@ int launch_wide_max_bwd(const WideBwdArgs& a, hipStream_t s) {
     if (a.Co * a.taps > 0xffff) return GEOA3_ENOSUPPORT;
     dim3 grid((a.N + 63) / 64, a.B);
     const size_t region = (size_t)WM_CI * 65 > 2 * (size_t)a.Co * a.taps ? (size_t)WM_CI * 65 : 2 * (size_t)a.Co * a.taps;
-    const size_t lds = (region + 2 * (size_t)a.Co * a.taps + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 3) * sizeof(float);
+    const size_t lds = (region + (size_t)a.Co * a.taps + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 3) * sizeof(float);
     if (a.taps == 1) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_max_bwd2_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,0 +1,314 @@
+// The sparse backward of a 1024-wide layer AND the 128 -> 64 layer behind it in one kernel (gfx950): what
+// wide_max_bwd2_kernel (pointnet_wide.hip) writes out -- the [B,128,N] gradient, 131 MB at B = 250 -- is consumed by a
+// gated 128 -> 64 convolution that reads it back.  Here the 64-column tile stays in LDS (column-major), is gated, and
+// goes through W2^T on the matrix core; only the [B,64,N] result leaves (a third of the bytes of the two kernels, one
+// launch).  Phases (1)-(3) are those of wide_max_bwd2_kernel: same hit lists, same sums in the same order.
+// Reference: the autograd of Model/PointNet.py:80-82,146-147 (conv3 / conv5 + max, conv2 / conv4 + relu).
+#include "pointnet_kernels.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr int WM_CI = 128;
+
+__device__ __forceinline__ unsigned bc_exp(float m) {
+  const unsigned E = (__float_as_uint(m) >> 23) & 0xffu;
+  return E < 14u ? 14u : (E > 254u ? 254u : E);
+}
+__device__ __forceinline__ float bc_scale(unsigned E) { return __uint_as_float((267u - E) << 23); }
+__device__ __forceinline__ float bc_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
+
+constexpr int BW2_WAVES = 8, BW2_THREADS = 64 * BW2_WAVES;
+constexpr int BC_PT = WM_CI + 4;   // floats per column of the tile (column-major here: the B operand reads 8 consecutive ci)
+template <int TAPS>
+__global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int COLS = 64;
+  float* s_acc = smem;                                                  // [64 columns][BC_PT]; before the walk: the flat list
+  int* s_flat = reinterpret_cast<int*>(smem);                           // [Co * TAPS] hits in (channel chunk, tap, channel) order
+  float* s_fg = smem + a.Co * TAPS;                                     // [Co * TAPS] their upstream gradients
+  const int region = max(COLS * BC_PT, 2 * a.Co * TAPS);
+  int* s_list = reinterpret_cast<int*>(smem + region);                  // [Co * TAPS] (co * TAPS + tap) | (column << 16), by column
+  // (a hit's upstream gradient is read again from g in the walk -- an L2 hit beside the weight row it multiplies --
+  //  instead of being carried in a second list: 12 KB of LDS less at three taps, one more workgroup per CU)
+  int* s_off = s_list + a.Co * TAPS;                                    // [COLS + 1] column counts -> start offsets
+  int* s_wcnt = s_off + COLS + 1;                                       // [BW2_WAVES + 1] hits found by each wave -> offsets
+  int* s_sidecol = s_wcnt + BW2_WAVES + 1;                              // [BW2_WAVES]
+  float* s_side = reinterpret_cast<float*>(s_sidecol + BW2_WAVES);      // [BW2_WAVES][128]
+  float* s_mx = s_side + BW2_WAVES * WM_CI;                             // [8] tile maxima of the waves, [8] weight maxima
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, m0 = blockIdx.x * COLS;
+  // requested now, used at the very end: the gate word of output row `lane`
+  unsigned long long gw2 = 0ull;
+  if (wave < 4) gw2 = a.Zmask2[((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * 64 + lane];
+  const float* gb = a.g + (size_t)b * a.Co;
+  const int* argb = a.arg + (size_t)b * a.Co;
+  if (tid <= COLS) s_off[tid] = 0;
+  __syncthreads();
+  // (1) ordered compaction.  Wave w looks at channels [w Co/8, (w+1) Co/8) in chunks of 64; a hit's place in the flat
+  // list follows (chunk, tap, channel): ballot + popcount, no ordering left to chance.
+  const int cpw = (a.Co + BW2_WAVES - 1) / BW2_WAVES, c_lo = wave * cpw, c_hi = min(a.Co, c_lo + cpw);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  {
+    int cnt = 0;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+      const int co = c0 + lane;
+      const bool in = co < c_hi;
+      const float g = in ? gb[co] : 0.f;
+      const int base = (in ? argb[co] : 0) - TAPS / 2 - m0;
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int c = base + tap;
+        const bool hit = g != 0.f && c >= 0 && c < COLS && m0 + c < a.N;
+        cnt += __popcll(__ballot(hit));
+        if (hit) atomicAdd(&s_off[c], 1);
+      }
+    }
+    if (lane == 0) s_wcnt[wave] = cnt;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < BW2_WAVES; ++w) {
+      const int c = s_wcnt[w];
+      s_wcnt[w] = run;
+      run += c;
+    }
+    s_wcnt[BW2_WAVES] = run;
+  }
+  if (tid >= 64 && tid < 128) {   // exclusive scan of the 64 column counts (wave 1)
+    const int cnt = s_off[lane];
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    s_off[lane] = incl - cnt;
+    if (lane == 63) s_off[COLS] = incl;
+  }
+  __syncthreads();
+  {
+    int pos = s_wcnt[wave];
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+      const int co = c0 + lane;
+      const bool in = co < c_hi;
+      const float g = in ? gb[co] : 0.f;
+      const int base = (in ? argb[co] : 0) - TAPS / 2 - m0;
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int c = base + tap;
+        const bool hit = g != 0.f && c >= 0 && c < COLS && m0 + c < a.N;
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+          const int slot = pos + __popcll(mask & lt);
+          s_flat[slot] = (co * TAPS + tap) | (c << 16);
+          s_fg[slot] = g;
+        }
+        pos += __popcll(mask);
+      }
+    }
+  }
+  __syncthreads();
+  // (2) stable placement by column: wave w owns columns 8 w .. 8 w + 7 and passes over the flat list in order, so
+  // every column's list keeps the flat order
+  const int total = s_off[COLS];
+  {
+    int basec[COLS / BW2_WAVES];
+#pragma unroll
+    for (int j = 0; j < COLS / BW2_WAVES; ++j) basec[j] = s_off[(COLS / BW2_WAVES) * wave + j];
+    for (int i0 = 0; i0 < total; i0 += 64) {
+      const int i = i0 + lane;
+      const int e = i < total ? s_flat[i] : -1;
+      const float g = i < total ? s_fg[i] : 0.f;
+      const int col = e >> 16;     // -1 for the padding lanes
+#pragma unroll
+      for (int j = 0; j < COLS / BW2_WAVES; ++j) {
+        const bool mine = col == (COLS / BW2_WAVES) * wave + j;
+        const unsigned long long mask = __ballot(mine);
+        if (mine) {
+          const int slot = basec[j] + __popcll(mask & lt);
+          s_list[slot] = e;
+        }
+        basec[j] += __popcll(mask);
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < COLS * BC_PT; e += BW2_THREADS) s_acc[e] = 0.f;   // the flat list is done with: the tile
+  __syncthreads();
+  // (3) walk: the flat list is cut into equal shares, one per wave -- arg-max columns cluster on a few "critical" points,
+  // so a split by columns leaves most waves idle.  A column that continues from the previous wave's share is summed
+  // into the wave's side row and added to the tile afterwards, in wave order (fixed order: deterministic).
+  {
+    const int per = (total + BW2_WAVES - 1) / BW2_WAVES;
+    const int lo = min(total, wave * per), hi = min(total, lo + per);
+    constexpr int U = 8;
+    const int ldW = a.ldW ? a.ldW : WM_CI;   // (co * TAPS + tap) -th row of 128 input channels
+    int cur = -1;
+    float acc0 = 0.f, acc1 = 0.f;
+    // the column of hit lo started in an earlier share <=> lo is not the first entry of that column's list
+    int side_col = -1;
+    if (lo < hi) {
+      const int c0 = s_list[lo] >> 16;
+      if (lo > s_off[c0]) side_col = c0;
+    }
+    bool in_side = side_col >= 0;
+    auto flush = [&]() {
+      if (cur < 0) return;
+      if (in_side) {
+        s_side[wave * WM_CI + 2 * lane] = acc0;
+        s_side[wave * WM_CI + 2 * lane + 1] = acc1;
+        in_side = false;
+      } else {
+        *reinterpret_cast<float2*>(s_acc + cur * BC_PT + 2 * lane) = make_float2(acc0, acc1);
+      }
+    };
+    for (int h0 = lo; h0 < hi; h0 += U) {
+      float2 w[U];
+      float gg[U];
+      int cc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = h0 + u < hi;
+        const int e = s_list[ok ? h0 + u : hi - 1];
+        w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)(e & 0xffff) * ldW + 2 * lane);
+        gg[u] = ok ? gb[(e & 0xffff) / TAPS] : 0.f;
+        cc[u] = ok ? e >> 16 : -2;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (cc[u] == -2) break;
+        if (cc[u] != cur) {
+          flush();
+          cur = cc[u];
+          acc0 = 0.f;
+          acc1 = 0.f;
+        }
+        acc0 += w[u].x * gg[u];
+        acc1 += w[u].y * gg[u];
+      }
+    }
+    flush();
+    if (lane == 0) s_sidecol[wave] = side_col;
+  }
+  __syncthreads();
+  if (tid < WM_CI) {
+    for (int w = 1; w < BW2_WAVES; ++w) {
+      const int c = s_sidecol[w];
+      if (c >= 0) s_acc[c * BC_PT + tid] += s_side[w * WM_CI + tid];
+    }
+  }
+  __syncthreads();
+  // (4) the 128 -> 64 layer behind it, on the tile while it is in LDS: gate by the relu bits of the 128-channel
+  // activation, tile maximum -> power-of-two scale; four waves take one 32 x 32 quadrant of W2^T tile each on the f16
+  // matrix core (a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi as in pointnet_conv_split.hip; W2^T's fragments were requested
+  // as fp32 at kernel start and are split here); the result leaves gated by the bits of the 64-channel activation.
+  const int tiles = (a.N + 63) >> 6;
+  {
+    const unsigned long long mkw = a.Zmask[((size_t)b * tiles + blockIdx.x) * WM_CI + (tid & 127)];
+    const int ci = tid & 127, c0 = (tid >> 7) * 16;
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = c0 + j;
+      float v = s_acc[c * BC_PT + ci];
+      v = ((mkw >> c) & 1ull) && m0 + c < a.N ? v : 0.f;
+      s_acc[c * BC_PT + ci] = v;
+      mx = fmaxf(mx, __builtin_fabsf(v));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) s_mx[wave] = mx;
+  }
+  const int qt = wave & 1, qc = (wave >> 1) & 1;     // waves 0-3: output rows 32 qt .., columns 32 qc ..
+  {   // maximum of W2^T [64][128] (every workgroup reads the 32 KB from L2: sixteen values per thread)
+    float wmax = 0.f;
+    const float4* w4 = reinterpret_cast<const float4*>(a.W2t) + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = w4[i * BW2_THREADS];
+      wmax = fmaxf(wmax, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+    }
+    wmax = wave_max(wmax);
+    if (lane == 0) s_mx[8 + wave] = wmax;
+  }
+  __syncthreads();
+  if (wave >= 4) return;
+  float tm = s_mx[0];
+#pragma unroll
+  for (int w = 1; w < BW2_WAVES; ++w) tm = fmaxf(tm, s_mx[w]);
+  float wm = s_mx[8];
+#pragma unroll
+  for (int w = 1; w < BW2_WAVES; ++w) wm = fmaxf(wm, s_mx[8 + w]);
+  const unsigned Ex = bc_exp(tm), Ew = bc_exp(wm);
+  const float sx = bc_scale(Ex), sw = bc_scale(Ew);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* brow = s_acc + (32 * qc + (lane & 31)) * BC_PT + (lane >> 5) * 8;
+  // this wave's fragments of W2^T (rows 32 qt + (lane & 31), k = 16 c + 8 (lane >> 5) .. + 7) stream from L2 one k-step ahead
+  const float* wr = a.W2t + (size_t)(32 * qt + (lane & 31)) * WM_CI + 8 * (lane >> 5);
+  float4 wq[2][2];
+  wq[0][0] = *reinterpret_cast<const float4*>(wr);
+  wq[0][1] = *reinterpret_cast<const float4*>(wr + 4);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c + 1 < 8) {
+      wq[(c + 1) & 1][0] = *reinterpret_cast<const float4*>(wr + 16 * (c + 1));
+      wq[(c + 1) & 1][1] = *reinterpret_cast<const float4*>(wr + 16 * (c + 1) + 4);
+    }
+    const float4 wa = wq[c & 1][0], wb = wq[c & 1][1];
+    const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    const float4 b0 = *reinterpret_cast<const float4*>(brow + c * 16);
+    const float4 b1 = *reinterpret_cast<const float4*>(brow + c * 16 + 4);
+    const float x8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    half8 wh, wl, xh, xl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float wv = w8[j] * sw, xv = x8[j] * sx;
+      const _Float16 a0 = (_Float16)wv, a1 = (_Float16)xv;
+      wh[j] = a0;
+      wl[j] = (_Float16)(wv - (float)a0);
+      xh[j] = a1;
+      xl[j] = (_Float16)(xv - (float)a1);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+  }
+  const float un = bc_unscale(Ex) * bc_unscale(Ew);
+  // acc[r]: row 32 qt + (r&3) + 8 (r>>2) + 4 (lane>>5), column 32 qc + (lane&31); gate word of row l in lane l of gw2
+  const int col = 32 * qc + (lane & 31), m = m0 + col;
+  float* Y = a.dY + (size_t)b * a.sYb + m;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rr = 32 * qt + (r & 3) + 8 * (r >> 2);   // + 4 (lane >> 5)
+    const unsigned g0 = qc ? (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(gw2 >> 32), rr)
+                           : (unsigned)__builtin_amdgcn_readlane((int)(unsigned)gw2, rr);
+    const unsigned g1 = qc ? (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(gw2 >> 32), rr + 4)
+                           : (unsigned)__builtin_amdgcn_readlane((int)(unsigned)gw2, rr + 4);
+    const unsigned gsel = lane < 32 ? g0 : g1;
+    const int row = rr + 4 * (lane >> 5);
+    if (m < a.N) Y[(size_t)row * a.ldY] = (gsel >> (lane & 31)) & 1u ? acc[r] * un : 0.f;
+  }
+}
+
+}  // namespace
+
+int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s) {
+  if ((a.taps != 1 && a.taps != 3) || !a.Zmask || !a.W2t || !a.Zmask2 || !a.dY || a.Co * a.taps > 0xffff)
+    return GEOA3_ENOSUPPORT;
+  dim3 grid((a.N + 63) / 64, a.B);
+  const size_t region = (size_t)64 * BC_PT > 2 * (size_t)a.Co * a.taps ? (size_t)64 * BC_PT : 2 * (size_t)a.Co * a.taps;
+  const size_t lds = (region + (size_t)a.Co * a.taps + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 16 + 3) * sizeof(float);
+  if (a.taps == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_conv_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wide_bwd_conv_kernel<1>, grid, dim3(BW2_THREADS), lds, s, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_conv_kernel<3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wide_bwd_conv_kernel<3>, grid, dim3(BW2_THREADS), lds, s, a);
+  }
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
