@@ -241,6 +241,15 @@ int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, c
     TRY(wide_bwd_conv(w.g1024, arg, t.w3, m128, t.w2t, m64, G64out, 1, B, N, s));
     return 0;
   }
+  if (!act64 && tl_split && m128 && fuse_bwd()) {   // the 3-channel T-Net: ... and its first layer's backward: dx += w1^T (..)
+    WideBwdArgs a{};
+    a.Zmask = m128;
+    a.g = w.g1024; a.arg = arg; a.W = t.w3;
+    a.W2t = t.w2t;
+    a.x3 = x3; a.w1 = t.w1; a.b1 = t.b1; a.dx3 = G64out;
+    a.Co = 1024; a.N = N; a.B = B; a.taps = 1;
+    return launch_wide_bwd_conv(a, s);
+  }
   TRY(wide_bwd(w.g1024, arg, t.w3, act128, m128, w.G128, 1, B, N, s));
   if (act64) TRY(conv(w.G128, 128, t.w2t, nullptr, G64out, 64, B, N, false, nullptr, false, s, nullptr, m64));
   else TRY(conv_gate_first(w.G128, 128, t.w2t, nullptr, x3, nullptr, t.w1, t.b1, B, N, s, G64out /* = dx */, 1));

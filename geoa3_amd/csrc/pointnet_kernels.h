@@ -126,6 +126,9 @@ struct WideBwdArgs {
   // Zmask2: relu bits of the 64-channel activation, [B][ceil(N/64)][64] words (ConvArgs::Ymask layout)
   const float* W2t; const unsigned long long* Zmask2;
   float* dY; long sYb; int ldY;
+  // ... or, with dx3: that layer is the one behind the 3-channel first layer (gate recomputed from x3 [B][3][N] with
+  // w1 [64][3], b1 [64]) and the first layer's backward finishes in the same kernel: dx3[b][d][n] += sum_o w1[o][d] dY[o][n]
+  const float* x3; const float* w1; const float* b1; float* dx3;
   int form;                                   // 0 = register accumulation over per-column lists (default), 1 = the first
                                               // form (LDS accumulation); same sums in the same order
 };

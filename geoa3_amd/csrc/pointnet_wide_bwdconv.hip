@@ -20,7 +20,8 @@ __device__ __forceinline__ float bc_unscale(unsigned E) { return __uint_as_float
 
 constexpr int BW2_WAVES = 8, BW2_THREADS = 64 * BW2_WAVES;
 constexpr int BC_PT = WM_CI + 4;   // floats per column of the tile (column-major here: the B operand reads 8 consecutive ci)
-template <int TAPS>
+template <int TAPS, bool GF = false>   // GF: the 64-channel activation is the 3-channel first layer (recomputed gate) and its
+                                       // backward finishes here: dx3 += w1^T (gated result), no [B,64,N] output
 __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int COLS = 64;
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, m0 = blockIdx.x * COLS;
   // requested now, used at the very end: the gate word of output row `lane`
   unsigned long long gw2 = 0ull;
-  if (wave < 4) gw2 = a.Zmask2[((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * 64 + lane];
+  if (!GF && wave < 4) gw2 = a.Zmask2[((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * 64 + lane];
+  float4* s_w1 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s_mx + 16) + 15) & ~(uintptr_t)15);   // GF: [64] (w1 row, b1), then [2][32] partial d x
+  if (GF && tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
   const float* gb = a.g + (size_t)b * a.Co;
   const int* argb = a.arg + (size_t)b * a.Co;
   if (tid <= COLS) s_off[tid] = 0;
@@ -278,6 +281,36 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   const float un = bc_unscale(Ex) * bc_unscale(Ew);
   // acc[r]: row 32 qt + (r&3) + 8 (r>>2) + 4 (lane>>5), column 32 qc + (lane&31); gate word of row l in lane l of gw2
   const int col = 32 * qc + (lane & 31), m = m0 + col;
+  if constexpr (GF) {
+    // gate = sign of the first layer, recomputed from the point (Model/PointNet.py:79 behind relu); q = w1^T (gated rows)
+    const bool in = m < a.N;
+    const float* xp = a.x3 + (size_t)b * 3 * a.N + (in ? m : a.N - 1);
+    const float x0 = xp[0], x1 = xp[a.N], x2 = xp[2 * (size_t)a.N];
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 w = s_w1[32 * qt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+      const float o = (w.x * x0 + w.y * x1 + w.z * x2 + w.w) > 0.f ? acc[r] * un : 0.f;
+      q0 += w.x * o;
+      q1 += w.y * o;
+      q2 += w.z * o;
+    }
+    q0 += __shfl_xor(q0, 32, 64);    // the two row halves of the tile (lanes l, l + 32 hold the same column)
+    q1 += __shfl_xor(q1, 32, 64);
+    q2 += __shfl_xor(q2, 32, 64);
+    float4* s_q = s_w1 + 64;          // [2 column blocks][32]: the partial sums of row tile 1
+    __syncthreads();                  // (waves 4-7 have left: the barrier counts the four that remain) s_w1 is read
+    if (qt == 1 && lane < 32) s_q[qc * 32 + lane] = make_float4(q0, q1, q2, 0.f);
+    __syncthreads();
+    if (qt == 0 && lane < 32 && in) {
+      const float4 o = s_q[qc * 32 + lane];
+      float* dxp = a.dx3 + (size_t)b * 3 * a.N + m;    // += : the trunk's gradient is there already
+      dxp[0] += q0 + o.x;
+      dxp[a.N] += q1 + o.y;
+      dxp[2 * (size_t)a.N] += q2 + o.z;
+    }
+    return;
+  }
   float* Y = a.dY + (size_t)b * a.sYb + m;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -295,12 +328,18 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
 }  // namespace
 
 int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s) {
-  if ((a.taps != 1 && a.taps != 3) || !a.Zmask || !a.W2t || !a.Zmask2 || !a.dY || a.Co * a.taps > 0xffff)
+  const bool gf = a.dx3 != nullptr;   // first-layer form: x3, w1, b1, dx3 instead of Zmask2 / dY
+  if ((a.taps != 1 && a.taps != 3) || !a.Zmask || !a.W2t || a.Co * a.taps > 0xffff ||
+      (gf ? (!a.x3 || !a.w1 || !a.b1 || a.taps != 1) : (!a.Zmask2 || !a.dY)))
     return GEOA3_ENOSUPPORT;
   dim3 grid((a.N + 63) / 64, a.B);
   const size_t region = (size_t)64 * BC_PT > 2 * (size_t)a.Co * a.taps ? (size_t)64 * BC_PT : 2 * (size_t)a.Co * a.taps;
-  const size_t lds = (region + (size_t)a.Co * a.taps + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 16 + 3) * sizeof(float);
-  if (a.taps == 1) {
+  const size_t lds = (region + (size_t)a.Co * a.taps + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 16 + 3 + 4 + 512) * sizeof(float);
+  if (a.taps == 1 && a.dx3) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_conv_kernel<1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((wide_bwd_conv_kernel<1, true>), grid, dim3(BW2_THREADS), lds, s, a);
+  } else if (a.taps == 1) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_conv_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wide_bwd_conv_kernel<1>, grid, dim3(BW2_THREADS), lds, s, a);
