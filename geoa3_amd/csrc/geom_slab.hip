@@ -436,18 +436,58 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
   int* Sr = s_rows[wave];
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int q0 = (blockIdx.x * 4 + wave) * KG_QPW;
+  // A query costs five dependent round trips (its coordinates + index, its prior neighbours, their coordinates, the cell
+  // table, the candidates).  The first three are taken off the critical path: lanes 0..KG_QPW-1 load the wave's queries
+  // at once, and while query qi is searched the prior indices of query qi + 2 and the neighbour coordinates of query
+  // qi + 1 are already in flight (K <= 64: one neighbour per lane).
+  float vqx = 0.f, vqy = 0.f, vqz = 0.f;
+  int vqo = 0;
+  if (lane < KG_QPW && q0 + lane < N) {
+    vqx = Sb[q0 + lane];
+    vqy = Sb[N + q0 + lane];
+    vqz = Sb[2 * N + q0 + lane];
+    vqo = Ib[q0 + lane];
+  }
+  const bool pipe = K <= 64;
+  auto load_prior = [&](int qi) {     // neighbour `lane` of query qi (or -1)
+    if (qi >= KG_QPW || q0 + qi >= N || lane >= K) return -1;
+    return (int)prior[((size_t)b * N + __builtin_amdgcn_readlane(vqo, qi)) * K + lane];
+  };
+  int jn = pipe ? load_prior(0) : -1;           // indices whose coordinates are requested next
+  float cx = 0.f, cy = 0.f, cz = 0.f;            // coordinates of the CURRENT query's neighbour
+  bool cok = true;
+  auto load_coords = [&](int j) {
+    cok = lane >= K || (j >= 0 && j < N);
+    const int jj = j >= 0 && j < N ? j : 0;
+    cx = Rb[jj];
+    cy = Rb[N + jj];
+    cz = Rb[2 * N + jj];
+  };
+  if (pipe) {
+    load_coords(jn);
+    jn = load_prior(1);
+  }
   for (int qi = 0; qi < KG_QPW; ++qi) {
     const int pos = q0 + qi;
     if (pos >= N) break;                       // wave-uniform
-    const float qx = Sb[pos], qy = Sb[N + pos], qz = Sb[2 * N + pos];
-    const int qo = Ib[pos];
+    const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vqx), qi));
+    const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vqy), qi));
+    const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vqz), qi));
+    const int qo = __builtin_amdgcn_readlane(vqo, qi);
     // radius: the largest distance to last iteration's K neighbours
     float t = 0.f;
     bool ok = true;
-    for (int m = lane; m < K; m += 64) {
-      const int j = prior[((size_t)b * N + qo) * K + m];
-      if (j < 0 || j >= N) ok = false;
-      else t = fmaxf(t, geoa3_sqdist(qx, qy, qz, Rb[j], Rb[N + j], Rb[2 * N + j]));
+    if (pipe) {
+      ok = cok;
+      if (lane < K && cok) t = geoa3_sqdist(qx, qy, qz, cx, cy, cz);
+      load_coords(jn);                 // query qi + 1
+      jn = load_prior(qi + 2);
+    } else {
+      for (int m = lane; m < K; m += 64) {
+        const int j = prior[((size_t)b * N + qo) * K + m];
+        if (j < 0 || j >= N) ok = false;
+        else t = fmaxf(t, geoa3_sqdist(qx, qy, qz, Rb[j], Rb[N + j], Rb[2 * N + j]));
+      }
     }
     float tau = wave_max(t);
     if (__any(!ok)) tau = S_INF;               // no usable radius: the whole grid
