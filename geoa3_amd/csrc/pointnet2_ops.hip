@@ -80,10 +80,15 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict_
     const int buf = j & 1;   // double buffered: the next round's writes cannot race this round's reads
     if (lane == 0) s_key[buf][wave] = key;
     __syncthreads();
-    unsigned long long k2 = lane < FPS_BLOCK / 64 ? s_key[buf][lane] : 0ull;
-    k2 = row16_max_u64(k2);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)k2);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(k2 >> 32));
+    // every lane reads the waves' keys (broadcast reads) and takes their maximum itself: no second DPP reduction in the
+    // round's dependent chain
+    unsigned long long k2 = s_key[buf][0];
+#pragma unroll
+    for (int w = 1; w < FPS_BLOCK / 64; ++w) {
+      const unsigned long long kw = s_key[buf][w];
+      k2 = kw > k2 ? kw : k2;
+    }
+    const unsigned lo = (unsigned)k2, hi = (unsigned)(k2 >> 32);
     // every point skipped: the reference's reduction returns its initial index 0
     old = (lo == 0u && hi == 0u) ? 0 : (int)((0xFFFFFFFFu - lo) & 0xFFFFu);
     if (tid == 0) idxs[(size_t)b * m + j] = old;
