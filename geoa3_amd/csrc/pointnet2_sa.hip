@@ -349,25 +349,50 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     {
       // one-hot B operand: element j of lane (sample, k half) for k-step ks is channel ch = 16 ks + 8h + j, non-zero
       // only in the lane of the channel's arg-max sample; the A operand is the W3^T image
-      float gm = fmaxf(__builtin_fabsf(s_gz[2 * lane]), __builtin_fabsf(s_gz[2 * lane + 1]));
-      const unsigned E = sa_exp(wave_max(gm));
+      const float g0 = s_gz[2 * lane], g1 = s_gz[2 * lane + 1];
+      const int a0 = s_arg[2 * lane], a1 = s_arg[2 * lane + 1];
+      const unsigned E = sa_exp(wave_max(fmaxf(__builtin_fabsf(g0), __builtin_fabsf(g1))));
       const float sg = sa_scale(E);
       f2 = sa_unscale(E) * L.scal[1];
+      // every channel's scaled gradient is split ONCE (by the lane that staged it) and kept with its arg-max sample as
+      // {hi | lo << 16, sample}: the operand construction below is then one 8-byte LDS read, two compares and two selects
+      // per (channel, lane half) plus byte permutes, instead of a multiply, two conversions, a subtraction, four compares
+      // and four selects in every lane
+      unsigned* s_pa = reinterpret_cast<unsigned*>(s_gz);   // [128][2], over s_gz / s_arg (this wave's own 1 KB)
+      {
+        const float z0 = g0 * sg, z1 = g1 * sg;
+        const _Float16 h0 = (_Float16)z0, h1 = (_Float16)z1;
+        const _Float16 l0 = (_Float16)(z0 - (float)h0), l1 = (_Float16)(z1 - (float)h1);
+        const unsigned p0 = (unsigned)__builtin_bit_cast(unsigned short, h0) | (unsigned)__builtin_bit_cast(unsigned short, l0) << 16;
+        const unsigned p1 = (unsigned)__builtin_bit_cast(unsigned short, h1) | (unsigned)__builtin_bit_cast(unsigned short, l1) << 16;
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<uint4v*>(s_pa + 4 * lane) = uint4v{p0, (unsigned)a0, p1, (unsigned)a1};
+      }
       const unsigned char* wr = L.w3h + l31 * SA_PH2 + h * 16;
 #pragma unroll 2
       for (int ks = 0; ks < 8; ++ks) {
-        half8 bh[2], bl[2];
+        unsigned s0[8], s1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int ch = 16 * ks + 8 * h + j;
-          const float gz = s_gz[ch] * sg;
-          const int am = s_arg[ch];
-          const _Float16 gh = (_Float16)gz, gl = (_Float16)(gz - (float)gh), zero = (_Float16)0.f;
-          bh[0][j] = am == l31 ? gh : zero;
-          bl[0][j] = am == l31 ? gl : zero;
-          bh[1][j] = am == 32 + l31 ? gh : zero;
-          bl[1][j] = am == 32 + l31 ? gl : zero;
+          const uint2 pa = *reinterpret_cast<const uint2*>(s_pa + 2 * ch);
+          s0[j] = (int)pa.y == l31 ? pa.x : 0u;
+          s1[j] = (int)pa.y == 32 + l31 ? pa.x : 0u;
         }
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        uint4v vh0, vl0, vh1, vl1;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          vh0[j2] = __builtin_amdgcn_perm(s0[2 * j2 + 1], s0[2 * j2], 0x05040100u);   // low halves: hi pieces
+          vl0[j2] = __builtin_amdgcn_perm(s0[2 * j2 + 1], s0[2 * j2], 0x07060302u);   // high halves: lo pieces
+          vh1[j2] = __builtin_amdgcn_perm(s1[2 * j2 + 1], s1[2 * j2], 0x05040100u);
+          vl1[j2] = __builtin_amdgcn_perm(s1[2 * j2 + 1], s1[2 * j2], 0x07060302u);
+        }
+        half8 bh[2], bl[2];
+        bh[0] = __builtin_bit_cast(half8, vh0);
+        bl[0] = __builtin_bit_cast(half8, vl0);
+        bh[1] = __builtin_bit_cast(half8, vh1);
+        bl[1] = __builtin_bit_cast(half8, vl1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32);
