@@ -94,6 +94,12 @@ bool fuse_bwd() {
   return !(e && e[0] == '0');
 }
 
+// GEOA3_FUSE_CHAIN=0: the trunk's 64-input layers as one kernel each instead of two chains (A/B switch)
+bool fuse_chain() {
+  const char* e = getenv("GEOA3_FUSE_CHAIN");
+  return !(e && e[0] == '0');
+}
+
 // Y = act(W X + bias) over [B][K][N] -> [B][Co][N]; shared weights [Co][K]
 int conv(const float* X, int K, const float* W, const float* bias, float* Y, int Co, int B, int N, bool relu,
          const float* Z, bool accumulate, hipStream_t s, unsigned long long* Ymask = nullptr,
@@ -211,8 +217,11 @@ int wide_bwd_conv(const float* g, const int* arg, const float* W, const unsigned
 // act64 == nullptr: the T-Net reads the cloud itself (K = 3) and its first layer is folded into conv2 (x3 given)
 int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* x3, float* act128,
                   unsigned long long* m128, float* pooled,
-                  int* arg, float* f4, float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s) {
-  if (tl_split && t.w2h) {   // conv2 (behind conv1 for the 3-channel T-Net) inside the wide kernel: act128 is never written
+                  int* arg, float* f4, float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s,
+                  bool have128 = false) {
+  if (have128) {   // act128 (and m128) already produced by the trunk's chain kernel
+    TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, nullptr, t.w3h16));
+  } else if (tl_split && t.w2h) {   // conv2 (behind conv1 for the 3-channel T-Net) inside the wide kernel: act128 is never written
     FrontLayer f{t.w2h, t.w2h_unscale, t.w2, t.b2, act64, act64 ? nullptr : x3, t.w1, t.b1, m128};
     TRY(wide(nullptr, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, &f));
   } else {
@@ -275,11 +284,25 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   if (hipMemsetAsync(w.keys, 0, (size_t)B * 1024 * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
   // input transform (Model/PointNet.py:137-138)
   TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
-  // trunk conv1, conv2 (:139-140)
-  TRY(conv_first(x, w.T3, p.w1, p.b1, p.w2, p.b2, w.h2, 64, B, N, s, w.m_h2));
-  // feature transform (:142-143)
-  TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s, w.m_c1));
-  TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
+  const bool chain = tl_split && fuse_chain();
+  if (chain && !p.t64.w2h) {
+    // trunk conv1, conv2 (:139-140) and the feature transform's conv1, conv2 (:78-80) in one kernel: h2 is written (the
+    // backward and conv3 read it), c1 exists only as gate bits, c2 is the T-Net's 1024-wide layer's input
+    ConvChainArgs a{};
+    a.x3 = x; a.T3 = w.T3; a.w1 = p.w1; a.b1 = p.b1;
+    a.N = N; a.B = B; a.ns = 3;
+    a.st[0] = ChainStage{p.w2, 0, p.b2, w.h2, (long)64 * N, w.m_h2, 64};
+    a.st[1] = ChainStage{p.t64.w1, 0, p.t64.b1, nullptr, 0, w.m_c1, 64};
+    a.st[2] = ChainStage{p.t64.w2, 0, p.t64.b2, w.c2, (long)128 * N, w.m_c2, 128};
+    TRY(launch_conv_chain(a, s));
+    TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s, true));
+  } else {
+    // trunk conv1, conv2 (:139-140)
+    TRY(conv_first(x, w.T3, p.w1, p.b1, p.w2, p.b2, w.h2, 64, B, N, s, w.m_h2));
+    // feature transform (:142-143)
+    TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s, w.m_c1));
+    TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
+  }
   // feature transform folded into conv3 (:143-144): W3 (T64^T h2) = (W3 T64^T) h2 -- one 64^3 product per instance
   // instead of a pass over [B,64,N]
   {
@@ -289,6 +312,16 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
     g.Y = w.W3eff; g.ldY = 64; g.sYb = 4096;
     g.M = 64; g.Nout = 64; g.K = 64; g.batch = B;
     TRY(launch_fc(g, s));
+  }
+  const bool chain34 = chain && !p.w4h;
+  if (chain34) {   // conv3, conv4 in one kernel: h3 exists only as gate bits
+    ConvChainArgs a{};
+    a.X = w.h2; a.sXb = (long)64 * N; a.ldX = N;
+    a.N = N; a.B = B; a.ns = 2;
+    a.st[0] = ChainStage{w.W3eff, 4096, p.b3, nullptr, 0, w.m_h3, 64};
+    a.st[1] = ChainStage{p.w4, 0, p.b4, w.h4, (long)128 * N, w.m_h4, 128};
+    TRY(launch_conv_chain(a, s));
+  } else {
     ConvArgs a{};
     a.split = tl_split;
     a.X = w.h2; a.sXb = (long)64 * N; a.ldX = N;
@@ -300,7 +333,9 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
     TRY(launch_conv_cm(a, s));
   }
   // conv4, conv5 + max (:145-147)
-  if (tl_split && p.w4h) {   // conv4 inside conv5's staging pass: h4 is never written
+  if (chain34) {
+    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16));
+  } else if (tl_split && p.w4h) {   // conv4 inside conv5's staging pass: h4 is never written
     FrontLayer f{p.w4h, p.w4h_unscale, p.w4, p.b4, w.h3, nullptr, nullptr, nullptr, w.m_h4};
     TRY(wide(nullptr, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, &f));
   } else {

@@ -54,6 +54,24 @@ struct ConvArgs {
   const void* Wimg; const float* Wun; int img_kc, img_c0;
 };
 int launch_conv_cm(const ConvArgs& a, hipStream_t s);         // dispatches on a.split
+
+// A chain of 64-input layers with relu in one kernel (pointnet_conv_chain.hip; split arithmetic, the bits of the
+// layer-by-layer launches): stage i reads the 64 rows stage i - 1 produced (stage 0: X [B][64][N], or, with x3, the folded
+// first layer as in ConvArgs); the stages before the last have 64 outputs, the last 128.
+struct ChainStage {
+  const float* W; long sWb;                   // [Co][64], k contiguous; sWb: per-instance weights (0 = shared)
+  const float* bias;                          // [Co]
+  float* Y; long sYb;                         // [B][Co][N] or null: the activation is not written (gate bits only)
+  unsigned long long* Ymask;                  // relu gate bits (ConvArgs::Ymask layout)
+  int Co;
+};
+struct ConvChainArgs {
+  const float* X; long sXb; int ldX;
+  const float* x3; const float* T3; const float* w1; const float* b1;
+  int N, B, ns;
+  ChainStage st[3];
+};
+int launch_conv_chain(const ConvChainArgs& a, hipStream_t s);
 int launch_conv_cm_split(const ConvArgs& a, hipStream_t s);
 
 // Y[m][o] = epi( sum_k X[m][k] * W[o][k] + bias[o] )   (fully connected layers, both directions)
