@@ -385,6 +385,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     q.Y = w.gT64; q.ldY = 64; q.sYb = 4096;
     q.M = 64; q.Nout = 64; q.K = 64; q.batch = B;
     TRY(launch_fc(q, s));
+    if (!(tl_split && fuse_chain())) {
     ConvArgs a{};   // dh2[b][i][n] = sum_o W3eff[b][o][i] G64a[b][o][n]
     a.split = tl_split;
     a.X = w.G64a; a.sXb = (long)64 * N; a.ldX = N;
@@ -392,7 +393,24 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     a.Y = w.dh2; a.sYb = (long)64 * N; a.ldY = N;
     a.Co = 64; a.K = 64; a.N = N; a.B = B;
     TRY(launch_conv_cm(a, s));
+    }
   }
+  const int nparts = (N + 255) / 256;
+  if (tl_split && fuse_chain()) {
+    // the T-Net branch's gradient goes to the dh2 buffer (the Gram kernel's scratch is consumed by now); then ONE kernel:
+    // dh2 = gate_h2(W3eff^T G64a + W_t64.conv1^T G), conv2's backward, trunk conv1 + input transform backward (dx, dT3
+    // partials) -- dh2 is never written
+    TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.m_c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.dh2, B, N, s));
+    ConvBwdChainArgs a{};
+    a.Xa = w.G64a; a.Wa = w.W3eff; a.sWa = 4096;
+    a.Xb = w.dh2; a.Wb = p.t64.w1;
+    a.Zmask = w.m_h2;
+    a.W2t = p.w2t;
+    a.x3 = x; a.T3 = w.T3; a.w1 = p.w1; a.b1 = p.b1;
+    a.dx = dx; a.dTpart = w.dTpart;
+    a.N = N; a.B = B;
+    TRY(launch_conv_bwd_chain(a, s));
+  } else {
   TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.m_c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
   // dh2 += W_t64.conv1^T G64a, then the relu gate of h2
   {
@@ -406,8 +424,8 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     TRY(launch_conv_cm(a, s));
   }
   // conv2 backward fused with trunk conv1 + input transform backward: dx, dT3 (partials per 256-point workgroup)
-  const int nparts = (N + 255) / 256;
   TRY(conv_gate_first(w.dh2, 64, p.w2t, nullptr, x, w.T3, p.w1, p.b1, B, N, s, dx, 0, w.dTpart));
+  }
   TRY(launch_reduce_dT(w.dTpart, nparts, w.gT3, B, s));
   // T-Net(3) backward; its last kernel adds the T-Net branch into dx
   TRY(tnet_bwd(p.t3, w.gT3, nullptr, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w, dx, B, N, s));

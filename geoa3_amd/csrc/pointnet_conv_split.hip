@@ -388,9 +388,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 &&
           if (GFIRST) o = cs_first_layer(s_w1[row0 + i], p0, p1, p2) > 0.f ? o : 0.f;
           if (BWD3) {
             const float4 w = s_w1[row0 + i];
-            q0 += w.x * o;
-            q1 += w.y * o;
-            q2 += w.z * o;
+            q0 = fmaf(w.x, o, q0);
+            q1 = fmaf(w.y, o, q1);
+            q2 = fmaf(w.z, o, q2);
           } else {
             Y[(size_t)(row0 + i) * a.ldY] = o;
           }
@@ -417,9 +417,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 &&
     float d0 = q0, d1 = q1, d2 = q2;
     if (a.T3) {
       const float* t = a.T3 + (size_t)b * 9;
-      d0 = t[0] * q0 + t[1] * q1 + t[2] * q2;
-      d1 = t[3] * q0 + t[4] * q1 + t[5] * q2;
-      d2 = t[6] * q0 + t[7] * q1 + t[8] * q2;
+      d0 = fmaf(t[2], q2, fmaf(t[1], q1, t[0] * q0));   // explicit: the chain kernel must form the same bits
+      d1 = fmaf(t[5], q2, fmaf(t[4], q1, t[3] * q0));
+      d2 = fmaf(t[8], q2, fmaf(t[7], q1, t[6] * q0));
     }
     if (live) {
       float* dxp = a.dx3 + (size_t)b * 3 * a.N + col;

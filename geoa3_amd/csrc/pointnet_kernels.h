@@ -72,6 +72,18 @@ struct ConvChainArgs {
   ChainStage st[3];
 };
 int launch_conv_chain(const ConvChainArgs& a, hipStream_t s);
+// the backward counterpart (pointnet_conv_chain.hip): dh2 = gate( Wa[b]^T Xa + Wb^T Xb ), then conv_gate_first's form with
+// W2t -- dx [B][3][N] written, dTpart [B][ceil(N/256)][9] partial sums; dh2 is never written
+struct ConvBwdChainArgs {
+  const float* Xa; const float* Wa; long sWa;   // [B][64][N]; [B][64 o][64 i] applied transposed (sWa: instance stride)
+  const float* Xb; const float* Wb;             // [B][64][N]; [64 o][64 i] applied transposed
+  const unsigned long long* Zmask;              // relu gate bits of the 64-channel activation the sum belongs to
+  const float* W2t;                             // [64][64] k contiguous
+  const float* x3; const float* T3; const float* w1; const float* b1;   // as ConvArgs (gate_first)
+  float* dx; float* dTpart;
+  int N, B;
+};
+int launch_conv_bwd_chain(const ConvBwdChainArgs& a, hipStream_t s);
 int launch_conv_cm_split(const ConvArgs& a, hipStream_t s);
 
 // Y[m][o] = epi( sum_k X[m][k] * W[o][k] + bias[o] )   (fully connected layers, both directions)
