@@ -226,7 +226,13 @@ int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* 
     TRY(wide(nullptr, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, &f));
   } else {
     if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s, m128));
-    else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s, m128));
+    else if (tl_split && fuse_chain()) {   // conv1 + conv2 of the 3-channel T-Net: the chain kernel with one stage
+      ConvChainArgs a{};
+      a.x3 = x3; a.w1 = t.w1; a.b1 = t.b1;
+      a.N = N; a.B = B; a.ns = 1;
+      a.st[0] = ChainStage{t.w2, 0, t.b2, act128, (long)128 * N, m128, 128};
+      TRY(launch_conv_chain(a, s));
+    } else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s, m128));
     TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, nullptr, t.w3h16));
   }
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));

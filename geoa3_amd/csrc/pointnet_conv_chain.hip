@@ -382,7 +382,7 @@ void launch_chain(const ConvChainArgs& a, hipStream_t s) {
 }  // namespace
 
 int launch_conv_chain(const ConvChainArgs& a, hipStream_t s) {
-  if (a.ns < 2 || a.ns > 3 || a.B <= 0 || a.N <= 0) return GEOA3_EINVAL;
+  if (a.ns < 1 || a.ns > 3 || a.B <= 0 || a.N <= 0) return GEOA3_EINVAL;
   for (int i = 0; i < a.ns; ++i) {
     if (!a.st[i].W || !a.st[i].bias || !a.st[i].Ymask) return GEOA3_EINVAL;
     if (a.st[i].Co != (i + 1 < a.ns ? 64 : 128)) return GEOA3_ENOSUPPORT;
@@ -390,6 +390,7 @@ int launch_conv_chain(const ConvChainArgs& a, hipStream_t s) {
   const bool first = a.x3 != nullptr;
   if (first ? (!a.w1 || !a.b1) : !a.X) return GEOA3_EINVAL;
   if (a.ns == 3 && first) launch_chain<3, true, 128>(a, s);
+  else if (a.ns == 1 && first) launch_chain<1, true, 128>(a, s);
   else if (a.ns == 2 && !first) launch_chain<2, false, 128>(a, s);
   else return GEOA3_ENOSUPPORT;
   GEOA3_CHECK_LAUNCH();
