@@ -155,6 +155,7 @@ struct WideBwdArgs {
   // kernel: dY[b][o][n] = gate2 . sum_ci W2t[o][ci] dX[b][ci][n] (dX stays in LDS; needs Zmask).  W2t [64][128];
   // Zmask2: relu bits of the 64-channel activation, [B][ceil(N/64)][64] words (ConvArgs::Ymask layout)
   const float* W2t; const unsigned long long* Zmask2;
+  float w2t_amax;                             // max |W2t| if the caller knows it (> 0), else 0: every workgroup computes it
   float* dY; long sYb; int ldY;
   // ... or, with dx3: that layer is the one behind the 3-channel first layer (gate recomputed from x3 [B][3][N] with
   // w1 [64][3], b1 [64]) and the first layer's backward finishes in the same kernel: dx3[b][d][n] += sum_o w1[o][d] dY[o][n]

@@ -41,6 +41,16 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   // requested now, used at the very end: the gate word of output row `lane`
   unsigned long long gw2 = 0ull;
   if (!GF && wave < 4) gw2 = a.Zmask2[((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * 64 + lane];
+  // ... and the gate word of tile row (tid & 127) of the 128-channel activation, and this wave's first W2^T fragments
+  const int tiles = (a.N + 63) >> 6;
+  const unsigned long long mkw = a.Zmask[((size_t)b * tiles + blockIdx.x) * WM_CI + (tid & 127)];
+  const int qt = wave & 1, qc = (wave >> 1) & 1;     // waves 0-3: output rows 32 qt .., columns 32 qc ..
+  const float* wr = a.W2t + (size_t)(32 * qt + (lane & 31)) * WM_CI + 8 * (lane >> 5);
+  float4 wq[2][2];
+  if (wave < 4) {
+    wq[0][0] = *reinterpret_cast<const float4*>(wr);
+    wq[0][1] = *reinterpret_cast<const float4*>(wr + 4);
+  }
   float4* s_w1 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s_mx + 16) + 15) & ~(uintptr_t)15);   // GF: [64] (w1 row, b1), then [2][32] partial d x
   if (GF && tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
   const float* gb = a.g + (size_t)b * a.Co;
@@ -206,9 +216,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   // activation, tile maximum -> power-of-two scale; four waves take one 32 x 32 quadrant of W2^T tile each on the f16
   // matrix core (a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi as in pointnet_conv_split.hip; W2^T's fragments were requested
   // as fp32 at kernel start and are split here); the result leaves gated by the bits of the 64-channel activation.
-  const int tiles = (a.N + 63) >> 6;
   {
-    const unsigned long long mkw = a.Zmask[((size_t)b * tiles + blockIdx.x) * WM_CI + (tid & 127)];
     const int ci = tid & 127, c0 = (tid >> 7) * 16;
     float mx = 0.f;
 #pragma unroll
@@ -222,8 +230,9 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     mx = wave_max(mx);
     if (lane == 0) s_mx[wave] = mx;
   }
-  const int qt = wave & 1, qc = (wave >> 1) & 1;     // waves 0-3: output rows 32 qt .., columns 32 qc ..
-  {   // maximum of W2^T [64][128] (every workgroup reads the 32 KB from L2: sixteen values per thread)
+  if (a.w2t_amax > 0.f) {   // max |W2^T| handed over by the caller (a property of the weights)
+    if (lane == 0) s_mx[8 + wave] = a.w2t_amax;
+  } else {   // maximum of W2^T [64][128] (every workgroup reads the 32 KB from L2: sixteen values per thread)
     float wmax = 0.f;
     const float4* w4 = reinterpret_cast<const float4*>(a.W2t) + tid;
 #pragma unroll
@@ -249,10 +258,6 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* brow = s_acc + (32 * qc + (lane & 31)) * BC_PT + (lane >> 5) * 8;
   // this wave's fragments of W2^T (rows 32 qt + (lane & 31), k = 16 c + 8 (lane >> 5) .. + 7) stream from L2 one k-step ahead
-  const float* wr = a.W2t + (size_t)(32 * qt + (lane & 31)) * WM_CI + 8 * (lane >> 5);
-  float4 wq[2][2];
-  wq[0][0] = *reinterpret_cast<const float4*>(wr);
-  wq[0][1] = *reinterpret_cast<const float4*>(wr + 4);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     if (c + 1 < 8) {

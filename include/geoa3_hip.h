@@ -170,6 +170,8 @@ typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 
                                [T = co/16][s = k/32][piece][lane][j] = piece(w3[16T + (lane&15)][32s + 8(lane>>4) + j])
                                (same scale: w3h_unscale): the layer then runs on `v_mfma_f32_16x16x32_f16`
                                (csrc/pointnet_wide16.hip) -- same arithmetic, higher sustained clock */
+  float w2t_amax;           /* optional: max |w2t| (exact).  > 0 spares every workgroup of the backward's fused sparse
+                               kernel a pass over the matrix for its power-of-two scale; 0 = computed in the kernel */
 } geoa3_tnet_weights;
 
 typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 */
@@ -199,6 +201,7 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
   const void *w4h;          /* optional, with w5h: w4 as split-fp16 fragments (K = 64): conv4 inside conv5's staging pass */
   float w4h_unscale;
   const void *w5h16;        /* optional, with w5h: w5 in 16x16x32 fragment order (see t3.w3h16) */
+  float w4t_amax;           /* optional: max |w4t| (see t3.w2t_amax) */
 } geoa3_pointnet_weights;
 
 /* bytes of scratch the forward+backward pair needs for a batch of B clouds of N points */

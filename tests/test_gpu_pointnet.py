@@ -70,6 +70,29 @@ def test_batch_independence(net):
             assert torch.equal(net(x[k:k + 1].contiguous())[0], full[k])
 
 
+@pytest.mark.parametrize("B,N", [(3, 256), (5, 1000), (2, 77), (9, 1024)])
+def test_chain_kernels_same_bits_as_layer_by_layer(B, N, monkeypatch):
+    """The chain kernels of the trunk (pointnet_conv_chain.hip: conv2 -> T-Net conv1 -> conv2, conv3 -> conv4, and the
+    backward of the front) against the one-layer-per-launch path (GEOA3_FUSE_CHAIN=0, read per call): logits and input
+    gradient bit for bit, ragged N (partly dead wavefronts) included."""
+    from geoa3_amd.pointnet import PointNet
+    n = PointNet(40)
+    n.load_state_dict(O.make_pointnet_state_dict(40, seed=0))
+    n.wide_mode = "f16x2"
+    n = n.cuda().eval()
+    pc, _ = O.make_synthetic_clouds(B, N, seed=17 * B + N)
+    w = torch.randn(B, 40, generator=torch.Generator().manual_seed(2)).cuda()
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GEOA3_FUSE_CHAIN", flag)
+        x = pc.cuda().requires_grad_()
+        lg = n(x)
+        (lg * w).sum().backward()
+        out[flag] = (lg.detach().clone(), x.grad.clone())
+    assert torch.equal(out["0"][0], out["1"][0])
+    assert torch.equal(out["0"][1], out["1"][1])
+
+
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 300.0, 1e6])
 def test_wide_split_operand_range(scale):
     """f16x2 mode carries every fp32 operand of the 1024-wide layers as two fp16 values after a power-of-two scaling
