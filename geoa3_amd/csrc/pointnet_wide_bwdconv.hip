@@ -41,16 +41,12 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   // requested now, used at the very end: the gate word of output row `lane`
   unsigned long long gw2 = 0ull;
   if (!GF && wave < 4) gw2 = a.Zmask2[((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * 64 + lane];
-  // ... and the gate word of tile row (tid & 127) of the 128-channel activation, and this wave's first W2^T fragments
+  // ... and the gate word of tile row (tid & 127) of the 128-channel activation
   const int tiles = (a.N + 63) >> 6;
   const unsigned long long mkw = a.Zmask[((size_t)b * tiles + blockIdx.x) * WM_CI + (tid & 127)];
   const int qt = wave & 1, qc = (wave >> 1) & 1;     // waves 0-3: output rows 32 qt .., columns 32 qc ..
   const float* wr = a.W2t + (size_t)(32 * qt + (lane & 31)) * WM_CI + 8 * (lane >> 5);
-  float4 wq[2][2];
-  if (wave < 4) {
-    wq[0][0] = *reinterpret_cast<const float4*>(wr);
-    wq[0][1] = *reinterpret_cast<const float4*>(wr + 4);
-  }
+
   float4* s_w1 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s_mx + 16) + 15) & ~(uintptr_t)15);   // GF: [64] (w1 row, b1), then [2][32] partial d x
   if (GF && tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
   const float* gb = a.g + (size_t)b * a.Co;
@@ -258,13 +254,21 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* brow = s_acc + (32 * qc + (lane & 31)) * BC_PT + (lane >> 5) * 8;
   // this wave's fragments of W2^T (rows 32 qt + (lane & 31), k = 16 c + 8 (lane >> 5) .. + 7) stream from L2 one k-step ahead
+  // (requested here, not at kernel start: fragments in flight across the list phases made the kernel 10-15 % slower)
+  constexpr int WQ = 2;   // k-steps of fragments in flight
+  float4 wq[WQ][2];
+#pragma unroll
+  for (int c = 0; c + 1 < WQ; ++c) {
+    wq[c][0] = *reinterpret_cast<const float4*>(wr + 16 * c);
+    wq[c][1] = *reinterpret_cast<const float4*>(wr + 16 * c + 4);
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    if (c + 1 < 8) {
-      wq[(c + 1) & 1][0] = *reinterpret_cast<const float4*>(wr + 16 * (c + 1));
-      wq[(c + 1) & 1][1] = *reinterpret_cast<const float4*>(wr + 16 * (c + 1) + 4);
+    if (c + WQ - 1 < 8) {
+      wq[(c + WQ - 1) % WQ][0] = *reinterpret_cast<const float4*>(wr + 16 * (c + WQ - 1));
+      wq[(c + WQ - 1) % WQ][1] = *reinterpret_cast<const float4*>(wr + 16 * (c + WQ - 1) + 4);
     }
-    const float4 wa = wq[c & 1][0], wb = wq[c & 1][1];
+    const float4 wa = wq[c % WQ][0], wb = wq[c % WQ][1];
     const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
     const float4 b0 = *reinterpret_cast<const float4*>(brow + c * 16);
     const float4 b1 = *reinterpret_cast<const float4*>(brow + c * 16 + 4);
