@@ -9,6 +9,7 @@
 // the compaction and the lexicographic (distance, index) selection are the same, and the bin function is monotone in
 // the coordinate, so the result is BIT-IDENTICAL to the all-pairs search for any input; a query without a usable
 // radius scans everything.
+#include <cstdlib>
 #include "geom_internal.h"
 #include "profile.h"
 
@@ -141,9 +142,48 @@ __device__ __forceinline__ bool slab_lex_less(float da, int ia, float db, int ib
   return (da < db) || (da == db && ia < ib);
 }
 
+// The K smallest of a thread's cnt <= CAP candidates by (distance, index), in order, into slots 0 .. K-1; returns the
+// K-th distance.  Small CAP: the whole list goes to registers as 64-bit keys (distance bits : index -- distances are
+// >= +0, so the bit patterns order like the values and one integer compare is the lexicographic one), every entry's
+// rank is counted over all pairs and the entry is written to the slot of its rank.  No dependent LDS round trips: the
+// selection loop below waits for two of them per step (K * cnt / 2 steps: ~30 us per call for a wavefront at K = 17).
 template <int CAP>
 __device__ __forceinline__ float slab_compact(uint16_t* cand, float* candd, int cnt, int K, int tid) {
   float kth = S_INF;
+  if constexpr (CAP <= 40) {
+    unsigned long long key[CAP];
+    int rank[CAP];
+#pragma unroll
+    for (int s = 0; s < CAP; ++s) {
+      const unsigned d = __float_as_uint(candd[s * SK_BLOCK + tid]);
+      const unsigned i = cand[s * SK_BLOCK + tid];
+      key[s] = s < cnt ? ((unsigned long long)d << 32) | i : ~0ull;
+      rank[s] = CAP - 1 - s;      // as if every later entry were smaller; corrected pair by pair
+    }
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+#pragma unroll
+      for (int j = i + 1; j < CAP; ++j) {
+        // lt = key[i] < key[j]; rank[i] -= lt; rank[j] += lt -- compare and both carries back to back (left to the
+        // compiler the compares are batched and their lane masks spilled: 4000 v_readlane / v_writelane)
+        unsigned long long m;
+        asm volatile("v_cmp_lt_u64 %2, %3, %4\n\tv_subbrev_co_u32 %0, vcc, 0, %0, %2\n\t"
+                     "v_addc_co_u32 %1, vcc, 0, %1, %2"
+                     : "+v"(rank[i]), "+v"(rank[j]), "=&s"(m)
+                     : "v"(key[i]), "v"(key[j])
+                     : "vcc");
+      }
+#pragma unroll
+    for (int s = 0; s < CAP; ++s) {
+      if (rank[s] < K) {
+        const float d = __uint_as_float((unsigned)(key[s] >> 32));
+        candd[rank[s] * SK_BLOCK + tid] = d;
+        cand[rank[s] * SK_BLOCK + tid] = (uint16_t)key[s];
+        if (rank[s] == K - 1) kth = d;
+      }
+    }
+    return kth;
+  }
   for (int p = 0; p < K; ++p) {
     float bd = candd[p * SK_BLOCK + tid];
     int bidx = cand[p * SK_BLOCK + tid];
@@ -175,8 +215,10 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
                                                             const int32_t* __restrict__ sidx,
                                                             const int32_t* __restrict__ bstart,
                                                             const SlabGeo* __restrict__ geo, float* __restrict__ dists,
-                                                            int32_t* __restrict__ idx) {
+                                                            int32_t* __restrict__ idx, unsigned long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+  if (stamps) st0 = __builtin_amdgcn_s_memtime();
   float* s_ref = reinterpret_cast<float*>(smem);                                    // 3*SK_CHUNK floats
   float* s_cd = s_ref + 3 * SK_CHUNK;                                               // [CAP][SK_BLOCK]
   uint16_t* s_ci = reinterpret_cast<uint16_t*>(s_cd + (size_t)CAP * SK_BLOCK);      // [CAP][SK_BLOCK]
@@ -199,16 +241,191 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
   }
   float tau = S_INF;
   if (prior != nullptr && live) {
+    // eight neighbours at a time: their indices, then their coordinates, all in flight together (one index / one point
+    // per trip of a loop with an exit is 2 K dependent round trips: 30 us of the kernel at K = 17)
     const int32_t* pr = prior + ((size_t)b * N + qo) * K;
     float t = 0.f;
     bool ok = true;
-    for (int m = 0; m < K; ++m) {
-      const int j = pr[m];
-      if (j < 0 || j >= N) {
-        ok = false;
-        break;
+    for (int m0 = 0; m0 < K; m0 += 8) {
+      int j[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) j[u] = m0 + u < K ? pr[m0 + u] : 0;
+      float px[8], py[8], pz[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ok = ok && j[u] >= 0 && j[u] < N;
+        const int jc = j[u] < 0 ? 0 : (j[u] >= N ? N - 1 : j[u]);
+        px[u] = Rb[jc];
+        py[u] = Rb[N + jc];
+        pz[u] = Rb[2 * N + jc];
       }
-      t = fmaxf(t, geoa3_sqdist(qx, qy, qz, Rb[j], Rb[N + j], Rb[2 * N + j]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (m0 + u < K) t = fmaxf(t, geoa3_sqdist(qx, qy, qz, px[u], py[u], pz[u]));
+    }
+    if (ok) tau = t;
+  }
+  if (!live) tau = -1.f;  // padding lanes never collect candidates
+  if (stamps) st1 = __builtin_amdgcn_s_memtime();
+  __syncthreads();
+  if (live) {
+    int blo = 0, bhi = SB_NB - 1;
+    if (tau < S_INF) {
+      const float qa = g.axis == 0 ? qx : (g.axis == 1 ? qy : qz);
+      const float r = sqrtf(tau) * 1.00001f + 1e-30f;
+      blo = slab_bin(qa - r, g.lo, g.inv_w);
+      bhi = slab_bin(qa + r, g.lo, g.inv_w);
+    }
+    atomicMin(&s_lo, blo);
+    atomicMax(&s_hi, bhi);
+  }
+  __syncthreads();
+  int c_lo = bs[s_lo], c_hi = bs[s_hi + 1];
+
+  // the list's fill state as the BYTE offset of its next distance slot, cnt * (4 SK_BLOCK) + 4 tid: the slot of the index
+  // list is half of it, an accepted candidate advances it by one row -- three address instructions per candidate less
+  // than from a count
+  static_assert(SK_BLOCK == 256, "aoff >> 10 is the count");
+  unsigned char* const cdb = reinterpret_cast<unsigned char*>(s_cd);
+  unsigned char* const cib = reinterpret_cast<unsigned char*>(s_ci);
+  unsigned aoff = 4u * tid;
+  int cnt = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    // pass 1 only runs if a (bad) prior left some lane with fewer than K candidates: everything, without pruning
+    for (int c0 = c_lo; c0 < c_hi; c0 += SK_CHUNK) {
+      const int cn = min(SK_CHUNK, c_hi - c0);
+      const int cn4 = (cn + 3) & ~3;
+      __syncthreads();
+      for (int j = tid; j < cn4; j += SK_BLOCK) {
+        const bool ok = j < cn;
+        // pad with NaN coordinates: the distance is NaN and `d <= tau` is false
+        s_ref[j] = ok ? Sb[c0 + j] : __builtin_nanf("");
+        s_ref[SK_CHUNK + j] = ok ? Sb[N + c0 + j] : __builtin_nanf("");
+        s_ref[2 * SK_CHUNK + j] = ok ? Sb[2 * N + c0 + j] : __builtin_nanf("");
+        s_id[j] = ok ? (uint16_t)Ib[c0 + j] : (uint16_t)0;
+      }
+      __syncthreads();
+      // the next four candidates are requested before this step's appends (LDS stores the loads may not be moved across):
+      // two waves per SIMD do not hide an LDS round trip per step (the last step's extra read stays inside the arrays)
+      if (stamps) st2 = __builtin_amdgcn_s_memtime();
+      float4 nx = *reinterpret_cast<const float4*>(&s_ref[0]);
+      float4 ny = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK]);
+      float4 nz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK]);
+      for (int j = 0; j < cn4; j += 4) {
+        const float4 rx = nx, ry = ny, rz = nz;
+        const int jn = j + 4 < SK_CHUNK ? j + 4 : j;
+        nx = *reinterpret_cast<const float4*>(&s_ref[jn]);
+        ny = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK + jn]);
+        nz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK + jn]);
+        // two candidates per instruction: v_pk_add_f32 / v_pk_mul_f32 are IEEE per component, so with contraction off
+        // the distances are the bits of geoa3_sqdist (3 sub + 3 mul + 2 add = 4 packed instructions per point)
+        float da[4];
+        slab_sqdist2(qx, qy, qz, rx.x, rx.y, ry.x, ry.y, rz.x, rz.y, da[0], da[1]);
+        slab_sqdist2(qx, qy, qz, rx.z, rx.w, ry.z, ry.w, rz.z, rz.w, da[2], da[3]);
+        // branch-free append: the candidate is written to the list's next slot whether it qualifies or not and the
+        // slot is kept only if it does (a passed-over `if` per candidate is a taken branch per candidate: with two
+        // waves per SIMD the scan ran at ~140 cycles per candidate).  cnt <= CAP - 4 here (the check below)
+        const uint2 ids = *reinterpret_cast<const uint2*>(&s_id[j]);
+        const unsigned id4[4] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          *reinterpret_cast<float*>(cdb + aoff) = da[u];
+          *reinterpret_cast<uint16_t*>(cib + (aoff >> 1)) = (uint16_t)id4[u];
+          aoff += da[u] <= tau ? 4u * SK_BLOCK : 0u;
+        }
+        if (__builtin_expect(__any(aoff > (unsigned)(CAP - 4) * 4u * SK_BLOCK + 4u * SK_BLOCK - 1u), 0)) {   // cnt > CAP - 4
+          cnt = (int)(aoff >> 10);
+          if (cnt >= K) {
+            tau = slab_compact<CAP>(s_ci, s_cd, cnt, K, tid);
+            aoff = (unsigned)K * 4u * SK_BLOCK + 4u * tid;
+          }
+        }
+      }
+    }
+    if (stamps) st3 = __builtin_amdgcn_s_memtime();
+    cnt = (int)(aoff >> 10);
+    const bool short_list = live && cnt < K && K <= N;
+    if (!__syncthreads_or(short_list)) break;
+    tau = live ? S_INF : -1.f;
+    cnt = 0;
+    aoff = 4u * tid;
+    c_lo = 0;
+    c_hi = N;
+  }
+
+  if (live) {
+    const int keep = cnt < K ? cnt : K;
+    slab_compact<CAP>(s_ci, s_cd, cnt, keep, tid);
+    if (stamps) st4 = __builtin_amdgcn_s_memtime();
+    float* od = dists + ((size_t)b * N + qo) * K;
+    int32_t* oi = idx + ((size_t)b * N + qo) * K;
+    for (int m = 0; m < K; ++m) {
+      od[m] = m < keep ? s_cd[m * SK_BLOCK + tid] : S_INF;
+      oi[m] = m < keep ? (int32_t)s_ci[m * SK_BLOCK + tid] : -1;
+    }
+  }
+  if (stamps && (tid & 63) == 0) {   // diagnostics (tools/knn_probe.py): per-wave phase clocks
+    unsigned long long* o = stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)) * 6;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The slab kernel for a cloud that fits one staging chunk (N <= SK_CHUNK) and short lists (K <= 20): a candidate is
+// remembered as its POSITION in the staged run (2 bytes) instead of (distance, index) (6 bytes); the distance is formed
+// again, from the same staged coordinates with the same un-fused operations (the same bits), when the list is ranked.
+// 34 KB of LDS per workgroup instead of 76: four workgroups per CU instead of two -- the scan is a dependent chain per
+// wavefront (compare -> list cursor -> store address) and runs at the rate of the wavefronts that interleave on a SIMD.
+// The ranking (64-bit keys in registers, every pair compared once) writes the result straight to memory.
+// ------------------------------------------------------------------------------------------
+constexpr int SP_CAP = 40;
+__global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void knn_slabp_kernel(const float* __restrict__ R, int N, int K,
+                                                             const int32_t* __restrict__ prior,
+                                                             const float* __restrict__ sorted,
+                                                             const int32_t* __restrict__ sidx,
+                                                             const int32_t* __restrict__ bstart,
+                                                             const SlabGeo* __restrict__ geo, float* __restrict__ dists,
+                                                             int32_t* __restrict__ idx) {
+  __shared__ __attribute__((aligned(16))) float s_ref[3 * SK_CHUNK];
+  __shared__ __attribute__((aligned(16))) uint16_t s_id[SK_CHUNK];
+  __shared__ __attribute__((aligned(16))) uint16_t s_pos[SP_CAP * SK_BLOCK];
+  __shared__ int s_lo, s_hi;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int pos = blockIdx.x * SK_BLOCK + tid;
+  const bool live = pos < N;
+  const float* Rb = R + (size_t)b * 3 * N;
+  const float* Sb = sorted + (size_t)b * 3 * N;
+  const int32_t* Ib = sidx + (size_t)b * N;
+  const int32_t* bs = bstart + (size_t)b * (SB_NB + 1);
+  const SlabGeo g = geo[b];
+  const int pc = live ? pos : N - 1;
+  const float qx = Sb[pc], qy = Sb[N + pc], qz = Sb[2 * N + pc];
+  const int qo = Ib[pc];                                     // the query's original index
+  if (tid == 0) {
+    s_lo = SB_NB;
+    s_hi = -1;
+  }
+  float tau = S_INF;
+  if (prior != nullptr && live) {
+    const int32_t* pr = prior + ((size_t)b * N + qo) * K;
+    float t = 0.f;
+    bool ok = true;
+    for (int m0 = 0; m0 < K; m0 += 8) {
+      int j[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) j[u] = m0 + u < K ? pr[m0 + u] : 0;
+      float px[8], py[8], pz[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ok = ok && j[u] >= 0 && j[u] < N;
+        const int jc = j[u] < 0 ? 0 : (j[u] >= N ? N - 1 : j[u]);
+        px[u] = Rb[jc];
+        py[u] = Rb[N + jc];
+        pz[u] = Rb[2 * N + jc];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (m0 + u < K) t = fmaxf(t, geoa3_sqdist(qx, qy, qz, px[u], py[u], pz[u]));
     }
     if (ok) tau = t;
   }
@@ -228,67 +445,116 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
   __syncthreads();
   int c_lo = bs[s_lo], c_hi = bs[s_hi + 1];
 
-  int cnt = 0;
+  // a thread's list: positions s_pos[slot][tid]; fill state = the BYTE offset of the next slot, cnt * 2 SK_BLOCK + 2 tid
+  static_assert(SK_BLOCK == 256, "poff >> 9 is the count");
+  unsigned char* const pb = reinterpret_cast<unsigned char*>(s_pos);
+  unsigned poff = 2u * tid;
+  // positions -> keys in registers: distance bits : original index : position (indices are distinct, so the position
+  // never decides an order; it rides along for the write-back); ~0 beyond the list
+  unsigned long long key[SP_CAP];
+  auto load_keys = [&](int cnt) {
+#pragma unroll
+    for (int s = 0; s < SP_CAP; ++s) {
+      const unsigned p = s_pos[s * SK_BLOCK + tid] & (SK_CHUNK - 1);
+      const float d = geoa3_sqdist(qx, qy, qz, s_ref[p], s_ref[SK_CHUNK + p], s_ref[2 * SK_CHUNK + p]);
+      key[s] = s < cnt ? ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned)s_id[p] << 16) | p : ~0ull;
+      if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // eight gathers in flight, not forty (registers)
+    }
+  };
+  // rank of entry i = the number of smaller keys: compare + carry per pair, back to back (left to the compiler the
+  // compares are batched and their lane masks spilled); no rank array -- the caller uses the rank at once (registers:
+  // four wavefronts per SIMD need the kernel under 128)
+#define SP_RANK(i, r)                                                                                            \
+  do {                                                                                                           \
+    r = 0;                                                                                                       \
+    _Pragma("unroll") for (int j_ = 0; j_ < SP_CAP; ++j_) {                                                      \
+      if (j_ != (i))                                                                                             \
+        asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"                             \
+                     : "+v"(r)                                                                                   \
+                     : "v"(key[j_]), "v"(key[i])                                                                 \
+                     : "vcc");                                                                                   \
+    }                                                                                                            \
+  } while (0)
   for (int pass = 0; pass < 2; ++pass) {
     // pass 1 only runs if a (bad) prior left some lane with fewer than K candidates: everything, without pruning
-    for (int c0 = c_lo; c0 < c_hi; c0 += SK_CHUNK) {
-      const int cn = min(SK_CHUNK, c_hi - c0);
-      const int cn4 = (cn + 3) & ~3;
-      __syncthreads();
-      for (int j = tid; j < cn4; j += SK_BLOCK) {
-        const bool ok = j < cn;
-        // pad with NaN coordinates: the distance is NaN and `d <= tau` is false
-        s_ref[j] = ok ? Sb[c0 + j] : __builtin_nanf("");
-        s_ref[SK_CHUNK + j] = ok ? Sb[N + c0 + j] : __builtin_nanf("");
-        s_ref[2 * SK_CHUNK + j] = ok ? Sb[2 * N + c0 + j] : __builtin_nanf("");
-        s_id[j] = ok ? (uint16_t)Ib[c0 + j] : (uint16_t)0;
-      }
-      __syncthreads();
-      for (int j = 0; j < cn4; j += 4) {
-        const float4 rx = *reinterpret_cast<const float4*>(&s_ref[j]);
-        const float4 ry = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK + j]);
-        const float4 rz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK + j]);
-        // two candidates per instruction: v_pk_add_f32 / v_pk_mul_f32 are IEEE per component, so with contraction off
-        // the distances are the bits of geoa3_sqdist (3 sub + 3 mul + 2 add = 4 packed instructions per point)
-        float da[4];
-        slab_sqdist2(qx, qy, qz, rx.x, rx.y, ry.x, ry.y, rz.x, rz.y, da[0], da[1]);
-        slab_sqdist2(qx, qy, qz, rx.z, rx.w, ry.z, ry.w, rz.z, rz.w, da[2], da[3]);
+    const int c0 = c_lo;
+    const int cn = min(SK_CHUNK, c_hi - c0);      // N <= SK_CHUNK: the whole run at once
+    const int cn4 = (cn + 3) & ~3;
+    __syncthreads();
+    for (int j = tid; j < cn4; j += SK_BLOCK) {
+      const bool ok = j < cn;
+      // pad with NaN coordinates: the distance is NaN and `d <= tau` is false
+      s_ref[j] = ok ? Sb[c0 + j] : __builtin_nanf("");
+      s_ref[SK_CHUNK + j] = ok ? Sb[N + c0 + j] : __builtin_nanf("");
+      s_ref[2 * SK_CHUNK + j] = ok ? Sb[2 * N + c0 + j] : __builtin_nanf("");
+      s_id[j] = ok ? (uint16_t)Ib[c0 + j] : (uint16_t)0;
+    }
+    __syncthreads();
+    float4 nx = *reinterpret_cast<const float4*>(&s_ref[0]);
+    float4 ny = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK]);
+    float4 nz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK]);
+    for (int j = 0; j < cn4; j += 4) {
+      const float4 rx = nx, ry = ny, rz = nz;
+      const int jn = j + 4 < SK_CHUNK ? j + 4 : j;
+      nx = *reinterpret_cast<const float4*>(&s_ref[jn]);
+      ny = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK + jn]);
+      nz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK + jn]);
+      float da[4];
+      slab_sqdist2(qx, qy, qz, rx.x, rx.y, ry.x, ry.y, rz.x, rz.y, da[0], da[1]);
+      slab_sqdist2(qx, qy, qz, rx.z, rx.w, ry.z, ry.w, rz.z, rz.w, da[2], da[3]);
+      // branch-free append: the position goes to the list's next slot whether the candidate qualifies or not, and the
+      // slot is kept only if it does.  cnt <= SP_CAP - 4 here (the check below)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float d = da[u];
-          if (d <= tau) {
-            s_cd[cnt * SK_BLOCK + tid] = d;
-            s_ci[cnt * SK_BLOCK + tid] = s_id[j + u];
-            ++cnt;
+      for (int u = 0; u < 4; ++u) {
+        *reinterpret_cast<uint16_t*>(pb + poff) = (uint16_t)(j + u);
+        poff += da[u] <= tau ? 2u * SK_BLOCK : 0u;
+      }
+      if (__builtin_expect(__any(poff > (unsigned)(SP_CAP - 4) * 2u * SK_BLOCK + 2u * SK_BLOCK - 1u), 0)) {   // cnt > CAP - 4
+        const int cnt = (int)(poff >> 9);
+        if (cnt >= K) {   // keep the K best (in order), tighten the radius; every old slot is in a register by now
+          load_keys(cnt);
+#pragma unroll
+          for (int s = 0; s < SP_CAP; ++s) {
+            int r;
+            SP_RANK(s, r);
+            if (r < K) s_pos[r * SK_BLOCK + tid] = (uint16_t)key[s];
+            if (r == K - 1) tau = __uint_as_float((unsigned)(key[s] >> 32));
           }
-        }
-        if (__builtin_expect(__any(cnt > CAP - 4), 0)) {
-          if (cnt >= K) {
-            tau = slab_compact<CAP>(s_ci, s_cd, cnt, K, tid);
-            cnt = K;
-          }
+          poff = (unsigned)K * 2u * SK_BLOCK + 2u * tid;
         }
       }
     }
+    const int cnt = (int)(poff >> 9);
     const bool short_list = live && cnt < K && K <= N;
     if (!__syncthreads_or(short_list)) break;
     tau = live ? S_INF : -1.f;
-    cnt = 0;
+    poff = 2u * tid;
     c_lo = 0;
     c_hi = N;
   }
 
   if (live) {
+    const int cnt = (int)(poff >> 9);
     const int keep = cnt < K ? cnt : K;
-    slab_compact<CAP>(s_ci, s_cd, cnt, keep, tid);
+    load_keys(cnt);
     float* od = dists + ((size_t)b * N + qo) * K;
     int32_t* oi = idx + ((size_t)b * N + qo) * K;
-    for (int m = 0; m < K; ++m) {
-      od[m] = m < keep ? s_cd[m * SK_BLOCK + tid] : S_INF;
-      oi[m] = m < keep ? (int32_t)s_ci[m * SK_BLOCK + tid] : -1;
+#pragma unroll
+    for (int s = 0; s < SP_CAP; ++s) {
+      int r;
+      SP_RANK(s, r);
+      if (r < keep) {
+        od[r] = __uint_as_float((unsigned)(key[s] >> 32));
+        oi[r] = (int32_t)((key[s] >> 16) & 0xffffu);
+      }
+    }
+    for (int m = keep; m < K; ++m) {   // fewer than K points in the cloud
+      od[m] = S_INF;
+      oi[m] = -1;
     }
   }
 }
+#undef SP_RANK
 
 // ------------------------------------------------------------------------------------------
 // Cell-grid search, one WAVEFRONT per query (the K = 33 / N = 4096 regime, where the per-thread lists of the slab kernel
@@ -648,6 +914,9 @@ SlabScratch slab_carve(void* base, int B, int N) {
 
 }  // namespace
 
+static unsigned long long* g_slab_stamps = nullptr;   // TEMPORARY diagnostics
+extern "C" void geoa3_debug_slab_stamps(void* p) { g_slab_stamps = static_cast<unsigned long long*>(p); }
+
 extern "C" int64_t geoa3_knn_self_scratch_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return -1;
   const size_t a = slab_carve(nullptr, B, N).total, g = grid_carve(nullptr, B, N).total;
@@ -683,9 +952,16 @@ extern "C" int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_slab_kernel<CAP>),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
     hipLaunchKernelGGL(knn_slab_kernel<CAP>, grid, dim3(SK_BLOCK), lds, s, pc, N, K, prior, sc.sorted, sc.sidx, \
-                       sc.bstart, sc.geo, dists, idx);                                                          \
+                       sc.bstart, sc.geo, dists, idx, g_slab_stamps);                                           \
   } while (0)
-    if (K <= 20) SLAB_LAUNCH(40);
+    static const bool slabp = !(getenv("GEOA3_SLABP") && getenv("GEOA3_SLABP")[0] == '0');   // A/B switch
+    // positions instead of (distance, index) lists: twice the occupancy -- for launches the (distance, index) kernel cannot
+    // hold at once (two workgroups per CU); a small shard's launch runs beside the victim's kernels, where the denser
+    // kernel cost more than it saved (32 instances: 0.500 -> 0.506 ms per iteration)
+    if (K <= 20 && N <= SK_CHUNK && !g_slab_stamps && slabp && (size_t)grid.x * grid.y > 512)
+      hipLaunchKernelGGL(knn_slabp_kernel, grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx, sc.bstart,
+                         sc.geo, dists, idx);
+    else if (K <= 20) SLAB_LAUNCH(40);
     else if (K <= 40) SLAB_LAUNCH(72);
     else SLAB_LAUNCH(96);
 #undef SLAB_LAUNCH
