@@ -215,10 +215,8 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
                                                             const int32_t* __restrict__ sidx,
                                                             const int32_t* __restrict__ bstart,
                                                             const SlabGeo* __restrict__ geo, float* __restrict__ dists,
-                                                            int32_t* __restrict__ idx, unsigned long long* stamps) {
+                                                            int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
-  if (stamps) st0 = __builtin_amdgcn_s_memtime();
   float* s_ref = reinterpret_cast<float*>(smem);                                    // 3*SK_CHUNK floats
   float* s_cd = s_ref + 3 * SK_CHUNK;                                               // [CAP][SK_BLOCK]
   uint16_t* s_ci = reinterpret_cast<uint16_t*>(s_cd + (size_t)CAP * SK_BLOCK);      // [CAP][SK_BLOCK]
@@ -266,7 +264,6 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
     if (ok) tau = t;
   }
   if (!live) tau = -1.f;  // padding lanes never collect candidates
-  if (stamps) st1 = __builtin_amdgcn_s_memtime();
   __syncthreads();
   if (live) {
     int blo = 0, bhi = SB_NB - 1;
@@ -307,7 +304,6 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
       __syncthreads();
       // the next four candidates are requested before this step's appends (LDS stores the loads may not be moved across):
       // two waves per SIMD do not hide an LDS round trip per step (the last step's extra read stays inside the arrays)
-      if (stamps) st2 = __builtin_amdgcn_s_memtime();
       float4 nx = *reinterpret_cast<const float4*>(&s_ref[0]);
       float4 ny = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK]);
       float4 nz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK]);
@@ -342,7 +338,6 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
         }
       }
     }
-    if (stamps) st3 = __builtin_amdgcn_s_memtime();
     cnt = (int)(aoff >> 10);
     const bool short_list = live && cnt < K && K <= N;
     if (!__syncthreads_or(short_list)) break;
@@ -356,17 +351,12 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
   if (live) {
     const int keep = cnt < K ? cnt : K;
     slab_compact<CAP>(s_ci, s_cd, cnt, keep, tid);
-    if (stamps) st4 = __builtin_amdgcn_s_memtime();
     float* od = dists + ((size_t)b * N + qo) * K;
     int32_t* oi = idx + ((size_t)b * N + qo) * K;
     for (int m = 0; m < K; ++m) {
       od[m] = m < keep ? s_cd[m * SK_BLOCK + tid] : S_INF;
       oi[m] = m < keep ? (int32_t)s_ci[m * SK_BLOCK + tid] : -1;
     }
-  }
-  if (stamps && (tid & 63) == 0) {   // diagnostics (tools/knn_probe.py): per-wave phase clocks
-    unsigned long long* o = stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)) * 6;
-    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = __builtin_amdgcn_s_memtime();
   }
 }
 
@@ -914,9 +904,6 @@ SlabScratch slab_carve(void* base, int B, int N) {
 
 }  // namespace
 
-static unsigned long long* g_slab_stamps = nullptr;   // TEMPORARY diagnostics
-extern "C" void geoa3_debug_slab_stamps(void* p) { g_slab_stamps = static_cast<unsigned long long*>(p); }
-
 extern "C" int64_t geoa3_knn_self_scratch_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return -1;
   const size_t a = slab_carve(nullptr, B, N).total, g = grid_carve(nullptr, B, N).total;
@@ -952,13 +939,13 @@ extern "C" int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_slab_kernel<CAP>),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
     hipLaunchKernelGGL(knn_slab_kernel<CAP>, grid, dim3(SK_BLOCK), lds, s, pc, N, K, prior, sc.sorted, sc.sidx, \
-                       sc.bstart, sc.geo, dists, idx, g_slab_stamps);                                           \
+                       sc.bstart, sc.geo, dists, idx);                                                          \
   } while (0)
     static const bool slabp = !(getenv("GEOA3_SLABP") && getenv("GEOA3_SLABP")[0] == '0');   // A/B switch
     // positions instead of (distance, index) lists: twice the occupancy -- for launches the (distance, index) kernel cannot
     // hold at once (two workgroups per CU); a small shard's launch runs beside the victim's kernels, where the denser
     // kernel cost more than it saved (32 instances: 0.500 -> 0.506 ms per iteration)
-    if (K <= 20 && N <= SK_CHUNK && !g_slab_stamps && slabp && (size_t)grid.x * grid.y > 512)
+    if (K <= 20 && N <= SK_CHUNK && slabp && (size_t)grid.x * grid.y > 512)
       hipLaunchKernelGGL(knn_slabp_kernel, grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx, sc.bstart,
                          sc.geo, dists, idx);
     else if (K <= 20) SLAB_LAUNCH(40);

@@ -1,5 +1,6 @@
-"""Where does knn_slab_kernel spend its time in the loop?  Runs the bench's attack to a steady state, then looks at the
-adversarial cloud + the prior lists the next K-NN launch would see (CPU analysis) and times the launch itself."""
+"""What the K-NN launch sees in the loop: runs the bench's attack to a steady state, then counts (on the CPU) the run of
+sorted points a workgroup scans and the candidates within a query's radius, and times the launch on its own.
+usage (GPU box): python3 tools/knn_probe.py [instances] [iterations]"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (helpers only)
@@ -46,50 +47,18 @@ print("scan range per WG: mean %.0f max %d" % (np.mean(tot), max(tot)))
 print("candidates within tau per query: mean %.1f p99 %d max %d; queries with > 36: %d of %d" % (
     passes.mean(), np.percentile(passes, 99), passes.max(), (passes > 36).sum(), passes.size))
 
-# per-wave phase clocks of one launch (s_memtime, 100 MHz constant clock)
+# the launch on its own (one stream), timed with events
 import ctypes as C
 from geoa3_amd import _lib
-lib = C.CDLL(_lib.LIB_PATH) if hasattr(_lib, "LIB_PATH") else _lib.load()
-stamps = torch.zeros(B * 4 * 4 * 6, dtype=torch.int64, device=dev)
-fn = lib.geoa3_debug_slab_stamps; fn.argtypes = [C.c_void_p]; fn.restype = None
-fn(stamps.data_ptr())
-r.step(steps, 0); torch.cuda.synchronize()
-fn(None)
-st = stamps.cpu().numpy().reshape(-1, 6).astype(np.float64)
-st = st[st[:, 0] > 0]
-d = np.diff(st, axis=1) / 100.0      # us
-names = ["prior/tau", "range+stage", "scan", "final compaction", "output"]
-for i, n in enumerate(names):
-    print("%-18s mean %7.2f us  max %7.2f" % (n, d[:, i].mean(), d[:, i].max()))
-print("wave lifetime mean %.2f max %.2f; kernel span %.2f us" % ((st[:, 5] - st[:, 0]).mean() / 100, (st[:, 5] - st[:, 0]).max() / 100, (st[:, 5].max() - st[:, 0].min()) / 100))
-s0 = np.sort(st[:, 0]); s5 = np.sort(st[:, 5])
-print("start stamps (sorted, minus min)/100:", np.round((s0[::max(1, len(s0)//16)] - s0[0]) / 100, 1))
-print("end stamps   (sorted, minus min start)/100:", np.round((s5[::max(1, len(s5)//16)] - s0[0]) / 100, 1))
-order = np.argsort(st[:, 0]); so = st[order]
-cuts = np.where(np.diff(so[:, 0]) > 1e6)[0] + 1
-for grp in np.split(so, cuts):
-    print("cluster: %3d waves, starts spread %.0f, first end %.0f, last end %.0f (units since the cluster's first start)" % (
-        len(grp), grp[:, 0].max() - grp[:, 0].min(), grp[:, 5].min() - grp[:, 0].min(), grp[:, 5].max() - grp[:, 0].min()))
-# the launch on its own (one stream), timed with events, stamps on
-fn(stamps.data_ptr()); stamps.zero_()
 lib2 = _lib.load()
 prior_t, out_t = t["knn"][r.knn_cur], t["knn"][1 - r.knn_cur]
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 sg = torch.cuda.current_stream().cuda_stream
 torch.cuda.synchronize()
-for rep in range(3):
-    stamps.zero_()
-    e0.record()
-    lib2.geoa3_knn_self(t["x"].data_ptr(), B, N, K, prior_t.data_ptr(), t["knn_d"].data_ptr(), out_t.data_ptr(),
-                        t["knn_scratch"].data_ptr(), 1, sg)
-    e1.record(); torch.cuda.synchronize()
-    print("knn_self alone: %.1f us (incl. the bin kernel)" % (e0.elapsed_time(e1) * 1e3))
-fn(None)
-st = stamps.cpu().numpy().reshape(-1, 6).astype(np.float64)
-print("rows with stamps:", int((st[:, 0] > 0).sum()), "of", len(st))
-st = st[st[:, 0] > 0]
-order = np.argsort(st[:, 0]); so = st[order]
-cuts = np.where(np.diff(so[:, 0]) > 3e6)[0] + 1
-for grp in np.split(so, cuts):
-    print("cluster: %3d waves, starts spread %.0f, lifetime mean %.0f, last end %.0f" % (
-        len(grp), grp[:, 0].max() - grp[:, 0].min(), (grp[:, 5] - grp[:, 0]).mean(), grp[:, 5].max() - grp[:, 0].min()))
+for method in (1, 2):
+    for rep in range(3):
+        e0.record()
+        lib2.geoa3_knn_self(t["x"].data_ptr(), B, N, K, prior_t.data_ptr(), t["knn_d"].data_ptr(), out_t.data_ptr(),
+                            t["knn_scratch"].data_ptr(), method, sg)
+        e1.record(); torch.cuda.synchronize()
+    print("knn_self method %d alone: %.1f us (incl. the sort kernel)" % (method, e0.elapsed_time(e1) * 1e3))
