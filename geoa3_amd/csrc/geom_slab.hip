@@ -941,11 +941,12 @@ extern "C" int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_
     hipLaunchKernelGGL(knn_slab_kernel<CAP>, grid, dim3(SK_BLOCK), lds, s, pc, N, K, prior, sc.sorted, sc.sidx, \
                        sc.bstart, sc.geo, dists, idx);                                                          \
   } while (0)
-    static const bool slabp = !(getenv("GEOA3_SLABP") && getenv("GEOA3_SLABP")[0] == '0');   // A/B switch
+    const char* sp = getenv("GEOA3_SLABP");   // A/B switch, read per call: 0 = never, 2 = whatever the launch size
+    const bool slabp = !(sp && sp[0] == '0'), slabp_always = sp && sp[0] == '2';
     // positions instead of (distance, index) lists: twice the occupancy -- for launches the (distance, index) kernel cannot
     // hold at once (two workgroups per CU); a small shard's launch runs beside the victim's kernels, where the denser
     // kernel cost more than it saved (32 instances: 0.500 -> 0.506 ms per iteration)
-    if (K <= 20 && N <= SK_CHUNK && slabp && (size_t)grid.x * grid.y > 512)
+    if (K <= 20 && N <= SK_CHUNK && slabp && ((size_t)grid.x * grid.y > 512 || slabp_always))
       hipLaunchKernelGGL(knn_slabp_kernel, grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx, sc.bstart,
                          sc.geo, dists, idx);
     else if (K <= 20) SLAB_LAUNCH(40);

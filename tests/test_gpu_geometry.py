@@ -263,7 +263,7 @@ def test_graph_pruned_search_is_bit_identical_to_brute_force(ops, N, K, Kg, scal
 @pytest.mark.parametrize("N,K,scale", [(1024, 17, 0.002), (1024, 17, 0.05), (1024, 17, 0.6), (700, 9, 0.02),
                                        (4096, 33, 0.01), (2048, 64, 0.01), (300, 17, 0.0), (40, 17, 0.05),
                                        (8192, 5, 0.01), (9000, 5, 0.01)])
-def test_slab_pruned_self_knn_is_bit_identical_to_brute_force(ops, N, K, scale):
+def test_slab_pruned_self_knn_is_bit_identical_to_brute_force(ops, N, K, scale, monkeypatch):
     """geoa3_knn_self (slab pruning along the longest axis) against the all-pairs kernel and the oracle: good priors
     (the clean cloud's table), stale priors (a different cloud's table), degenerate priors (duplicates / out of range:
     the unpruned second pass) and no prior; duplicate points give exact ties."""
@@ -293,6 +293,13 @@ def test_slab_pruned_self_knn_is_bit_identical_to_brute_force(ops, N, K, scale):
         for prior in (clean, stale, bad, None):
             d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch, method=method)
             assert torch.equal(i, bi) and torch.equal(d, bd), (method, prior is None)
+    if N <= 1024 and kk <= 20:
+        # the position-list form of the slab kernel (knn_slabp_kernel), which the library takes for large launches only
+        monkeypatch.setenv("GEOA3_SLABP", "2")
+        for prior in (clean, stale, bad):
+            d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch, method=1)
+            assert torch.equal(i, bi) and torch.equal(d, bd)
+        monkeypatch.delenv("GEOA3_SLABP")
     d, i = ops.knn_self_planar(advD, kk, prior=clean, scratch=None)
     assert torch.equal(i, bi) and torch.equal(d, bd)
     # in place over the prior (the loop's double buffer may alias)
