@@ -9,6 +9,7 @@
 // else, and the cell range carries a margin far above float rounding, so the result is BIT-IDENTICAL to the
 // all-pairs search (tests/test_gpu_geometry.py) for any input: a query far from every point simply scans more
 // cells (in the limit: all of them, i.e. the all-pairs work).
+#include <cstdlib>
 #include "geom_internal.h"
 #include "profile.h"
 
@@ -154,10 +155,12 @@ __device__ __forceinline__ void grid_ball(const int* __restrict__ s_start, float
   }
 }
 
+constexpr int NN1_WIDE = 16;   // a query whose ball touches more grid columns is walked by the whole wavefront
+
 template <int PPT, int MODE = 0>   // MODE (tools/ub/nn1_ub.hip): 1 = build only, 2 = seeds only (no ball walk)
 __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ A, const float* __restrict__ R, int Na,
                                                       int Nr, const int32_t* prior_ar, const int32_t* prior_ra,
-                                                      float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra) {
+                                                      float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, int wide_thr) {
   // prior_* (optional, may alias i_*): a searched-cloud index per query -- last iteration's answer -- used as the seed
   extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
   const int b = blockIdx.x;
@@ -178,10 +181,12 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
   const GridGeom g = grid_build<GT, PPT>(P, M, s_start, s_fill, s_px, s_py, s_pz, s_pi, s_red);
 
   if (MODE == 1) return;
-  for (int t = threadIdx.x; t < Nq; t += GT) {
+  for (int t0 = 0; t0 < Nq; t0 += GT) {     // (uniform trips: the wave-wide walk below needs every lane)
+    const int t = t0 + threadIdx.x;
+    const bool valid = t < Nq;
     // equal-sized clouds: walk the queries in the searched cloud's cell order (query i is a perturbation of point i
     // in the attack loop), so that the lanes of a wavefront look at the same few cells
-    const int q = Nq == M ? s_pi[t] : t;
+    const int q = valid ? (Nq == M ? s_pi[t] : t) : 0;
     const float qx = Q[q], qy = Q[Nq + q], qz = Q[2 * Nq + q];
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
     // seed: any real point gives a valid radius.  Last iteration's nearest neighbour when the caller has it,
@@ -196,7 +201,17 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
       const int n = nx * ny;
       atomicAdd(reinterpret_cast<unsigned long long*>(d_ar) + 2 + (n <= 4 ? 0 : (n <= 16 ? 1 : (n <= 64 ? 2 : 3))), 1ull);
     }
-    if (MODE != 2) grid_ball(s_start, fx, fy, fz, sqrtf(best), g.inv_h, [&](int s, int e) {
+    // A query's ball touches ~5 grid columns on average, but a few queries (outliers: a large distance to their seed)
+    // touch up to 64, and a wavefront walks as long as its widest lane: 33 column steps on average for 4.9 useful ones
+    // (s_memtime + counters).  So a lane walks its own box only if it is small; the wide boxes are taken one after the
+    // other by the WHOLE wave, a column per lane, and reduced with the same lexicographic (distance, index) minimum --
+    // the same candidates, the same result.
+    const float rad = sqrtf(best);
+    const float rho = rad * g.inv_h * 1.00001f + 1e-4f;   // (grid_ball's radius in cells)
+    const int bx0 = grid_coord(fx - rho), bx1 = grid_coord(fx + rho), by0 = grid_coord(fy - rho), by1 = grid_coord(fy + rho);
+    const int bny = by1 - by0 + 1, bcols = (bx1 - bx0 + 1) * bny;
+    const bool wide = MODE == 0 && valid && bcols > wide_thr;
+    if (MODE != 2 && !wide && valid) grid_ball(s_start, fx, fy, fz, rad, g.inv_h, [&](int s, int e) {
       if (MODE == 3) {   // statistics: columns visited, candidates
         atomicAdd(reinterpret_cast<unsigned long long*>(d_ar), 1ull);
         atomicAdd(reinterpret_cast<unsigned long long*>(d_ar) + 1, (unsigned long long)(e - s));
@@ -209,7 +224,52 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
         bi = take ? i : bi;
       }
     });
-    if (MODE != 3) {
+    if (MODE == 0) {
+      constexpr int nact = 64;
+      const int myrank = threadIdx.x & 63;
+      unsigned long long todo = __ballot(wide);
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        auto bcf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+        const float wqx = bcf(qx), wqy = bcf(qy), wqz = bcf(qz), wfx = bcf(fx), wfy = bcf(fy), wfz = bcf(fz), wrho = bcf(rho);
+        const int wx0 = __builtin_amdgcn_readlane(bx0, src), wy0 = __builtin_amdgcn_readlane(by0, src);
+        const int wny = __builtin_amdgcn_readlane(bny, src), wcols = __builtin_amdgcn_readlane(bcols, src);
+        float cbest = bcf(best);
+        int cbi = __builtin_amdgcn_readlane(bi, src);
+        const float rho2 = wrho * wrho;
+        for (int c = myrank; c < wcols; c += nact) {      // this lane's columns of the box: the body of grid_ball
+          const int xx = wx0 + c / wny, yy = wy0 + c % wny;
+          const float ex = fmaxf(fmaxf((float)xx - wfx, wfx - (float)(xx + 1)), 0.f);
+          const float ey = fmaxf(fmaxf((float)yy - wfy, wfy - (float)(yy + 1)), 0.f);
+          const float rem = rho2 - ex * ex - ey * ey;
+          if (rem < 0.f) continue;
+          const float zr = __builtin_amdgcn_sqrtf(rem) + 1e-4f;
+          const int col = (xx * GG + yy) * GG;
+          const int js = s_start[col + grid_coord(wfz - zr)], je = s_start[col + grid_coord(wfz + zr) + 1];
+          for (int j = js; j < je; ++j) {
+            const float d = geoa3_sqdist(wqx, wqy, wqz, s_px[j], s_py[j], s_pz[j]);
+            const int i = s_pi[j];
+            const bool take = d < cbest || (d == cbest && i < cbi);
+            cbest = take ? d : cbest;
+            cbi = take ? i : cbi;
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {      // lexicographic minimum over the wave
+          const float od = __shfl_xor(cbest, o, 64);
+          const int oi = __shfl_xor(cbi, o, 64);
+          const bool take = od < cbest || (od == cbest && oi < cbi);
+          cbest = take ? od : cbest;
+          cbi = take ? oi : cbi;
+        }
+        if ((int)(threadIdx.x & 63) == src) {
+          best = cbest;
+          bi = cbi;
+        }
+      }
+    }
+    if (MODE != 3 && valid) {
       dout[q] = best;
       iout[q] = bi;
     }
@@ -228,6 +288,8 @@ int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr,
   const int M = Na > Nr ? Na : Nr;
   if (M > 4 * GT || (d_ra == nullptr) != (i_ra == nullptr)) return GEOA3_ENOSUPPORT;
   const size_t lds = grid_nn1_lds(M);
+  const char* wt = getenv("GEOA3_NN1_WIDE");   // A/B: columns above which a query's box is walked by the whole wave
+  const int wide_thr = wt ? atoi(wt) : NN1_WIDE;
   dim3 grid(B, d_ra ? 2 : 1);
 #define GEOA3_GRID_CASE(PPT)                                                                                    \
   if (M <= PPT * GT) {                                                                                          \
@@ -235,7 +297,7 @@ int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr,
     if (lds > 64 * 1024)                                                                                        \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(GT), lds, s, a, r, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra);                     \
+    hipLaunchKernelGGL(kern, grid, dim3(GT), lds, s, a, r, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, wide_thr);                     \
     GEOA3_CHECK_LAUNCH();                                                                                       \
     return GEOA3_OK;                                                                                            \
   }

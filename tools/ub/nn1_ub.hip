@@ -14,9 +14,9 @@ float run(const float* A, const float* R, int B, int N, int* prior_ar, int* prio
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, A, R, N, N, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, A, R, N, N, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, NN1_WIDE);
   hipEventRecord(e0, 0);
-  for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, A, R, N, N, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra);
+  for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, A, R, N, N, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, NN1_WIDE);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     const size_t lds = grid_nn1_lds(N);
     auto k = grid_nn1_kernel<1, 3>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, dA, dR, N, N, i_ar, i_ra, (float*)cnt, i_ar, (float*)cnt, i_ra);
+    hipLaunchKernelGGL(k, dim3(B, 2), dim3(GT), lds, 0, dA, dR, N, N, i_ar, i_ra, (float*)cnt, i_ar, (float*)cnt, i_ra, NN1_WIDE);
     unsigned long long h[8]; hipMemcpy(h, cnt, 64, hipMemcpyDeviceToHost);
     printf("columns iterated per query: <=4: %llu  <=16: %llu  <=64: %llu  >64: %llu\n", h[2], h[3], h[4], h[5]);
     printf("per query: %.1f columns, %.1f candidates\n", h[0] / (2.0 * B * N), h[1] / (2.0 * B * N));
