@@ -383,7 +383,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     g.Y = w.P64; g.ldY = 64; g.sYb = 4096;
     g.M = 64; g.Nout = 64; g.K = N; g.batch = B;
     // f16 matrix pipe; partial sums of the four workgroups per instance go through dh2 (written only afterwards:
-    // 4 * 4096 floats per instance fit its 64 * N from N = 256 on, and gram64_parts(N) is 1 below N = 385)
+    // 8 * 4096 floats per instance fit its 64 * N from N = 512 on, and gram64_parts(N) is at most 4 below N = 897)
     if (tl_split) TRY(launch_gram64(w.h2, w.G64a, B, N, w.P64, w.dh2, s));
     else TRY(launch_fc(g, s));
     FcArgs q{};   // dT64[b][i][j] = sum_o P[b][i][o] W3[o][j]

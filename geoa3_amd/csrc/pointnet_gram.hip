@@ -124,10 +124,13 @@ __global__ __launch_bounds__(256) void gram64_reduce_kernel(const float* __restr
 
 }  // namespace
 
-// scratch: B * parts * 4096 floats with parts = gram64_parts(N) (1: P is written directly, scratch unused)
+// scratch: B * parts * 4096 floats with parts = gram64_parts(N) (1: P is written directly, scratch unused).  A function
+// of N only (never of the batch): an instance's sums must not depend on which other instances share the launch.  Eight
+// parts from 8 chunks on: one chunk per workgroup at N = 1024 -- the same 53 us as four at 250 instances, 13.6 against
+// 20.4 us on a 32-instance shard
 int gram64_parts(int N) {
   const int chunks = (N + GR_CHK - 1) / GR_CHK;
-  return chunks >= 4 ? 4 : 1;
+  return chunks >= 8 ? 8 : (chunks >= 4 ? 4 : 1);
 }
 
 int launch_gram64(const float* A, const float* G, int B, int N, float* P, float* scratch, hipStream_t s) {
