@@ -12,13 +12,13 @@ namespace {
 constexpr float NORM_EPS = 1e-12f;  // Lib/utility.py:30 (_normalize eps)
 
 // | < normalize(q - p), n > | summed over the k neighbours listed in nb[1..k] (nb[0] is dropped).
-template <typename Nbr, typename Fetch>
+template <typename Fetch>
 __device__ __forceinline__ float kappa_point(float px, float py, float pz, float nx, float ny, float nz,
-                                             Nbr nb, int k, Fetch fetch) {   // nb(m): index of the m-th neighbour
+                                             const int32_t* __restrict__ nb, int k, Fetch fetch) {
   float acc = 0.f;
   for (int m = 1; m <= k; ++m) {
     float qx, qy, qz;
-    fetch(nb(m), qx, qy, qz);
+    fetch(nb[m], qx, qy, qz);
     const float vx = qx - px, vy = qy - py, vz = qz - pz;
     const float r = sqrtf(vx * vx + vy * vy + vz * vz);
     const float inv = 1.0f / fmaxf(r, NORM_EPS);
@@ -45,16 +45,13 @@ __global__ __launch_bounds__(256) void kappa_kernel(const float* __restrict__ pc
     y = P[N + j];
     z = P[2 * N + j];
   };
-  kappa[(size_t)b * N + i] = kappa_point(P[i], P[N + i], P[2 * N + i], nx, ny, nz, [&](int m) { return nb[m]; }, k, fetch);
+  kappa[(size_t)b * N + i] = kappa_point(P[i], P[N + i], P[2 * N + i], nx, ny, nz, nb, k, fetch);
 }
 
 // ------------------------------------------------------------------------------------------
 // Fused objective: one workgroup per instance.
 // ------------------------------------------------------------------------------------------
 constexpr int GEO_BLOCK = 1024;
-constexpr int GEO_HUB = 32;       // an owner with a longer reverse list hands it to a wavefront
-constexpr int GEO_HUBCAP = 256;   // entries of the workgroup's hub worklist
-constexpr int GEO_HUB_EPL = 16;   // list entries per lane of the wavefront that ranks a hub's list (1024 entries)
 constexpr int GEO_WAVES = GEO_BLOCK / GEOA3_WAVE;
 
 struct MaxIdx {
@@ -73,7 +70,7 @@ __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {  // larger value,
 // exact), scan, unordered fill, then every owner sorts its own short list by source key.  A contribution is recomputed
 // by the owner with the expression its source uses for its own share, so the two agree bit for bit.
 template <bool DET>
-__global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args A, int rcap, int nrm_in_lds, int nb_off) {
+__global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args A, int rcap, int nrm_in_lds) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = A.N, k = A.k, b = blockIdx.x, tid = threadIdx.x;
   float* s_ax = sm;            // adv planes
@@ -102,16 +99,6 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
     s_gy[i] = 0.f;
     s_gz[i] = 0.f;
   }
-  // the instance's neighbour table [N][k+1] as 16-bit indices in LDS when it fits (nb_off = its offset in floats, 0 = it
-  // does not): the passes below walk it four times, one neighbour per trip -- from memory each trip is an L2 round trip
-  uint16_t* s_nb = reinterpret_cast<uint16_t*>(sm + nb_off);
-  if (nb_off && do_curv) {
-    const int32_t* T = A.knn_adv + bN * (size_t)(k + 1);
-    for (int e = tid; e < N * (k + 1); e += GEO_BLOCK) s_nb[e] = (uint16_t)T[e];
-  }
-  auto nbr = [&](int i, int m) -> int {
-    return nb_off ? (int)s_nb[i * (k + 1) + m] : A.knn_adv[(bN + i) * (size_t)(k + 1) + m];
-  };
   __syncthreads();
 
   // ---- phase A: per-point terms and block reductions
@@ -129,13 +116,13 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
     if (do_curv) {
       const int ni = A.i_ao[bN + i];
       const float* Nm = A.normal_ori + (size_t)b * 3 * Nr;
+      const int32_t* nb = A.knn_adv + (bN + i) * (size_t)(k + 1);
       auto fetch = [&](int j, float& x, float& y, float& z) {
         x = s_ax[j];
         y = s_ay[j];
         z = s_az[j];
       };
-      const float kap = kappa_point(s_ax[i], s_ay[i], s_az[i], Nm[ni], Nm[Nr + ni], Nm[2 * Nr + ni],
-                                    [&](int m) { return nbr(i, m); }, k, fetch);
+      const float kap = kappa_point(s_ax[i], s_ay[i], s_az[i], Nm[ni], Nm[Nr + ni], Nm[2 * Nr + ni], nb, k, fetch);
       const float e = kap - (A.kappa_ori ? A.kappa_ori[bNr + ni] : 0.f);
       s_e[i] = e;
       sum_e2 += e * e;
@@ -196,8 +183,6 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
     const float c_cd = A.w_dis * invN * 2.0f;
     const float c_cd_r = A.w_dis * (1.0f / (float)Nr) * 2.0f;
     const int k1 = k + 1;
-    __shared__ int s_hub[GEO_HUBCAP], s_nhub_[1];
-    int* const s_nhub = s_nhub_;
     int* s_cnt = reinterpret_cast<int*>(s_red + GEO_WAVES * 5 + 4);   // [N + 1] counts -> offsets
     float* s_nrm = reinterpret_cast<float*>(s_cnt + N + 1);            // [3 N] normal of every adversarial point (optional)
     int* rlist = reinterpret_cast<int*>(s_nrm + (nrm_in_lds ? 3 * N : 0));   // [rcap] reverse lists of the current chunk
@@ -268,10 +253,11 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
       if (do_curv) {
         float nx, ny, nz;
         normal_of(i, nx, ny, nz);
+        const int32_t* nb = A.knn_adv + (bN + i) * (size_t)k1;
         const float dk = coeff(i);
         for (int m = 1; m <= k; ++m) {
           float dvx, dvy, dvz;
-          pair_grad(px, py, pz, nx, ny, nz, dk, nbr(i, m), dvx, dvy, dvz);
+          pair_grad(px, py, pz, nx, ny, nz, dk, nb[m], dvx, dvy, dvz);
           gx -= dvx;
           gy -= dvy;
           gz -= dvz;
@@ -294,7 +280,7 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
         int q;
         if (knn) {
           const int i = lo + e / k, m = e - (e / k) * k + 1;
-          q = nbr(i, m);
+          q = A.knn_adv[(bN + i) * (size_t)k1 + m];
         } else {
           q = A.i_oa[bNr + lo + e];
         }
@@ -323,7 +309,7 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
         int q, key;
         if (knn) {
           const int i = lo + e / k, m = e - (e / k) * k + 1;
-          q = nbr(i, m);
+          q = A.knn_adv[(bN + i) * (size_t)k1 + m];
           key = i * k1 + m;
         } else {
           q = A.i_oa[bNr + lo + e];
@@ -332,65 +318,21 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
         rlist[atomicAdd(&s_cnt[q], 1)] = key;
       }
       __syncthreads();
-      // source `key`'s pull on owner i (at p): what the owner adds to its gradient
-      const unsigned k1_magic = (unsigned)((0x100000000ull + (unsigned)k1 - 1u) / (unsigned)k1);
-      auto pull = [&](int i, float px, float py, float pz, int key, float& dvx, float& dvy, float& dvz) {
-        if (knn) {               // point `src` lists this point as one of its neighbours
-          const int src = (int)__umulhi((unsigned)key, k1_magic);   // = key / k1 (exact: key * k1 < 2^32)
-          float nx, ny, nz;
-          normal_of(src, nx, ny, nz);
-          pair_grad(s_ax[src], s_ay[src], s_az[src], nx, ny, nz, coeff(src), i, dvx, dvy, dvz);
-        } else {                 // clean point `key` has this point as its nearest adversarial point
-          dvx = cr * (px - ori[key]);
-          dvy = cr * (py - ori[Nr + key]);
-          dvz = cr * (pz - ori[2 * Nr + key]);
-        }
-      };
-      // Owners with a SHORT list (the rule: a point is in ~k lists) sort and add on their own.  A few points -- the
-      // cloud's hubs -- sit in hundreds of lists: one thread sorting and adding such a list alone held the whole
-      // workgroup for 60 % of the kernel; they go to a worklist and a WAVEFRONT takes each: ranks by counting (every lane
-      // its own entries against all), the pulls 64 at a time, one per lane, and their sum in ascending key order
-      // through v_readlane -- the same additions in the same order as the serial loop.
-      if (tid == 0) *s_nhub = 0;
-      __syncthreads();
       for (int i = tid; i < N; i += GEO_BLOCK) {
         const int st = i ? s_cnt[i - 1] : 0, n = s_cnt[i] - st;
         if (n == 0) continue;
         int* L = rlist + st;
-        if (n > GEO_HUB) {
-          const int slot = atomicAdd(s_nhub, 1);
-          if (slot < GEO_HUBCAP) {
-            s_hub[slot] = i;
-            continue;
-          }
-        }
-        if (n <= GEO_HUB) {
-          // ascending by source key, in REGISTERS: the list (padded with INT_MAX), every entry's rank by comparing all
-          // pairs once (keys are distinct), each entry written to the slot of its rank.  An insertion sort in LDS waits
-          // for a round trip per move: ~n^2 / 4 of them on a list filled in the free order of the atomics -- 60 % of the
-          // kernel at n ~ 16-28
-          int v[GEO_HUB], r[GEO_HUB];
-#pragma unroll
-          for (int a = 0; a < GEO_HUB; ++a) {
-            const int x = L[a < n ? a : n - 1];
-            v[a] = a < n ? x : 0x7fffffff;
-            r[a] = GEO_HUB - 1 - a;     // as if every later entry were smaller; corrected pair by pair
-          }
-#pragma unroll
-          for (int a = 0; a < GEO_HUB; ++a)
-#pragma unroll
-            for (int c = a + 1; c < GEO_HUB; ++c) {
-              unsigned long long m;   // lt = v[a] < v[c]; r[a] -= lt; r[c] += lt (compare + both carries back to back)
-              asm volatile("v_cmp_lt_i32 %2, %3, %4\n\tv_subbrev_co_u32 %0, vcc, 0, %0, %2\n\t"
-                           "v_addc_co_u32 %1, vcc, 0, %1, %2"
-                           : "+v"(r[a]), "+v"(r[c]), "=&s"(m)
-                           : "v"(v[a]), "v"(v[c])
-                           : "vcc");
+        if (n <= 24) {           // ascending by source key: insertion sort; heap sort for the rare long list
+          for (int a = 1; a < n; ++a) {
+            const int v = L[a];
+            int c = a - 1;
+            while (c >= 0 && L[c] > v) {
+              L[c + 1] = L[c];
+              --c;
             }
-#pragma unroll
-          for (int a = 0; a < GEO_HUB; ++a)
-            if (a < n) L[r[a]] = v[a];
-        } else {   // (a long list the worklist had no room for: heap sort)
+            L[c + 1] = v;
+          }
+        } else {
           auto sift = [&](int start, int end) {
             int root = start;
             for (;;) {
@@ -414,87 +356,25 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
         }
         float gx = s_gx[i], gy = s_gy[i], gz = s_gz[i];
         const float px = s_ax[i], py = s_ay[i], pz = s_az[i];
-        for (int e0 = 0; e0 < n; e0 += 4) {   // four pulls in flight (each a chain of dependent LDS reads), added in order
-          float dvx[4], dvy[4], dvz[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) pull(i, px, py, pz, L[e0 + u < n ? e0 + u : n - 1], dvx[u], dvy[u], dvz[u]);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (e0 + u < n) {
-              gx += dvx[u];
-              gy += dvy[u];
-              gz += dvz[u];
-            }
+        for (int e = 0; e < n; ++e) {
+          const int key = L[e];
+          if (knn) {               // point `src` lists this point as one of its neighbours
+            const int src = key / k1;
+            float nx, ny, nz, dvx, dvy, dvz;
+            normal_of(src, nx, ny, nz);
+            pair_grad(s_ax[src], s_ay[src], s_az[src], nx, ny, nz, coeff(src), i, dvx, dvy, dvz);
+            gx += dvx;
+            gy += dvy;
+            gz += dvz;
+          } else {                 // clean point `key` has this point as its nearest adversarial point
+            gx += cr * (px - ori[key]);
+            gy += cr * (py - ori[Nr + key]);
+            gz += cr * (pz - ori[2 * Nr + key]);
+          }
         }
         s_gx[i] = gx;
         s_gy[i] = gy;
         s_gz[i] = gz;
-      }
-      __syncthreads();
-      {
-        const int nh = min(*s_nhub, GEO_HUBCAP), wave = tid >> 6, lane = tid & 63;
-        for (int h = wave; h < nh; h += GEO_WAVES) {
-          const int i = s_hub[h];
-          const int st = i ? s_cnt[i - 1] : 0, n = s_cnt[i] - st;
-          int* L = rlist + st;
-          // ranks (keys are distinct): lane l holds entries l, l + 64, ..; all reads before the first write
-          int val[GEO_HUB_EPL], rk[GEO_HUB_EPL];
-          const bool fits = n <= 64 * GEO_HUB_EPL;
-          if (fits) {
-#pragma unroll
-            for (int u = 0; u < GEO_HUB_EPL; ++u) {
-              const int e = lane + 64 * u;
-              val[u] = e < n ? L[e] : 0x7fffffff;
-              rk[u] = 0;
-            }
-            for (int j = 0; j < n; ++j) {
-              const int v = L[j];     // the same address in every lane: a broadcast read
-#pragma unroll
-              for (int u = 0; u < GEO_HUB_EPL; ++u) rk[u] += v < val[u] ? 1 : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < GEO_HUB_EPL; ++u)
-              if (lane + 64 * u < n) L[rk[u]] = val[u];
-          } else if (lane == 0) {   // (beyond 64 * GEO_HUB_EPL entries: one lane, insertion by binary heap as above)
-            auto sift = [&](int start, int end) {
-              int root = start;
-              for (;;) {
-                int child = 2 * root + 1;
-                if (child > end) break;
-                if (child + 1 <= end && L[child] < L[child + 1]) ++child;
-                if (L[root] >= L[child]) break;
-                const int tmp = L[root];
-                L[root] = L[child];
-                L[child] = tmp;
-                root = child;
-              }
-            };
-            for (int h0 = (n - 2) / 2; h0 >= 0; --h0) sift(h0, n - 1);
-            for (int end = n - 1; end > 0; --end) {
-              const int tmp = L[0];
-              L[0] = L[end];
-              L[end] = tmp;
-              sift(0, end - 1);
-            }
-          }
-          float gx = s_gx[i], gy = s_gy[i], gz = s_gz[i];        // (uniform over the wave)
-          const float px = s_ax[i], py = s_ay[i], pz = s_az[i];
-          for (int e0 = 0; e0 < n; e0 += 64) {
-            float dvx = 0.f, dvy = 0.f, dvz = 0.f;
-            if (e0 + lane < n) pull(i, px, py, pz, L[e0 + lane], dvx, dvy, dvz);
-            const int cn = min(64, n - e0);
-            for (int l = 0; l < cn; ++l) {      // in ascending key order, as the serial loop adds them
-              gx += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dvx), l));
-              gy += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dvy), l));
-              gz += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dvz), l));
-            }
-          }
-          if (lane == 0) {
-            s_gx[i] = gx;
-            s_gy[i] = gy;
-            s_gz[i] = gz;
-          }
-        }
       }
       __syncthreads();
     };
@@ -548,9 +428,10 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
         const int ni = A.i_ao[bN + i];
         const float* Nm = A.normal_ori + (size_t)b * 3 * Nr;
         const float nx = Nm[ni], ny = Nm[Nr + ni], nz = Nm[2 * Nr + ni];
+        const int32_t* nb = A.knn_adv + (bN + i) * (size_t)(k + 1);
         const float dk = (A.dkappa ? A.dkappa[bN + i] : A.w_curv * invN * 2.0f * s_e[i]) / (float)k;
         for (int m = 1; m <= k; ++m) {
-          const int q = nbr(i, m);
+          const int q = nb[m];
           const float vx = s_ax[q] - px, vy = s_ay[q] - py, vz = s_az[q] - pz;
           const float r = sqrtf(vx * vx + vy * vy + vz * vz);
           const float inv = 1.0f / fmaxf(r, NORM_EPS);
@@ -619,26 +500,18 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
     // them in one chunk when they fit (N = 1024, k = 16: 70 KB), at least 2048 entries otherwise
     const size_t Nr = a->Nr > 0 ? a->Nr : a->N;
     const size_t idx = ((size_t)a->N + 1) * sizeof(int), nrm = (size_t)3 * a->N * sizeof(float);
-    const size_t cap = 160 * 1024 - 2048, all = (size_t)a->N * a->k > Nr ? (size_t)a->N * a->k : Nr;
+    const size_t cap = 160 * 1024 - 512, all = (size_t)a->N * a->k > Nr ? (size_t)a->N * a->k : Nr;
     if (base + idx + 2048 * sizeof(int) > cap) return GEOA3_ENOSUPPORT;
     const int nrm_in = a->normal_ori && base + idx + nrm + (all < 8192 ? all : 8192) * sizeof(int) <= cap;
     size_t rcap = (cap - base - idx - (nrm_in ? nrm : 0)) / sizeof(int);
     if (rcap > all) rcap = all;
     if (rcap < 1) rcap = 1;
-    size_t lds = base + idx + (nrm_in ? nrm : 0) + rcap * sizeof(int);
-    // ... and, if all of that left room, the neighbour table itself as 16-bit indices (N = 1024, k = 16: 35 KB)
-    const size_t nbb = a->knn_adv && a->N <= 65535 ? (size_t)a->N * (a->k + 1) * sizeof(uint16_t) : 0;
-    int nb_off = 0;
-    if (nbb && rcap == all && ((lds + 3) & ~(size_t)3) + nbb <= cap) {
-      lds = (lds + 3) & ~(size_t)3;
-      nb_off = (int)(lds / sizeof(float));
-      lds += nbb;
-    }
+    const size_t lds = base + idx + (nrm_in ? nrm : 0) + rcap * sizeof(int);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geo_loss_grad_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     geoa3_prof_begin(GEOA3_PROF_GEO, geoa3_stream(stream));
     hipLaunchKernelGGL(geo_loss_grad_kernel<true>, dim3(a->B), dim3(GEO_BLOCK), lds, geoa3_stream(stream), *a, (int)rcap,
-                       nrm_in, nb_off);
+                       nrm_in);
     geoa3_prof_end(GEOA3_PROF_GEO, geoa3_stream(stream));
     GEOA3_CHECK_LAUNCH();
     return GEOA3_OK;
@@ -648,7 +521,7 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geo_loss_grad_kernel<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   geoa3_prof_begin(GEOA3_PROF_GEO, geoa3_stream(stream));
-  hipLaunchKernelGGL(geo_loss_grad_kernel<false>, dim3(a->B), dim3(GEO_BLOCK), lds, geoa3_stream(stream), *a, 0, 0, 0);
+  hipLaunchKernelGGL(geo_loss_grad_kernel<false>, dim3(a->B), dim3(GEO_BLOCK), lds, geoa3_stream(stream), *a, 0, 0);
   geoa3_prof_end(GEOA3_PROF_GEO, geoa3_stream(stream));
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
