@@ -10,6 +10,7 @@
 // the coordinate, so the result is BIT-IDENTICAL to the all-pairs search for any input; a query without a usable
 // radius scans everything.
 #include <cstdlib>
+#include <utility>
 #include "geom_internal.h"
 #include "profile.h"
 
@@ -368,8 +369,24 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
 // wavefront (compare -> list cursor -> store address) and runs at the rate of the wavefronts that interleave on a SIMD.
 // The ranking (64-bit keys in registers, every pair compared once) writes the result straight to memory.
 // ------------------------------------------------------------------------------------------
-constexpr int SP_CAP = 40;
-__global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void knn_slabp_kernel(const float* __restrict__ R, int N, int K,
+// compile-time loops (indices into register arrays must be constants; a 56 x 56 nest is beyond the unroller's budget)
+template <typename F, int... S>
+__device__ __forceinline__ void sp_static_for_impl(F&& f, std::integer_sequence<int, S...>) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+template <int N_, typename F>
+__device__ __forceinline__ void sp_static_for(F&& f) {
+  sp_static_for_impl(f, std::make_integer_sequence<int, N_>{});
+}
+// r += (kj < ki): compare + carry back to back (left to the compiler the compares are batched and their masks spilled)
+__device__ __forceinline__ void sp_count_less(int& r, unsigned long long kj, unsigned long long ki) {
+  asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r) : "v"(kj), "v"(ki) : "vcc");
+}
+
+// MULTI: a cloud of more than one staging chunk (N <= 65535) and / or longer lists (K <= SP_CAP - 16): the positions are
+// those of the whole sorted cloud and the ranking gathers the coordinates from memory (L2) instead of the staged chunk.
+template <int SP_CAP, bool MULTI>
+__global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI ? 3 : 4, MULTI ? 3 : 4))) void knn_slabp_kernel(const float* __restrict__ R, int N, int K,
                                                              const int32_t* __restrict__ prior,
                                                              const float* __restrict__ sorted,
                                                              const int32_t* __restrict__ sidx,
@@ -443,32 +460,38 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
   // never decides an order; it rides along for the write-back); ~0 beyond the list
   unsigned long long key[SP_CAP];
   auto load_keys = [&](int cnt) {
-#pragma unroll
-    for (int s = 0; s < SP_CAP; ++s) {
-      const unsigned p = s_pos[s * SK_BLOCK + tid] & (SK_CHUNK - 1);
-      const float d = geoa3_sqdist(qx, qy, qz, s_ref[p], s_ref[SK_CHUNK + p], s_ref[2 * SK_CHUNK + p]);
-      key[s] = s < cnt ? ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned)s_id[p] << 16) | p : ~0ull;
+    sp_static_for<SP_CAP>([&](auto S_) {
+      constexpr int s = decltype(S_)::value;
+      unsigned p = s_pos[s * SK_BLOCK + tid];
+      float d;
+      unsigned id;
+      if (MULTI) {
+        p = p < (unsigned)N ? p : 0u;     // (slots beyond the list hold anything)
+        d = geoa3_sqdist(qx, qy, qz, Sb[p], Sb[N + p], Sb[2 * N + p]);
+        id = (unsigned)Ib[p];
+      } else {
+        p &= SK_CHUNK - 1;
+        d = geoa3_sqdist(qx, qy, qz, s_ref[p], s_ref[SK_CHUNK + p], s_ref[2 * SK_CHUNK + p]);
+        id = s_id[p];
+      }
+      key[s] = s < cnt ? ((unsigned long long)__float_as_uint(d) << 32) | (id << 16) | p : ~0ull;
       if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // eight gathers in flight, not forty (registers)
-    }
+    });
   };
-  // rank of entry i = the number of smaller keys: compare + carry per pair, back to back (left to the compiler the
-  // compares are batched and their lane masks spilled); no rank array -- the caller uses the rank at once (registers:
-  // four wavefronts per SIMD need the kernel under 128)
-#define SP_RANK(i, r)                                                                                            \
-  do {                                                                                                           \
-    r = 0;                                                                                                       \
-    _Pragma("unroll") for (int j_ = 0; j_ < SP_CAP; ++j_) {                                                      \
-      if (j_ != (i))                                                                                             \
-        asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"                             \
-                     : "+v"(r)                                                                                   \
-                     : "v"(key[j_]), "v"(key[i])                                                                 \
-                     : "vcc");                                                                                   \
-    }                                                                                                            \
-  } while (0)
+  // rank of entry s = the number of smaller keys; no rank array -- the caller uses the rank at once (registers)
+  auto rank_of = [&](auto S_) {
+    constexpr int s = decltype(S_)::value;
+    int r = 0;
+    sp_static_for<SP_CAP>([&](auto J_) {
+      constexpr int j = decltype(J_)::value;
+      if constexpr (j != s) sp_count_less(r, key[j], key[s]);
+    });
+    return r;
+  };
   for (int pass = 0; pass < 2; ++pass) {
     // pass 1 only runs if a (bad) prior left some lane with fewer than K candidates: everything, without pruning
-    const int c0 = c_lo;
-    const int cn = min(SK_CHUNK, c_hi - c0);      // N <= SK_CHUNK: the whole run at once
+   for (int c0 = c_lo; c0 < c_hi; c0 += SK_CHUNK) {      // (!MULTI: N <= SK_CHUNK, the whole run at once)
+    const int cn = min(SK_CHUNK, c_hi - c0);
     const int cn4 = (cn + 3) & ~3;
     __syncthreads();
     for (int j = tid; j < cn4; j += SK_BLOCK) {
@@ -496,24 +519,24 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       // slot is kept only if it does.  cnt <= SP_CAP - 4 here (the check below)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        *reinterpret_cast<uint16_t*>(pb + poff) = (uint16_t)(j + u);
+        *reinterpret_cast<uint16_t*>(pb + poff) = (uint16_t)((MULTI ? c0 : 0) + j + u);
         poff += da[u] <= tau ? 2u * SK_BLOCK : 0u;
       }
       if (__builtin_expect(__any(poff > (unsigned)(SP_CAP - 4) * 2u * SK_BLOCK + 2u * SK_BLOCK - 1u), 0)) {   // cnt > CAP - 4
         const int cnt = (int)(poff >> 9);
         if (cnt >= K) {   // keep the K best (in order), tighten the radius; every old slot is in a register by now
           load_keys(cnt);
-#pragma unroll
-          for (int s = 0; s < SP_CAP; ++s) {
-            int r;
-            SP_RANK(s, r);
+          sp_static_for<SP_CAP>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            const int r = rank_of(S_);
             if (r < K) s_pos[r * SK_BLOCK + tid] = (uint16_t)key[s];
             if (r == K - 1) tau = __uint_as_float((unsigned)(key[s] >> 32));
-          }
+          });
           poff = (unsigned)K * 2u * SK_BLOCK + 2u * tid;
         }
       }
     }
+   }
     const int cnt = (int)(poff >> 9);
     const bool short_list = live && cnt < K && K <= N;
     if (!__syncthreads_or(short_list)) break;
@@ -529,22 +552,20 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     load_keys(cnt);
     float* od = dists + ((size_t)b * N + qo) * K;
     int32_t* oi = idx + ((size_t)b * N + qo) * K;
-#pragma unroll
-    for (int s = 0; s < SP_CAP; ++s) {
-      int r;
-      SP_RANK(s, r);
+    sp_static_for<SP_CAP>([&](auto S_) {
+      constexpr int s = decltype(S_)::value;
+      const int r = rank_of(S_);
       if (r < keep) {
         od[r] = __uint_as_float((unsigned)(key[s] >> 32));
         oi[r] = (int32_t)((key[s] >> 16) & 0xffffu);
       }
-    }
+    });
     for (int m = keep; m < K; ++m) {   // fewer than K points in the cloud
       od[m] = S_INF;
       oi[m] = -1;
     }
   }
 }
-#undef SP_RANK
 
 // ------------------------------------------------------------------------------------------
 // Cell-grid search, one WAVEFRONT per query (the K = 33 / N = 4096 regime, where the per-thread lists of the slab kernel
@@ -947,8 +968,11 @@ extern "C" int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_
     // hold at once (two workgroups per CU); a small shard's launch runs beside the victim's kernels, where the denser
     // kernel cost more than it saved (32 instances: 0.500 -> 0.506 ms per iteration)
     if (K <= 20 && N <= SK_CHUNK && slabp && ((size_t)grid.x * grid.y > 512 || slabp_always))
-      hipLaunchKernelGGL(knn_slabp_kernel, grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx, sc.bstart,
-                         sc.geo, dists, idx);
+      hipLaunchKernelGGL((knn_slabp_kernel<40, false>), grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx,
+                         sc.bstart, sc.geo, dists, idx);
+    else if (K <= 40 && N <= 65535 && slabp && ((size_t)grid.x * grid.y > 512 || slabp_always))
+      hipLaunchKernelGGL((knn_slabp_kernel<56, true>), grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx,
+                         sc.bstart, sc.geo, dists, idx);
     else if (K <= 20) SLAB_LAUNCH(40);
     else if (K <= 40) SLAB_LAUNCH(72);
     else SLAB_LAUNCH(96);

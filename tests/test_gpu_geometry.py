@@ -293,8 +293,9 @@ def test_slab_pruned_self_knn_is_bit_identical_to_brute_force(ops, N, K, scale, 
         for prior in (clean, stale, bad, None):
             d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch, method=method)
             assert torch.equal(i, bi) and torch.equal(d, bd), (method, prior is None)
-    if N <= 1024 and kk <= 20:
-        # the position-list form of the slab kernel (knn_slabp_kernel), which the library takes for large launches only
+    if kk <= 40:
+        # the position-list forms of the slab kernel (knn_slabp_kernel<40, false> / <56, true>), which the library takes
+        # for large launches only
         monkeypatch.setenv("GEOA3_SLABP", "2")
         for prior in (clean, stale, bad):
             d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch, method=1)
