@@ -119,6 +119,22 @@ def pmc_traffic(kernel_substr, cfg_tag):
     return None, None
 
 
+def spawn_ranks(n):
+    """Run this script as n ranks of one node under torch.distributed.run (rendezvous on 127.0.0.1, a free port) and
+    return the launcher's exit code.  The parent stays CPU-only: nothing here imports torch."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +159,12 @@ def main():
                     help="victim (PointNetPP = configs[3]: SSG classifier)")
     a = ap.parse_args()
     npoint, knn = a.npoint, a.knn
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process group (torch.distributed.run)
+        # before this process has imported torch or touched the GPU, and leave with its return code (a process that has
+        # initialised the GPU must never exec another program on this pool)
+        sys.exit(spawn_ranks(a.gpus))
 
     import torch
     import torch.distributed as dist
@@ -324,6 +346,8 @@ def main():
             "unit": "iterations/s of a 250-instance batch", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(host_submit_ms, 4),
             "higher_is_better": True,
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
             "scaling": "weak" if mode == "weak" else "strong",
             "vs_baseline": None,
             "dtype": "f32",

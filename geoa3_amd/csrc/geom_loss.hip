@@ -62,15 +62,9 @@ __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {  // larger value,
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 
-// DET: the gradient is accumulated by the OWNER of every point in a fixed order (own terms, then the contributions it
-// receives from other points sorted by their source) instead of with LDS float atomics, whose order is free: bit-for-
-// bit reproducible, independent of timing and of which other instances share the batch.  The reverse lists (who pulls
-// on point q: its occurrences in other points' neighbour lists, and the clean points whose nearest adversarial point it
-// is) are built per launch in LDS, for as many sources at a time as fit (rcap entries): histogram (integer atomics:
-// exact), scan, unordered fill, then every owner sorts its own short list by source key.  A contribution is recomputed
-// by the owner with the expression its source uses for its own share, so the two agree bit for bit.
-template <bool DET>
-__global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args A, int rcap, int nrm_in_lds) {
+// The non-deterministic form (geoa3_geo_args.deterministic == 0): neighbour terms are scattered with LDS float atomics,
+// whose order is free.  The default is the pair-parallel, owner-ordered pair of kernels below.
+__global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_atomic_kernel(geoa3_geo_args A) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = A.N, k = A.k, b = blockIdx.x, tid = threadIdx.x;
   float* s_ax = sm;            // adv planes
@@ -177,214 +171,7 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
   if (A.grad == nullptr) return;
   const int hd_arg = __float_as_int(s_red[GEO_WAVES * 5]);
 
-  // ---- phase B (deterministic): own terms, then the pulls every point receives, source by source in ascending order
-  if constexpr (DET) {
-    const float invN = 1.0f / (float)N;
-    const float c_cd = A.w_dis * invN * 2.0f;
-    const float c_cd_r = A.w_dis * (1.0f / (float)Nr) * 2.0f;
-    const int k1 = k + 1;
-    int* s_cnt = reinterpret_cast<int*>(s_red + GEO_WAVES * 5 + 4);   // [N + 1] counts -> offsets
-    float* s_nrm = reinterpret_cast<float*>(s_cnt + N + 1);            // [3 N] normal of every adversarial point (optional)
-    int* rlist = reinterpret_cast<int*>(s_nrm + (nrm_in_lds ? 3 * N : 0));   // [rcap] reverse lists of the current chunk
-    const float* Nm = A.normal_ori ? A.normal_ori + (size_t)b * 3 * Nr : nullptr;
-    if (do_curv && nrm_in_lds)
-      for (int i = tid; i < N; i += GEO_BLOCK) {
-        const int ni = A.i_ao[bN + i];
-        s_nrm[i] = Nm[ni];
-        s_nrm[N + i] = Nm[Nr + ni];
-        s_nrm[2 * N + i] = Nm[2 * Nr + ni];
-      }
-    __syncthreads();
-    auto normal_of = [&](int i, float& nx, float& ny, float& nz) {
-      if (nrm_in_lds) {
-        nx = s_nrm[i];
-        ny = s_nrm[N + i];
-        nz = s_nrm[2 * N + i];
-      } else {
-        const int ni = A.i_ao[bN + i];
-        nx = Nm[ni];
-        ny = Nm[Nr + ni];
-        nz = Nm[2 * Nr + ni];
-      }
-    };
-    // d kappa-term / d q for the pair (centre with normal n and coefficient dk, neighbour q): what the centre subtracts
-    // from its own gradient and q adds to its
-    auto pair_grad = [&](float px, float py, float pz, float nx, float ny, float nz, float dk, int q, float& dvx,
-                         float& dvy, float& dvz) {
-      const float vx = s_ax[q] - px, vy = s_ay[q] - py, vz = s_az[q] - pz;
-      const float r = sqrtf(vx * vx + vy * vy + vz * vz);
-      const float inv = 1.0f / fmaxf(r, NORM_EPS);
-      const float ux = vx * inv, uy = vy * inv, uz = vz * inv;
-      const float t = ux * nx + uy * ny + uz * nz;
-      const float sg = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
-      const float c = dk * sg * inv;
-      if (r >= NORM_EPS) {  // d(v/|v|)/dv = (I - u u^T)/|v|
-        dvx = c * (nx - t * ux);
-        dvy = c * (ny - t * uy);
-        dvz = c * (nz - t * uz);
-      } else {  // clamp active: v/eps, the norm path carries no gradient
-        dvx = c * nx;
-        dvy = c * ny;
-        dvz = c * nz;
-      }
-    };
-    auto coeff = [&](int i) {
-      return (A.dkappa ? A.dkappa[bN + i] : A.w_curv * invN * 2.0f * s_e[i]) / (float)k;
-    };
-    // own terms
-    for (int i = tid; i < N; i += GEO_BLOCK) {
-      float gx = 0.f, gy = 0.f, gz = 0.f;
-      const float px = s_ax[i], py = s_ay[i], pz = s_az[i];
-      if (do_cd || do_hd) {
-        const int j = A.i_ao[bN + i];
-        const float dx = px - ori[j], dy = py - ori[Nr + j], dz = pz - ori[2 * Nr + j];
-        float c = do_cd ? c_cd : 0.f;
-        if (do_hd && i == hd_arg) c += A.w_hd * 2.0f;
-        gx += c * dx;
-        gy += c * dy;
-        gz += c * dz;
-      }
-      if (do_l2) {
-        const float c = A.w_dis * 2.0f;
-        gx += c * (px - ori[i]);
-        gy += c * (py - ori[Nr + i]);
-        gz += c * (pz - ori[2 * Nr + i]);
-      }
-      if (do_curv) {
-        float nx, ny, nz;
-        normal_of(i, nx, ny, nz);
-        const int32_t* nb = A.knn_adv + (bN + i) * (size_t)k1;
-        const float dk = coeff(i);
-        for (int m = 1; m <= k; ++m) {
-          float dvx, dvy, dvz;
-          pair_grad(px, py, pz, nx, ny, nz, dk, nb[m], dvx, dvy, dvz);
-          gx -= dvx;
-          gy -= dvy;
-          gz -= dvz;
-        }
-      }
-      s_gx[i] = gx;
-      s_gy[i] = gy;
-      s_gz[i] = gz;
-    }
-    // received terms.  Sources are taken in CHUNKS whose reverse lists fit LDS (ascending: neighbour pairs (i, m) keyed
-    // i * (k+1) + m, then the clean points); per chunk: histogram over destinations (integer atomics: exact), scan, fill
-    // (free order), then every owner sorts its short list by key and adds the contributions in that order -- the result
-    // does not depend on the chunking.
-    const float cr = (Nr != N) ? c_cd_r : c_cd;
-    auto pass = [&](bool knn, int lo, int hi) {     // kNN pairs of the centres lo..hi-1, or the clean points lo..hi-1
-      const int nent = knn ? (hi - lo) * k : hi - lo;
-      for (int i = tid; i <= N; i += GEO_BLOCK) s_cnt[i] = 0;
-      __syncthreads();
-      for (int e = tid; e < nent; e += GEO_BLOCK) {
-        int q;
-        if (knn) {
-          const int i = lo + e / k, m = e - (e / k) * k + 1;
-          q = A.knn_adv[(bN + i) * (size_t)k1 + m];
-        } else {
-          q = A.i_oa[bNr + lo + e];
-        }
-        atomicAdd(&s_cnt[q], 1);
-      }
-      __syncthreads();
-      if (tid < GEOA3_WAVE) {    // exclusive scan of s_cnt[0..N]: 64 lanes x consecutive runs
-        const int per = (N + 1 + GEOA3_WAVE - 1) / GEOA3_WAVE, a0 = tid * per, a1 = min(a0 + per, N + 1);
-        int sum = 0;
-        for (int i = a0; i < a1; ++i) sum += s_cnt[i];
-        int incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int v = __shfl_up(incl, o, 64);
-          if (tid >= o) incl += v;
-        }
-        int run = incl - sum;
-        for (int i = a0; i < a1; ++i) {
-          const int c = s_cnt[i];
-          s_cnt[i] = run;
-          run += c;
-        }
-      }
-      __syncthreads();
-      for (int e = tid; e < nent; e += GEO_BLOCK) {   // fill: s_cnt[q] advances from the start to the end of q's list
-        int q, key;
-        if (knn) {
-          const int i = lo + e / k, m = e - (e / k) * k + 1;
-          q = A.knn_adv[(bN + i) * (size_t)k1 + m];
-          key = i * k1 + m;
-        } else {
-          q = A.i_oa[bNr + lo + e];
-          key = lo + e;
-        }
-        rlist[atomicAdd(&s_cnt[q], 1)] = key;
-      }
-      __syncthreads();
-      for (int i = tid; i < N; i += GEO_BLOCK) {
-        const int st = i ? s_cnt[i - 1] : 0, n = s_cnt[i] - st;
-        if (n == 0) continue;
-        int* L = rlist + st;
-        if (n <= 24) {           // ascending by source key: insertion sort; heap sort for the rare long list
-          for (int a = 1; a < n; ++a) {
-            const int v = L[a];
-            int c = a - 1;
-            while (c >= 0 && L[c] > v) {
-              L[c + 1] = L[c];
-              --c;
-            }
-            L[c + 1] = v;
-          }
-        } else {
-          auto sift = [&](int start, int end) {
-            int root = start;
-            for (;;) {
-              int child = 2 * root + 1;
-              if (child > end) break;
-              if (child + 1 <= end && L[child] < L[child + 1]) ++child;
-              if (L[root] >= L[child]) break;
-              const int tmp = L[root];
-              L[root] = L[child];
-              L[child] = tmp;
-              root = child;
-            }
-          };
-          for (int h0 = (n - 2) / 2; h0 >= 0; --h0) sift(h0, n - 1);
-          for (int end = n - 1; end > 0; --end) {
-            const int tmp = L[0];
-            L[0] = L[end];
-            L[end] = tmp;
-            sift(0, end - 1);
-          }
-        }
-        float gx = s_gx[i], gy = s_gy[i], gz = s_gz[i];
-        const float px = s_ax[i], py = s_ay[i], pz = s_az[i];
-        for (int e = 0; e < n; ++e) {
-          const int key = L[e];
-          if (knn) {               // point `src` lists this point as one of its neighbours
-            const int src = key / k1;
-            float nx, ny, nz, dvx, dvy, dvz;
-            normal_of(src, nx, ny, nz);
-            pair_grad(s_ax[src], s_ay[src], s_az[src], nx, ny, nz, coeff(src), i, dvx, dvy, dvz);
-            gx += dvx;
-            gy += dvy;
-            gz += dvz;
-          } else {                 // clean point `key` has this point as its nearest adversarial point
-            gx += cr * (px - ori[key]);
-            gy += cr * (py - ori[Nr + key]);
-            gz += cr * (pz - ori[2 * Nr + key]);
-          }
-        }
-        s_gx[i] = gx;
-        s_gy[i] = gy;
-        s_gz[i] = gz;
-      }
-      __syncthreads();
-    };
-    if (do_curv) {
-      const int cs = max(1, rcap / k);
-      for (int lo = 0; lo < N; lo += cs) pass(true, lo, min(N, lo + cs));
-    }
-    if (two_side)
-      for (int lo = 0; lo < Nr; lo += rcap) pass(false, lo, min(Nr, lo + rcap));
-  } else {
+  {
   // ---- phase B: d constrain / d adv.  Own-point terms go through registers, neighbour terms
     //      are scattered with LDS float atomics (ds_add_f32).
     const float invN = 1.0f / (float)N;

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
 #pragma unroll
         for (int c = 0; c < GPG_CT; ++c) {
           if (c >= nc) break;
-          if (MODE == 1 || (MODE == 0 && distinct)) {
+          // (plain updates only on a wave's OWN copy: with one shared copy other waves' rows hit the same points)
+          if (MODE == 1 || (MODE == 0 && PRIV && distinct)) {
             if (!dup) s_acc[c * N + i] += lane == 0 ? v[p][c] + dsum[c] : v[p][c];
           } else if (MODE == 2) {
             if (v[p][c] + dsum[c] == 123.456f) s_acc[c * N + i] = 1.f;

@@ -49,6 +49,24 @@ def test_bench_two_ranks_strong_scaling_on_one_gpu():
     assert out["roofline"]["frac"] > 0 and out["roofline"]["executed_frac"] == pytest.approx(3 * out["roofline"]["frac"], rel=1e-2)
 
 
+@pytest.mark.timeout(900)
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the way the driver calls `--gpus 1`): the parent must start the two
+    ranks itself (a child torch.distributed.run, before anything touches the GPU) and rank 0's line must say so."""
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--presteps",
+           "2", "--single-mode", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=REPO, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo"
+    assert out["config"]["instances_per_gpu"] == 125 and out["scaling"] == "strong"
+
+
 _WORKER = r"""
 import os, sys, pickle
 import numpy as np, torch, torch.distributed as dist

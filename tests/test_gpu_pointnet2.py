@@ -80,6 +80,28 @@ def test_gather_group_and_grads(pn2):
     np.testing.assert_allclose(f.grad.cpu().numpy(), P2.group_points_grad(go2, idx2, N).numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,M", [(2048, 256), (4096, 200), (1024, 128)])
+def test_group_points_grad_large_clouds(pn2, N, M):
+    """nsample == 64 beyond 1024 points: ONE accumulator copy shared by the workgroup's four waves (LDS has no room for
+    four) -- rows of different centres overlap, so every update there must be atomic (a plain read-modify-write on the
+    shared copy lost updates: round-2 advisor finding).  Real ball-query rows (ascending, padded with the first index)
+    and random tables."""
+    g = torch.Generator().manual_seed(N)
+    B, C = 2, 19
+    xyz = _cloud(B, N, 300 + N)
+    centres = xyz[:, torch.randperm(N, generator=g)[:M]].contiguous()
+    idx = P2.ball_query(centres, xyz, 0.35, 64)
+    assert (idx[:, :, 1:] != idx[:, :, :1]).any()
+    go = torch.randn(B, C, M, 64, generator=g)
+    ref = P2.group_points_grad(go, idx, N).numpy()
+    for _ in range(3):
+        got = pn2.ext.group_points_grad(go.cuda(), idx.cuda(), N).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-4)
+    idx_r = torch.randint(0, N, (B, M, 64), generator=g, dtype=torch.int32)
+    np.testing.assert_allclose(pn2.ext.group_points_grad(go.cuda(), idx_r.cuda(), N).cpu().numpy(),
+                               P2.group_points_grad(go, idx_r, N).numpy(), rtol=2e-5, atol=2e-4)
+
+
 def test_cpu_rejected(pn2):
     from geoa3_amd._lib import Geoa3Error
     with pytest.raises(Geoa3Error):
