@@ -4,6 +4,7 @@
 // Attacker/geoA3_attack.py:131-166.  The reference builds [b,3,n,k] neighbour tensors with knn_gather and
 // lets autograd scatter the gradient back; here one workgroup owns one instance, keeps the cloud and the
 // gradient accumulators in LDS, and never materialises the neighbour tensor.
+#include <type_traits>
 #include "common.h"
 #include "profile.h"
 
@@ -62,9 +63,15 @@ __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {  // larger value,
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 
-// The non-deterministic form (geoa3_geo_args.deterministic == 0): neighbour terms are scattered with LDS float atomics,
-// whose order is free.  The default is the pair-parallel, owner-ordered pair of kernels below.
-__global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_atomic_kernel(geoa3_geo_args A) {
+// DET: the gradient is accumulated by the OWNER of every point in a fixed order (own terms, then the contributions it
+// receives from other points sorted by their source) instead of with LDS float atomics, whose order is free: bit-for-
+// bit reproducible, independent of timing and of which other instances share the batch.  The reverse lists (who pulls
+// on point q: its occurrences in other points' neighbour lists, and the clean points whose nearest adversarial point it
+// is) are built per launch in LDS, for as many sources at a time as fit (rcap entries): histogram (integer atomics:
+// exact), scan, unordered fill, then every owner sorts its own short list by source key.  A contribution is recomputed
+// by the owner with the expression its source uses for its own share, so the two agree bit for bit.
+template <bool DET>
+__global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args A, int rcap, int nrm_in_lds) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = A.N, k = A.k, b = blockIdx.x, tid = threadIdx.x;
   float* s_ax = sm;            // adv planes
@@ -171,7 +178,214 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_atomic_kernel(geoa3_g
   if (A.grad == nullptr) return;
   const int hd_arg = __float_as_int(s_red[GEO_WAVES * 5]);
 
-  {
+  // ---- phase B (deterministic): own terms, then the pulls every point receives, source by source in ascending order
+  if constexpr (DET) {
+    const float invN = 1.0f / (float)N;
+    const float c_cd = A.w_dis * invN * 2.0f;
+    const float c_cd_r = A.w_dis * (1.0f / (float)Nr) * 2.0f;
+    const int k1 = k + 1;
+    int* s_cnt = reinterpret_cast<int*>(s_red + GEO_WAVES * 5 + 4);   // [N + 1] counts -> offsets
+    float* s_nrm = reinterpret_cast<float*>(s_cnt + N + 1);            // [3 N] normal of every adversarial point (optional)
+    int* rlist = reinterpret_cast<int*>(s_nrm + (nrm_in_lds ? 3 * N : 0));   // [rcap] reverse lists of the current chunk
+    const float* Nm = A.normal_ori ? A.normal_ori + (size_t)b * 3 * Nr : nullptr;
+    if (do_curv && nrm_in_lds)
+      for (int i = tid; i < N; i += GEO_BLOCK) {
+        const int ni = A.i_ao[bN + i];
+        s_nrm[i] = Nm[ni];
+        s_nrm[N + i] = Nm[Nr + ni];
+        s_nrm[2 * N + i] = Nm[2 * Nr + ni];
+      }
+    __syncthreads();
+    auto normal_of = [&](int i, float& nx, float& ny, float& nz) {
+      if (nrm_in_lds) {
+        nx = s_nrm[i];
+        ny = s_nrm[N + i];
+        nz = s_nrm[2 * N + i];
+      } else {
+        const int ni = A.i_ao[bN + i];
+        nx = Nm[ni];
+        ny = Nm[Nr + ni];
+        nz = Nm[2 * Nr + ni];
+      }
+    };
+    // d kappa-term / d q for the pair (centre with normal n and coefficient dk, neighbour q): what the centre subtracts
+    // from its own gradient and q adds to its
+    auto pair_grad = [&](float px, float py, float pz, float nx, float ny, float nz, float dk, int q, float& dvx,
+                         float& dvy, float& dvz) {
+      const float vx = s_ax[q] - px, vy = s_ay[q] - py, vz = s_az[q] - pz;
+      const float r = sqrtf(vx * vx + vy * vy + vz * vz);
+      const float inv = 1.0f / fmaxf(r, NORM_EPS);
+      const float ux = vx * inv, uy = vy * inv, uz = vz * inv;
+      const float t = ux * nx + uy * ny + uz * nz;
+      const float sg = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
+      const float c = dk * sg * inv;
+      if (r >= NORM_EPS) {  // d(v/|v|)/dv = (I - u u^T)/|v|
+        dvx = c * (nx - t * ux);
+        dvy = c * (ny - t * uy);
+        dvz = c * (nz - t * uz);
+      } else {  // clamp active: v/eps, the norm path carries no gradient
+        dvx = c * nx;
+        dvy = c * ny;
+        dvz = c * nz;
+      }
+    };
+    auto coeff = [&](int i) {
+      return (A.dkappa ? A.dkappa[bN + i] : A.w_curv * invN * 2.0f * s_e[i]) / (float)k;
+    };
+    // own terms
+    for (int i = tid; i < N; i += GEO_BLOCK) {
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+      const float px = s_ax[i], py = s_ay[i], pz = s_az[i];
+      if (do_cd || do_hd) {
+        const int j = A.i_ao[bN + i];
+        const float dx = px - ori[j], dy = py - ori[Nr + j], dz = pz - ori[2 * Nr + j];
+        float c = do_cd ? c_cd : 0.f;
+        if (do_hd && i == hd_arg) c += A.w_hd * 2.0f;
+        gx += c * dx;
+        gy += c * dy;
+        gz += c * dz;
+      }
+      if (do_l2) {
+        const float c = A.w_dis * 2.0f;
+        gx += c * (px - ori[i]);
+        gy += c * (py - ori[Nr + i]);
+        gz += c * (pz - ori[2 * Nr + i]);
+      }
+      if (do_curv) {
+        float nx, ny, nz;
+        normal_of(i, nx, ny, nz);
+        const int32_t* nb = A.knn_adv + (bN + i) * (size_t)k1;
+        const float dk = coeff(i);
+        for (int m = 1; m <= k; ++m) {
+          float dvx, dvy, dvz;
+          pair_grad(px, py, pz, nx, ny, nz, dk, nb[m], dvx, dvy, dvz);
+          gx -= dvx;
+          gy -= dvy;
+          gz -= dvz;
+        }
+      }
+      s_gx[i] = gx;
+      s_gy[i] = gy;
+      s_gz[i] = gz;
+    }
+    // received terms.  Sources are taken in CHUNKS whose reverse lists fit LDS (ascending: neighbour pairs (i, m) keyed
+    // i * (k+1) + m, then the clean points); per chunk: histogram over destinations (integer atomics: exact), scan, fill
+    // (free order), then every owner sorts its short list by key and adds the contributions in that order -- the result
+    // does not depend on the chunking.
+    const float cr = (Nr != N) ? c_cd_r : c_cd;
+    auto pass = [&](bool knn, int lo, int hi) {     // kNN pairs of the centres lo..hi-1, or the clean points lo..hi-1
+      const int nent = knn ? (hi - lo) * k : hi - lo;
+      for (int i = tid; i <= N; i += GEO_BLOCK) s_cnt[i] = 0;
+      __syncthreads();
+      for (int e = tid; e < nent; e += GEO_BLOCK) {
+        int q;
+        if (knn) {
+          const int i = lo + e / k, m = e - (e / k) * k + 1;
+          q = A.knn_adv[(bN + i) * (size_t)k1 + m];
+        } else {
+          q = A.i_oa[bNr + lo + e];
+        }
+        atomicAdd(&s_cnt[q], 1);
+      }
+      __syncthreads();
+      if (tid < GEOA3_WAVE) {    // exclusive scan of s_cnt[0..N]: 64 lanes x consecutive runs
+        const int per = (N + 1 + GEOA3_WAVE - 1) / GEOA3_WAVE, a0 = tid * per, a1 = min(a0 + per, N + 1);
+        int sum = 0;
+        for (int i = a0; i < a1; ++i) sum += s_cnt[i];
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o, 64);
+          if (tid >= o) incl += v;
+        }
+        int run = incl - sum;
+        for (int i = a0; i < a1; ++i) {
+          const int c = s_cnt[i];
+          s_cnt[i] = run;
+          run += c;
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < nent; e += GEO_BLOCK) {   // fill: s_cnt[q] advances from the start to the end of q's list
+        int q, key;
+        if (knn) {
+          const int i = lo + e / k, m = e - (e / k) * k + 1;
+          q = A.knn_adv[(bN + i) * (size_t)k1 + m];
+          key = i * k1 + m;
+        } else {
+          q = A.i_oa[bNr + lo + e];
+          key = lo + e;
+        }
+        rlist[atomicAdd(&s_cnt[q], 1)] = key;
+      }
+      __syncthreads();
+      for (int i = tid; i < N; i += GEO_BLOCK) {
+        const int st = i ? s_cnt[i - 1] : 0, n = s_cnt[i] - st;
+        if (n == 0) continue;
+        int* L = rlist + st;
+        if (n <= 24) {           // ascending by source key: insertion sort; heap sort for the rare long list
+          for (int a = 1; a < n; ++a) {
+            const int v = L[a];
+            int c = a - 1;
+            while (c >= 0 && L[c] > v) {
+              L[c + 1] = L[c];
+              --c;
+            }
+            L[c + 1] = v;
+          }
+        } else {
+          auto sift = [&](int start, int end) {
+            int root = start;
+            for (;;) {
+              int child = 2 * root + 1;
+              if (child > end) break;
+              if (child + 1 <= end && L[child] < L[child + 1]) ++child;
+              if (L[root] >= L[child]) break;
+              const int tmp = L[root];
+              L[root] = L[child];
+              L[child] = tmp;
+              root = child;
+            }
+          };
+          for (int h0 = (n - 2) / 2; h0 >= 0; --h0) sift(h0, n - 1);
+          for (int end = n - 1; end > 0; --end) {
+            const int tmp = L[0];
+            L[0] = L[end];
+            L[end] = tmp;
+            sift(0, end - 1);
+          }
+        }
+        float gx = s_gx[i], gy = s_gy[i], gz = s_gz[i];
+        const float px = s_ax[i], py = s_ay[i], pz = s_az[i];
+        for (int e = 0; e < n; ++e) {
+          const int key = L[e];
+          if (knn) {               // point `src` lists this point as one of its neighbours
+            const int src = key / k1;
+            float nx, ny, nz, dvx, dvy, dvz;
+            normal_of(src, nx, ny, nz);
+            pair_grad(s_ax[src], s_ay[src], s_az[src], nx, ny, nz, coeff(src), i, dvx, dvy, dvz);
+            gx += dvx;
+            gy += dvy;
+            gz += dvz;
+          } else {                 // clean point `key` has this point as its nearest adversarial point
+            gx += cr * (px - ori[key]);
+            gy += cr * (py - ori[Nr + key]);
+            gz += cr * (pz - ori[2 * Nr + key]);
+          }
+        }
+        s_gx[i] = gx;
+        s_gy[i] = gy;
+        s_gz[i] = gz;
+      }
+      __syncthreads();
+    };
+    if (do_curv) {
+      const int cs = max(1, rcap / k);
+      for (int lo = 0; lo < N; lo += cs) pass(true, lo, min(N, lo + cs));
+    }
+    if (two_side)
+      for (int lo = 0; lo < Nr; lo += rcap) pass(false, lo, min(Nr, lo + rcap));
+  } else {
   // ---- phase B: d constrain / d adv.  Own-point terms go through registers, neighbour terms
     //      are scattered with LDS float atomics (ds_add_f32).
     const float invN = 1.0f / (float)N;
@@ -258,6 +472,464 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_atomic_kernel(geoa3_g
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Deterministic objective for clouds of at most 1024 points (the default there): one 1024-thread workgroup per instance
+// as above, but every (centre, neighbour) PAIR a lane and no dependent chain longer than one round trip.
+//
+// The kernel above walks a point's k neighbours in serial loops with a dependent load of the neighbour index inside, four
+// times over (kappa, own terms, histogram, fill), sorts every reverse list by insertion through LDS and recomputes the
+// pulls one after the other: ~100 us per launch whatever the batch size.  Here:
+//   phase 1  lane = pair (i, m), G = 2^ceil(log2 k) lanes per centre, N G / 1024 passes with the next pass's table entries
+//            already in flight: kappa_adv[i] and e[i] by a G-lane butterfly (DPP), the pair's gradient term, its negative
+//            summed over m (the centre's own curvature term), and the pair appends its SOURCE index to the row of its
+//            destination in LDS (integer atomic: exact; free order) -- the reverse lists exist after one pass over the
+//            table, no histogram / scan / fill.  The clean points append themselves (N + j) to their nearest
+//            adversarial point's row.
+//   phase 2  thread = owner: its row sorted in REGISTERS (bitonic network of 16 / 32 / 64 keys, no LDS traffic), the pulls
+//            recomputed from the LDS-resident cloud, normals and coefficients with the expression phase 1 uses, added
+//            in ascending source order.
+// Measured steps on the way (250 / 32 instances): a separate pair kernel + range workgroups that gather 12-byte pull
+// records from memory: 37 + 72 / 7 + 47 us (the random record reads); the same with a CSR built by global atomics:
+// 113 + 148 + 103 us (global atomics run at ~50 G/s here).  Bit-for-bit reproducible for any batch composition.
+// Rows that overflow their capacity (coincident points) are summed by their owner from a scan of the table, in the same
+// order.
+// ------------------------------------------------------------------------------------------
+constexpr int GEO_T = 1024;
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {   // sum over aligned groups of G lanes, in every lane of the group
+  if (G >= 2) v += dpp_f32<0xB1, 0xF>(v, 0.f);           // lane ^ 1
+  if (G >= 4) v += dpp_f32<0x4E, 0xF>(v, 0.f);           // lane ^ 2
+  if (G >= 8) v += dpp_f32<0x141, 0xF>(v, 0.f);          // row_half_mirror
+  if (G >= 16) v += dpp_f32<0x140, 0xF>(v, 0.f);         // row_mirror
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ascending bitonic sort of W keys held in registers (fully unrolled: indices are compile-time constants)
+template <int W>
+__device__ __forceinline__ void geo_sort_regs(int (&v)[W]) {
+#pragma unroll
+  for (int k2 = 2; k2 <= W; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k2) == 0;
+          const int lo = min(v[i], v[l]), hi = max(v[i], v[l]);
+          v[i] = up ? lo : hi;
+          v[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+}
+
+// d |<normalize(q - p), n>| * dk / d q for the pair (centre p with normal n and coefficient dk, neighbour q): what the
+// centre subtracts from its own gradient and q adds to its
+// The pair kernel is bound by VALU issue on the one CU that holds an instance (~100 instructions per pair term, a third
+// of them the IEEE sqrt / division sequences): v_sqrt_f32 and v_rcp_f32 (1 ulp each) take 8 us off 51 (250 instances).
+// Two ulp per pair term is far inside the parity bars (values rtol 2e-5, gradients 1e-4; the summation order already
+// differs from torch's); -DGEOA3_GEO_IEEE restores the correctly rounded forms.
+#ifdef GEOA3_GEO_IEEE
+#define GEO_SQRT(x) sqrtf(x)
+#define GEO_RCP(x) (1.0f / (x))
+#else
+#define GEO_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define GEO_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+__device__ __forceinline__ void geo_pair_grad(float px, float py, float pz, float nx, float ny, float nz, float dk, float qx,
+                                              float qy, float qz, float& dvx, float& dvy, float& dvz, float& t_out) {
+  const float vx = qx - px, vy = qy - py, vz = qz - pz;
+  const float r = GEO_SQRT(vx * vx + vy * vy + vz * vz);
+  const float inv = GEO_RCP(fmaxf(r, NORM_EPS));
+  const float ux = vx * inv, uy = vy * inv, uz = vz * inv;
+  const float t = ux * nx + uy * ny + uz * nz;
+  const float sg = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
+  const float c = dk * sg * inv;
+  if (r >= NORM_EPS) {  // d(v/|v|)/dv = (I - u u^T)/|v|
+    dvx = c * (nx - t * ux);
+    dvy = c * (ny - t * uy);
+    dvz = c * (nz - t * uz);
+  } else {              // clamp active: v/eps, the norm path carries no gradient
+    dvx = c * nx;
+    dvy = c * ny;
+    dvz = c * nz;
+  }
+  t_out = t;
+}
+
+template <int G>
+__global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int C, int R) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = A.N, k = A.k, k1 = k + 1, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Nr = A.Nr > 0 ? A.Nr : N;
+  // a random access costs one 16-byte LDS read per record instead of three or four 4-byte ones (bank conflicts are paid
+  // per instruction): (x, y, z, coefficient) and (normal, -) of every adversarial point
+  float4* s_p = reinterpret_cast<float4*>(sm);           // [N] point + curvature coefficient dk (phase 1: kappa_ori[nn])
+  float4* s_n = s_p + N;                                  // [N] normal of the nearest clean point
+  float* s_gx = sm + 8 * N;                               // own curvature term of every centre
+  float* s_gy = sm + 9 * N;
+  float* s_gz = sm + 10 * N;
+  int* s_cnt = reinterpret_cast<int*>(sm + 11 * N);       // row lengths
+  float* s_red = sm + 12 * N;                             // [16 * 5 + 4]
+  uint16_t* s_rows = reinterpret_cast<uint16_t*>(s_red + 16 * 5 + 4);  // [N][C + 1] source ids, fill order
+  const int stride = C + 1;
+  // Small batches: an instance is split over gridDim.y workgroups by OWNER range [r0, r0 + R) -- every workgroup stages
+  // the cloud and forms every centre's coefficient (the pulls need the sources'), but keeps rows, sorts and receives
+  // only for its own points: the LDS-bound parts (appends, receives) shrink with the range.  Same bits for any split.
+  const int r0 = blockIdx.y * R;
+  const float* adv = A.adv + (size_t)b * 3 * N;
+  const float* ori = A.ori + (size_t)b * 3 * Nr;
+  const size_t bN = (size_t)b * N, bNr = (size_t)b * Nr;
+  const bool do_curv = (A.w_curv != 0.f || A.dkappa != nullptr) && A.knn_adv != nullptr;
+  const bool do_cd = A.dis_type == 1, do_l2 = A.dis_type == 2;
+  const bool two_side = do_cd && !A.single_side && A.d_oa != nullptr;
+  const bool do_hd = A.w_hd != 0.f && A.d_ao != nullptr;
+  const bool want_grad = A.grad != nullptr;
+  const bool first = blockIdx.y == 0;       // writes the loss values and kappa_adv
+  constexpr int CPP = GEO_T / G;    // centres per pass
+  const int32_t* tab = do_curv ? A.knn_adv + bN * (size_t)k1 : nullptr;
+
+  // ---- stage.  Every load that does not depend on another is issued here (one round trip), the gathers through the
+  // nearest-point index right behind them (a second one).
+  const int m = tid % G, cl = tid / G;
+  // this lane's column of the neighbour table for ALL passes (N / CPP <= G of them): every load in flight before the
+  // first pass (one pass ahead left most of each load's latency exposed: 16 passes x ~1 us)
+  int q_all[G];
+#pragma unroll
+  for (int p = 0; p < G; ++p) {
+    const int c = p * CPP + cl;
+    q_all[p] = (do_curv && c < N && m < k) ? tab[(size_t)c * k1 + 1 + m] : 0;
+  }
+  const bool me_valid = tid < N;
+  const int me = me_valid ? tid : N - 1;
+  const float px = adv[me], py = adv[N + me], pz = adv[2 * N + me];
+  const int nn = A.i_ao ? A.i_ao[bN + me] : 0;
+  const float d_me = A.d_ao ? A.d_ao[bN + me] : 0.f;
+  float sum_oa = 0.f;
+  int oa_first = 0;
+  if (two_side) {
+    for (int i = tid; i < Nr; i += GEO_T) sum_oa += A.d_oa[bNr + i];
+    if (tid < Nr) oa_first = A.i_oa[bNr + tid];
+  }
+  const float dkap_me = (do_curv && A.dkappa) ? A.dkappa[bN + me] : 0.f;
+  float ox = 0.f, oy = 0.f, oz = 0.f;            // the nearest clean point (own Chamfer / Hausdorff term)
+  if (do_cd || do_hd) {
+    ox = ori[nn];
+    oy = ori[Nr + nn];
+    oz = ori[2 * Nr + nn];
+  }
+  float lx = 0.f, ly = 0.f, lz = 0.f;            // the clean point of the same index (L2 term)
+  if (do_l2) {
+    lx = ori[me];
+    ly = ori[Nr + me];
+    lz = ori[2 * Nr + me];
+  }
+  if (me_valid) {
+    s_cnt[me] = 0;
+    float kori = 0.f;
+    float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (do_curv) {
+      const float* Nm = A.normal_ori + (size_t)b * 3 * Nr;
+      nv = make_float4(Nm[nn], Nm[Nr + nn], Nm[2 * Nr + nn], 0.f);
+      kori = A.kappa_ori ? A.kappa_ori[bNr + nn] : 0.f;
+    }
+    s_p[me] = make_float4(px, py, pz, kori);     // (phase 1 turns .w into the coefficient)
+    s_n[me] = nv;
+  }
+  __syncthreads();
+
+  // ---- phase 1: pairs
+  float sum_e2 = 0.f;
+  if (do_curv) {
+    const float invN = 1.0f / (float)N;
+#pragma unroll
+    for (int p = 0; p < G; ++p) {
+      const int c0 = p * CPP;
+      if (c0 >= N) break;
+      const int c = c0 + cl;
+      const bool cvalid = c < N, active = cvalid && m < k;
+      const int cc = cvalid ? c : N - 1;
+      const int q = active ? q_all[p] : cc;
+      const float4 cp = s_p[cc], nv = s_n[cc], qp = s_p[q];
+      if (active && want_grad && (unsigned)(q - r0) < (unsigned)R) {   // the reverse list of q: source c
+        const int slot = atomicAdd(&s_cnt[q], 1);
+        if (slot < C) s_rows[(q - r0) * stride + slot] = (uint16_t)c;
+      }
+      // kappa term, as kappa_point()
+      const float vx = qp.x - cp.x, vy = qp.y - cp.y, vz = qp.z - cp.z;
+      const float r = GEO_SQRT(vx * vx + vy * vy + vz * vz);
+      const float inv = GEO_RCP(fmaxf(r, NORM_EPS));
+      const float t = (vx * inv) * nv.x + (vy * inv) * nv.y + (vz * inv) * nv.z;
+      const float kap = group_sum<G>(active ? fabsf(t) : 0.f) / (float)k;
+      const float e = kap - cp.w;          // (.w still holds kappa_ori[nn]: the group reads it before its lane 0 writes)
+      const float dkap = A.dkappa ? A.dkappa[bN + cc] : 0.f;
+      const float dk = (A.dkappa ? dkap : A.w_curv * invN * 2.0f * e) / (float)k;
+      float dvx, dvy, dvz, t2;
+      geo_pair_grad(cp.x, cp.y, cp.z, nv.x, nv.y, nv.z, dk, qp.x, qp.y, qp.z, dvx, dvy, dvz, t2);
+      const float sx = group_sum<G>(active ? dvx : 0.f), sy = group_sum<G>(active ? dvy : 0.f),
+                  sz = group_sum<G>(active ? dvz : 0.f);
+      if (m == 0 && cvalid) {
+        sum_e2 += e * e;
+        if (A.kappa_adv && first) A.kappa_adv[bN + c] = kap;
+        s_p[c].w = dk;
+        s_gx[c] = -sx;
+        s_gy[c] = -sy;
+        s_gz[c] = -sz;
+      }
+    }
+  }
+  (void)dkap_me;
+  if (two_side && want_grad)       // the clean points: source id N + j in the row of their nearest adversarial point
+    for (int j = tid; j < Nr; j += GEO_T) {
+      const int q = j == tid ? oa_first : A.i_oa[bNr + j];
+      if ((unsigned)(q - r0) >= (unsigned)R) continue;
+      const int slot = atomicAdd(&s_cnt[q], 1);
+      if (slot < C) s_rows[(q - r0) * stride + slot] = (uint16_t)(N + j);
+    }
+
+  // ---- loss values and the Hausdorff arg-max
+  float sum_ao = 0.f;
+  MaxIdx hd{-__builtin_inff(), 0x7fffffff};
+  if (me_valid) {
+    if (do_cd) sum_ao = d_me;
+    if (do_l2) {
+      const float dx = px - lx, dy = py - ly, dz = pz - lz;
+      sum_ao = dx * dx + dy * dy + dz * dz;
+    }
+    if (do_hd) hd = MaxIdx{d_me, me};
+  }
+  sum_ao = wave_sum(sum_ao);
+  sum_oa = wave_sum(sum_oa);
+  sum_e2 = wave_sum(sum_e2);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxIdx other{__shfl_xor(hd.v, o, 64), __shfl_xor(hd.i, o, 64)};
+    hd = better(hd, other);
+  }
+  if (lane == 0) {
+    s_red[wave * 5 + 0] = sum_ao;
+    s_red[wave * 5 + 1] = sum_oa;
+    s_red[wave * 5 + 2] = sum_e2;
+    s_red[wave * 5 + 3] = hd.v;
+    s_red[wave * 5 + 4] = __int_as_float(hd.i);
+  }
+  __syncthreads();
+  {   // every thread forms the arg-max itself (sixteen broadcast reads); thread 0 writes the values
+    float a = 0.f, o = 0.f, e2 = 0.f;
+    MaxIdx h{-__builtin_inff(), 0x7fffffff};
+#pragma unroll
+    for (int w = 0; w < GEO_T / 64; ++w) {
+      a += s_red[w * 5 + 0];
+      o += s_red[w * 5 + 1];
+      e2 += s_red[w * 5 + 2];
+      h = better(h, MaxIdx{s_red[w * 5 + 3], __float_as_int(s_red[w * 5 + 4])});
+    }
+    hd = h;
+    if (tid == 0 && first) {
+      const float invN = 1.0f / (float)N;
+      float dis = 0.f;
+      if (do_cd) dis = a * invN + (two_side ? o * (1.0f / (float)Nr) : 0.f);
+      if (do_l2) dis = a;
+      const float hdv = do_hd ? h.v : 0.f;
+      const float curv = do_curv ? e2 * invN : 0.f;
+      float con = 0.f;
+      if (A.dis_type != 0) con = A.w_dis * dis;
+      if (do_hd) con = con + A.w_hd * hdv;
+      if (do_curv) con = con + A.w_curv * curv;
+      if (A.dis_loss) A.dis_loss[b] = dis;
+      if (A.hd_loss) A.hd_loss[b] = hdv;
+      if (A.curv_loss) A.curv_loss[b] = curv;
+      if (A.constrain) A.constrain[b] = con;
+    }
+  }
+  if (!want_grad) return;
+  const int hd_arg = hd.i;
+  const bool mine = me_valid && (unsigned)(me - r0) < (unsigned)R;     // this thread owns a point of the range
+
+  // ---- phase 2: every owner sums its own terms, then what it receives in ascending source order
+  const float invN = 1.0f / (float)N;
+  const float c_cd = A.w_dis * invN * 2.0f;
+  const float cr = (Nr != N) ? A.w_dis * (1.0f / (float)Nr) * 2.0f : c_cd;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (mine) {
+    if (do_cd || do_hd) {
+      const float dx = px - ox, dy = py - oy, dz = pz - oz;
+      float c = do_cd ? c_cd : 0.f;
+      if (do_hd && me == hd_arg) c += A.w_hd * 2.0f;
+      gx += c * dx;
+      gy += c * dy;
+      gz += c * dz;
+    }
+    if (do_l2) {
+      const float c = A.w_dis * 2.0f;
+      gx += c * (px - lx);
+      gy += c * (py - ly);
+      gz += c * (pz - lz);
+    }
+    if (do_curv) {
+      gx += s_gx[me];
+      gy += s_gy[me];
+      gz += s_gz[me];
+    }
+  }
+  auto receive_rec = [&](int src, float4 sp, float4 sn) {      // the same with the records already read
+    if (src < N) {
+      float dvx, dvy, dvz, t2;
+      geo_pair_grad(sp.x, sp.y, sp.z, sn.x, sn.y, sn.z, sp.w, px, py, pz, dvx, dvy, dvz, t2);
+      gx += dvx;
+      gy += dvy;
+      gz += dvz;
+    } else {
+      const int jj = src - N;
+      gx += cr * (px - ori[jj]);
+      gy += cr * (py - ori[Nr + jj]);
+      gz += cr * (pz - ori[2 * Nr + jj]);
+    }
+  };
+  auto receive = [&](int src) {
+    if (src < N) {              // point `src` lists this point as one of its neighbours
+      const float4 sp = s_p[src], sn = s_n[src];
+      float dvx, dvy, dvz, t2;
+      geo_pair_grad(sp.x, sp.y, sp.z, sn.x, sn.y, sn.z, sp.w, px, py, pz, dvx, dvy, dvz, t2);
+      gx += dvx;
+      gy += dvy;
+      gz += dvz;
+    } else {                    // clean point `src - N` has this point as its nearest adversarial point
+      const int jj = src - N;
+      gx += cr * (px - ori[jj]);
+      gy += cr * (py - ori[Nr + jj]);
+      gz += cr * (pz - ori[2 * Nr + jj]);
+    }
+  };
+  const int ncnt = mine ? s_cnt[me] : 0;
+  const int n = ncnt <= C ? ncnt : 0;
+  uint16_t* L = s_rows + (mine ? me - r0 : 0) * stride;
+  int nmax = n;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  // Rows are sorted in registers as runs of at most 32 keys, written back in place (the row is this thread's); a row of
+  // 33..64 keys is two runs merged while it is consumed (a 64-key network needs more than the 128 registers a lane has
+  // at 1024 threads, and in-degree + clean points exceeds 32 for some point of most instances).
+  auto sort_run = [&](auto wc, int base) __attribute__((always_inline)) {
+    constexpr int W = decltype(wc)::value;
+    int key[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) key[j] = base + j < n ? (int)L[base + j] : 0x7fffffff;
+    geo_sort_regs<W>(key);
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if (base + j < n) L[base + j] = (uint16_t)key[j];
+  };
+  if (nmax > 1 && nmax <= 16) {
+    sort_run(std::integral_constant<int, 16>{}, 0);
+  } else if (nmax > 16 && nmax <= 64) {
+#pragma unroll 1
+    for (int base = 0; base < nmax; base += 32) sort_run(std::integral_constant<int, 32>{}, base);   // (one copy of the network)
+  } else if (nmax > 64) {      // selection sort through LDS (rows this long need k > 24)
+    for (int e = 0; e + 1 < n; ++e) {
+      int bj = e, bv = L[e];
+      for (int j = e + 1; j < n; ++j) {
+        const int kk = L[j];
+        if (kk < bv) {
+          bv = kk;
+          bj = j;
+        }
+      }
+      L[bj] = L[e];
+      L[e] = (uint16_t)bv;
+    }
+  }
+  // The row is one sorted run [0, n), or -- 33..64 keys -- two: [0, 32) and [32, n).  Each run holds its neighbour
+  // sources first, then its clean points (ids >= N).  The clean points' pulls need coordinates from memory: they are taken
+  // after the neighbour pulls, four loads in flight, so that no wavefront waits for one lane's global load inside the
+  // main loop (with them inside it, the loop ran at ~1 us per iteration).
+  const bool two_runs = nmax > 32 && nmax <= 64;
+  const int e0 = two_runs ? (n < 32 ? n : 32) : n;       // end of run 0
+  int ka = e0, kb = n;                                    // ends of the runs' neighbour parts
+  while (ka > 0 && (int)L[ka - 1] >= N) --ka;
+  while (kb > e0 && (int)L[kb - 1] >= N) --kb;
+  const int nk = ka + (kb - e0);
+  int nkmax = nk;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nkmax = max(nkmax, __shfl_xor(nkmax, o, 64));
+  if (!two_runs) {
+    // (rolled: unrolled, the kernel is 19 K instructions); the next source's records are read while this one's term
+    // is formed
+    int src = nk > 0 ? (int)L[0] : 0;
+    float4 sp = s_p[src], sn = s_n[src];
+    for (int j = 0; j < nkmax; ++j) {
+      const int src1 = j + 1 < nk ? (int)L[j + 1] : 0;
+      const float4 sp1 = s_p[src1], sn1 = s_n[src1];
+      if (j < nk) receive_rec(src, sp, sn);
+      src = src1;
+      sp = sp1;
+      sn = sn1;
+    }
+  } else {                             // merged
+    int i0 = 0, i1 = e0;
+    for (int j = 0; j < nkmax; ++j)
+      if (j < nk) {
+        const int a0 = i0 < ka ? (int)L[i0] : 0x7fffffff, a1 = i1 < kb ? (int)L[i1] : 0x7fffffff;
+        const bool first_run = a0 <= a1;
+        receive(first_run ? a0 : a1);
+        i0 += first_run ? 1 : 0;
+        i1 += first_run ? 0 : 1;
+      }
+  }
+  if (__builtin_amdgcn_ballot_w64(n > nk) != 0) {     // clean points, ascending (merged the same way)
+    int i0 = ka, i1 = kb;
+    for (int left = n - nk; __builtin_amdgcn_ballot_w64(left > 0) != 0; left -= 4) {
+      int id[4];
+      float v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        id[u] = -1;
+        if (u < left) {
+          const int a0 = i0 < e0 ? (int)L[i0] : 0x7fffffff, a1 = i1 < n ? (int)L[i1] : 0x7fffffff;
+          const bool first_run = a0 <= a1;
+          id[u] = (first_run ? a0 : a1) - N;
+          i0 += first_run ? 1 : 0;
+          i1 += first_run ? 0 : 1;
+          v[u][0] = ori[id[u]];
+          v[u][1] = ori[Nr + id[u]];
+          v[u][2] = ori[2 * Nr + id[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (id[u] >= 0) {
+          gx += cr * (px - v[u][0]);
+          gy += cr * (py - v[u][1]);
+          gz += cr * (pz - v[u][2]);
+        }
+    }
+  }
+  if (ncnt > C) {
+    // overflowed row (coincident points): the owner walks the table itself, sources ascending, then the clean points
+    if (do_curv)
+      for (int src = 0; src < N; ++src) {
+        bool hit = false;
+        for (int mm = 1; mm <= k; ++mm) hit |= tab[(size_t)src * k1 + mm] == me;
+        if (hit) receive(src);
+      }
+    if (two_side)
+      for (int j = 0; j < Nr; ++j)
+        if (A.i_oa[bNr + j] == me) receive(N + j);
+  }
+  if (mine) {
+    float* Gd = A.grad + (size_t)b * 3 * N;
+    Gd[me] = gx;
+    Gd[N + me] = gy;
+    Gd[2 * N + me] = gz;
+  }
+}
+
 }  // namespace
 
 extern "C" int geoa3_kappa(const float* pc, const float* normal, const int32_t* knn_idx, const int32_t* nn_idx,
@@ -280,15 +952,61 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
   if ((a->w_curv != 0.f || a->dkappa) && (!a->knn_adv || !a->normal_ori || !a->i_ao || a->k <= 0))
     return GEOA3_EINVAL;
   if (a->w_curv != 0.f && !a->dkappa && !a->kappa_ori) return GEOA3_EINVAL;
+  const bool do_curv = (a->w_curv != 0.f || a->dkappa) && a->knn_adv;
+  if ((a->deterministic || !a->grad) && a->N <= GEO_T && a->k <= 64) {
+    // the pair-parallel kernel: the cloud, its normals, coefficients and own terms (10 N floats), row lengths, and one row
+    // of C source ids per point; rows of 2 (k + clean points per point) + 16 ids (in-degrees of a k-NN graph concentrate
+    // around k), at least 32, at most what fits
+    const int N = a->N, Nr = a->Nr > 0 ? a->Nr : a->N;
+    const bool two_side = a->dis_type == 1 && !a->single_side && a->d_oa != nullptr;
+    if (two_side && !a->i_oa) return GEOA3_EINVAL;
+    const int per = (do_curv ? a->k : 0) + (two_side ? (Nr + N - 1) / N : 0);
+    const size_t fixed = ((size_t)12 * N + 16 * 5 + 4) * sizeof(float);
+    const size_t room = 160 * 1024 - 256 - fixed;
+    // owner ranges per instance: enough workgroups for the chip when the batch is small (a function of the batch size only
+    // -- and the results do not depend on it)
+    int S = 1;
+    while (S < 4 && a->B * S * 2 <= 256 && (N + 2 * S - 1) / (2 * S) >= 64 && a->grad) S *= 2;
+    const int R = (((N + S - 1) / S + 63) / 64) * 64;
+    int C = 2 * per + 16 < 32 ? 32 : 2 * per + 16;
+    const int Cfit = (int)(room / ((size_t)R * sizeof(uint16_t))) - 1;
+    if (C > Cfit) C = Cfit;
+    if (N + Nr < 65535 && C >= 32 && 2 * C >= 3 * per + 16) {
+      const size_t lds = fixed + (size_t)R * (C + 1) * sizeof(uint16_t);
+      int G = 1;
+      while (G < a->k && do_curv) G *= 2;
+      hipStream_t s = geoa3_stream(stream);
+      geoa3_prof_begin(GEOA3_PROF_GEO, s);
+#define GEOA3_FUSED_CASE(GG)                                                                                           \
+  if (G == GG) {                                                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geo_fused_kernel<GG>),                                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+    hipLaunchKernelGGL(geo_fused_kernel<GG>, dim3(a->B, S), dim3(GEO_T), lds, s, *a, C, R);                                  \
+  }
+      GEOA3_FUSED_CASE(1)
+      GEOA3_FUSED_CASE(2)
+      GEOA3_FUSED_CASE(4)
+      GEOA3_FUSED_CASE(8)
+      GEOA3_FUSED_CASE(16)
+      GEOA3_FUSED_CASE(32)
+      GEOA3_FUSED_CASE(64)
+#undef GEOA3_FUSED_CASE
+      geoa3_prof_end(GEOA3_PROF_GEO, s);
+      GEOA3_CHECK_LAUNCH();
+      return GEOA3_OK;
+    }
+  }
   const size_t base = ((size_t)7 * a->N + GEO_WAVES * 5 + 4) * sizeof(float);
   if (base > 160 * 1024) return GEOA3_ENOSUPPORT;  // N <= ~5800 points per instance
-  if (a->deterministic && a->grad) {
+  const size_t det_idx = ((size_t)a->N + 1) * sizeof(int);
+  // (clouds whose reverse lists do not fit beside the cloud -- N > ~4800 -- take the atomic kernel: same values, free
+  // summation order, documented in geoa3_hip.h)
+  if (a->deterministic && a->grad && base + det_idx + 2048 * sizeof(int) <= 160 * 1024 - 512) {
     // counts / offsets, then (if they fit) the per-point normals, then the reverse lists of one chunk of sources: all of
     // them in one chunk when they fit (N = 1024, k = 16: 70 KB), at least 2048 entries otherwise
     const size_t Nr = a->Nr > 0 ? a->Nr : a->N;
     const size_t idx = ((size_t)a->N + 1) * sizeof(int), nrm = (size_t)3 * a->N * sizeof(float);
     const size_t cap = 160 * 1024 - 512, all = (size_t)a->N * a->k > Nr ? (size_t)a->N * a->k : Nr;
-    if (base + idx + 2048 * sizeof(int) > cap) return GEOA3_ENOSUPPORT;
     const int nrm_in = a->normal_ori && base + idx + nrm + (all < 8192 ? all : 8192) * sizeof(int) <= cap;
     size_t rcap = (cap - base - idx - (nrm_in ? nrm : 0)) / sizeof(int);
     if (rcap > all) rcap = all;

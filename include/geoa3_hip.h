@@ -139,7 +139,10 @@ typedef struct geoa3_geo_args {
   float* grad;             /* [B,3,N] d constrain[b] / d adv[b]                        */
   /* deterministic != 0: every point's gradient is summed by its owner in a fixed order (own terms, then the pulls it
    * receives sorted by source) instead of with LDS float atomics: bit-for-bit reproducible and independent of the rest
-   * of the batch (what the reference's scatter-adds -- knn_gather / index backward -- do not promise either). */
+   * of the batch (what the reference's scatter-adds -- knn_gather / index backward -- do not promise either).
+   * Clouds of at most 1024 points take the pair-parallel kernel (a lane per (centre, neighbour) pair, reverse lists as
+   * fixed-capacity rows in LDS, rows sorted in registers); up to ~4800 points the one-workgroup kernel with LDS reverse
+   * lists; beyond (up to ~5800) the sums fall back to LDS float atomics (free order) whatever this flag says. */
   int32_t deterministic;
 } geoa3_geo_args;
 int geoa3_geo_loss_grad(const geoa3_geo_args* args, void* stream);
