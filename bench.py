@@ -88,14 +88,22 @@ def cpu_baseline(arch, npoint, knn, budget_s=20.0, threads=0):
 
     run(2, 1)                                   # first-touch costs (thread pool, allocator) stay out of the sizing run
     per_inst_it = run(4, 1) / 4.0
-    b = int(max(4, min(BATCH, budget_s / max(per_inst_it, 1e-6))))
-    iters = int(max(1, min(20, budget_s / max(per_inst_it * b, 1e-6))))
-    dt = run(b, iters)
+    # sample: b instances x (1 untimed + `iters` timed) iterations, ~budget_s of CPU work in all.  The untimed first
+    # iteration (step 0: nothing to rank, cold caches at this size) is measured on its own by a run of exactly one
+    # iteration and subtracted: timed = T(b, 1 + iters) - T(b, 1), so every timed iteration is a non-step-0 iterate.
+    iters = 2
+    b = int(max(4, min(BATCH, budget_s / max(per_inst_it * (2 + iters), 1e-6))))
+    if b == BATCH:
+        iters = int(max(2, min(20, budget_s / max(per_inst_it * b, 1e-6) - 2)))
+    t_first = run(b, 1)
+    t_all = run(b, 1 + iters)
+    dt = max(t_all - t_first, 1e-9)
     return {"value": b * iters / dt / BATCH, "unit": "attack-iterations/sec (250-instance batch)",
             "cores": threads, "host_cores": host_cores, "kind": "port",
             "sample": "oracle attack() (%s victim, N=%d, CE + CD + HD + curvature k=%d, reference success check = b "
-                      "batch-1 forwards): %d instances x %d iterations in %.1f s on %d threads; instance-iterations/s "
-                      "/ 250" % (arch, npoint, knn, b, iters, dt, threads)}
+                      "batch-1 forwards): %d instances x %d iterations (steps 1..%d, after one untimed step-0 iteration "
+                      "at this size) in %.1f s on %d threads; instance-iterations/s / 250"
+                      % (arch, npoint, knn, b, iters, iters, dt, threads)}
 
 
 def pmc_traffic(kernel_substr, cfg_tag):

@@ -189,6 +189,9 @@ class AttackRunner:
         cfg, t = self.cfg, self.t
         if self.native:   # re-read the folded weights: a cached runner must see a victim whose weights were reloaded
             self.packed = self.net.packed(self.dev)
+            if isinstance(self.net, PointNet):
+                from .pointnet import ab_flags
+                self.packed.struct.flags = ab_flags()
         self.ori = pc_ori.to(self.dev, torch.float32).contiguous()
         self.nrm = normal_ori.to(self.dev, torch.float32).contiguous()
         self.gt = gt.to(self.dev, torch.int32).contiguous()

@@ -197,7 +197,11 @@ __global__ __launch_bounds__(256) void attack_update_kernel(int B, int N, const 
     float w = offset[e];
     if (optim == 0) {  // torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8
       // torch forms 1 - beta in DOUBLE and rounds once: 0.1f and 0.001f (1.0f - 0.999f in float is 0.00099998713:
-      // 1.3e-5 off in v, 6.5e-6 in the step -- found by the adam/* reference trace, tests/test_gpu_forward_step.py)
+      // 1.3e-5 off in v, 6.5e-6 in the step -- found by the adam/* reference trace, tests/test_gpu_forward_step.py).
+      // The trace was recorded with torch 2.10.0 (CPU, the single-tensor path: exp_avg.lerp_(grad, 1 - beta1), i.e.
+      // m + 0.1 (g - m); exp_avg_sq.mul_(beta2).addcmul_(g, g, value = 1 - beta2)); the form below agrees with it to the
+      // bar the test states (2 ulp of the iterate + 3e-7 of the step), not bit for bit -- older torch (mul_/add_) rounds
+      // m differently in the last place, so no bit claim is made for any version.
       const float m = am[e] * 0.9f + g * 0.1f;
       const float v = av[e] * 0.999f + (g * g) * 0.001f;
       am[e] = m;

@@ -9,7 +9,6 @@
 // else, and the cell range carries a margin far above float rounding, so the result is BIT-IDENTICAL to the
 // all-pairs search (tests/test_gpu_geometry.py) for any input: a query far from every point simply scans more
 // cells (in the limit: all of them, i.e. the all-pairs work).
-#include <cstdlib>
 #include "geom_internal.h"
 #include "profile.h"
 
@@ -288,8 +287,7 @@ int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr,
   const int M = Na > Nr ? Na : Nr;
   if (M > 4 * GT || (d_ra == nullptr) != (i_ra == nullptr)) return GEOA3_ENOSUPPORT;
   const size_t lds = grid_nn1_lds(M);
-  const char* wt = getenv("GEOA3_NN1_WIDE");   // A/B: columns above which a query's box is walked by the whole wave
-  const int wide_thr = wt ? atoi(wt) : NN1_WIDE;
+  const int wide_thr = NN1_WIDE;
   dim3 grid(B, d_ra ? 2 : 1);
 #define GEOA3_GRID_CASE(PPT)                                                                                    \
   if (M <= PPT * GT) {                                                                                          \

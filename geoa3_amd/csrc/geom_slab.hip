@@ -9,7 +9,6 @@
 // the compaction and the lexicographic (distance, index) selection are the same, and the bin function is monotone in
 // the coordinate, so the result is BIT-IDENTICAL to the all-pairs search for any input; a query without a usable
 // radius scans everything.
-#include <cstdlib>
 #include <utility>
 #include "geom_internal.h"
 #include "profile.h"
@@ -938,7 +937,7 @@ extern "C" int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_
   geoa3_prof_begin(GEOA3_PROF_KNN, s);
   int rc = GEOA3_OK;
   // method 0: the cell grid (one wave per query) for large lists / large clouds, the slab kernel otherwise
-  const bool grid = method == 2 || (method == 0 && (K > 20 || N >= 2048));
+  const bool grid = method == 2 || (method == 0 && (K > 20 || N >= 2048));   // (1, 3, 4: the slab kernels)
   if (!prior || !scratch || N > SB_T * SB_PPT || K > N || ((uintptr_t)scratch & 255) != 0) {
     rc = geoa3_launch_knn(pc, pc, B, N, N, K, prior, dists, idx, nullptr, s);   // nothing to prune with
   } else if (grid && K <= KG_CAP - 64) {
@@ -962,8 +961,8 @@ extern "C" int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_
     hipLaunchKernelGGL(knn_slab_kernel<CAP>, grid, dim3(SK_BLOCK), lds, s, pc, N, K, prior, sc.sorted, sc.sidx, \
                        sc.bstart, sc.geo, dists, idx);                                                          \
   } while (0)
-    const char* sp = getenv("GEOA3_SLABP");   // A/B switch, read per call: 0 = never, 2 = whatever the launch size
-    const bool slabp = !(sp && sp[0] == '0'), slabp_always = sp && sp[0] == '2';
+    // method 3 / 4 (tests, A/B runs): the (distance, index)-list kernel / the position-list kernel whatever the launch size
+    const bool slabp = method != 3, slabp_always = method == 4;
     // positions instead of (distance, index) lists: twice the occupancy -- for launches the (distance, index) kernel cannot
     // hold at once (two workgroups per CU); a small shard's launch runs beside the victim's kernels, where the denser
     // kernel cost more than it saved (32 instances: 0.500 -> 0.506 ms per iteration)

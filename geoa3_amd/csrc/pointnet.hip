@@ -88,17 +88,12 @@ thread_local int tl_split = 0;
     if (rc__ != 0) return rc__; \
   } while (0)
 
-// GEOA3_FUSE_BWD=0: the sparse backward and the 128 -> 64 layer behind it as two kernels (A/B switch)
-bool fuse_bwd() {
-  const char* e = getenv("GEOA3_FUSE_BWD");
-  return !(e && e[0] == '0');
-}
-
-// GEOA3_FUSE_CHAIN=0: the trunk's 64-input layers as one kernel each instead of two chains (A/B switch)
-bool fuse_chain() {
-  const char* e = getenv("GEOA3_FUSE_CHAIN");
-  return !(e && e[0] == '0');
-}
+// geoa3_pointnet_weights.flags (A/B switches, set by the caller: the library reads no environment):
+// GEOA3_PN_NO_FUSE_BWD: the sparse backward and the 128 -> 64 layer behind it as two kernels;
+// GEOA3_PN_NO_CHAIN: the trunk's 64-input layers as one kernel each instead of chains.  Same bits either way.
+thread_local int tl_flags = 0;
+bool fuse_bwd() { return !(tl_flags & GEOA3_PN_NO_FUSE_BWD); }
+bool fuse_chain() { return !(tl_flags & GEOA3_PN_NO_CHAIN); }
 
 // Y = act(W X + bias) over [B][K][N] -> [B][Co][N]; shared weights [Co][K]
 int conv(const float* X, int K, const float* W, const float* bias, float* Y, int Co, int B, int N, bool relu,
@@ -288,6 +283,7 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   Ws w = carve(workspace, B, N, pw->classes);
   const geoa3_pointnet_weights& p = *pw;
   tl_split = p.w5h != nullptr;
+  tl_flags = p.flags;
   if (hipMemsetAsync(w.keys, 0, (size_t)B * 1024 * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
   // input transform (Model/PointNet.py:137-138)
   TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
@@ -363,6 +359,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   Ws w = carve(workspace, B, N, pw->classes);
   const geoa3_pointnet_weights& p = *pw;
   tl_split = p.w5h != nullptr;
+  tl_flags = p.flags;
   // classifier head
   TRY(fc(dlogits, p.classes, p.f3t, nullptr, w.g256, 256, B, false, w.f7, s));
   TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.f6, s));

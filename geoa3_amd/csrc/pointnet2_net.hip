@@ -48,10 +48,22 @@ inline Img img_of(const void* base, int i) {
   const char* b = static_cast<const char*>(base) + img_off(i);
   return Img{b, reinterpret_cast<const float*>(b + (size_t)IMG_R[i] * IMG_K[i] * 4)};
 }
+// every matrix either direction reads (a NULL here would fault inside a kernel instead of returning GEOA3_EINVAL)
+bool weights_complete(const geoa3_pn2ssg_weights& p) {
+  const void* need[] = {p.sa1.w1, p.sa1.b1, p.sa1.w2, p.sa1.b2, p.sa1.w3, p.sa1.b3, p.sa2_wx, p.sa2_wf, p.sa2_b0, p.sa2_wft,
+                        p.sa2_w1, p.sa2_b1, p.sa2_w1t, p.sa2_w2, p.sa2_b2, p.sa2_w2t, p.sa3_wx, p.sa3_wf, p.sa3_b0,
+                        p.sa3_wft, p.sa3_w1, p.sa3_b1, p.sa3_w1t, p.sa3_w2, p.sa3_b2, p.f1, p.fb1, p.f1t, p.f2, p.fb2,
+                        p.f2t, p.f3, p.fb3, p.f3t};
+  for (const void* q : need)
+    if (!q) return false;
+  return true;
+}
+
 int pack_images(const geoa3_pn2ssg_weights& p, void* base, hipStream_t s) {
   const float* W[IM_COUNT] = {p.sa2_wf, p.sa2_w1, p.sa2_w2, p.sa2_w1t, p.sa2_wft, p.sa3_wf, p.sa3_w1, p.sa3_w2, p.sa3_w2t,
                               p.sa3_w1t, p.sa3_wft};
   for (int i = 0; i < IM_COUNT; ++i) {
+    if (i == IM_SA3_W2T) continue;   // (slot kept so the offsets stay; the backward walks sa3_w2 sparsely instead)
     const Img im = img_of(base, i);
     TRY(launch_frag_image(W[i], IMG_R[i], IMG_K[i], const_cast<void*>(im.p), const_cast<float*>(im.un), s));
   }
@@ -274,43 +286,6 @@ __global__ __launch_bounds__(256) void affine3_grad_kernel(const float* __restri
     q[2] = sign * a2;
   }
 }
-// out[b][c][m][s] = relu(PT[b][idx[b][m][s]][c] + shift[b][c][m]), C = 128, S = 64: geoa3_pn2_group_shift_relu with the
-// source POINT-major, so a lane gathers its sample's 128 channels as 32 16-byte loads of one 512-byte row instead of
-// 128 4-byte loads from 128 rows (the channel-major form is bound by the texture addresser: one lane per cycle per CU,
-// 0.46 ms for [250,128,128,64]).  One wavefront per (instance, centre); stores are 256-byte rows as before.
-__global__ __launch_bounds__(256) void group_shift_relu_t_kernel(const float* __restrict__ PT, const int32_t* __restrict__ idx,
-                                                                 const float* __restrict__ shift, float* __restrict__ out,
-                                                                 unsigned long long* __restrict__ gate, int N, int M) {
-  const int b = blockIdx.y, j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (j >= M) return;
-  const int i = idx[((size_t)b * M + j) * 64 + lane];
-  const float4* src = reinterpret_cast<const float4*>(PT + ((size_t)b * N + i) * 128);
-  const float sh0 = shift[((size_t)b * 128 + lane) * M + j], sh1 = shift[((size_t)b * 128 + 64 + lane) * M + j];
-  float* O = out + ((size_t)b * 128 * M + j) * 64 + lane;
-  const size_t cs = (size_t)M * 64;
-  unsigned long long gw0 = 0ull, gw1 = 0ull;
-#pragma unroll
-  for (int c4 = 0; c4 < 32; ++c4) {
-    const float4 g = src[c4];
-    const int sv = __float_as_int(c4 < 16 ? sh0 : sh1), l0 = (4 * c4) & 63;
-    const float s0 = __int_as_float(__builtin_amdgcn_readlane(sv, l0));
-    const float s1 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 1));
-    const float s2 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 2));
-    const float s3 = __int_as_float(__builtin_amdgcn_readlane(sv, l0 + 3));
-    const float o0 = fmaxf(g.x + s0, 0.f), o1 = fmaxf(g.y + s1, 0.f), o2 = fmaxf(g.z + s2, 0.f), o3 = fmaxf(g.w + s3, 0.f);
-    O[(4 * c4 + 0) * cs] = o0;
-    O[(4 * c4 + 1) * cs] = o1;
-    O[(4 * c4 + 2) * cs] = o2;
-    O[(4 * c4 + 3) * cs] = o3;
-    // relu gate bits (bit = sample) of channel c land in lane c & 63 of word c >> 6
-    const unsigned long long k0 = __ballot(o0 > 0.f), k1 = __ballot(o1 > 0.f), k2 = __ballot(o2 > 0.f), k3 = __ballot(o3 > 0.f);
-    unsigned long long& gw = c4 < 16 ? gw0 : gw1;
-    gw = lane == l0 ? k0 : (lane == l0 + 1 ? k1 : (lane == l0 + 2 ? k2 : (lane == l0 + 3 ? k3 : gw)));
-  }
-  unsigned long long* G = gate + ((size_t)b * M + j) * 128;
-  G[lane] = gw0;
-  G[64 + lane] = gw1;
-}
 // a[i] += b[i]
 __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -371,7 +346,7 @@ extern "C" int geoa3_pn2ssg_pack_images(const geoa3_pn2ssg_weights* pw, void* im
 extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float* x, int B, int N, float* logits,
                                     void* workspace, void* stream) {
   if (!pw || !x || !logits || !workspace || B <= 0 || N < M1 || pw->classes <= 0) return GEOA3_EINVAL;
-  if (((uintptr_t)workspace & 255) != 0) return GEOA3_EINVAL;
+  if (((uintptr_t)workspace & 255) != 0 || !weights_complete(*pw)) return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
   const geoa3_pn2ssg_weights& p = *pw;
   Ws w = carve(workspace, B, N);
@@ -430,7 +405,8 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
 
 extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float* x, const float* dlogits, int B, int N,
                                      float* dx, void* workspace, void* stream) {
-  if (!pw || !x || !dlogits || !dx || !workspace || B <= 0 || N < M1) return GEOA3_EINVAL;
+  if (!pw || !x || !dlogits || !dx || !workspace || B <= 0 || N < M1 || pw->classes <= 0) return GEOA3_EINVAL;
+  if (((uintptr_t)workspace & 255) != 0 || !weights_complete(*pw)) return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
   const geoa3_pn2ssg_weights& p = *pw;
   Ws w = carve(workspace, B, N);

@@ -158,6 +158,13 @@ def fuse_front() -> bool:
     return os.environ.get("GEOA3_FUSE_FRONT", "0") == "1"
 
 
+def ab_flags() -> int:
+    """geoa3_pointnet_weights.flags from the A/B switches of the environment (read HERE, by the host side: the library
+    itself reads no environment): GEOA3_FUSE_BWD=0 / GEOA3_FUSE_CHAIN=0 select the unfused kernels (same bits)."""
+    return ((1 if os.environ.get("GEOA3_FUSE_BWD", "1") == "0" else 0) |
+            (2 if os.environ.get("GEOA3_FUSE_CHAIN", "1") == "0" else 0))
+
+
 class PackedPointNet:
     """Device copies of the packed weights + the ctypes struct handed to the library."""
 
@@ -187,7 +194,9 @@ class PackedPointNet:
         def tnet(p: Dict[str, Tensor], K: int) -> TnetWeights:
             return TnetWeights(K=K, **{f[0]: pick(p, f[0]) for f in TnetWeights._fields_ if f[0] != "K"})
 
-        fields = {f[0]: pick(packed, f[0]) for f in PointNetWeights._fields_ if f[0] not in ("classes", "t3", "t64")}
+        fields = {f[0]: pick(packed, f[0]) for f in PointNetWeights._fields_
+                  if f[0] not in ("classes", "t3", "t64", "flags")}
+        fields["flags"] = ab_flags()
         self.struct = PointNetWeights(classes=self.classes, t3=tnet(packed["t3"], 3), t64=tnet(packed["t64"], 64),
                                       **fields)
 
@@ -207,6 +216,7 @@ class _PointNetFn(torch.autograd.Function):
             ws_cache["ws"] = ws
         logits = torch.empty(B, packed.classes, device=x.device, dtype=torch.float32)
         s = torch.cuda.current_stream().cuda_stream
+        packed.struct.flags = ab_flags()
         check(lib.geoa3_pointnet_forward(C.byref(packed.struct), x.data_ptr(), B, N, logits.data_ptr(),
                                          ws.data_ptr(), s), "geoa3_pointnet_forward")
         ctx.packed, ctx.ws = packed, ws

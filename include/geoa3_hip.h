@@ -76,7 +76,9 @@ int geoa3_knn(const float* q, const float* r, int B, int Nq, int Nr, int K,
  *   method 2 (grid): the cloud is counting-sorted into a 16^3 grid and ONE WAVEFRONT per query walks the cell rows its
  *            ball touches, collects candidates by ballot and picks the K smallest by rank counting (no per-thread
  *            lists: the form for K > 20 or N >= 2048);
- *   method 0: picks by (K, N).
+ *   method 0: picks by (K, N) -- and, for the slab search, by launch size between two bit-identical kernels: candidates
+ *            kept as (distance, index) pairs (method 3 forces it) or as 2-byte positions (method 4; denser, the choice
+ *            for launches of more than 512 workgroups).
  * Without `prior` or `scratch`, or for N > 8192, it runs the all-pairs kernel.  scratch:
  * geoa3_knn_self_scratch_bytes(B, N) bytes, 256-byte aligned, contents irrelevant.
  * Replaces knn_points(adv, adv, K=k+1) at Lib/loss_utils.py:77. */
@@ -177,6 +179,8 @@ typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 
                                kernel a pass over the matrix for its power-of-two scale; 0 = computed in the kernel */
 } geoa3_tnet_weights;
 
+#define GEOA3_PN_NO_FUSE_BWD 1 /* sparse backward and the 128 -> 64 layer behind it as two kernels (same bits) */
+#define GEOA3_PN_NO_CHAIN 2    /* the 64-input layers one kernel each instead of chains (same bits) */
 typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 */
   int32_t classes;
   geoa3_tnet_weights t3, t64;
@@ -205,6 +209,7 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
   float w4h_unscale;
   const void *w5h16;        /* optional, with w5h: w5 in 16x16x32 fragment order (see t3.w3h16) */
   float w4t_amax;           /* optional: max |w4t| (see t3.w2t_amax) */
+  int32_t flags;            /* GEOA3_PN_* bits; 0 = the default kernels */
 } geoa3_pointnet_weights;
 
 /* bytes of scratch the forward+backward pair needs for a batch of B clouds of N points */

@@ -296,11 +296,10 @@ def test_slab_pruned_self_knn_is_bit_identical_to_brute_force(ops, N, K, scale, 
     if kk <= 40:
         # the position-list forms of the slab kernel (knn_slabp_kernel<40, false> / <56, true>), which the library takes
         # for large launches only
-        monkeypatch.setenv("GEOA3_SLABP", "2")
-        for prior in (clean, stale, bad):
-            d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch, method=1)
-            assert torch.equal(i, bi) and torch.equal(d, bd)
-        monkeypatch.delenv("GEOA3_SLABP")
+        for method in (3, 4):     # 3: the (distance, index)-list slab kernel, 4: the position-list kernel, whatever the size
+            for prior in (clean, stale, bad):
+                d, i = ops.knn_self_planar(advD, kk, prior=prior, scratch=scratch, method=method)
+                assert torch.equal(i, bi) and torch.equal(d, bd), method
     d, i = ops.knn_self_planar(advD, kk, prior=clean, scratch=None)
     assert torch.equal(i, bi) and torch.equal(d, bd)
     # in place over the prior (the loop's double buffer may alias)
