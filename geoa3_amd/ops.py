@@ -181,37 +181,10 @@ def geo_loss_grad(adv: Tensor, ori: Tensor, *, normal_ori=None, kappa_ori=None, 
 _KNN = collections.namedtuple("KNN", ["dists", "idx", "knn"])
 
 
-class _KnnPointsFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, p1, p2, K):
-        q = p1.detach().permute(0, 2, 1).contiguous()
-        r = p2.detach().permute(0, 2, 1).contiguous()
-        if K == 1:
-            d, i, _, _ = nn1_pair(q, r, both=False)
-            d, i = d.unsqueeze(-1), i.unsqueeze(-1)
-        else:
-            d, i = knn_planar(q, r, K)
-        idx = i.long()
-        ctx.save_for_backward(p1, p2, idx)
-        ctx.mark_non_differentiable(idx)
-        return d, idx
-
-    @staticmethod
-    def backward(ctx, gd, _gi):
-        # pytorch3d knn backward: dp1 += 2 g (p1 - p2[idx]);  dp2[idx] -= the same (scatter-add)
-        p1, p2, idx = ctx.saved_tensors
-        b, n1, K = idx.shape
-        nb = knn_gather(p2, idx)                         # [b,n1,K,3]
-        diff = 2.0 * gd.unsqueeze(-1) * (p1.unsqueeze(2) - nb)
-        g1 = diff.sum(2)
-        g2 = torch.zeros_like(p2)
-        g2.scatter_add_(1, idx.reshape(b, n1 * K, 1).expand(b, n1 * K, 3), -diff.reshape(b, n1 * K, 3))
-        return g1, g2, None
-
-
 def knn_points(p1: Tensor, p2: Tensor, K: int = 1, **_ignored):
     """pytorch3d.ops.knn_points(p1 [b,n1,3], p2 [b,n2,3], K) -> KNN(dists, idx, knn=None)."""
-    d, idx = _KnnPointsFn.apply(p1, p2, K)
+    from . import library  # noqa: F401  (registers geoa3::knn_points with its autograd formula)
+    d, idx = torch.ops.geoa3.knn_points(p1, p2, int(K))
     return _KNN(d, idx, None)
 
 

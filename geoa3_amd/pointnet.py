@@ -283,6 +283,8 @@ class PointNet(nn.Module):
         self._packed_key = None
         self._ws_cache: dict = {}
         self.wide_mode: Optional[str] = None       # None = GEOA3_WIDE_MODE / 'f16x2'; see default_wide_mode()
+        from . import library
+        self._handle = library.register_net(self)  # the scalar the custom op geoa3::pointnet_forward takes for this module
 
     def _weights_key(self, device):
         return (str(device), self.wide_mode or default_wide_mode(), fuse_front(), wide_shape("conv5"), wide_shape("tnet")) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
@@ -298,4 +300,51 @@ class PointNet(nn.Module):
         assert pc.size(1) == 3
         if self.training:
             raise NotImplementedError("only the eval-mode forward (the attack's victim) is implemented")
+        if torch.compiler.is_compiling():   # traced: the registered custom op (geoa3_amd/library.py), same kernels
+            return torch.ops.geoa3.pointnet_forward(pc, self._handle)
         return _PointNetFn.apply(pc, self.packed(pc.device), self._ws_cache)
+
+    @property
+    def classes(self) -> int:
+        return self.num_class
+
+
+def _ws_for(net: "PointNet", x: Tensor):
+    lib = _lib.load()
+    B, _, N = x.shape
+    nbytes = lib.geoa3_pointnet_workspace_bytes(B, N, net.num_class)
+    ws = net._ws_cache.get("ws")
+    if ws is None or ws.numel() < nbytes or ws.device != x.device:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        net._ws_cache["ws"] = ws
+    return ws
+
+
+def pointnet_forward_raw(net: "PointNet", x: Tensor) -> Tensor:
+    """The library's forward on x [b,3,n] -> logits (implementation of the custom op geoa3::pointnet_forward)."""
+    x = x.detach().contiguous().float()
+    packed = net.packed(x.device)
+    B, _, N = x.shape
+    ws = _ws_for(net, x)
+    logits = torch.empty(B, packed.classes, device=x.device, dtype=torch.float32)
+    packed.struct.flags = ab_flags()
+    check(_lib.load().geoa3_pointnet_forward(C.byref(packed.struct), x.data_ptr(), B, N, logits.data_ptr(), ws.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "geoa3_pointnet_forward")
+    net._ws_cache["version"] = net._ws_cache.get("version", 0) + 1
+    net._ws_cache["holds"] = (x.data_ptr(), x._version, tuple(x.shape))
+    return logits
+
+
+def pointnet_backward_raw(net: "PointNet", x: Tensor, dlogits: Tensor) -> Tensor:
+    """d (logits . dlogits) / dx (implementation of geoa3::pointnet_backward): the workspace must hold the forward of
+    this x; it is recomputed when a later forward has overwritten it (a traced graph may reorder calls)."""
+    x = x.detach().contiguous().float()
+    if net._ws_cache.get("holds") != (x.data_ptr(), x._version, tuple(x.shape)):
+        pointnet_forward_raw(net, x)
+    packed = net.packed(x.device)
+    B, _, N = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().geoa3_pointnet_backward(C.byref(packed.struct), x.data_ptr(), dlogits.contiguous().float().data_ptr(),
+                                              B, N, dx.data_ptr(), net._ws_cache["ws"].data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "geoa3_pointnet_backward")
+    return dx
