@@ -141,38 +141,50 @@ __device__ __forceinline__ void sa_swap32(float& a, float& b) {   // a[32..63] <
 // Layers 1 and 2 for the wave's 64 samples (lane = sample, p = xyz[sample] - centroid).
 // h2[cb][t][r]: relu'd layer-2 output, MFMA D layout: channel t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), sample cb*32 + (lane&31).
 // m1lo / m1hi: bit k set = layer-1 channel k of THIS LANE'S sample is active (z > 0).
+// TWICE (the backward kernel): layer 1 is evaluated a first time for the relu masks and the wave's maximum (the power-of-
+// two scale of the fp16 split needs it before any operand is formed), then sixteen channels at a time right in front of
+// the k-step that consumes them -- 48 live registers less than holding all of h1, for 192 more FMAs against ~3500 vector
+// instructions per centroid (the backward spilled at its 256-register budget).  Same values, same scale, same bits.
+template <bool TWICE = false>
 __device__ __forceinline__ void sa1_hidden(const Sa1Lds& L, float px, float py, float pz, int lane, f32x16 (&h2)[2][2],
                                            unsigned& m1lo, unsigned& m1hi) {
-  float h1[64];
+  float h1[TWICE ? 16 : 64];
   m1lo = 0u;
   m1hi = 0u;
+  float m = 0.f;
 #pragma unroll
   for (int k = 0; k < 64; ++k) {
     const float4 w = *reinterpret_cast<const float4*>(L.w1 + 4 * k);
     const float z = w.x * px + w.y * py + w.z * pz + w.w;
-    h1[k] = fmaxf(z, 0.f);
+    if (!TWICE) h1[k] = fmaxf(z, 0.f);
+    m = fmaxf(m, z);
     if (k < 32) m1lo |= (z > 0.f ? 1u : 0u) << k;
     else m1hi |= (z > 0.f ? 1u : 0u) << (k - 32);
     if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
+  m = fmaxf(m, 0.f);                                          // max of relu(z)
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) h2[c][t][r] = 0.f;
-  float m = 0.f;
-#pragma unroll
-  for (int k = 0; k < 64; ++k) m = fmaxf(m, h1[k]);          // h1 >= 0
   const unsigned E = sa_exp(wave_max(m));
   const float sx = sa_scale(E);
   const unsigned char* wr = L.w2h + (lane & 31) * SA_PH + (lane >> 5) * 16;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {                                // 16 layer-1 channels = one k-step
+    if (TWICE) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(L.w1 + 4 * (16 * c + k));
+        h1[k] = fmaxf(w.x * px + w.y * py + w.z * pz + w.w, 0.f);
+      }
+    }
     half8 xh[2], xl[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v0 = h1[16 * c + j] * sx, v1 = h1[16 * c + 8 + j] * sx;
+      float v0 = h1[(TWICE ? 0 : 16 * c) + j] * sx, v1 = h1[(TWICE ? 0 : 16 * c) + 8 + j] * sx;
       sa_swap32(v0, v1);                                       // v0: samples 0..31, v1: 32..63; lanes (sample, k half)
       const _Float16 a0 = (_Float16)v0, a1 = (_Float16)v1;
       xh[0][j] = a0;
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     unsigned m1lo, m1hi, m2[2] = {0u, 0u};   // m2[cb] bit t*16 + r: layer-2 activation (D layout) is positive
     {
       f32x16 h2[2][2];
-      sa1_hidden(L, px, py, pz, lane, h2, m1lo, m1hi);
+      sa1_hidden<true>(L, px, py, pz, lane, h2, m1lo, m1hi);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -337,27 +349,21 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
           for (int r = 0; r < 16; ++r) m2[cb] |= (h2[cb][t][r] > 0.f ? 1u : 0u) << (t * 16 + r);
     }
-    // d h2 [64 x 64 samples] = W3^T dz3, dz3 one-hot per channel (only the arg-max sample carries gradient)
-    f32x16 d2[2][2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d2[cb][t][r] = 0.f;
-    float f2;   // d2 holds (d h2) / f2
+    float dpx_, dpy_, dpz_;
+    // d h2 [64 x 64 samples] = W3^T dz3, dz3 one-hot per channel (only the arg-max sample carries gradient).
+    // The two column blocks (samples 0-31, 32-63) go through the three backward products ONE AFTER THE OTHER: with both
+    // in flight the accumulators alone are 128 registers (d2, d1: 2 x 2 x 16 each) and the kernel spilled 61 dwords per
+    // lane at its 256-register budget -- 1.7 GB of scratch traffic per launch (PMC: 1.97 GB against 0.28 GB algorithmic).
+    // Sequentially the weight fragments are read from LDS twice and each block takes its own power-of-two scales.
     {
-      // one-hot B operand: element j of lane (sample, k half) for k-step ks is channel ch = 16 ks + 8h + j, non-zero
-      // only in the lane of the channel's arg-max sample; the A operand is the W3^T image
+      // every channel's scaled gradient is split ONCE (by the lane that staged it) and kept with its arg-max sample as
+      // {hi | lo << 16, sample}: the operand construction below is then one 8-byte LDS read, a compare and a select
+      // per (channel, lane half) plus byte permutes
       const float g0 = s_gz[2 * lane], g1 = s_gz[2 * lane + 1];
       const int a0 = s_arg[2 * lane], a1 = s_arg[2 * lane + 1];
       const unsigned E = sa_exp(wave_max(fmaxf(__builtin_fabsf(g0), __builtin_fabsf(g1))));
       const float sg = sa_scale(E);
-      f2 = sa_unscale(E) * L.scal[1];
-      // every channel's scaled gradient is split ONCE (by the lane that staged it) and kept with its arg-max sample as
-      // {hi | lo << 16, sample}: the operand construction below is then one 8-byte LDS read, two compares and two selects
-      // per (channel, lane half) plus byte permutes, instead of a multiply, two conversions, a subtraction, four compares
-      // and four selects in every lane
+      const float f2 = sa_unscale(E) * L.scal[1];     // d2 holds (d h2) / f2
       unsigned* s_pa = reinterpret_cast<unsigned*>(s_gz);   // [128][2], over s_gz / s_arg (this wave's own 1 KB)
       {
         const float z0 = g0 * sg, z1 = g1 * sg;
@@ -368,118 +374,115 @@ __global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         typedef unsigned uint4v __attribute__((ext_vector_type(4)));
         *reinterpret_cast<uint4v*>(s_pa + 4 * lane) = uint4v{p0, (unsigned)a0, p1, (unsigned)a1};
       }
-      const unsigned char* wr = L.w3h + l31 * SA_PH2 + h * 16;
-#pragma unroll 2
-      for (int ks = 0; ks < 8; ++ks) {
-        unsigned s0[8], s1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int ch = 16 * ks + 8 * h + j;
-          const uint2 pa = *reinterpret_cast<const uint2*>(s_pa + 2 * ch);
-          s0[j] = (int)pa.y == l31 ? pa.x : 0u;
-          s1[j] = (int)pa.y == 32 + l31 ? pa.x : 0u;
-        }
-        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-        uint4v vh0, vl0, vh1, vl1;
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) {
-          vh0[j2] = __builtin_amdgcn_perm(s0[2 * j2 + 1], s0[2 * j2], 0x05040100u);   // low halves: hi pieces
-          vl0[j2] = __builtin_amdgcn_perm(s0[2 * j2 + 1], s0[2 * j2], 0x07060302u);   // high halves: lo pieces
-          vh1[j2] = __builtin_amdgcn_perm(s1[2 * j2 + 1], s1[2 * j2], 0x05040100u);
-          vl1[j2] = __builtin_amdgcn_perm(s1[2 * j2 + 1], s1[2 * j2], 0x07060302u);
-        }
-        half8 bh[2], bl[2];
-        bh[0] = __builtin_bit_cast(half8, vh0);
-        bl[0] = __builtin_bit_cast(half8, vl0);
-        bh[1] = __builtin_bit_cast(half8, vh1);
-        bl[1] = __builtin_bit_cast(half8, vl1);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32);
-          const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32 + 64 * SA_PH2);
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            d2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[cb], d2[cb][t], 0, 0, 0);
-            d2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[cb], d2[cb][t], 0, 0, 0);
-            d2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cb], d2[cb][t], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // through relu 2, then d h1 = W2^T dz2 with the accumulator registers as B operands (registers 8s..8s+7 of tile t
-    // = k-step 2t + s in the accumulator's row order; the W2^T image follows it)
-    f32x16 d1[2][2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d1[cb][t][r] = 0.f;
-    float f1;   // d1 holds (d h1) / f1
-    {
-      float m = 0.f;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      float part[2][3];
+#pragma unroll 1
+      for (int cb = 0; cb < 2; ++cb) {
+        asm volatile("" ::: "memory");   // (the weight fragments are re-read per block: no hoisting out of this loop)
+        f32x16 d2[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            d2[cb][t][r] = ((m2[cb] >> (t * 16 + r)) & 1u) ? d2[cb][t][r] : 0.f;
-            m = fmaxf(m, __builtin_fabsf(d2[cb][t][r]));
+          for (int r = 0; r < 16; ++r) d2[t][r] = 0.f;
+        {
+          // one-hot B operand: element j of lane (sample, k half) for k-step ks is channel ch = 16 ks + 8h + j, non-zero
+          // only in the lane of the channel's arg-max sample; the A operand is the W3^T image
+          const unsigned char* wr = L.w3h + l31 * SA_PH2 + h * 16;
+          const int mysample = cb * 32 + l31;
+#pragma unroll 2
+          for (int ks = 0; ks < 8; ++ks) {
+            unsigned s0[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int ch = 16 * ks + 8 * h + j;
+              const uint2 pa = *reinterpret_cast<const uint2*>(s_pa + 2 * ch);
+              s0[j] = (int)pa.y == mysample ? pa.x : 0u;
+            }
+            typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+            uint4v vh0, vl0;
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+              vh0[j2] = __builtin_amdgcn_perm(s0[2 * j2 + 1], s0[2 * j2], 0x05040100u);   // low halves: hi pieces
+              vl0[j2] = __builtin_amdgcn_perm(s0[2 * j2 + 1], s0[2 * j2], 0x07060302u);   // high halves: lo pieces
+            }
+            const half8 bh = __builtin_bit_cast(half8, vh0), bl = __builtin_bit_cast(half8, vl0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32);
+              const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32 + 64 * SA_PH2);
+              d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, d2[t], 0, 0, 0);
+              d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, d2[t], 0, 0, 0);
+              d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, d2[t], 0, 0, 0);
+            }
           }
-      const unsigned E = sa_exp(wave_max(m));
-      const float sx = sa_scale(E);
-      f1 = f2 * sa_unscale(E) * L.scal[0];
-      const unsigned char* wr = L.w2t + l31 * SA_PH + h * 16;
+        }
+        // through relu 2, then d h1 = W2^T dz2 with the accumulator registers as B operands (registers 8s..8s+7 of tile
+        // t = k-step 2t + s in the accumulator's row order; the W2^T image follows it)
+        f32x16 d1[2];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        half8 bh[2], bl[2];
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+          for (int r = 0; r < 16; ++r) d1[t][r] = 0.f;
+        float f1;   // d1 holds (d h1) / f1
+        {
+          const unsigned mm = cb ? m2[1] : m2[0];
+          float m = 0.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float v = d2[cb][ks >> 1][8 * (ks & 1) + j] * sx;
-            const _Float16 a = (_Float16)v;
-            bh[cb][j] = a;
-            bl[cb][j] = (_Float16)(v - (float)a);
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              d2[t][r] = ((mm >> (t * 16 + r)) & 1u) ? d2[t][r] : 0.f;
+              m = fmaxf(m, __builtin_fabsf(d2[t][r]));
+            }
+          const unsigned E1 = sa_exp(wave_max(m));
+          const float sx = sa_scale(E1);
+          f1 = f2 * sa_unscale(E1) * L.scal[0];
+          const unsigned char* wr = L.w2t + l31 * SA_PH + h * 16;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            half8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float v = d2[ks >> 1][8 * (ks & 1) + j] * sx;
+              const _Float16 a = (_Float16)v;
+              bh[j] = a;
+              bl[j] = (_Float16)(v - (float)a);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32);
+              const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32 + 64 * SA_PH);
+              d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, d1[t], 0, 0, 0);
+              d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, d1[t], 0, 0, 0);
+              d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, d1[t], 0, 0, 0);
+            }
           }
+        }
+        // through relu 1 (mask of sample cb*32 + l31 lives in that lane) and the K = 3 layer
+        {
+          const unsigned mlo = __shfl(m1lo, cb * 32 + l31, 64), mhi = __shfl(m1hi, cb * 32 + l31, 64);
+          float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32);
-          const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32 + 64 * SA_PH);
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            d1[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[cb], d1[cb][t], 0, 0, 0);
-            d1[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[cb], d1[cb][t], 0, 0, 0);
-            d1[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cb], d1[cb][t], 0, 0, 0);
-          }
+            for (int r = 0; r < 16; ++r) {
+              const int kk = (r & 3) + 8 * (r >> 2) + 4 * h;     // bit within the word of tile t
+              const bool on = (((t == 0 ? mlo : mhi) >> kk) & 1u) != 0u;
+              const float z = on ? d1[t][r] * f1 : 0.f;
+              const float4 wv = *reinterpret_cast<const float4*>(L.w1 + 4 * (t * 32 + kk));
+              sx += wv.x * z;
+              sy += wv.y * z;
+              sz += wv.z * z;
+            }
+          part[cb][0] = sx + __shfl_xor(sx, 32, 64);
+          part[cb][1] = sy + __shfl_xor(sy, 32, 64);
+          part[cb][2] = sz + __shfl_xor(sz, 32, 64);
         }
       }
+      dpx_ = h ? part[1][0] : part[0][0];
+      dpy_ = h ? part[1][1] : part[0][1];
+      dpz_ = h ? part[1][2] : part[0][2];
     }
-    // through relu 1 (mask of sample cb*32 + l31 lives in that lane) and the K = 3 layer
-    float part[2][3];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const unsigned mlo = __shfl(m1lo, cb * 32 + l31, 64), mhi = __shfl(m1hi, cb * 32 + l31, 64);
-      float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kk = (r & 3) + 8 * (r >> 2) + 4 * h;     // bit within the word of tile t
-          const bool on = (((t == 0 ? mlo : mhi) >> kk) & 1u) != 0u;
-          const float z = on ? d1[cb][t][r] * f1 : 0.f;
-          const float4 wv = *reinterpret_cast<const float4*>(L.w1 + 4 * (t * 32 + kk));
-          sx += wv.x * z;
-          sy += wv.y * z;
-          sz += wv.z * z;
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-      part[cb][0] = sx + __shfl_xor(sx, 32, 64);
-      part[cb][1] = sy + __shfl_xor(sy, 32, 64);
-      part[cb][2] = sz + __shfl_xor(sz, 32, 64);
-    }
-    const float dpx = h ? part[1][0] : part[0][0], dpy = h ? part[1][1] : part[0][1], dpz = h ? part[1][2] : part[0][2];
+    const float dpx = dpx_, dpy = dpy_, dpz = dpz_;
     // scatter to the gathered points (entries repeating the row's first index -- the ball query's padding -- leave as
     // one add) and minus the sum to the centroid
     const int i0 = __shfl(i, 0, 64);
