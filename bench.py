@@ -419,9 +419,13 @@ def main():
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, "profiles/" + src
         if other is not None:
             omode, osteps, odt, okms = other
+            oroof = conv5_roofline(omode, okms.get(TAG_CONV5))
+            otr, osrc = pmc_traffic("wide_max2_kernel<3" if omode == "f32" else "wide16_kernel<3", "c2f32" if omode == "f32" else "c2")
+            if oroof and otr is not None and B == BATCH and npoint == NPOINT:
+                oroof["traffic"], oroof["traffic_source"] = otr, "profiles/%s (rocprofv3 --pmc passes of this mode)" % osrc
             out["other_wide_mode"] = {"wide_mode": omode, "value": round((total_instances * osteps / odt) / BATCH, 3),
                                       "ms_per_step": round(odt / osteps * 1e3, 4), "steps": osteps,
-                                      "roofline": conv5_roofline(omode, okms.get(TAG_CONV5)),
+                                      "roofline": oroof,
                                       "kernels_ms": {"conv5_wide_max": okms.get(TAG_CONV5),
                                                      "tnet_wide_max(x2)": okms.get(TAG_TNET)}}
         if proxy is not None:

@@ -12,6 +12,7 @@ import sys
 
 TITLES = {"c2": "configs[1]: PointNet 1024-pt, 250 instances (`python3 bench.py --no-cpu-baseline --single-mode`)",
           "p32": "configs[2] proxy: one rank's 32-instance shard (`bench.py --instances 32 --no-proxy-full`)",
+          "c2f32": "configs[1] with GEOA3_WIDE_MODE=f32 (every convolution on the fp32 MFMA: the bench line's `other_wide_mode`)",
           "c4": "configs[3]: PointNet++ SSG (`bench.py --arch PointNetPP`)",
           "c5": "configs[4]: PointNet 4096-pt, k=32 (`bench.py --npoint 4096 --knn 32`)"}
 
@@ -79,7 +80,7 @@ def one(src, cfg, dst):
 
 def main(src, dst):
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
-    for cfg in ("c2", "p32", "c4", "c5"):
+    for cfg in ("c2", "c2f32", "p32", "c4", "c5"):
         if os.path.isdir(os.path.join(src, cfg)):
             one(src, cfg, "%s_%s" % (dst, cfg))
     for f in glob.glob(os.path.join(src, "bench_*.json")):
