@@ -209,8 +209,63 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
     const float rho = rad * g.inv_h * 1.00001f + 1e-4f;   // (grid_ball's radius in cells)
     const int bx0 = grid_coord(fx - rho), bx1 = grid_coord(fx + rho), by0 = grid_coord(fy - rho), by1 = grid_coord(fy + rho);
     const int bny = by1 - by0 + 1, bcols = (bx1 - bx0 + 1) * bny;
+    if (MODE == 4) {
+      // BALANCED walk: the (query, column) pairs of the wavefront's 64 queries are dealt evenly over its lanes -- a query's
+      // ball touches 4.9 columns on average but up to 64, and with a query per lane the wavefront walks as long as its
+      // widest lane.  Prefix sums of the column counts (LDS, one row per wave) map pair t to (query lane, column); the
+      // query's box comes over by lane permutes; a pair's best candidate goes into the query's 64-bit key (distance
+      // bits : index -- the lexicographic (distance, index) order) with an LDS atomic minimum.  Same candidates, same
+      // result.
+      unsigned long long* s_key = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(s_pi + M) + 7) & ~(uintptr_t)7);   // [GT]
+      int* s_pre = reinterpret_cast<int*>(s_key + GT);                                    // [GW][64]
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      const int nc = valid ? bcols : 0;
+      int incl = nc;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      s_pre[wv * 64 + lane] = incl - nc;
+      s_key[threadIdx.x] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi;
+      const int* pre = s_pre + wv * 64;
+      for (int t0p = 0; t0p < total; t0p += 64) {      // (uniform trips: the lane permutes below need every source lane)
+        const int t = t0p + lane;
+        const bool act = t < total;
+        int l = 0;                       // the last lane whose exclusive prefix is <= t (lanes without columns repeat the
+#pragma unroll                           // prefix of the lane before them: "last" skips them)
+        for (int st = 32; st > 0; st >>= 1) l += (pre[l + st] <= t) ? st : 0;
+        const int c = act ? t - pre[l] : 0;
+        const float wqx = __shfl(qx, l, 64), wqy = __shfl(qy, l, 64), wqz = __shfl(qz, l, 64);
+        const float wfx = __shfl(fx, l, 64), wfy = __shfl(fy, l, 64), wfz = __shfl(fz, l, 64), wrho = __shfl(rho, l, 64);
+        const int wx0 = __shfl(bx0, l, 64), wy0 = __shfl(by0, l, 64), wny = __shfl(bny, l, 64);
+        const int xx = wx0 + c / wny, yy = wy0 + c % wny;
+        const float ex = fmaxf(fmaxf((float)xx - wfx, wfx - (float)(xx + 1)), 0.f);
+        const float ey = fmaxf(fmaxf((float)yy - wfy, wfy - (float)(yy + 1)), 0.f);
+        const float rem = wrho * wrho - ex * ex - ey * ey;
+        if (act && rem >= 0.f) {
+          const float zr = __builtin_amdgcn_sqrtf(rem) + 1e-4f;
+          const int col = (xx * GG + yy) * GG;
+          const int js = s_start[col + grid_coord(wfz - zr)], je = s_start[col + grid_coord(wfz + zr) + 1];
+          float cbest = G_INF;
+          int cbi = 0x7fffffff;
+          for (int j = js; j < je; ++j) {
+            const float d = geoa3_sqdist(wqx, wqy, wqz, s_px[j], s_py[j], s_pz[j]);
+            const int i = s_pi[j];
+            const bool take = d < cbest || (d == cbest && i < cbi);
+            cbest = take ? d : cbest;
+            cbi = take ? i : cbi;
+          }
+          if (je > js) atomicMin(&s_key[wv * 64 + l], ((unsigned long long)__float_as_uint(cbest) << 32) | (unsigned)cbi);
+        }
+      }
+      const unsigned long long k = s_key[threadIdx.x];
+      best = __uint_as_float((unsigned)(k >> 32));
+      bi = (int)(unsigned)k;
+    }
     const bool wide = MODE == 0 && valid && bcols > wide_thr;
-    if (MODE != 2 && !wide && valid) grid_ball(s_start, fx, fy, fz, rad, g.inv_h, [&](int s, int e) {
+    if (MODE != 2 && MODE != 4 && !wide && valid) grid_ball(s_start, fx, fy, fz, rad, g.inv_h, [&](int s, int e) {
       if (MODE == 3) {   // statistics: columns visited, candidates
         atomicAdd(reinterpret_cast<unsigned long long*>(d_ar), 1ull);
         atomicAdd(reinterpret_cast<unsigned long long*>(d_ar) + 1, (unsigned long long)(e - s));
@@ -275,7 +330,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
   }
 }
 
-size_t grid_nn1_lds(int M) { return ((size_t)(GC + 4) + GC + GW * 8 + 4 * (size_t)M) * 4; }
+size_t grid_nn1_lds(int M) { return ((size_t)(GC + 4) + GC + GW * 8 + 4 * (size_t)M + 2 + 2 * GT + GW * 64) * 4; }
 
 }  // namespace
 
@@ -291,7 +346,7 @@ int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr,
   dim3 grid(B, d_ra ? 2 : 1);
 #define GEOA3_GRID_CASE(PPT)                                                                                    \
   if (M <= PPT * GT) {                                                                                          \
-    auto kern = grid_nn1_kernel<PPT>;                                                                           \
+    auto kern = grid_nn1_kernel<PPT, 4>;                                                                         \
     if (lds > 64 * 1024)                                                                                        \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                      \

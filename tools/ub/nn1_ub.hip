@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
   printf("noise %.2f\n", noise);
   printf("full, own-index seed  %.1f us\n", run<0>(dA, dR, B, N, nullptr, nullptr, d_ar, i_ar, d_ra, i_ra, 10));
   printf("full, prior seed      %.1f us\n", run<0>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
+  printf("balanced, prior seed  %.1f us\n", run<4>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
   printf("build only            %.1f us\n", run<1>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
   printf("seeds only            %.1f us\n", run<2>(dA, dR, B, N, i_ar, i_ra, d_ar, i_ar, d_ra, i_ra, 10));
   {
