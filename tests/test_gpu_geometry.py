@@ -387,3 +387,69 @@ def test_grid_nn1_is_bit_identical_to_brute_force(ops, B, Na, Nr, kind):
         again = ops.nn1_pair(dev(a), dev(r), method="grid", prior=prior)
         for w, x in zip(want, again):
             assert torch.equal(w, x)
+
+
+def _objective_inputs(ops, adv, ori, nrm, k):
+    advD, oriD, nrmD = dev(adv), dev(ori), dev(nrm)
+    d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(advD, oriD)
+    _, knn_ori = ops.knn_planar(oriD, oriD, k + 1)
+    kap = ops.kappa(oriD, nrmD, knn_ori)
+    _, knn_adv = ops.knn_planar(advD, advD, k + 1)
+    return dict(normal_ori=nrmD, kappa_ori=kap, d_ao=d_ao, i_ao=i_ao, d_oa=d_oa, i_oa=i_oa, knn_adv=knn_adv, k=k,
+                dis_type=1, w_dis=1.0, w_hd=0.1, w_curv=1.0), advD, oriD
+
+
+def _oracle_objective(adv, ori, nrm, k):
+    a = adv.clone().requires_grad_()
+    ka, _ = O.get_kappa_adv(a, ori, nrm, k)
+    con = O.chamfer_loss(a, ori) + 0.1 * O.hausdorff_loss(a, ori) + O.curvature_loss(a, ori, ka, O.get_kappa_ori(ori, nrm, k))
+    (g,) = torch.autograd.grad(con.sum(), a)
+    return con.detach(), g
+
+
+@pytest.mark.parametrize("N,k,kind", [(1024, 16, "coincident120"), (700, 16, "coincident40"), (512, 8, "coincident40"),
+                                      (1024, 16, "plain"), (2048, 16, "plain")])
+def test_pair_parallel_objective_special_paths(ops, N, k, kind):
+    """The pair-parallel objective kernel (clouds of at most 1024 points) off its fast path: exactly coincident points
+    all list the lowest-indexed of their twins (ties go to the lower index), which therefore collect 40 / 120 sources
+    each -- rows of 33..64 sources (two sorted runs merged) and rows beyond the LDS capacity (summed by their owner from
+    the table) -- through zero-length pairs (the clamped normalisation); 2048 points take the one-workgroup kernel.  Against the oracle's autograd, reproducible bit
+    for bit, and independent of the batch (a batch of one is split over four owner-range workgroups, a large one is
+    not)."""
+    B = 3
+    ori, nrm = O.make_synthetic_clouds(B, N, seed=N + k)
+    g = torch.Generator().manual_seed(N)
+    adv = ori + 0.02 * torch.randn(B, 3, N, generator=g)
+    ncoin = int(kind[len("coincident"):]) if kind.startswith("coincident") else 0
+    if ncoin:
+        adv[:, :, 100:100 + ncoin] = adv[:, :, 100:101]
+    kw, advD, oriD = _objective_inputs(ops, adv, ori, nrm, k)
+    if ncoin:
+        deg = torch.zeros(B, N, device="cuda").scatter_add_(1, kw["knn_adv"][:, :, 1:].reshape(B, -1).long(),
+                                                          torch.ones(B, N * k, device="cuda"))
+        assert deg.max().item() >= ncoin - 2       # the lowest-indexed twins are listed by all the others
+    out = ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)
+    con, grad = out["constrain"].clone(), out["grad"].clone()
+    want_con, want_g = _oracle_objective(adv, ori, nrm, k)
+    np.testing.assert_allclose(con.cpu().numpy(), want_con.numpy(), rtol=5e-5, atol=1e-7)
+    # (coincident points: the gradient of |v| / max(|v|, eps) at v = 0 is implementation defined in torch's autograd as
+    # here -- compare away from them)
+    keep = torch.ones(N, dtype=torch.bool)
+    if ncoin:
+        involved = (kw["knn_adv"].cpu()[:, :, :].unsqueeze(-1) == torch.arange(100, 100 + ncoin).view(1, 1, 1, -1)).any(-1).any(-1).any(0)
+        keep &= ~involved
+        keep[100:100 + ncoin] = False
+    scale = want_g.abs().max().item()
+    np.testing.assert_allclose(grad.cpu()[:, :, keep].numpy(), want_g[:, :, keep].numpy(), rtol=2e-4, atol=2e-6 * max(scale, 1.0))
+    for _ in range(3):
+        again = ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)
+        assert torch.equal(again["grad"], grad) and torch.equal(again["constrain"], con)
+    # batch independence: instance 1 alone (B = 1: four owner-range workgroups) and inside a batch of 160 copies (one)
+    one = {n: (v[1:2].contiguous() if torch.is_tensor(v) else v) for n, v in kw.items()}
+    alone = ops.geo_loss_grad(advD[1:2].contiguous(), oriD[1:2].contiguous(), deterministic=True, **one)
+    assert torch.equal(alone["grad"][0], grad[1]) and torch.equal(alone["constrain"][0], con[1])
+    if N <= 1024:
+        many = {n: (v[1:2].expand(160, *v.shape[1:]).contiguous() if torch.is_tensor(v) else v) for n, v in kw.items()}
+        big = ops.geo_loss_grad(advD[1:2].expand(160, 3, N).contiguous(), oriD[1:2].expand(160, 3, N).contiguous(),
+                                deterministic=True, **many)
+        assert torch.equal(big["grad"][77], grad[1]) and torch.equal(big["constrain"][159], con[1])
