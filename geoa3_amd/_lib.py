@@ -40,7 +40,7 @@ class PointNetWeights(C.Structure):
         "w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "w5", "b5", "w5p", "w4t", "w3t", "w2t",
         "f1", "fb1", "f2", "fb2", "f3", "fb3", "f1t", "f2t", "f3t", "w5h")] + [("w5h_unscale", C.c_float), ("w4h", vp),
                                                                                  ("w4h_unscale", C.c_float), ("w5h16", vp),
-                                                                                 ("w4t_amax", C.c_float), ("flags", C.c_int32), ("w5_wsumt", vp), ("w5_fnorm", vp)]
+                                                                                 ("w4t_amax", C.c_float), ("flags", C.c_int32)]
 
 
 class Sa1Weights(C.Structure):
@@ -129,7 +129,6 @@ SIGNATURES = {
     "geoa3_conv1x1_max64": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, vp]),
     "geoa3_conv1x1_onehot64": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, vp]),
     "geoa3_conv1x1": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, vp]),
-    "geoa3_debug_wide16": (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_debug_fc": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_debug_conv_cm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_profile_enable": (C.c_int, [C.c_int]),

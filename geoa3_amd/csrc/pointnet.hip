@@ -165,32 +165,11 @@ struct FrontLayer {
   const float* h64; const float* x3; const float* w1; const float* b1;
   unsigned long long* m128;
 };
-// scratch + weight-derived arrays of the two-pass form of conv5 (pointnet_wide16.hip: filter, decide, refine)
-struct TwoPass {
-  void* scratch;             // >= (192 B N + 640 B (N / 128) + ...) bytes: the backward's G128 buffer (idle in the forward)
-  const float *Wf, *wsumt, *wnorm;
-};
-
 int wide(const float* X, const float* W, const void* Wh, float unscale, const float* bias, float* out, int* arg,
          unsigned long long* keys, int taps, int B, int N, hipStream_t s, const FrontLayer* f = nullptr,
-         const void* Wh16 = nullptr, const TwoPass* tp = nullptr) {
+         const void* Wh16 = nullptr) {
   WideArgs a{};
   a.Wh16 = Wh16;
-  if (tp && Wh16 && taps == 3 && !f) {
-    const size_t tiles = (size_t)(N + 127) / 128;
-    char* q = static_cast<char*>(tp->scratch);
-    auto take = [&](size_t bytes) {
-      void* r = q;
-      q += (bytes + 255) / 256 * 256;
-      return r;
-    };
-    a.f_rec = (float*)take((size_t)B * tiles * 1024 * 16);
-    a.f_mean = (float*)take((size_t)B * tiles * 128 * 4);
-    a.f_tile = (float*)take((size_t)B * tiles * 16);
-    a.f_list = (int*)take(((size_t)B * tiles * 2048 + (size_t)B * tiles) * 4);
-    a.Wf = tp->Wf; a.f_wsumt = tp->wsumt; a.f_wnorm = tp->wnorm;
-    a.two_pass = 1;
-  }
   if (f) {
     a.W2h = f->w2h; a.w2_unscale = f->w2_unscale; a.W2f = f->w2; a.b2 = f->b2;
     a.Xin = f->h64; a.sXinb = (long)64 * N; a.ldXin = N;
@@ -357,18 +336,14 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
     TRY(launch_conv_cm(a, s));
   }
   // conv4, conv5 + max (:145-147)
-  // conv5 in two passes (one-product filter on the centred tiles, exact evaluation of the survivors) when the host packed
-  // what it needs: 192 B N + ~1 KB per tile of scratch in G128 (512 B N bytes, written by the backward only)
-  const TwoPass tp{w.G128, p.w5, p.w5_wsumt, p.w5_fnorm};
-  const TwoPass* tpp = (p.w5_wsumt && p.w5_fnorm && p.w5h16 && !(p.flags & GEOA3_PN_NO_TWO_PASS)) ? &tp : nullptr;
   if (chain34) {
-    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16, tpp));
+    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16));
   } else if (tl_split && p.w4h) {   // conv4 inside conv5's staging pass: h4 is never written
     FrontLayer f{p.w4h, p.w4h_unscale, p.w4, p.b4, w.h3, nullptr, nullptr, nullptr, w.m_h4};
     TRY(wide(nullptr, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, &f));
   } else {
     TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s, w.m_h4));
-    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16, tpp));
+    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16));
   }
   // classifier head (:150-152), dropout is the identity in eval mode
   TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));

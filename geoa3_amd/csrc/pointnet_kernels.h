@@ -128,20 +128,7 @@ struct WideArgs {
   const float* x3; const float* w1; const float* b1;   // [B][3][N], [64][3], [64]
   unsigned long long* Ymask;
   unsigned long long* stamps;                 // diagnostics (tools/bench_wide.py --stamps): s_memtime trace of workgroup 0
-  // filter pass (pointnet_wide16.hip, wide16_filter_kernel): per (instance, 128-point tile, channel) the two largest
-  // ONE-product values of the centred tile and the point of the largest, per (instance, tile) the channel means and the
-  // norms its error bound needs
-  float* f_rec;                               // [B][tiles][Co][4]: v1, v2, point (as int bits), -
-  float* f_mean;                              // [B][tiles][128]
-  float* f_tile;                              // [B][tiles][4]: max 3-tap norm of the centred points, |mean|, -, -
-  // ... and what the decide / refine passes of the two-pass form need (launch_wide16_two_pass)
-  const float* Wf;                            // [Co][TAPS*128] fp32 (the exact evaluation)
-  const float* f_wsumt;                       // [128][Co]: sum over the taps of W, transposed (the mean's term)
-  const float* f_wnorm;                       // [2][Co]: |w_c| over TAPS*128, then the weight image's absolute slack factor
-  int* f_list;                                // [B][tiles][Co] survivors per tile; [B][tiles] counts behind them
-  int two_pass;                               // 1: launch_wide_max_split16 runs filter + decide + refine (conv5 only)
 };
-int launch_wide16_two_pass(const WideArgs& a, hipStream_t s);
 int launch_wide_max(const WideArgs& a, hipStream_t s);          // dispatches on a.Wh
 int launch_wide_max_split(const WideArgs& a, hipStream_t s);    // pointnet_wide_split.hip
 int launch_wide_max_split16(const WideArgs& a, hipStream_t s);  // pointnet_wide16.hip

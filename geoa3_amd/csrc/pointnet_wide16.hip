@@ -257,261 +257,6 @@ __global__ __launch_bounds__(W16_THREADS, OCC) void wide16_kernel(WideArgs a, in
   flush();
 }
 
-// ------------------------------------------------------------------------------------------
-// Filter pass of the max-fused layer: ONE fp16 product per term (a third of the matrix work) on the CENTRED tile.
-// x_p = m + d_p (m = the tile's mean per input channel): x_p . w = m . wsum + d_p . w; all points of a tile share the
-// first term, so only d_p . w decides which point is a channel's maximum, and its one-product error is bounded by
-// ~2^-10 |d_p| |w| with |d| ~ 0.18 |x| on these clouds.  Per (tile, channel) the two largest approximate values and the
-// point of the largest leave; a later pass forms the rigorous bounds, keeps the points that can still be the maximum of
-// their (instance, channel) -- 1.2-1.4 of 1024 (tools/filter_refine_probe.py) -- and evaluates those exactly.
-// Zero padding (cloud ends, ragged tiles) is x = 0, i.e. d = -m: the identity above holds for every tap.
-// ------------------------------------------------------------------------------------------
-template <int TAPS, int OCC, int GROUPS>
-__global__ __launch_bounds__(W16_THREADS, OCC) void wide16_filter_kernel(WideArgs a, int slots_per_xcd) {
-  constexpr int KS = TAPS * 4;
-  constexpr int PF = 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // one piece: [130 rows][288 B]
-  __shared__ float s_max[4];
-  __shared__ float s_mean[128];
-  __shared__ float s_pn[4][W16_ROWS];       // per wave: partial squared norms of the centred points (rows 0..129)
-  __shared__ float s_hn[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, q4 = lane >> 4;
-  const int N = a.N, tiles = (N + W16_PTS - 1) / W16_PTS;
-  constexpr int SPLIT = 8 / GROUPS;
-  const int per_inst = tiles * SPLIT;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int inst_x = (a.B - xcd + 7) / 8;
-  const int units = inst_x * per_inst;
-  const half8* Wall = reinterpret_cast<const half8*>(a.Wh16);
-  const int nmine = units > slot ? (units - slot + slots_per_xcd - 1) / slots_per_xcd : 0;
-  for (int it = 0; it < nmine; ++it) {
-    const int u = slot + it * slots_per_xcd;
-    const int qi = u / per_inst, r = u - qi * per_inst;
-    const int b = xcd + 8 * qi, tile = r / SPLIT, half = r - tile * SPLIT;
-    const int n0 = tile * W16_PTS;
-    const float* X = a.X + (size_t)b * a.sXb;
-    float xv[2][4][8], xhalo = 0.f;
-    {
-      int ldx = a.ldX;
-      asm volatile("" : "+s"(ldx));
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int n = n0 + pass * 64 + lane;
-        const bool in = n < N;
-        const float* px = X + (in ? n : 0);
-#pragma unroll
-        for (int oc = 0; oc < 4; ++oc)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float v = px[(size_t)(((wave + 4 * oc) * 8 + i) * ldx)];
-            xv[pass][oc][i] = in ? v : 0.f;
-          }
-      }
-      if (TAPS == 3) {
-        const int n = tid < 128 ? n0 - 1 : n0 + W16_PTS;
-        if (n >= 0 && n < N) xhalo = X[(size_t)((tid & 127) * ldx) + n];
-      }
-    }
-    __syncthreads();     // (the previous unit's readers of the LDS tile and of s_mean are done)
-    // channel means over the tile's 128 rows (this wave's 32 channels), centred values, partial point norms
-    float pn0 = 0.f, pn1 = 0.f, m = 0.f, bad_f = 0.f;
-#pragma unroll
-    for (int oc = 0; oc < 4; ++oc)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float mean = wave_sum(xv[0][oc][i] + xv[1][oc][i]) * (1.0f / W16_PTS);
-        if (lane == 0) s_mean[(wave + 4 * oc) * 8 + i] = mean;
-        const float d0 = xv[0][oc][i] - mean, d1 = xv[1][oc][i] - mean;
-        xv[0][oc][i] = d0;
-        xv[1][oc][i] = d1;
-        pn0 += d0 * d0;
-        pn1 += d1 * d1;
-        m = fmaxf(m, fmaxf(__builtin_fabsf(d0), __builtin_fabsf(d1)));
-        bad_f += d0 - d0 + d1 - d1;      // NaN / inf anywhere -> NaN
-      }
-    s_pn[wave][1 + lane] = pn0;
-    s_pn[wave][65 + lane] = pn1;
-    __syncthreads();
-    float hn = 0.f;
-    if (TAPS == 3) {
-      xhalo -= s_mean[tid & 127];        // (zero padding at the cloud's ends: x = 0, d = -mean)
-      m = fmaxf(m, __builtin_fabsf(xhalo));
-      hn = wave_sum(xhalo * xhalo);      // waves 0, 1: the left halo point's channels 0-63, 64-127; 2, 3: the right one's
-    }
-    m = wave_max(m);
-    if (lane == 0) {
-      s_max[wave] = m;
-      s_hn[wave] = hn;
-    }
-    __syncthreads();
-    m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-    unsigned E = (__float_as_uint(m) >> 23) & 0xffu;
-    bool bad = E == 255u || bad_f != bad_f;
-    E = E < 14u ? 14u : (E > 254u ? 254u : E);
-    const float scale = __uint_as_float((267u - E) << 23), unscale = a.unscale * __uint_as_float((E - 13u) << 23);
-    // squared norm of every centred row (the four waves' partial sums), then the largest three-tap sum of the tile
-    float nrm3 = 0.f;
-    if (tid < W16_ROWS) {
-      float pn;
-      if (tid == 0) pn = s_hn[0] + s_hn[1];
-      else if (tid == W16_ROWS - 1) pn = s_hn[2] + s_hn[3];
-      else pn = (s_pn[0][tid] + s_pn[1][tid]) + (s_pn[2][tid] + s_pn[3][tid]);
-      s_pn[0][tid] = pn;     // (own entry only: read above by the same thread)
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int p = 1 + pass * 64 + lane;
-#pragma unroll
-      for (int oc = 0; oc < 4; ++oc) {
-        half8 hi;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) hi[i] = (_Float16)(xv[pass][oc][i] * scale);
-        *reinterpret_cast<half8*>(smem_raw + p * W16_ROWB + (wave + 4 * oc) * 16) = hi;
-      }
-    }
-    if (TAPS == 3) {
-      unsigned char* dst = smem_raw + (tid < 128 ? 0 : W16_ROWS - 1) * W16_ROWB + (tid & 127) * 2;
-      *reinterpret_cast<_Float16*>(dst) = (_Float16)(xhalo * scale);
-    }
-    if (__syncthreads_or(bad))
-      for (int c = tid; c < a.Co; c += W16_THREADS) atomicMax(a.keys + (size_t)b * a.Co + c, ~0ull);
-    if (tid < W16_PTS) {
-      const int p = 1 + tid;
-      nrm3 = TAPS == 3 ? s_pn[0][p - 1] + s_pn[0][p] + s_pn[0][p + 1] : s_pn[0][p];
-      if (n0 + tid >= N) nrm3 = 0.f;     // (not a candidate)
-    }
-    nrm3 = wave_max(nrm3);
-    if (half == 0) {
-      float msq = 0.f;
-      if (tid < 128) {
-        const float mv = s_mean[tid];
-        a.f_mean[((size_t)b * tiles + tile) * 128 + tid] = mv;
-        msq = mv * mv;
-      }
-      msq = wave_sum(msq);
-      if (lane == 0) {
-        s_max[wave] = nrm3;
-        s_hn[wave] = msq;
-      }
-    } else if (lane == 0) {
-      s_max[wave] = nrm3;
-    }
-    __syncthreads();
-    if (half == 0 && tid == 0) {
-      float* T = a.f_tile + ((size_t)b * tiles + tile) * 4;
-      T[0] = sqrtf(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
-      T[1] = sqrtf(s_hn[0] + s_hn[1]);
-    }
-    const unsigned char* abase = smem_raw + (p16 + (TAPS == 1 ? 1 : 0)) * W16_ROWB + q4 * 16;
-    auto a_rd = [&](int s, int t, half8& h) {
-      h = *reinterpret_cast<const half8*>(abase + ((s >> 2) + 16 * t) * W16_ROWB + (s & 3) * 64);
-    };
-    auto wbase = [&](int g, int c2) {
-      const int co = (half * GROUPS + g) * 128 + wave * 32 + 16 * c2;
-      return Wall + (size_t)(co / 16) * KS * 2 * 64 + lane;
-    };
-    half8 wf[PF][2];
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-      const half8* W0 = wbase(0, c2);
-#pragma unroll
-      for (int f = 0; f < PF; ++f) wf[f][c2] = W0[(size_t)(2 * f) * 64];
-    }
-    half8 Ah[2][4];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a_rd(0, 4 * hf + t, Ah[hf][t]);
-#pragma unroll 1
-    for (int g = 0; g < GROUPS; ++g) {
-      const half8 *Wp[2], *Wn[2];
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
-        Wp[c2] = wbase(g, c2);
-        Wn[c2] = wbase(g + 1 < GROUPS ? g + 1 : g, c2);
-      }
-      f32x4 acc[8][2];
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[t][c2][i] = 0.f;
-#pragma unroll 1
-      for (int s0 = 0; s0 < KS; s0 += PF) {
-#pragma unroll
-        for (int f = 0; f < PF; ++f) {
-          const int s = s0 + f;
-          const int sn = s + 1 < KS ? s + 1 : 0;
-          half8 wh[2];
-#pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) {
-            wh[c2] = wf[f][c2];
-            const half8* src = s + PF < KS ? Wp[c2] + (size_t)(2 * 64) * (s + PF) : Wn[c2] + (size_t)(2 * 64) * (s + PF - KS);
-            wf[f][c2] = src[0];
-          }
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-              for (int c2 = 0; c2 < 2; ++c2)
-                acc[4 * hf + t][c2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[hf][t], wh[c2], acc[4 * hf + t][c2], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a_rd(sn, 4 * hf + t, Ah[hf][t]);
-          }
-        }
-      }
-      // lane: channel co0 + 16 c2 + p16; acc[t][c2][r]: point n0 + 16 t + 4 q4 + r.  The three largest values and the
-      // points of the two largest (ascending point order, strict >: the lowest index among equals)
-      const bool full = n0 + W16_PTS <= N;
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
-        float v1 = -__builtin_inff(), v2 = -__builtin_inff(), v3 = -__builtin_inff();
-        int c1 = 0, cc2 = 0;
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const int n = n0 + 16 * t + 4 * q4 + r4;
-            const float x = (full || n < N) ? acc[t][c2][r4] : -__builtin_inff();
-            const bool g1 = x > v1, g2 = x > v2;
-            v3 = g2 ? v2 : fmaxf(v3, x);
-            v2 = g1 ? v1 : (g2 ? x : v2);
-            cc2 = g1 ? c1 : (g2 ? n : cc2);
-            v1 = g1 ? x : v1;
-            c1 = g1 ? n : c1;
-          }
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {     // merge with the partner lane's triple (both sorted)
-          const float o1 = __shfl_xor(v1, o, 64), o2 = __shfl_xor(v2, o, 64), o3 = __shfl_xor(v3, o, 64);
-          const int oc1 = __shfl_xor(c1, o, 64), oc2 = __shfl_xor(cc2, o, 64);
-          // first: the larger head (ties: the lower point); second: the loser's head or the winner's second
-          const bool tk = o1 > v1 || (o1 == v1 && oc1 < c1);
-          const float a1 = tk ? o1 : v1, a2 = tk ? o2 : v2, a3 = tk ? o3 : v3;     // winner's triple
-          const int ac1 = tk ? oc1 : c1, ac2 = tk ? oc2 : cc2;
-          const float b1 = tk ? v1 : o1, b2 = tk ? v2 : o2;                         // loser's head and second
-          const int bc1 = tk ? c1 : oc1;
-          const bool s2 = b1 > a2 || (b1 == a2 && bc1 < ac2);                      // second = the loser's head?
-          v1 = a1;
-          c1 = ac1;
-          v2 = s2 ? b1 : a2;
-          cc2 = s2 ? bc1 : ac2;
-          v3 = s2 ? fmaxf(a2, b2) : fmaxf(a3, b1);
-        }
-        if (lane < 16) {
-          const int co = (half * GROUPS + g) * 128 + wave * 32 + 16 * c2 + lane;
-          float4* R = reinterpret_cast<float4*>(a.f_rec) + ((size_t)b * tiles + tile) * a.Co + co;
-          // the two points as tile-local indices in one word
-          *R = make_float4(v1 * unscale, v2 * unscale, v3 * unscale, __int_as_float((c1 - n0) | ((cc2 - n0) << 8)));
-        }
-      }
-    }
-  }
-}
-
 template <int TAPS, int OCC, int GROUPS, bool DESYNC>
 void launch16(const WideArgs& a, hipStream_t s) {
   auto kern = wide16_kernel<TAPS, OCC, GROUPS, DESYNC>;
@@ -522,261 +267,8 @@ void launch16(const WideArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// ------------------------------------------------------------------------------------------
-// Decide: per (instance, channel) the rigorous bounds of every tile's best approximate value and the survivors.
-//   S_p = m_t . wsum_c + (d_p . w_c)~            (the second term: wide16_filter_kernel, one product per term)
-//   |(d_p . w_c)~ - d_p . w_c| <= E_t,c = 1.05 * 2^-10 * max_p |d_p| * |w_c|  +  slack_c * max_p |d_p|
-// (fp16 rounding of both operands: 2^-11 each; fp32 accumulation of 384 exact products: 384 * 2^-24 = 0.023 * 2^-10;
-// subnormal halves of the scaled weights: the absolute term; m . wsum in double: 2^-24 relative, inside the 1.05).
-// A tile survives when its upper bound reaches the largest lower bound of the instance's tiles; its best point is the
-// survivor unless the tile's SECOND best also reaches it -- then every point of the tile is evaluated.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void wide_filter_decide_kernel(WideArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float s_m[];     // [tiles][128] means, then [tiles] counters
-  const int b = blockIdx.x, c = threadIdx.x, tiles = (a.N + W16_PTS - 1) / W16_PTS;
-  int* s_cnt = reinterpret_cast<int*>(s_m + tiles * 128);
-  for (int i = threadIdx.x; i < tiles * 128; i += 1024) s_m[i] = a.f_mean[(size_t)b * tiles * 128 + i];
-  if (threadIdx.x < tiles) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const float wn = a.f_wnorm[c], slack = a.f_wnorm[a.Co + c];
-  const float4* R = reinterpret_cast<const float4*>(a.f_rec) + (size_t)b * tiles * a.Co + c;
-  const float* T = a.f_tile + (size_t)b * tiles * 4;
-  float lo = -__builtin_inff();
-  constexpr int TC = 8;          // tiles per chunk (their mean terms in registers)
-  auto mean_terms = [&](int t0, double (&mw)[TC]) {
-#pragma unroll
-    for (int j = 0; j < TC; ++j) mw[j] = 0.0;
-    for (int ci0 = 0; ci0 < 128; ci0 += 16) {       // sixteen weight loads in flight
-      float w[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) w[u] = a.f_wsumt[(size_t)(ci0 + u) * a.Co + c];
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-#pragma unroll
-        for (int j = 0; j < TC; ++j)
-          if (t0 + j < tiles) mw[j] += (double)s_m[(t0 + j) * 128 + ci0 + u] * (double)w[u];
-    }
-  };
-  auto bounds = [&](int t, double mwt, float& base, float& wide, float4& r) {
-    r = R[(size_t)t * a.Co];
-    const float E = (1.05f * 0.0009765625f * wn + slack) * T[t * 4] * 1.0001f;
-    base = (float)mwt;
-    // (the float conversion of the mean term and the additions round: 3 * 2^-24 of the operands -- the comparison is kept
-    //  conservative by widening with 4e-7 of them)
-    wide = E + 4e-7f * (__builtin_fabsf(base) + __builtin_fabsf(r.x));
-  };
-  auto emit = [&](int t, float base, float wide, const float4& r) {
-    if (base + r.x + wide >= lo) {
-      const bool second = base + r.y + wide >= lo, multi = base + r.z + wide >= lo;
-      const int pts = __float_as_int(r.w), p1 = pts & 127, p2 = (pts >> 8) & 127;
-      int* Lt = a.f_list + ((size_t)b * tiles + t) * 2 * a.Co;
-      if (multi) {          // a third point of the tile can still be the maximum: the whole tile (rare)
-        Lt[atomicAdd(&s_cnt[t], 1)] = c | (1 << 17);
-      } else {
-        const int slot = atomicAdd(&s_cnt[t], second ? 2 : 1);
-        Lt[slot] = c | (p1 << 10);
-        if (second) Lt[slot + 1] = c | (p2 << 10);
-      }
-    }
-  };
-  if (tiles <= TC) {             // (N <= 1024: one chunk, the mean terms formed once)
-    double mw[TC];
-    mean_terms(0, mw);
-    float base[TC], wide[TC];
-    float4 r[TC];
-#pragma unroll
-    for (int j = 0; j < TC; ++j)
-      if (j < tiles) {
-        bounds(j, mw[j], base[j], wide[j], r[j]);
-        lo = fmaxf(lo, base[j] + r[j].x - wide[j]);
-      }
-#pragma unroll
-    for (int j = 0; j < TC; ++j)
-      if (j < tiles) emit(j, base[j], wide[j], r[j]);
-  } else {
-    for (int pass = 0; pass < 2; ++pass)      // pass 0: the largest lower bound; pass 1: the survivors
-      for (int t0 = 0; t0 < tiles; t0 += TC) {
-        double mw[TC];
-        mean_terms(t0, mw);
-#pragma unroll
-        for (int j = 0; j < TC; ++j) {
-          const int t = t0 + j;
-          if (t >= tiles) break;
-          float base, wide;
-          float4 r;
-          bounds(t, mw[j], base, wide, r);
-          if (pass == 0) lo = fmaxf(lo, base + r.x - wide);
-          else emit(t, base, wide, r);
-        }
-      }
-  }
-  __syncthreads();
-  if (threadIdx.x < tiles) a.f_list[(size_t)a.B * tiles * 2 * a.Co + (size_t)b * tiles + threadIdx.x] = s_cnt[threadIdx.x];
-}
-
-// Refine: the survivors of one (instance, tile), evaluated exactly -- fp32 FMA over the 384 products, lane-strided partial
-// sums + a fixed DPP tree -- from the tile staged point-major in LDS, and published through the running-maximum keys of
-// the one-pass kernels (order independent: deterministic; ties to the lower point).
-constexpr int RF_THREADS = 1024, RF_PITCH = 129;
-template <int TAPS>
-__global__ __launch_bounds__(RF_THREADS) void wide_filter_refine_kernel(WideArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float s_x[];      // [130 rows][RF_PITCH]: row r = point n0 - 1 + r
-  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N, tiles = (N + W16_PTS - 1) / W16_PTS, n0 = tile * W16_PTS;
-  const int cnt = a.f_list[(size_t)a.B * tiles * 2 * a.Co + (size_t)b * tiles + tile];
-  if (cnt == 0) return;
-  const float* X = a.X + (size_t)b * a.sXb;
-  const int* L = a.f_list + ((size_t)b * tiles + tile) * 2 * a.Co;
-  int* s_l = reinterpret_cast<int*>(s_x + W16_ROWS * RF_PITCH);      // [cnt <= 2 Co] the survivors of this tile
-  for (int e = tid; e < cnt; e += RF_THREADS) s_l[e] = L[e];
-  {   // the tile, point-major: every load of a thread in flight before its first store (17 per thread)
-    constexpr int SPT = (128 * W16_ROWS + RF_THREADS - 1) / RF_THREADS;
-    float v[SPT];
-#pragma unroll
-    for (int u = 0; u < SPT; ++u) {
-      const int e = tid + u * RF_THREADS;              // coalesced along the points of a channel's row
-      const int ch = e / W16_ROWS, r = e - ch * W16_ROWS, n = n0 - 1 + r;
-      v[u] = (e < 128 * W16_ROWS && n >= 0 && n < N) ? X[(size_t)ch * a.ldX + n] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < SPT; ++u) {
-      const int e = tid + u * RF_THREADS;
-      const int ch = e / W16_ROWS, r = e - ch * W16_ROWS;
-      if (e < 128 * W16_ROWS) s_x[r * RF_PITCH + ch] = v[u];
-    }
-  }
-  __syncthreads();
-  constexpr int KL = TAPS * 128 / 64;      // products per lane
-  constexpr int NWV = RF_THREADS / 64, EB = 4;      // entries per batch: their weight rows are requested together
-  for (int e0 = wave * EB; e0 < cnt; e0 += NWV * EB) {
-    int ent[EB];
-    float w[EB][KL];
-#pragma unroll
-    for (int u = 0; u < EB; ++u) ent[u] = s_l[min(e0 + u, cnt - 1)];
-#pragma unroll
-    for (int u = 0; u < EB; ++u) {
-      const float* Wc = a.Wf + (size_t)(ent[u] & 1023) * (TAPS * 128);
-#pragma unroll
-      for (int j = 0; j < KL; ++j) w[u][j] = Wc[lane + 64 * j];
-    }
-    // the value of point n0 + p: rows p .. p + TAPS - 1 (row 0 = point n0 - 1); lane-strided partial sums, then the tree
-    auto partial = [&](int p, const float (&wr)[KL]) {
-      float acc = 0.f;
-#pragma unroll
-      for (int j = 0; j < KL; ++j) {
-        const int k = lane + 64 * j, tap = k >> 7, ch = k & 127;
-        acc = fmaf(s_x[(p + tap + (TAPS == 1 ? 1 : 0)) * RF_PITCH + ch], wr[j], acc);
-      }
-      return acc;
-    };
-    float part[EB];
-#pragma unroll
-    for (int u = 0; u < EB; ++u) part[u] = partial((ent[u] >> 10) & 127, w[u]);
-#pragma unroll
-    for (int u = 0; u < EB; ++u) {
-      if (e0 + u >= cnt) break;
-      const int c = ent[u] & 1023;
-      if (!((ent[u] >> 17) & 1)) {
-        const float v = wave_sum(part[u]);
-        if (lane == 0) atomicMax(a.keys + (size_t)b * a.Co + c, wide_key(v, n0 + ((ent[u] >> 10) & 127)));
-      } else {              // the whole tile for this channel (a third point could still be the maximum: rare)
-        float best = -__builtin_inff();
-        int bn = 0;
-        const int np = min(W16_PTS, N - n0);
-        for (int p0 = 0; p0 < np; p0 += 4) {      // four points in flight (same arithmetic per point as above)
-          float acc[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = partial(min(p0 + q, np - 1), w[u]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float v = wave_sum(acc[q]);
-            if (p0 + q < np && v > best) {
-              best = v;
-              bn = p0 + q;
-            }
-          }
-        }
-        if (lane == 0) atomicMax(a.keys + (size_t)b * a.Co + c, wide_key(best, n0 + bn));
-      }
-    }
-  }
-}
-
-// filter pass only (diagnostics / the two-pass form of conv5)
-int launch_wide16_filter(const WideArgs& a, hipStream_t s, int occ, int groups = 4) {
-  if (a.Co != 1024 || a.taps != 3 || !a.keys || !a.Wh16 || !a.f_rec || !a.f_mean || !a.f_tile) return GEOA3_ENOSUPPORT;
-  constexpr int LDS1 = W16_PIECEB;
-#define GEOA3_FILT(OCCV)                                                                                              \
-  {                                                                                                                   \
-    auto kern = wide16_filter_kernel<3, OCCV, 4>;                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);  \
-    hipLaunchKernelGGL(kern, dim3(32 * OCCV * 8), dim3(W16_THREADS), LDS1, s, a, 32 * OCCV);                           \
-  }
-  if (groups == 8) {
-    auto kern = wide16_filter_kernel<3, 2, 8>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-    hipLaunchKernelGGL(kern, dim3(32 * 2 * 8), dim3(W16_THREADS), LDS1, s, a, 32 * 2);
-  } else if (occ == 2) GEOA3_FILT(2) else if (occ == 3) GEOA3_FILT(3) else GEOA3_FILT(4)
-#undef GEOA3_FILT
-  GEOA3_CHECK_LAUNCH();
-  return GEOA3_OK;
-}
-
-extern "C" int geoa3_debug_wide16(const float* X, const void* Wh16, float unscale, const float* bias, float* out, int32_t* arg,
-                                  void* keys, float* f_rec, float* f_mean, float* f_tile, const float* Wf,
-                                  const float* wsumt, const float* wnorm, int32_t* f_list, int B, int N, int variant,
-                                  void* stream) {
-  WideArgs a{};
-  a.X = X; a.sXb = (long)128 * N; a.ldX = N;
-  a.Wh16 = Wh16; a.unscale = unscale; a.bias = bias;
-  a.out = out; a.arg = arg; a.keys = (unsigned long long*)keys;
-  a.Co = 1024; a.N = N; a.B = B; a.taps = 3;
-  a.f_rec = f_rec; a.f_mean = f_mean; a.f_tile = f_tile;
-  a.Wf = Wf; a.f_wsumt = wsumt; a.f_wnorm = wnorm; a.f_list = f_list;
-  if (variant == 0) return launch_wide_max_split16(a, geoa3_stream(stream));
-  if (variant == 10) return launch_wide16_two_pass(a, geoa3_stream(stream));
-  if (variant == 11 || variant == 12) {
-    a.variant = variant;
-    return launch_wide16_two_pass(a, geoa3_stream(stream));
-  }
-  if (variant == 8) return launch_wide16_filter(a, geoa3_stream(stream), 2, 8);
-  return launch_wide16_filter(a, geoa3_stream(stream), variant);
-}
-
-int launch_wide16_two_pass(const WideArgs& a, hipStream_t s) {
-  if (a.Co != 1024 || a.taps != 3 || !a.keys || !a.Wh16 || !a.f_rec || !a.f_mean || !a.f_tile || !a.Wf || !a.f_wsumt ||
-      !a.f_wnorm || !a.f_list)
-    return GEOA3_ENOSUPPORT;
-  const int tiles = (a.N + W16_PTS - 1) / W16_PTS;
-  if (!a.keys_clean &&
-      hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess)
-    return GEOA3_ELAUNCH;
-  const int rc = launch_wide16_filter(a, s, 2, 8);   // all eight channel groups per unit: the tile is staged once
-  if (rc != GEOA3_OK) return rc;
-  const size_t lds_d = ((size_t)tiles * 128 + tiles) * sizeof(float);
-  if (lds_d > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_filter_decide_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
-  hipLaunchKernelGGL(wide_filter_decide_kernel, dim3(a.B), dim3(1024), lds_d, s, a);
-  if (a.variant == 11) return GEOA3_OK;   // (tools/bench_filter.py: phase timing)
-  const size_t lds_r = ((size_t)W16_ROWS * RF_PITCH + 2 * a.Co) * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_filter_refine_kernel<3>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
-  hipLaunchKernelGGL(wide_filter_refine_kernel<3>, dim3(tiles, a.B), dim3(RF_THREADS), lds_r, s, a);
-  if (a.variant == 12) return GEOA3_OK;
-  launch_wide_finalize(a, s);
-  GEOA3_CHECK_LAUNCH();
-  return GEOA3_OK;
-}
-
 int launch_wide_max_split16(const WideArgs& a, hipStream_t s) {
   if (a.Co != 1024 || (a.taps != 1 && a.taps != 3) || !a.keys || !a.Wh16) return GEOA3_ENOSUPPORT;
-  if (a.two_pass && a.taps == 3) {
-    geoa3_prof_begin(GEOA3_PROF_CONV5, s);
-    const int rc = launch_wide16_two_pass(a, s);
-    geoa3_prof_end(GEOA3_PROF_CONV5, s);
-    return rc;
-  }
   const int tag = a.taps == 3 ? GEOA3_PROF_CONV5 : GEOA3_PROF_TNETWIDE;
   geoa3_prof_begin(tag, s);
   if (!a.keys_clean &&

@@ -9,7 +9,6 @@ There is no CPU forward: a CPU input raises.
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 from typing import Dict, Optional
 
@@ -129,13 +128,7 @@ def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
     out.update({k: v.float().contiguous() for k, v in t.items()})
     out["w5h"], out["w5h_unscale"] = pack_wide_split(out["w5"], 3)
     out["w4h"], out["w4h_unscale"] = pack_wide_split(out["w4"], 1)
-    out["w5h16"], un16 = pack_wide_split16(out["w5"])
-    # the two-pass form of conv5 (csrc/pointnet_wide16.hip): the mean's term needs sum_taps w5 (in float64, rounded once),
-    # the error bound |w5[c]| (rounded UP) and the absolute slack of the fp16 weight image per unit of activation norm
-    w5d = out["w5"].double()
-    out["w5_wsumt"] = w5d.view(-1, 3, 128).sum(1).t().float().contiguous()
-    out["w5_fnorm"] = torch.stack(((w5d.norm(dim=1) * (1.0 + 2.0 ** -22)).float(),
-                                   torch.full((w5d.shape[0],), un16 * 2.0 ** -25 * math.sqrt(384.0) * 1.01))).contiguous()
+    out["w5h16"], _ = pack_wide_split16(out["w5"])
     out["w4t_amax"] = float(out["w4t"].abs().max()) if os.environ.get("GEOA3_W2T_AMAX", "1") != "0" else 0.0
     return out
 
@@ -169,8 +162,7 @@ def ab_flags() -> int:
     """geoa3_pointnet_weights.flags from the A/B switches of the environment (read HERE, by the host side: the library
     itself reads no environment): GEOA3_FUSE_BWD=0 / GEOA3_FUSE_CHAIN=0 select the unfused kernels (same bits)."""
     return ((1 if os.environ.get("GEOA3_FUSE_BWD", "1") == "0" else 0) |
-            (2 if os.environ.get("GEOA3_FUSE_CHAIN", "1") == "0" else 0) |
-            (4 if os.environ.get("GEOA3_TWO_PASS", "1") == "0" else 0))
+            (2 if os.environ.get("GEOA3_FUSE_CHAIN", "1") == "0" else 0))
 
 
 class PackedPointNet:
@@ -193,7 +185,7 @@ class PackedPointNet:
         def pick(p: Dict[str, object], name: str):
             if name in ("w3h", "w5h", "w2h", "w4h") and (not split or (name in ("w2h", "w4h") and not fuse_front())):
                 return None
-            if name in ("w5h16", "w5_wsumt", "w5_fnorm") and (not split or wide_shape("conv5") != 16):
+            if name == "w5h16" and (not split or wide_shape("conv5") != 16):
                 return None
             if name == "w3h16" and (not split or wide_shape("tnet") != 16):
                 return None

@@ -181,7 +181,6 @@ typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 
 
 #define GEOA3_PN_NO_FUSE_BWD 1 /* sparse backward and the 128 -> 64 layer behind it as two kernels (same bits) */
 #define GEOA3_PN_NO_CHAIN 2    /* the 64-input layers one kernel each instead of chains (same bits) */
-#define GEOA3_PN_NO_TWO_PASS 4 /* conv5 as ONE three-product pass over every point (same arg-max up to fp32 ties) */
 typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 */
   int32_t classes;
   geoa3_tnet_weights t3, t64;
@@ -211,12 +210,6 @@ typedef struct geoa3_pointnet_weights {  /* PointNet, Model/PointNet.py:96-160 *
   const void *w5h16;        /* optional, with w5h: w5 in 16x16x32 fragment order (see t3.w3h16) */
   float w4t_amax;           /* optional: max |w4t| (see t3.w2t_amax) */
   int32_t flags;            /* GEOA3_PN_* bits; 0 = the default kernels */
-  /* optional, with w5h16 (both or neither): conv5 + max in TWO passes -- a one-product filter on the tile-centred
-   * activations with a rigorous error bound, then the exact evaluation (fp32 FMA) of the points that can still be a
-   * channel's maximum (1.2 of 1024 on average).  w5_wsumt [128][1024] = sum over the three taps of w5, transposed;
-   * w5_fnorm [2][1024] = |w5[c]| over its 384 entries (rounded up), then the absolute slack of the fp16 weight image per
-   * unit of the activations' norm (w5h_unscale * 2^-25 * sqrt(384)) */
-  const float *w5_wsumt, *w5_fnorm;
 } geoa3_pointnet_weights;
 
 /* bytes of scratch the forward+backward pair needs for a batch of B clouds of N points */

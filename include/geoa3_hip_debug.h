@@ -47,12 +47,6 @@ int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const
                         int Co, int relu, int split /* 1: split-fp16 operands */, void* stream);
 
 
-/* conv5 on the 16x16x32 kernel (variant 0), its one-product filter pass alone (variant = workgroups per CU: 2, 3, 4), or
- * the two-pass form filter + decide + refine (variant 10): tools/bench_filter.py */
-int geoa3_debug_wide16(const float* X, const void* Wh16, float unscale, const float* bias, float* out, int32_t* arg,
-                       void* keys, float* f_rec, float* f_mean, float* f_tile, const float* Wf, const float* wsumt,
-                       const float* wnorm, int32_t* f_list, int B, int N, int variant, void* stream);
-
 #ifdef __cplusplus
 }
 #endif
