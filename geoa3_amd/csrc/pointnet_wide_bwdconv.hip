@@ -57,13 +57,28 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   // list follows (chunk, tap, channel): ballot + popcount, no ordering left to chance.
   const int cpw = (a.Co + BW2_WAVES - 1) / BW2_WAVES, c_lo = wave * cpw, c_hi = min(a.Co, c_lo + cpw);
   const unsigned long long lt = (1ull << lane) - 1ull;
+  // a wave's channels are at most two chunks of 64 for Co = 1024: their (gradient, arg-max) pairs are loaded ONCE, both
+  // chunks in flight together, and serve the counting pass and the placement pass (they used to be re-read: two dependent
+  // L2 round trips of the ~16 us a workgroup lives)
+  constexpr int MAXCH = 2;
+  float gch[MAXCH];
+  int bch[MAXCH];
+  const bool regs = cpw <= 64 * MAXCH;
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch) {
+    const int co = c_lo + 64 * ch + lane;
+    const bool in = regs && co < c_hi;
+    gch[ch] = in ? gb[co] : 0.f;
+    bch[ch] = (in ? argb[co] : 0) - TAPS / 2 - m0;
+  }
   {
     int cnt = 0;
-    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+    int chn = 0;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64, ++chn) {
       const int co = c0 + lane;
       const bool in = co < c_hi;
-      const float g = in ? gb[co] : 0.f;
-      const int base = (in ? argb[co] : 0) - TAPS / 2 - m0;
+      const float g = regs ? (chn == 0 ? gch[0] : gch[1]) : (in ? gb[co] : 0.f);
+      const int base = regs ? (chn == 0 ? bch[0] : bch[1]) : ((in ? argb[co] : 0) - TAPS / 2 - m0);
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
         const int c = base + tap;
@@ -98,11 +113,12 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   __syncthreads();
   {
     int pos = s_wcnt[wave];
-    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+    int chn = 0;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64, ++chn) {
       const int co = c0 + lane;
       const bool in = co < c_hi;
-      const float g = in ? gb[co] : 0.f;
-      const int base = (in ? argb[co] : 0) - TAPS / 2 - m0;
+      const float g = regs ? (chn == 0 ? gch[0] : gch[1]) : (in ? gb[co] : 0.f);
+      const int base = regs ? (chn == 0 ? bch[0] : bch[1]) : ((in ? argb[co] : 0) - TAPS / 2 - m0);
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
         const int c = base + tap;
