@@ -29,7 +29,7 @@ prior = r.t["knn"][r.knn_cur].clone()
 r.step(150, 0)
 x = r.t["x"].clone()
 scratch = ops.knn_self_scratch(B, N, dev)
-for m in (1, 3, 4, 2, 5):
+for m in (1, 3, 4, 2):
     us = timeit(lambda: ops.knn_self_planar(x, K, prior=prior, scratch=scratch, method=m), 10)
     print("method %d: %.1f us" % (m, us))
 # candidates within tau
