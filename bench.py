@@ -183,7 +183,10 @@ def main():
     dev = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
     torch.cuda.set_device(dev)
     backend = os.environ.get("GEOA3_BENCH_BACKEND", "nccl")   # "gloo": functional test of the N>1 path on one GPU
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the process group is created even for ONE rank: a 1-GPU box then still runs the
+    # RCCL initialisation, the barriers and the device-tensor all-reduce of the N > 1 path
+    use_dist = "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -233,7 +236,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -267,7 +270,7 @@ def main():
         submit[0] = time.perf_counter() - t0      # host time to ENQUEUE the steps (== dt: the host is the bound)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -354,8 +357,8 @@ def main():
             "unit": "iterations/s of a 250-instance batch", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(host_submit_ms, 4),
             "higher_is_better": True,
-            "ranks_seen": dist.get_world_size() if world > 1 else 1,
-            "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
+            "ranks_seen": dist.get_world_size() if use_dist else 1,
+            "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if use_dist else None,
             "scaling": "weak" if mode == "weak" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
@@ -459,7 +462,7 @@ def main():
             except Exception as e:  # the baseline never blocks the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

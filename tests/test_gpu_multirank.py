@@ -67,6 +67,78 @@ def test_bench_spawns_its_own_ranks():
     assert out["config"]["instances_per_gpu"] == 125 and out["scaling"] == "strong"
 
 
+@pytest.mark.timeout(900)
+def test_bench_one_rank_over_rccl():
+    """The nccl (= RCCL) path on the one GPU a test box has: under a launcher bench.py creates the process group for a
+    single rank too -- RCCL initialisation with device_id, the barriers and the device-tensor all-reduce of the timing run
+    for real (several ranks on one device are refused by RCCL, so gloo carries the 2-rank tests above)."""
+    env = _env()
+    env.pop("GEOA3_BENCH_BACKEND")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps",
+           "4", "--warmup", "1", "--presteps", "2", "--single-mode", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=REPO, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out["backend"].startswith("rccl")
+    assert out["config"]["instances_per_gpu"] == 250
+
+
+_RCCL_WORKER = r"""
+import os, sys, pickle
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from oracle import geoa3_oracle as O
+from geoa3_amd.attack import AttackRunner, attack, unpack_input
+from geoa3_amd.distributed import sharded_attack
+from geoa3_amd.pointnet import PointNet
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+net = PointNet(40); net.load_state_dict(O.make_pointnet_state_dict(40, seed=0)); net = net.cuda().eval()
+cfg = O.AttackCfg(curv_loss_knn=8, binary_max_steps=2, iter_max_steps=5, lr=0.005, initial_const=500.0)
+ori, nrm = O.make_synthetic_clouds(5, 128, seed=43)
+with torch.no_grad():
+    gt = net(ori.cuda()).argmax(1).cpu()
+g = torch.Generator().manual_seed(6)
+inits = [torch.randn(5, 3, 128, generator=g) * 1e-3 for _ in range(2)]
+data = [ori.permute(0, 2, 1).unsqueeze(1).contiguous(), nrm.permute(0, 2, 1).unsqueeze(1).contiguous(), gt.view(5, 1)]
+pc, nm, g_, t_ = unpack_input(data, False)
+
+def run_shard(pc, normal, gt_, tgt_, inits_, global_batch, sync):
+    r = AttackRunner(net, pc.shape[0], pc.shape[2], cfg, dev, global_batch)
+    r.setup(pc, normal, gt_, tgt_)
+    r.run([o.to(dev) for o in inits_], sync_last_label=sync)
+    return r.results()
+
+out = sharded_attack(run_shard, pc, nm, g_, t_, inits)      # broadcast + all_gather of DEVICE tensors through RCCL
+full = attack(net, data, cfg, 0, 1, init_offsets=[i.cuda() for i in inits], verbose=False)
+res = dict(backend=dist.get_backend(), bit_equal=bool(torch.equal(out[0].cpu(), full[0].cpu())),
+           succ=bool((np.asarray(out[2]) == np.asarray(full[2])).all()), steps=list(out[3]) == list(full[3]),
+           loss=float(np.abs(np.asarray(out[4], dtype=np.float64) - np.asarray(full[4], dtype=np.float64)).max()))
+pickle.dump(res, open({out!r}, "wb"))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(900)
+def test_sharded_attack_collectives_over_rccl_one_rank(tmp_path):
+    """geoa3_amd.distributed on the nccl backend (one rank): the last-label broadcast and the ragged all-gathers move
+    device tensors through RCCL and return the single-process result bit for bit."""
+    script, outp = tmp_path / "worker.py", tmp_path / "res.pkl"
+    script.write_text(_RCCL_WORKER.format(repo=REPO, out=str(outp)))
+    env = _env()
+    env.pop("GEOA3_BENCH_BACKEND")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=REPO, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import pickle
+    res = pickle.load(open(outp, "rb"))
+    assert res["backend"] == "nccl" and res["bit_equal"] and res["succ"] and res["steps"] and res["loss"] == 0.0, res
+
+
 _WORKER = r"""
 import os, sys, pickle
 import numpy as np, torch, torch.distributed as dist
