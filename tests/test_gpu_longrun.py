@@ -28,7 +28,12 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 # bars (relative unless noted); see DESIGN.md section 2, row "long run"
 BEST_RTOL = {"n256_b8": 0.05, "n1024_b4": 0.05, "n256_b8_hard": 0.10}   # best constrain loss per instance
-WINDOW_RTOL = {"n256_b8": 0.01, "n1024_b4": 0.01, "n256_b8_hard": 0.01}   # 50-step window means of loss_n (batch mean)
+# 50-step window means of loss_n (batch mean).  The bar is set by the chaos of the loop itself, measured with
+# tools/longrun_noise.py (profiles/round3_longrun_noise.txt): 13 deterministic runs whose start is perturbed by k*1e-7
+# spread over 0.2-0.5 % (median) / 1.1 % (max) of the reference's window means, 13 repeats of the atomics loop over
+# 0.3 % / 1.5 %; the CPU oracle under the same perturbation: 0.05-0.25 % (4 runs).  Constrain windows: 2 x this bar
+# (observed max 3.9 %).
+WINDOW_RTOL = {"n256_b8": 0.025, "n1024_b4": 0.025, "n256_b8_hard": 0.025}
 ROBUST_STEPS = 3         # an instance counts as robustly (un)successful in a binary step with >= 3 / 0 adversarial steps
 
 
@@ -162,7 +167,7 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
             a2, c2 = got_con[s, w:w + 50].mean(), ref_con[s, w:w + 50].mean()
             rows.append([s, w, float(a), float(c), float(a2), float(c2)])
             chk(abs(a - c) <= wr * abs(c) + 1e-3, "loss_n window", s, w, a, c)
-            chk(abs(a2 - c2) <= 5 * wr * abs(c2) + 1e-6, "constrain window", s, w, a2, c2)   # (4-8 instances: observed <= 3.2 %)
+            chk(abs(a2 - c2) <= 2 * wr * abs(c2) + 1e-6, "constrain window", s, w, a2, c2)
     report["windows"] = rows
     # the first iterations are still a shared trajectory: tight
     dev = np.abs(out["loss_n"][0, :12] - g[pre + "tr_loss_n"][0, :12]) / (np.abs(g[pre + "tr_loss_n"][0, :12]) + 0.1)
