@@ -394,7 +394,13 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
                                                              int32_t* __restrict__ idx) {
   __shared__ __attribute__((aligned(16))) float s_ref[3 * SK_CHUNK];
   __shared__ __attribute__((aligned(16))) uint16_t s_id[SK_CHUNK];
-  __shared__ __attribute__((aligned(16))) uint16_t s_pos[SP_CAP * SK_BLOCK];
+  // !MULTI: the lists' LDS also holds, before the scan, the cloud in ORIGINAL order and last iteration's lists (the seed
+  // radius is formed from LDS, not by 4 K scattered loads per thread) and, after it, the sorted rows on their way out
+  constexpr int SP_KMAX = 20;
+  constexpr int SP_SEED = 3 * SK_CHUNK * 4 + SK_BLOCK * SP_KMAX * 2;
+  constexpr int SP_UNION = !MULTI && SP_SEED > SP_CAP * SK_BLOCK * 2 ? SP_SEED : SP_CAP * SK_BLOCK * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char s_un[SP_UNION];
+  uint16_t* const s_pos = reinterpret_cast<uint16_t*>(s_un);
   __shared__ int s_lo, s_hi;
   const int b = blockIdx.y, tid = threadIdx.x;
   const int pos = blockIdx.x * SK_BLOCK + tid;
@@ -412,7 +418,36 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
     s_hi = -1;
   }
   float tau = S_INF;
-  if (prior != nullptr && live) {
+  if (!MULTI && prior != nullptr) {
+    // The seed radius: the largest distance to last iteration's K neighbours.  The cloud (original order) and the
+    // workgroup's 256 rows of the old table are staged through LDS with coalesced loads (a wavefront fetches ITS 64 rows:
+    // 64 K consecutive elements of ~4 rows per load instruction instead of 64 rows), then every thread walks its row.
+    float* const s_org = reinterpret_cast<float*>(s_un);
+    uint16_t* const s_pri = reinterpret_cast<uint16_t*>(s_un + 3 * SK_CHUNK * 4);
+    for (int j = tid; j < 3 * N; j += SK_BLOCK) s_org[j] = Rb[j];
+    s_id[tid] = (uint16_t)qo;
+    __syncthreads();
+    const int w0 = tid & ~63, lane = tid & 63;
+    const float inv_k = 1.0f / (float)K;
+    for (int e = lane; e < 64 * K; e += 64) {
+      const int row = (int)(((float)e + 0.5f) * inv_k), m = e - row * K;
+      const int32_t v = prior[((size_t)b * N + s_id[w0 + row]) * K + m];
+      s_pri[w0 * K + e] = (uint16_t)(v < 0 || v >= N ? 0xffff : v);
+    }
+    __syncthreads();
+    if (live) {
+      float t = 0.f;
+      bool ok = true;
+      for (int m = 0; m < K; ++m) {
+        const unsigned j = s_pri[tid * K + m];
+        ok = ok && j != 0xffffu;
+        const int jc = j >= (unsigned)N ? N - 1 : (int)j;
+        t = fmaxf(t, geoa3_sqdist(qx, qy, qz, s_org[jc], s_org[N + jc], s_org[2 * N + jc]));
+      }
+      if (ok) tau = t;
+    }
+  }
+  if (MULTI && prior != nullptr && live) {
     const int32_t* pr = prior + ((size_t)b * N + qo) * K;
     float t = 0.f;
     bool ok = true;
@@ -458,8 +493,8 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
   // positions -> keys in registers: distance bits : original index : position (indices are distinct, so the position
   // never decides an order; it rides along for the write-back); ~0 beyond the list
   unsigned long long key[SP_CAP];
-  auto load_keys = [&](int cnt) {
-    sp_static_for<SP_CAP>([&](auto S_) {
+  auto load_keys = [&](auto C_, int cnt) {
+    sp_static_for<decltype(C_)::value>([&](auto S_) {
       constexpr int s = decltype(S_)::value;
       unsigned p = s_pos[s * SK_BLOCK + tid];
       float d;
@@ -478,10 +513,10 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
     });
   };
   // rank of entry s = the number of smaller keys; no rank array -- the caller uses the rank at once (registers)
-  auto rank_of = [&](auto S_) {
+  auto rank_of = [&](auto C_, auto S_) {
     constexpr int s = decltype(S_)::value;
     int r = 0;
-    sp_static_for<SP_CAP>([&](auto J_) {
+    sp_static_for<decltype(C_)::value>([&](auto J_) {
       constexpr int j = decltype(J_)::value;
       if constexpr (j != s) sp_count_less(r, key[j], key[s]);
     });
@@ -524,10 +559,10 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
       if (__builtin_expect(__any(poff > (unsigned)(SP_CAP - 4) * 2u * SK_BLOCK + 2u * SK_BLOCK - 1u), 0)) {   // cnt > CAP - 4
         const int cnt = (int)(poff >> 9);
         if (cnt >= K) {   // keep the K best (in order), tighten the radius; every old slot is in a register by now
-          load_keys(cnt);
+          load_keys(std::integral_constant<int, SP_CAP>{}, cnt);
           sp_static_for<SP_CAP>([&](auto S_) {
             constexpr int s = decltype(S_)::value;
-            const int r = rank_of(S_);
+            const int r = rank_of(std::integral_constant<int, SP_CAP>{}, S_);
             if (r < K) s_pos[r * SK_BLOCK + tid] = (uint16_t)key[s];
             if (r == K - 1) tau = __uint_as_float((unsigned)(key[s] >> 32));
           });
@@ -545,23 +580,72 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
     c_hi = N;
   }
 
-  if (live) {
-    const int cnt = (int)(poff >> 9);
-    const int keep = cnt < K ? cnt : K;
-    load_keys(cnt);
-    float* od = dists + ((size_t)b * N + qo) * K;
-    int32_t* oi = idx + ((size_t)b * N + qo) * K;
-    sp_static_for<SP_CAP>([&](auto S_) {
-      constexpr int s = decltype(S_)::value;
-      const int r = rank_of(S_);
-      if (r < keep) {
-        od[r] = __uint_as_float((unsigned)(key[s] >> 32));
-        oi[r] = (int32_t)((key[s] >> 16) & 0xffffu);
+  if constexpr (MULTI) {
+    if (live) {
+      const int cnt = (int)(poff >> 9);
+      const int keep = cnt < K ? cnt : K;
+      constexpr std::integral_constant<int, SP_CAP> C_{};
+      load_keys(C_, cnt);
+      float* od = dists + ((size_t)b * N + qo) * K;
+      int32_t* oi = idx + ((size_t)b * N + qo) * K;
+      sp_static_for<SP_CAP>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        const int r = rank_of(C_, S_);
+        if (r < keep) {
+          od[r] = __uint_as_float((unsigned)(key[s] >> 32));
+          oi[r] = (int32_t)((key[s] >> 16) & 0xffffu);
+        }
+      });
+      for (int m = keep; m < K; ++m) {   // fewer than K points in the cloud
+        od[m] = S_INF;
+        oi[m] = -1;
       }
-    });
-    for (int m = keep; m < K; ++m) {   // fewer than K points in the cloud
-      od[m] = S_INF;
-      oi[m] = -1;
+    }
+  } else {
+    // The final ranking at the length the wavefront's lists actually have -- seeded, a list holds the K old neighbours
+    // plus the few points that came inside their radius: 20 or 28 slots instead of SP_CAP (every pair of slots is
+    // compared: 380 / 756 pairs instead of 1560); the same keys in the same order either way.  The sorted rows leave
+    // through LDS: a row is K consecutive floats, so 64 consecutive elements of the workgroup's 256 K are ~4 rows per
+    // store instruction instead of 64 (measured: the scattered stores were a quarter of the kernel).
+    const int cnt = live ? (int)(poff >> 9) : 0;
+    const int keep = cnt < K ? cnt : K;
+    const int cls = !__any(cnt > 20) ? 0 : (!__any(cnt > 28) ? 1 : 2);       // uniform over the wavefront
+    constexpr std::integral_constant<int, 20> C20{};
+    constexpr std::integral_constant<int, 28> C28{};
+    constexpr std::integral_constant<int, SP_CAP> CXX{};
+    if (cls == 0) load_keys(C20, cnt);
+    else if (cls == 1) load_keys(C28, cnt);
+    else load_keys(CXX, cnt);
+    __syncthreads();                       // every list, the staged run and its ids are in registers: the LDS is free
+    float* const s_od = reinterpret_cast<float*>(s_un);          // [256][K]
+    uint16_t* const s_oi = reinterpret_cast<uint16_t*>(s_ref);   // [256][K]
+    s_id[tid] = (uint16_t)qo;
+    for (int m = keep; m < K; ++m) {       // fewer than K points in the cloud (and the padding lanes)
+      s_od[tid * K + m] = S_INF;
+      s_oi[tid * K + m] = 0xffff;
+    }
+    auto rank_out = [&](auto C_) {
+      sp_static_for<decltype(C_)::value>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        const int r = rank_of(C_, S_);
+        if (r < keep) {
+          s_od[tid * K + r] = __uint_as_float((unsigned)(key[s] >> 32));
+          s_oi[tid * K + r] = (uint16_t)(key[s] >> 16);
+        }
+      });
+    };
+    if (cls == 0) rank_out(C20);
+    else if (cls == 1) rank_out(C28);
+    else rank_out(CXX);
+    __syncthreads();
+    const float inv_k = 1.0f / (float)K;
+    const int rows = min(SK_BLOCK, N - (int)blockIdx.x * SK_BLOCK);
+    for (int e = tid; e < rows * K; e += SK_BLOCK) {
+      const int row = (int)(((float)e + 0.5f) * inv_k), m = e - row * K;
+      const size_t o = ((size_t)b * N + s_id[row]) * K + m;
+      const unsigned v = s_oi[e];
+      dists[o] = s_od[e];
+      idx[o] = v == 0xffffu ? -1 : (int32_t)v;
     }
   }
 }
