@@ -5,6 +5,7 @@
 // launch).  Phases (1)-(3) are those of wide_max_bwd2_kernel: same hit lists, same sums in the same order.
 // Reference: the autograd of Model/PointNet.py:80-82,146-147 (conv3 / conv5 + max, conv2 / conv4 + relu).
 #include "pointnet_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -29,10 +30,14 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   int* s_flat = reinterpret_cast<int*>(smem);                           // [Co * TAPS] hits in (channel chunk, tap, channel) order
   float* s_fg = smem + a.Co * TAPS;                                     // [Co * TAPS] their upstream gradients
   const int region = max(COLS * BC_PT, 2 * a.Co * TAPS);
-  int* s_list = reinterpret_cast<int*>(smem + region);                  // [Co * TAPS] (co * TAPS + tap) | (column << 16), by column
+  // the hits by column: (co * TAPS + tap) | (column << 16); one tap: co | (column << 10) in 16 bits -- with the side rows
+  // doubling as the first layer's table (GF) the workgroup stays under 40 KB of LDS: four per CU instead of three
+  using list_t = typename std::conditional<TAPS == 1, uint16_t, int>::type;
+  constexpr int LSH = TAPS == 1 ? 10 : 16;
+  list_t* s_list = reinterpret_cast<list_t*>(smem + region);            // [Co * TAPS]
   // (a hit's upstream gradient is read again from g in the walk -- an L2 hit beside the weight row it multiplies --
   //  instead of being carried in a second list: 12 KB of LDS less at three taps, one more workgroup per CU)
-  int* s_off = s_list + a.Co * TAPS;                                    // [COLS + 1] column counts -> start offsets
+  int* s_off = reinterpret_cast<int*>(smem + region) + (TAPS == 1 ? a.Co / 2 : a.Co * TAPS);   // [COLS + 1] column counts -> start offsets
   int* s_wcnt = s_off + COLS + 1;                                       // [BW2_WAVES + 1] hits found by each wave -> offsets
   int* s_sidecol = s_wcnt + BW2_WAVES + 1;                              // [BW2_WAVES]
   float* s_side = reinterpret_cast<float*>(s_sidecol + BW2_WAVES);      // [BW2_WAVES][128]
@@ -47,8 +52,10 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   const int qt = wave & 1, qc = (wave >> 1) & 1;     // waves 0-3: output rows 32 qt .., columns 32 qc ..
   const float* wr = a.W2t + (size_t)(32 * qt + (lane & 31)) * WM_CI + 8 * (lane >> 5);
 
-  float4* s_w1 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s_mx + 16) + 15) & ~(uintptr_t)15);   // GF: [64] (w1 row, b1), then [2][32] partial d x
-  if (GF && tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
+  // GF: [64] (w1 row, b1), then [2][32] partial d x -- in the side rows, once the walk is done with them
+  float4* s_w1 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s_side) + 15) & ~(uintptr_t)15);
+  float4 w1row = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (GF && tid < 64) w1row = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
   const float* gb = a.g + (size_t)b * a.Co;
   const int* argb = a.arg + (size_t)b * a.Co;
   if (tid <= COLS) s_off[tid] = 0;
@@ -144,7 +151,6 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     for (int i0 = 0; i0 < total; i0 += 64) {
       const int i = i0 + lane;
       const int e = i < total ? s_flat[i] : -1;
-      const float g = i < total ? s_fg[i] : 0.f;
       const int col = e >> 16;     // -1 for the padding lanes
 #pragma unroll
       for (int j = 0; j < COLS / BW2_WAVES; ++j) {
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
         const unsigned long long mask = __ballot(mine);
         if (mine) {
           const int slot = basec[j] + __popcll(mask & lt);
-          s_list[slot] = e;
+          s_list[slot] = TAPS == 1 ? (list_t)((e & 0xffff) | ((e >> 16) << LSH)) : (list_t)e;
         }
         basec[j] += __popcll(mask);
       }
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     // the column of hit lo started in an earlier share <=> lo is not the first entry of that column's list
     int side_col = -1;
     if (lo < hi) {
-      const int c0 = s_list[lo] >> 16;
+      const int c0 = (int)s_list[lo] >> LSH;
       if (lo > s_off[c0]) side_col = c0;
     }
     bool in_side = side_col >= 0;
@@ -195,10 +201,11 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const bool ok = h0 + u < hi;
-        const int e = s_list[ok ? h0 + u : hi - 1];
-        w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)(e & 0xffff) * ldW + 2 * lane);
-        gg[u] = ok ? gb[(e & 0xffff) / TAPS] : 0.f;
-        cc[u] = ok ? e >> 16 : -2;
+        const int e = (int)s_list[ok ? h0 + u : hi - 1];
+        const int er = e & ((1 << LSH) - 1);
+        w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)er * ldW + 2 * lane);
+        gg[u] = ok ? gb[er / TAPS] : 0.f;
+        cc[u] = ok ? e >> LSH : -2;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     }
   }
   __syncthreads();
+  if (GF && tid < 64) s_w1[tid] = w1row;    // (read behind the next barriers)
   // (4) the 128 -> 64 layer behind it, on the tile while it is in LDS: gate by the relu bits of the 128-channel
   // activation, tile maximum -> power-of-two scale; four waves take one 32 x 32 quadrant of W2^T tile each on the f16
   // matrix core (a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi as in pointnet_conv_split.hip; W2^T's fragments were requested
@@ -354,12 +362,12 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
 
 int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s) {
   const bool gf = a.dx3 != nullptr;   // first-layer form: x3, w1, b1, dx3 instead of Zmask2 / dY
-  if ((a.taps != 1 && a.taps != 3) || !a.Zmask || !a.W2t || a.Co * a.taps > 0xffff ||
+  if ((a.taps != 1 && a.taps != 3) || !a.Zmask || !a.W2t || a.Co * a.taps > 0xffff || (a.taps == 1 && a.Co > 1024) ||
       (gf ? (!a.x3 || !a.w1 || !a.b1 || a.taps != 1) : (!a.Zmask2 || !a.dY)))
     return GEOA3_ENOSUPPORT;
   dim3 grid((a.N + 63) / 64, a.B);
   const size_t region = (size_t)64 * BC_PT > 2 * (size_t)a.Co * a.taps ? (size_t)64 * BC_PT : 2 * (size_t)a.Co * a.taps;
-  const size_t lds = (region + (size_t)a.Co * a.taps + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 16 + 3 + 4 + 512) * sizeof(float);
+  const size_t lds = (region + (a.taps == 1 ? (size_t)a.Co / 2 : (size_t)a.Co * a.taps) + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 16 + 3 + 4) * sizeof(float);
   if (a.taps == 1 && a.dx3) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_conv_kernel<1, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
