@@ -472,8 +472,10 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
   }
   if (!live) tau = -1.f;  // padding lanes never collect candidates
   __syncthreads();
+  int blo = SB_NB, bhi = -1;
   if (live) {
-    int blo = 0, bhi = SB_NB - 1;
+    blo = 0;
+    bhi = SB_NB - 1;
     if (tau < S_INF) {
       const float qa = g.axis == 0 ? qx : (g.axis == 1 ? qy : qz);
       const float r = sqrtf(tau) * 1.00001f + 1e-30f;
@@ -483,6 +485,10 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
     atomicMin(&s_lo, blo);
     atomicMax(&s_hi, bhi);
   }
+  // the workgroup stages the union of its 256 windows; a WAVEFRONT scans only the union of its own 64 (the queries are
+  // consecutive along the slab axis: ~2/3 of the workgroup's run)
+  const int w_blo = -(int)wave_max(-(float)blo), w_bhi = (int)wave_max((float)bhi);
+  int wv_lo = w_blo <= w_bhi ? bs[w_blo] : 0, wv_hi = w_blo <= w_bhi ? bs[w_bhi + 1] : 0;
   __syncthreads();
   int c_lo = bs[s_lo], c_hi = bs[s_hi + 1];
 
@@ -537,10 +543,11 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
       s_id[j] = ok ? (uint16_t)Ib[c0 + j] : (uint16_t)0;
     }
     __syncthreads();
-    float4 nx = *reinterpret_cast<const float4*>(&s_ref[0]);
-    float4 ny = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK]);
-    float4 nz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK]);
-    for (int j = 0; j < cn4; j += 4) {
+    const int j_lo = min(max(wv_lo - c0, 0), SK_CHUNK - 4) & ~3, j_hi = (min(wv_hi - c0, cn) + 3) & ~3;
+    float4 nx = *reinterpret_cast<const float4*>(&s_ref[j_lo]);
+    float4 ny = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK + j_lo]);
+    float4 nz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK + j_lo]);
+    for (int j = j_lo; j < j_hi; j += 4) {
       const float4 rx = nx, ry = ny, rz = nz;
       const int jn = j + 4 < SK_CHUNK ? j + 4 : j;
       nx = *reinterpret_cast<const float4*>(&s_ref[jn]);
@@ -578,6 +585,8 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
     poff = 2u * tid;
     c_lo = 0;
     c_hi = N;
+    wv_lo = 0;
+    wv_hi = N;
   }
 
   if constexpr (MULTI) {
