@@ -168,6 +168,7 @@ class AttackRunner:
                       else self.lib.geoa3_pointnet_workspace_bytes(bw, ne, self.classes))
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.state: Optional[AttackState] = None
+        self._ws_fwd_shape = None       # (B, N) of the last victim forward that used self.ws
 
     # ------------------------------------------------------------------------------------
     def _p(self, x: Optional[Tensor]):
@@ -243,8 +244,22 @@ class AttackRunner:
 
     def _native_forward(self, pts: Tensor, out: Tensor, s: int):
         fn = self.lib.geoa3_pn2ssg_forward if self.ssg else self.lib.geoa3_pointnet_forward
-        check(fn(C.byref(self.packed.struct), pts.data_ptr(), pts.shape[0], pts.shape[2], out.data_ptr(),
-                 self.ws.data_ptr(), s), "victim forward")
+        st = self.packed.struct
+        shape = (int(pts.shape[0]), int(pts.shape[2]))
+        # PointNet: a forward of the same shape as the last one on this workspace finds its arg-max keys zero already
+        # (GEOA3_PN_KEYS_CLEAN: no clearing launch); the weight table is shared with the module, so the bit is set for
+        # this call only
+        clean = not self.ssg and self._ws_fwd_shape == shape
+        self._ws_fwd_shape = None
+        if clean:
+            st.flags |= 4
+        try:
+            check(fn(C.byref(st), pts.data_ptr(), pts.shape[0], pts.shape[2], out.data_ptr(), self.ws.data_ptr(), s),
+                  "victim forward")
+        finally:
+            if clean:
+                st.flags &= ~4
+        self._ws_fwd_shape = shape
 
     def _native_backward(self, pts: Tensor, dlogits: Tensor, dx: Tensor, s: int):
         fn = self.lib.geoa3_pn2ssg_backward if self.ssg else self.lib.geoa3_pointnet_backward

@@ -91,6 +91,7 @@ thread_local int tl_split = 0;
 // geoa3_pointnet_weights.flags (A/B switches, set by the caller: the library reads no environment):
 // GEOA3_PN_NO_FUSE_BWD: the sparse backward and the 128 -> 64 layer behind it as two kernels;
 // GEOA3_PN_NO_CHAIN: the trunk's 64-input layers as one kernel each instead of chains.  Same bits either way.
+// GEOA3_PN_KEYS_CLEAN: see include/geoa3_hip.h.
 thread_local int tl_flags = 0;
 bool fuse_bwd() { return !(tl_flags & GEOA3_PN_NO_FUSE_BWD); }
 bool fuse_chain() { return !(tl_flags & GEOA3_PN_NO_CHAIN); }
@@ -284,7 +285,9 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   const geoa3_pointnet_weights& p = *pw;
   tl_split = p.w5h != nullptr;
   tl_flags = p.flags;
-  if (hipMemsetAsync(w.keys, 0, (size_t)B * 1024 * sizeof(unsigned long long), s) != hipSuccess) return GEOA3_ELAUNCH;
+  if (!(p.flags & GEOA3_PN_KEYS_CLEAN) &&
+      hipMemsetAsync(w.keys, 0, (size_t)B * 1024 * sizeof(unsigned long long), s) != hipSuccess)
+    return GEOA3_ELAUNCH;
   // input transform (Model/PointNet.py:137-138)
   TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
   const bool chain = tl_split && fuse_chain();

@@ -390,7 +390,6 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_max_bwd2_kernel(WideBwdArgs 
     for (int i0 = 0; i0 < total; i0 += 64) {
       const int i = i0 + lane;
       const int e = i < total ? s_flat[i] : -1;
-      const float g = i < total ? s_fg[i] : 0.f;
       const int col = e >> 16;     // -1 for the padding lanes
 #pragma unroll
       for (int j = 0; j < COLS / BW2_WAVES; ++j) {
