@@ -150,33 +150,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float4* s_w1 = reinterpret_cast<float4*>(cc_smem + NBLK * CC_BLK);   // [64] (w1 row, b1)
   float* s_red = reinterpret_cast<float*>(s_w1 + 64);                  // [NBLK][4 waves]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cblk = blockIdx.x, b = blockIdx.y;
-  const int col = cblk * 256 + wave * 64 + lane;
-  const bool live = col < a.N, wave_live = cblk * 256 + wave * 64 < a.N;
-  const unsigned long long livemask = __builtin_amdgcn_ballot_w64(live);
-  const size_t mword = ((size_t)b * ((a.N + 63) >> 6) + (size_t)(cblk * 4 + wave));   // x Co: gate words [B][column block][row]
-
-  float o[64];   // this lane's point: the 64 input rows of the current stage
-  float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-  if (FIRST) {
-    const float* xp = a.x3 + (size_t)b * 3 * a.N + (live ? col : a.N - 1);
-    const float x0 = xp[0], x1 = xp[a.N], x2 = xp[2 * (size_t)a.N];
-    p0 = x0;
-    p1 = x1;
-    p2 = x2;
-    if (a.T3) {   // bmm(pc^T, T)^T : x'[c] = sum_d x[d] T[d][c]   (Model/PointNet.py:138)
-      const float* t = a.T3 + (size_t)b * 9;
-      p0 = x0 * t[0] + x1 * t[3] + x2 * t[6];
-      p1 = x0 * t[1] + x1 * t[4] + x2 * t[7];
-      p2 = x0 * t[2] + x1 * t[5] + x2 * t[8];
-    }
-    if (tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
-  } else {   // all 64 rows in flight at once
-    const float* X = a.X + (size_t)b * a.sXb;      // uniform row base + lane offset: scalar-base addressing
-    const unsigned xc = (unsigned)(live ? col : a.N - 1);
-#pragma unroll
-    for (int u = 0; u < 64; ++u) o[u] = (X + (size_t)u * a.ldX)[xc];
-  }
+  const int b = blockIdx.y;
+  const int nblk256 = (a.N + 255) >> 8;
+  if (FIRST && tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
 
   // ---- weights of every stage: 64 x 64 values per block, 16 per thread (element e = tid + 256 i: row e / 64, k = e % 64),
   // the block's maximum, its power-of-two scale, the two fp16 images in LDS; per-row bias, one row per lane
@@ -198,9 +174,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
   }
+  // The workgroup's column blocks of 256 points (gridDim.x workgroups per instance share them round robin: the weight
+  // images above are built once per workgroup, and a launch of 1000 blocks becomes ONE round of 500 workgroups on the 512
+  // slots of the chip instead of two rounds of which the second is 95 % full).  No barrier below: the waves run apart.
+  for (int cblk = blockIdx.x; cblk < nblk256; cblk += gridDim.x) {
+  const int col = cblk * 256 + wave * 64 + lane;
+  const bool live = col < a.N, wave_live = cblk * 256 + wave * 64 < a.N;
+  const unsigned long long livemask = __builtin_amdgcn_ballot_w64(live);
+  const size_t mword = ((size_t)b * ((a.N + 63) >> 6) + (size_t)(cblk * 4 + wave));   // x Co: gate words [B][column block][row]
+  float o[64];   // this lane's point: the 64 input rows of the current stage
   if (FIRST) {
+    const float* xp = a.x3 + (size_t)b * 3 * a.N + (live ? col : a.N - 1);
+    const float x0 = xp[0], x1 = xp[a.N], x2 = xp[2 * (size_t)a.N];
+    float p0 = x0, p1 = x1, p2 = x2;
+    if (a.T3) {   // bmm(pc^T, T)^T : x'[c] = sum_d x[d] T[d][c]   (Model/PointNet.py:138)
+      const float* t = a.T3 + (size_t)b * 9;
+      p0 = x0 * t[0] + x1 * t[3] + x2 * t[6];
+      p1 = x0 * t[1] + x1 * t[4] + x2 * t[7];
+      p2 = x0 * t[2] + x1 * t[5] + x2 * t[8];
+    }
 #pragma unroll
     for (int u = 0; u < 64; ++u) o[u] = fmaxf(cc_first_layer(s_w1[u], p0, p1, p2), 0.f);
+  } else {   // all 64 rows in flight at once
+    const float* X = a.X + (size_t)b * a.sXb;      // uniform row base + lane offset: scalar-base addressing
+    const unsigned xc = (unsigned)(live ? col : a.N - 1);
+#pragma unroll
+    for (int u = 0; u < 64; ++u) o[u] = (X + (size_t)u * a.ldX)[xc];
   }
 
 #pragma unroll
@@ -242,6 +241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int r = 0; r < 64; ++r) o[r] = res[r];
     }
+  }
   }
 }
 
@@ -376,7 +376,10 @@ void launch_chain(const ConvChainArgs& a, hipStream_t s) {
   auto kern = conv_chain_kernel<NS, FIRST, COL>;
   // (up to 74 KB of dynamic LDS)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3((a.N + 255) / 256, a.B), dim3(256), lds, s, a);
+  // two column blocks per workgroup when that still leaves more than one round of workgroups (never for a small shard)
+  const int nblk = (a.N + 255) / 256;
+  const int gx = (size_t)nblk * a.B > 768 ? (nblk + 1) / 2 : nblk;
+  hipLaunchKernelGGL(kern, dim3(gx, a.B), dim3(256), lds, s, a);
 }
 
 }  // namespace
