@@ -92,6 +92,29 @@ def test_pointnet_batch_rows_independent_full_size(clouds):
         assert torch.equal(xs.grad, x.grad[lo:hi])            # the input gradient is deterministic and per-row
 
 
+def test_pointnet_full_size_is_run_to_run_deterministic(clouds):
+    """Three evaluations of the same 250-instance batch: logits and input gradient equal bit for bit (a race in a
+    kernel shows here every time; the row-independence test above only sees it when the two launches differ)."""
+    from geoa3_amd.data import synthetic_state_dict
+    from geoa3_amd.pointnet import PointNet
+    _, _, adv = clouds
+    net = PointNet(40)
+    net.load_state_dict(synthetic_state_dict(40, seed=0))
+    net = net.cuda().eval()
+    w = torch.randn(B, 40, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    ref = None
+    for _ in range(3):
+        x = adv.clone().requires_grad_()
+        out = net(x)
+        (out * w).sum().backward()
+        cur = (out.detach().clone(), x.grad.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur[0], ref[0])
+            assert torch.equal(cur[1], ref[1])
+
+
 def test_full_config2_attack_smoke_statistics():
     """2 binary steps x 60 iterations of the real config (B=250): every instance's loss history is finite, the
     success mask matches best_step, and recorded adversarial clouds really fool the network."""
