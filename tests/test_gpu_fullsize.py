@@ -115,6 +115,35 @@ def test_pointnet_full_size_is_run_to_run_deterministic(clouds):
             assert torch.equal(cur[1], ref[1])
 
 
+def test_attack_loop_full_size_is_run_to_run_deterministic(clouds):
+    """Two runs of 30 inner iterations of the full objective at B = 250 (deterministic gradient sums, both streams):
+    iterate, Adam state and loss history equal bit for bit."""
+    import bench
+    from geoa3_amd.attack import AttackRunner
+    from geoa3_amd.data import synthetic_state_dict
+    from geoa3_amd.pointnet import PointNet
+    ori, nrm, _ = clouds
+    net = PointNet(40)
+    net.load_state_dict(synthetic_state_dict(40, seed=0))
+    net = net.cuda().eval()
+    with torch.no_grad():
+        gt = net(ori).argmax(1)
+    steps = 30
+    init = (torch.randn(B, 3, N, generator=torch.Generator().manual_seed(11)) * 1e-3).cuda()
+    res = []
+    for _ in range(2):
+        cfg = bench.cfg_full_geoa3(steps + 4, N, K - 1)
+        r = AttackRunner(net, B, N, cfg, torch.device("cuda"))
+        r.setup(ori, nrm, gt, gt)
+        r.begin_search_step(init)
+        for s in range(steps):
+            r.step(s, 0)
+        torch.cuda.synchronize()
+        res.append({k: r.t[k].clone() for k in ("x", "m", "v", "loss_hist")})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
 def test_full_config2_attack_smoke_statistics():
     """2 binary steps x 60 iterations of the real config (B=250): every instance's loss history is finite, the
     success mask matches best_step, and recorded adversarial clouds really fool the network."""
