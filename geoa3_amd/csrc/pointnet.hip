@@ -65,7 +65,7 @@ Ws carve(void* base, int B, int N, int classes) {
   w.g256 = (float*)take(b * 256);
   w.gT64 = (float*)take(b * 4096);
   w.gT3 = (float*)take(b * 16);
-  w.dTpart = (float*)take(b * 9 * (size_t)((N + 255) / 256));
+  w.dTpart = (float*)take(b * GEOA3_DT_PITCH * (size_t)((N + 255) / 256));
   const size_t n64 = (size_t)(N + 63) / 64;
   w.m_a2 = (unsigned long long*)take(b * 128 * n64 * 2);
   w.m_h2 = (unsigned long long*)take(b * 64 * n64 * 2);

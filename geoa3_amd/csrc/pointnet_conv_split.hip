@@ -440,9 +440,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 &&
         if (lane == 0) s_part[wave * 9 + i] = v;
       }
       __syncthreads();
-      if (tid < 9)
-        a.dTpart[((size_t)b * gridDim.y + cblk) * 9 + tid] =
+      if (tid < 9) {
+        a.dTpart[((size_t)b * gridDim.y + cblk) * GEOA3_DT_PITCH + tid] =
             s_part[tid] + s_part[9 + tid] + s_part[18 + tid] + s_part[27 + tid];
+        geoa3_release_stores();    // the next kernel reads these at once (common.h)
+      }
     }
   }
 }

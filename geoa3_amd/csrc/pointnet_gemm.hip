@@ -223,9 +223,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         if (lane == 0) s_part[wave * 9 + i] = v;
       }
       __syncthreads();
-      if (tid < 9)
-        a.dTpart[((size_t)b * gridDim.x + blockIdx.x) * 9 + tid] =
+      if (tid < 9) {
+        a.dTpart[((size_t)b * gridDim.x + blockIdx.x) * GEOA3_DT_PITCH + tid] =
             s_part[tid] + s_part[9 + tid] + s_part[18 + tid] + s_part[27 + tid];
+        geoa3_release_stores();    // the next kernel reads these at once (common.h)
+      }
     }
   }
 }
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void reduce_dT_kernel(const float* __restrict_
   if (e >= total) return;
   const int b = e / 9, i = e - b * 9;
   float v = 0.f;
-  for (int w = 0; w < nparts; ++w) v += part[((size_t)b * nparts + w) * 9 + i];
+  for (int w = 0; w < nparts; ++w) v += part[((size_t)b * nparts + w) * GEOA3_DT_PITCH + i];
   dT[e] = v;
 }
 

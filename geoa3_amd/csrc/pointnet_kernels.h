@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+constexpr int GEOA3_DT_PITCH = 32;   // floats per row of the dT3 partial sums (ConvArgs::dTpart)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // exact-fp32 matrix core op: D(32x32) += A(32x2) * B(2x32).  Lane l supplies A[l&31][l>>5] and
@@ -36,7 +38,8 @@ struct ConvArgs {
   int produce_first, gate_first;
   // with gate_first: finish the first layer's backward in the epilogue instead of writing Y (Model/PointNet.py:79,
   // 137-139 backward): q = w1^T (gated result), dx[b][d][n] (+)= sum_c T[d][c] q[c]  (`accumulate` selects +=), and,
-  // when dTpart != null, per-workgroup partial sums of dT[d][c] = sum_n x[d][n] q[c][n] into dTpart[b][gridDim.x][9]
+  // when dTpart != null, per-workgroup partial sums of dT[d][c] = sum_n x[d][n] q[c][n] into dTpart[b][gridDim.x][GEOA3_DT_PITCH]
+  // (9 values in a 128-byte row of their own: no two workgroups, i.e. no two XCDs' L2 caches, write to one cache line)
   float* dx3;                                 // [B][3][N] or null (= write Y as usual)
   float* dTpart;
   int split;                                  // 1: split-fp16 operands on the f16 matrix pipe (pointnet_conv_split.hip)
@@ -73,7 +76,7 @@ struct ConvChainArgs {
 };
 int launch_conv_chain(const ConvChainArgs& a, hipStream_t s);
 // the backward counterpart (pointnet_conv_chain.hip): dh2 = gate( Wa[b]^T Xa + Wb^T Xb ), then conv_gate_first's form with
-// W2t -- dx [B][3][N] written, dTpart [B][ceil(N/256)][9] partial sums; dh2 is never written
+// W2t -- dx [B][3][N] written, dTpart [B][ceil(N/256)][GEOA3_DT_PITCH] partial sums; dh2 is never written
 struct ConvBwdChainArgs {
   const float* Xa; const float* Wa; long sWa;   // [B][64][N]; [B][64 o][64 i] applied transposed (sWa: instance stride)
   const float* Xb; const float* Wb;             // [B][64][N]; [64 o][64 i] applied transposed

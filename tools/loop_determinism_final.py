@@ -1,0 +1,75 @@
+"""Sequential runs of N attack iterations (a fresh runner each, nothing between the steps): final iterate of run 0 against
+every later run.  Environment switches pass through (GEOA3_GEO_STREAM=0, ...)."""
+import os, sys, gc, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import bench
+from geoa3_amd.attack import AttackRunner
+from geoa3_amd.data import synthetic_state_dict, synthetic_clouds
+from geoa3_amd.pointnet import PointNet
+B, N, K = 250, 1024, 17
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+ori, nrm = synthetic_clouds(B, N, seed=2024)
+ori, nrm = ori.cuda(), nrm.cuda()
+if os.environ.get("ARCH") == "PointNetPP":
+    from geoa3_amd.pointnet2 import PointNet2ClassificationSSG
+    torch.manual_seed(0)
+    net = PointNet2ClassificationSSG(use_xyz=True, use_normal=False).cuda().eval()
+else:
+    net = PointNet(40); net.load_state_dict(synthetic_state_dict(40, seed=0)); net = net.cuda().eval()
+with torch.no_grad():
+    gt = net(ori).argmax(1)
+init = (torch.randn(B, 3, N, generator=torch.Generator().manual_seed(11)) * 1e-3).cuda()
+ref, bad = None, 0
+for rep in range(reps):
+    cfg = bench.cfg_full_geoa3(steps + 4, N, K - 1)
+    r = AttackRunner(net, B, N, cfg, torch.device("cuda"))
+    if os.environ.get("NO_KEYS_CLEAN") == "1":
+        r._native_forward_orig = r._native_forward
+        def fwd(pts, out, s, r=r):
+            r._ws_fwd_shape = None
+            return r._native_forward_orig(pts, out, s)
+        r._native_forward = fwd
+    if os.environ.get("DUMMY_FILL") == "1":     # a fill kernel in front of every forward, but not on the keys
+        r._nf = r._native_forward
+        dummy = torch.zeros(int(os.environ.get("DUMMY_ELEMS", "512000")), device="cuda")
+        def fwd2(pts, out, s, r=r, dummy=dummy):
+            dummy.zero_()
+            return r._nf(pts, out, s)
+        r._native_forward = fwd2
+    if os.environ.get("HIP_MEMSET_DUMMY") == "1":     # hipMemsetAsync in front of every forward, on a buffer of its own
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        r._nf3 = r._native_forward
+        dbuf = torch.empty(2048000, dtype=torch.uint8, device="cuda")
+        def fwd3(pts, out, s, r=r, dbuf=dbuf):
+            hip.hipMemsetAsync(ctypes.c_void_p(dbuf.data_ptr()), 0, ctypes.c_size_t(dbuf.numel()), ctypes.c_void_p(s))
+            return r._nf3(pts, out, s)
+        r._native_forward = fwd3
+    if os.environ.get("KEYS_MEMSET_PY") == "1":       # the keys cleared from Python (same bytes as the library's memset)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        r._nf4 = r._native_forward
+        def fwd4(pts, out, s, r=r):
+            hip.hipMemsetAsync(ctypes.c_void_p(r.ws.data_ptr() + B * 128 * N * 4), 0, ctypes.c_size_t(B * 1024 * 8), ctypes.c_void_p(s))
+            return r._nf4(pts, out, s)
+        r._native_forward = fwd4
+    if os.environ.get("ZERO_WS") == "1":
+        r.ws.zero_()
+    if os.environ.get("FILL_WS") == "1":
+        r.ws.fill_(0x7f)
+    r.setup(ori, nrm, gt, gt)
+    r.begin_search_step(init)
+    for s in range(steps):
+        r.step(s, 0)
+    torch.cuda.synchronize()
+    x = r.t["x"].clone()
+    if ref is None:
+        ref = x
+    elif not torch.equal(ref, x):
+        bad += 1
+        d = (ref != x).nonzero()
+        print("run %d differs: %d elems, rows %s" % (rep, d.shape[0], sorted(set(d[:, 0].tolist()))[:8]), flush=True)
+    del r
+    gc.collect()
+print("%s: %d of %d runs differ from run 0" % (" ".join("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith(("GEOA3_", "NO_KEYS", "DUMMY", "HIP_MEM", "KEYS_", "ZERO_", "FILL_", "ARCH"))), bad, reps - 1))
