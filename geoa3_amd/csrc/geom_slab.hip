@@ -22,10 +22,13 @@ constexpr int SK_BLOCK = 256;
 constexpr int SK_CHUNK = 1024;
 constexpr float S_INF = __builtin_inff();
 
-struct SlabGeo {
+// (per-instance records and rows written by one workgroup each and read by the next kernel: a 128-byte line of their own,
+//  no two workgroups -- XCDs -- write into one cache line)
+struct alignas(128) SlabGeo {
   float lo, inv_w;
   int axis, pad;
 };
+constexpr int SB_PITCH = 544;         // ints per row of bin starts (SB_NB + 1 = 513, rounded up to whole lines)
 
 __device__ __forceinline__ int slab_bin(float v, float lo, float inv_w) {
   const int c = (int)floorf((v - lo) * inv_w);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(SB_T) void slab_bin_kernel(const float* __restrict_
       sidx[(size_t)b * N + pos] = i;
     }
   }
-  for (int e = tid; e <= SB_NB; e += SB_T) bstart[(size_t)b * (SB_NB + 1) + e] = s_start[e];
+  for (int e = tid; e <= SB_NB; e += SB_T) bstart[(size_t)b * SB_PITCH + e] = s_start[e];
   if (tid == 0) geo[b] = SlabGeo{alo, inv_w, axis, 0};
 }
 
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
   const float* Rb = R + (size_t)b * 3 * N;
   const float* Sb = sorted + (size_t)b * 3 * N;
   const int32_t* Ib = sidx + (size_t)b * N;
-  const int32_t* bs = bstart + (size_t)b * (SB_NB + 1);
+  const int32_t* bs = bstart + (size_t)b * SB_PITCH;
   const SlabGeo g = geo[b];
   const int pc = live ? pos : N - 1;
   const float qx = Sb[pc], qy = Sb[N + pc], qz = Sb[2 * N + pc];
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
   const float* Rb = R + (size_t)b * 3 * N;
   const float* Sb = sorted + (size_t)b * 3 * N;
   const int32_t* Ib = sidx + (size_t)b * N;
-  const int32_t* bs = bstart + (size_t)b * (SB_NB + 1);
+  const int32_t* bs = bstart + (size_t)b * SB_PITCH;
   const SlabGeo g = geo[b];
   const int pc = live ? pos : N - 1;
   const float qx = Sb[pc], qy = Sb[N + pc], qz = Sb[2 * N + pc];
@@ -677,7 +680,8 @@ constexpr int KG_T = 1024, KG_PPT = 8;       // cell sort: up to 8192 points
 constexpr int KG_CAP = 256;                  // entries of a wave's candidate list
 constexpr int KG_QPW = 8;                    // queries per wave (sequential)
 
-struct GridGeo {
+constexpr int KG_PITCH = ((16 * 16 * 16 + 1 + 31) / 32) * 32;   // ints per row of cell starts: whole lines
+struct alignas(128) GridGeo {
   float lox, loy, loz, inv_h;
 };
 
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(KG_T) void knn_cellsort_kernel(const float* __restr
   int run = incl - sum;
 #pragma unroll
   for (int w = 0; w < 16; ++w) run += (w < wave) ? s_wsum[w] : 0;
-  int32_t* cs = cstart + (size_t)b * (KG_CELLS + 1);
+  int32_t* cs = cstart + (size_t)b * KG_PITCH;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     s_cnt[4 * tid + u] = run;     // from here on: the fill cursor of the cell
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
   const float* Rb = R + (size_t)b * 3 * N;
   const float* Sb = sorted + (size_t)b * 3 * N;
   const int32_t* Ib = sidx + (size_t)b * N;
-  const int32_t* cs = cstart + (size_t)b * (KG_CELLS + 1);
+  const int32_t* cs = cstart + (size_t)b * KG_PITCH;
   const GridGeo g = geo[b];
   unsigned long long* L = s_key[wave];
   int* P = s_rowp[wave];
@@ -985,7 +989,7 @@ GridScratch grid_carve(void* base, int B, int N) {
   };
   s.sorted = (float*)take((size_t)B * 3 * N * 4);
   s.sidx = (int32_t*)take((size_t)B * N * 4);
-  s.cstart = (int32_t*)take((size_t)B * (KG_CELLS + 1) * 4);
+  s.cstart = (int32_t*)take((size_t)B * KG_PITCH * 4);
   s.geo = (GridGeo*)take((size_t)B * sizeof(GridGeo));
   s.total = off;
   return s;
@@ -1009,7 +1013,7 @@ SlabScratch slab_carve(void* base, int B, int N) {
   };
   s.sorted = (float*)take((size_t)B * 3 * N * 4);
   s.sidx = (int32_t*)take((size_t)B * N * 4);
-  s.bstart = (int32_t*)take((size_t)B * (SB_NB + 1) * 4);
+  s.bstart = (int32_t*)take((size_t)B * SB_PITCH * 4);
   s.geo = (SlabGeo*)take((size_t)B * sizeof(SlabGeo));
   s.total = off;
   return s;
