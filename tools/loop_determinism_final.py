@@ -6,7 +6,7 @@ import bench
 from geoa3_amd.attack import AttackRunner
 from geoa3_amd.data import synthetic_state_dict, synthetic_clouds
 from geoa3_amd.pointnet import PointNet
-B, N, K = 250, 1024, 17
+B, N, K = int(os.environ.get("NB", 250)), int(os.environ.get("NPTS", 1024)), int(os.environ.get("KNN", 16)) + 1
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ori, nrm = synthetic_clouds(B, N, seed=2024)
@@ -72,4 +72,4 @@ for rep in range(reps):
         print("run %d differs: %d elems, rows %s" % (rep, d.shape[0], sorted(set(d[:, 0].tolist()))[:8]), flush=True)
     del r
     gc.collect()
-print("%s: %d of %d runs differ from run 0" % (" ".join("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith(("GEOA3_", "NO_KEYS", "DUMMY", "HIP_MEM", "KEYS_", "ZERO_", "FILL_", "ARCH"))), bad, reps - 1))
+print("%s: %d of %d runs differ from run 0" % (" ".join("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith(("GEOA3_", "NO_KEYS", "DUMMY", "HIP_MEM", "KEYS_", "ZERO_", "FILL_", "ARCH", "NB", "NPTS", "KNN"))), bad, reps - 1))
