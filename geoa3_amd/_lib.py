@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgeoa3_hip.so")
+# GEOA3_LIB_PATH: a variant build of the same sources for an A/B run of tools/ (python -m geoa3_amd.build --variant DIR ...)
+LIB_PATH = os.environ.get("GEOA3_LIB_PATH") or os.path.join(_HERE, "lib", "libgeoa3_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
@@ -129,6 +130,8 @@ SIGNATURES = {
     "geoa3_conv1x1_max64": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, vp]),
     "geoa3_conv1x1_onehot64": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, vp]),
     "geoa3_conv1x1": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, vp]),
+    "geoa3_debug_pointnet_workspace_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
+                                                        C.POINTER(C.c_int64), C.c_int]),
     "geoa3_debug_fc": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_debug_conv_cm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_profile_enable": (C.c_int, [C.c_int]),

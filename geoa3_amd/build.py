@@ -33,23 +33,24 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _digest(path: str) -> str:
+def _digest(path: str, flags=None) -> str:
     h = hashlib.sha1()
     for p in [path] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
             os.path.join(HERE, "..", "include", "geoa3_hip.h"), os.path.join(HERE, "..", "include", "geoa3_hip_debug.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(flags or FLAGS).encode())
     return h.hexdigest()
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
+    flags = flags or FLAGS
+    obj = os.path.join(objdir, os.path.basename(src) + ".o")
     stamp = obj + ".sha1"
-    dig = _digest(src)
+    dig = _digest(src, flags)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -60,21 +61,31 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, extra_flags=(), libdir: str = LIBDIR) -> str:
+    """The product library (no arguments), or a variant build for tools/ (extra -D flags, its own directory; loaded
+    through GEOA3_LIB_PATH, see _lib.py)."""
+    objdir, lib = os.path.join(libdir, "obj"), os.path.join(libdir, "libgeoa3_hip.so")
+    flags = FLAGS + list(extra_flags)
+    os.makedirs(objdir, exist_ok=True)
     srcs = sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+        objs = list(ex.map(lambda s: _compile(s, force, objdir, flags), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < newest:
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
-        print("built", LIB, "%.0f KB" % (os.path.getsize(LIB) / 1024))
-    return LIB
+        print("built", lib, "%.0f KB" % (os.path.getsize(lib) / 1024))
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    # python -m geoa3_amd.build [--force] [--variant DIR -DX=Y ...]
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build(force="--force" in sys.argv, libdir=os.path.abspath(sys.argv[i + 1]),
+              extra_flags=[f for f in sys.argv[i + 2:] if f.startswith("-D")])
+    else:
+        build(force="--force" in sys.argv)

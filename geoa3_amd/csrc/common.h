@@ -13,18 +13,11 @@
     if (e__ != hipSuccess) return GEOA3_ELAUNCH;     \
   } while (0)
 
-// ------------------------------------------------------------------------------------------
-// geoa3_release_stores(): what this wavefront has stored so far is released at agent scope (s_waitcnt + buffer_wbl2 sc1
-// on gfx950: the XCD's L2 writes its dirty lines back).  Needed where the LAST instructions of a workgroup store a small
-// result that the FIRST instructions of the next kernel in the stream read -- measured on the per-workgroup partial sums
-// of dT3 (36 bytes per workgroup, four workgroups of possibly different XCDs to a cache line): once in ~25 runs of 30
-// attack iterations the reducer read the previous iteration's partial for one of the last instances of the batch, the
-// kernel boundary alone did not make the store visible to a reader behind another XCD's L2.  With the release behind the
-// store: 0 of 156 runs (tools/loop_determinism_final.py; tests/test_gpu_fullsize.py::test_attack_loop_full_size_is_run_to_
-// run_deterministic).  Per WAVEFRONT of every kernel it costs a factor of 2.8 on the iteration (measured): it sits only
-// behind such stores, one wavefront per workgroup.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void geoa3_release_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+// GEOA3_HAZARD_PROBE=1 (tools/ub/dtpart_pair.hip only; never set for the product build) restores the round-2/3 build of
+// conv_bwd_chain_kernel with two wavefronts per SIMD, the configuration DESIGN 5a's hazard was found on.
+#ifndef GEOA3_HAZARD_PROBE
+#define GEOA3_HAZARD_PROBE 0
+#endif
 
 static inline hipStream_t geoa3_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -172,7 +172,6 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
     if (A.hd_loss) A.hd_loss[b] = hdv;
     if (A.curv_loss) A.curv_loss[b] = curv;
     if (A.constrain) A.constrain[b] = con;
-    geoa3_release_stores();   // four bytes per instance and array: neighbours in the line come from other workgroups (common.h)
     s_red[GEO_WAVES * 5] = __int_as_float(h.i);
   }
   __syncthreads();
@@ -747,7 +746,6 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
       if (A.hd_loss) A.hd_loss[b] = hdv;
       if (A.curv_loss) A.curv_loss[b] = curv;
       if (A.constrain) A.constrain[b] = con;
-      geoa3_release_stores();   // four bytes per instance and array: neighbours in the line come from other workgroups (common.h)
     }
   }
   if (!want_grad) return;

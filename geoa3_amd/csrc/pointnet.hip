@@ -275,6 +275,27 @@ extern "C" int64_t geoa3_pointnet_workspace_bytes(int B, int N, int classes) {
   return (int64_t)carve(nullptr, B, N, classes).total;
 }
 
+// diagnostics (geoa3_hip_debug.h): names and byte offsets of the workspace's buffers, in address order
+extern "C" int geoa3_debug_pointnet_workspace_layout(int B, int N, int classes, const char** names, int64_t* offsets,
+                                                     int cap) {
+  if (B <= 0 || N <= 0 || classes <= 0) return -1;
+  char* const base = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 40);
+  const Ws w = carve(base, B, N, classes);
+  const struct { const char* name; const void* p; } f[] = {
+      {"a2", w.a2}, {"keys", w.keys}, {"p3", w.p3}, {"i3", w.i3}, {"tf4", w.tf4}, {"tf5", w.tf5}, {"T3", w.T3},
+      {"h2", w.h2}, {"c1", w.c1}, {"c2", w.c2}, {"q3", w.q3}, {"iq3", w.iq3}, {"qf4", w.qf4}, {"qf5", w.qf5},
+      {"T64", w.T64}, {"W3eff", w.W3eff}, {"h3", w.h3}, {"h4", w.h4}, {"p5", w.p5}, {"i5", w.i5}, {"f6", w.f6},
+      {"f7", w.f7}, {"G128", w.G128}, {"G64a", w.G64a}, {"P64", w.P64}, {"dh2", w.dh2}, {"g1024", w.g1024},
+      {"g512", w.g512}, {"g256", w.g256}, {"gT64", w.gT64}, {"gT3", w.gT3}, {"dTpart", w.dTpart}, {"m_a2", w.m_a2},
+      {"m_h2", w.m_h2}, {"m_c1", w.m_c1}, {"m_c2", w.m_c2}, {"m_h3", w.m_h3}, {"m_h4", w.m_h4}};
+  const int n = (int)(sizeof(f) / sizeof(f[0]));
+  for (int i = 0; i < n && i < cap; ++i) {
+    names[i] = f[i].name;
+    offsets[i] = (int64_t)(static_cast<const char*>(f[i].p) - base);
+  }
+  return n;
+}
+
 extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const float* x, int B, int N, float* logits,
                                       void* workspace, void* stream) {
   if (!pw || !x || !logits || !workspace || B <= 0 || N <= 0) return GEOA3_EINVAL;

@@ -443,7 +443,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH <= 8 &&
       if (tid < 9) {
         a.dTpart[((size_t)b * gridDim.y + cblk) * GEOA3_DT_PITCH + tid] =
             s_part[tid] + s_part[9 + tid] + s_part[18 + tid] + s_part[27 + tid];
-        geoa3_release_stores();    // the next kernel reads these at once (common.h)
       }
     }
   }

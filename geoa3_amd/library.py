@@ -216,10 +216,26 @@ import weakref
 _NETS = weakref.WeakValueDictionary()   # handle -> geoa3_amd.pointnet.PointNet (custom ops take tensors and scalars only)
 
 
+import itertools
+
+_NEXT_HANDLE = itertools.count(1)
+
+
 def register_net(net) -> int:
-    """A handle for `net` (a geoa3_amd.pointnet.PointNet in eval mode) to pass to geoa3::pointnet_forward."""
-    h = id(net)
+    """A handle for `net` (a geoa3_amd.pointnet.PointNet in eval mode) to pass to geoa3::pointnet_forward.  Handles
+    come from a counter (never reused); a copy of a module (copy.deepcopy / pickle carry the integer along) registers
+    itself again through net_handle()."""
+    h = next(_NEXT_HANDLE)
     _NETS[h] = net
+    return h
+
+
+@torch.compiler.assume_constant_result
+def net_handle(net) -> int:
+    """The handle under which `net` itself is registered (re-registered if the stored one belongs to another module)."""
+    h = getattr(net, "_handle", None)
+    if h is None or _NETS.get(h) is not net:
+        h = net._handle = register_net(net)
     return h
 
 

@@ -221,6 +221,7 @@ class _PointNetFn(torch.autograd.Function):
                                          ws.data_ptr(), s), "geoa3_pointnet_forward")
         ctx.packed, ctx.ws = packed, ws
         ctx.ws_version = ws_cache["version"] = ws_cache.get("version", 0) + 1
+        ws_cache.pop("holds", None)     # the custom-op backward must not take these activations for its own x
         ctx.ws_cache = ws_cache
         ctx.save_for_backward(x)
         return logits
@@ -301,7 +302,8 @@ class PointNet(nn.Module):
         if self.training:
             raise NotImplementedError("only the eval-mode forward (the attack's victim) is implemented")
         if torch.compiler.is_compiling():   # traced: the registered custom op (geoa3_amd/library.py), same kernels
-            return torch.ops.geoa3.pointnet_forward(pc, self._handle)
+            from . import library
+            return torch.ops.geoa3.pointnet_forward(pc, library.net_handle(self))
         return _PointNetFn.apply(pc, self.packed(pc.device), self._ws_cache)
 
     @property

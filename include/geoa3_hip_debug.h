@@ -46,6 +46,10 @@ int geoa3_debug_fc(const float* X, const float* W, const float* bias, float* Y, 
 int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, int N, int K,
                         int Co, int relu, int split /* 1: split-fp16 operands */, void* stream);
 
+/* Names and byte offsets (address order) of the buffers geoa3_pointnet_forward / _backward keep in their workspace:
+ * tools/iteration_replay_soak.py attributes a run-to-run difference to the kernel that wrote it.  Returns the number
+ * of buffers (names[i] are static strings). */
+int geoa3_debug_pointnet_workspace_layout(int B, int N, int classes, const char** names, int64_t* offsets, int cap);
 
 #ifdef __cplusplus
 }

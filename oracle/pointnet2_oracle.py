@@ -158,6 +158,22 @@ def make_pn2_state_dict(seed: int = 0):
     return sd
 
 
+def calibrate_pn2_state_dict(sd, n_clouds: int = 16, npoint: int = 1024, seed: int = 12345):
+    """The last layer rescaled on a fixed set of synthetic clouds so that the logits are centred per class with unit
+    spread across instances (as geoa3_oracle.make_pointnet_state_dict does for PointNet): the raw random-init SSG net
+    maps every cloud to the same class with a margin no attack step changes, which would leave the long-run success
+    bookkeeping untested (tests/golden/make_golden_long.py)."""
+    from . import geoa3_oracle as O
+    calib, _ = O.make_synthetic_clouds(n_clouds, npoint, seed=seed)
+    sd = dict(sd)
+    with torch.no_grad():
+        lg = pointnet2_ssg_forward(sd, calib)
+        gain = 1.0 / lg.std(0).mean().clamp(min=1e-6)
+        sd["fc_layer.7.bias"] = (sd["fc_layer.7.bias"] - lg.mean(0)) * gain
+        sd["fc_layer.7.weight"] = sd["fc_layer.7.weight"] * gain
+    return sd
+
+
 def pointnet2_ssg_forward(sd, pc: Tensor) -> Tensor:
     """Eval-mode PointNet2ClassificationSSG.forward (Model/PointNetPP_ssg.py:106-124 over
     pointnet2_modules.py:29-74 and pointnet2_utils.py:296-333,349-379), functional over a state_dict.

@@ -43,9 +43,33 @@ def test_under_a_launcher_no_second_spawn(monkeypatch):
     sys.path.insert(0, REPO)
     bench = importlib.import_module("bench")
     monkeypatch.setattr(bench, "spawn_ranks", lambda n: (_ for _ in ()).throw(AssertionError("spawned twice")))
-    monkeypatch.setenv("WORLD_SIZE", "2")
+    for k, v in (("WORLD_SIZE", "2"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29999")):
+        monkeypatch.setenv(k, v)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
     import torch
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: (_ for _ in ()).throw(RuntimeError("reached the measurement")))
+    with pytest.raises(RuntimeError, match="reached the measurement"):
+        bench.main()
+
+
+def test_stray_world_size_is_not_a_launcher(monkeypatch):
+    """WORLD_SIZE=1 exported by a scheduler without RANK / MASTER_PORT: plain `python bench.py` stays single-process
+    (no env:// rendezvous), and `--gpus N` still spawns its own ranks."""
+    sys.path.insert(0, REPO)
+    bench = importlib.import_module("bench")
+    for k in ("RANK", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    spawned = []
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n: spawned.append(n) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert spawned == [2]
+    import torch
+    import torch.distributed as dist
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **k: (_ for _ in ()).throw(AssertionError("rendezvous")))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: (_ for _ in ()).throw(RuntimeError("reached the measurement")))
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
     with pytest.raises(RuntimeError, match="reached the measurement"):
         bench.main()

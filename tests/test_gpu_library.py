@@ -87,3 +87,24 @@ def test_pointnet_module_under_compile():
         (g,) = torch.autograd.grad((lg * w).sum(), x)
         out.append((lg.detach(), g))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_custom_op_backward_after_an_interleaved_eager_forward():
+    """geoa3::pointnet_forward(x), then an eager net(y) (which overwrites the workspace), then the custom op's backward:
+    the backward must notice that the workspace no longer holds x's activations and recompute them."""
+    from geoa3_amd import library
+    from geoa3_amd.pointnet import PointNet
+    net = PointNet(40)
+    net.load_state_dict(O.make_pointnet_state_dict(40, seed=0))
+    net = net.cuda().eval()
+    x0, _, _ = _inputs(3, 256, 21)
+    y, _, _ = _inputs(3, 256, 22)
+    w = torch.randn(3, 40, generator=torch.Generator().manual_seed(3)).cuda()
+    x = x0.clone().requires_grad_()
+    (want,) = torch.autograd.grad((net(x) * w).sum(), x)
+    x = x0.clone().requires_grad_()
+    lg = torch.ops.geoa3.pointnet_forward(x, library.net_handle(net))
+    with torch.no_grad():
+        net(y)
+    (got,) = torch.autograd.grad((lg * w).sum(), x)
+    assert torch.equal(got, want)

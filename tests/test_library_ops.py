@@ -53,3 +53,20 @@ def test_fake_kernels_cover_optional_arguments():
         out = torch.ops.geoa3.geo_loss_grad(adv, ori, None, None, d_ar, i_ar, d_ra, i_ra, None, None, 0, 1, False, 1.0,
                                             0.1, 0.0, True)
         assert [tuple(o.shape) for o in out] == [(3,), (3,), (3,), (3,), (3, 3, 50)]
+
+
+def test_net_handles_are_per_module_and_survive_deepcopy():
+    """A copied module carries the original's integer along; net_handle() registers the copy under its own handle, so the
+    custom op resolves each module to ITS weights and workspace (handles come from a counter, never from id())."""
+    import copy
+    from geoa3_amd.pointnet import PointNet
+    a = PointNet(40)
+    b = copy.deepcopy(a)
+    assert b._handle == a._handle and library._NETS[a._handle] is a
+    hb = library.net_handle(b)
+    assert hb != a._handle and library._NETS[hb] is b and library.net_handle(a) == a._handle
+    assert library.net_handle(b) == hb
+    del a
+    import gc
+    gc.collect()
+    assert library.net_handle(b) == hb and PointNet(40)._handle not in (hb,)
