@@ -385,10 +385,13 @@ __device__ __forceinline__ void sp_count_less(int& r, unsigned long long kj, uns
   asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r) : "v"(kj), "v"(ki) : "vcc");
 }
 
+// Three waves per SIMD (168 VGPRs): at four (128) the 40-slot ranking spilled 35 registers -- 140 bytes of scratch per lane,
+// 36 MB each way per launch at 250 instances (round 3's PMC: 141 MB moved against 55 MB algorithmic); the kernel's own time
+// is the same or a little lower (143 vs 144-155 us in the bench's one-stream figure), the iteration unchanged.
 // MULTI: a cloud of more than one staging chunk (N <= 65535) and / or longer lists (K <= SP_CAP - 16): the positions are
 // those of the whole sorted cloud and the ranking gathers the coordinates from memory (L2) instead of the staged chunk.
 template <int SP_CAP, bool MULTI>
-__global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI ? 3 : 4, MULTI ? 3 : 4))) void knn_slabp_kernel(const float* __restrict__ R, int N, int K,
+__global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void knn_slabp_kernel(const float* __restrict__ R, int N, int K,
                                                              const int32_t* __restrict__ prior,
                                                              const float* __restrict__ sorted,
                                                              const int32_t* __restrict__ sidx,

@@ -1,5 +1,8 @@
 """Long-horizon, run-level parity with the reference (SURVEY 7 'run-level statistics'; fixtures of
-tests/golden/make_golden_long.py: the reference's own attack() for 4 x 200 / 5 x 120 / 3 x 150 iterations).
+tests/golden/make_golden_long.py: the reference's own attack() for 5 x 120 / 5 x 100 / 4 x 150 / 3 x 150 / 3 x 100
+iterations -- untargeted with a dominating constrain term, targeted at the least likely class, a victim with x3 logit
+margins, N = 256 and 1024, the PointNet and the PointNet++ SSG victim.  In every case the reference finds its best
+iterate tens of steps into a binary step, the constants move both ways).
 
 After hundreds of Adam steps two fp32 implementations no longer share a trajectory (a 1e-9 difference on a near-zero
 gradient becomes a +-lr step, an arg-min flips, ...), so what is compared is what a user of the attack sees:
@@ -9,8 +12,9 @@ gradient becomes a +-lr step, an arg-min flips, ...), so what is compared is wha
 Both arithmetic modes of the MFMA layers and both summation modes of the objective's gradient are held to the same bars.
 
 The `output_label` quirk (geoA3_attack.py:298,375: the label of the LAST instance at the LAST step decides for every
-instance) makes the binary search of the 'hard' case hinge on a logit margin of ~5e-3; there the reference's last labels
-are replayed through the hook the sharded runs use, so the comparison is about the per-instance state.
+instance) makes the binary search hinge on one logit margin per binary step (5e-3 in `n256_b8_hard`): the reference's last
+labels are replayed through the hook the sharded runs use, so the comparison is about the per-instance state -- and the
+run's OWN last labels are held to the reference's wherever the reference's margin there is not a near-tie.
 """
 import json
 import os
@@ -20,20 +24,22 @@ import pytest
 import torch
 
 from oracle import geoa3_oracle as O
-from tests.golden.make_golden_long import LONG_CASES
+from tests.golden.make_golden_long import LONG_CASES, adversarial, oracle_net, victim_state_dict
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 # bars (relative unless noted); see DESIGN.md section 2, row "long run"
-BEST_RTOL = {"n256_b8": 0.05, "n1024_b4": 0.05, "n256_b8_hard": 0.10}   # best constrain loss per instance
+BEST_RTOL = {"n256_b8_hard": 0.10, "n256_b8_tgt": 0.10, "n1024_b8_hard": 0.10, "n1024_b4_margin": 0.10,
+             "pn2_n1024_b4_tgt": 0.10}   # best constrain loss per instance
 # 50-step window means of loss_n (batch mean).  The bar is set by the chaos of the loop itself, measured with
 # tools/longrun_noise.py (profiles/round3_longrun_noise.txt): 13 deterministic runs whose start is perturbed by k*1e-7
 # spread over 0.2-0.5 % (median) / 1.1 % (max) of the reference's window means, 13 repeats of the atomics loop over
 # 0.3 % / 1.5 %; the CPU oracle under the same perturbation: 0.05-0.25 % (4 runs).  Constrain windows: 2 x this bar
 # (observed max 3.9 %).
-WINDOW_RTOL = {"n256_b8": 0.025, "n1024_b4": 0.025, "n256_b8_hard": 0.025}
+WINDOW_RTOL = {"n256_b8_hard": 0.025, "n256_b8_tgt": 0.025, "n1024_b8_hard": 0.025, "n1024_b4_margin": 0.025,
+               "pn2_n1024_b4_tgt": 0.025}
 ROBUST_STEPS = 3         # an instance counts as robustly (un)successful in a binary step with >= 3 / 0 adversarial steps
 
 
@@ -42,23 +48,30 @@ def long_golden():
     return np.load(os.path.join(REPO, "tests", "golden", "geoa3_golden_long.npz"), allow_pickle=False)
 
 
-def _net(mode):
-    from geoa3_amd.pointnet import PointNet
-    n = PointNet(40)
-    n.load_state_dict(O.make_pointnet_state_dict(40, seed=0))
-    n = n.cuda().eval()
-    n.wide_mode = mode
-    return n
+def _net(mode, case=None):
+    case = case or LONG_CASES["n256_b8_hard"]
+    sd = victim_state_dict(case)
+    if case["arch"] == "PointNet":
+        from geoa3_amd.pointnet import PointNet
+        n = PointNet(40)
+        n.load_state_dict(sd)
+        n = n.cuda().eval()
+        n.wide_mode = mode
+        return n
+    from geoa3_amd.pointnet2 import PointNet2ClassificationSSG
+    n = PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    n.load_state_dict(sd)
+    return n.cuda().eval()
 
 
 def _run(net, cfg, g, pre, deterministic, replay_last):
     from geoa3_amd.attack import AttackRunner
     cfg.deterministic = deterministic
-    ori, nrm, gt = T(g[pre + "ori"]), T(g[pre + "nrm"]), T(g[pre + "gt"])
+    ori, nrm, gt, tgt = T(g[pre + "ori"]), T(g[pre + "nrm"]), T(g[pre + "gt"]), T(g[pre + "tgt"])
     inits = [T(a).cuda() for a in g[pre + "inits"]]
     b, _, n = ori.shape
     r = AttackRunner(net, b, n, cfg, torch.device("cuda"))
-    r.setup(ori, nrm, gt, gt)
+    r.setup(ori, nrm, gt, tgt)
     S, Tn = cfg.binary_max_steps, cfg.iter_max_steps
     scale, hist, labels, con = [], [], [], []
     begin = r.begin_search_step
@@ -77,8 +90,10 @@ def _run(net, cfg, g, pre, deterministic, replay_last):
 
     ref_last = g[pre + "tr_pred"][:, -1, -1]
     state = {"s": 0}
+    own_last = []
 
     def sync(last_label):
+        own_last.append(int(last_label.item()))
         if replay_last:
             last_label.fill_(int(ref_last[state["s"]]))
         state["s"] += 1
@@ -88,23 +103,35 @@ def _run(net, cfg, g, pre, deterministic, replay_last):
     return dict(succ=np.asarray(succ), best_loss=r.t["best_loss"].cpu().numpy(), best_step=np.asarray(best_step),
                 scale=np.stack(scale), loss_n=np.stack(hist),
                 pred=torch.stack(labels).cpu().numpy().reshape(S, Tn, b),
-                con=torch.stack(con).cpu().numpy().reshape(S, Tn, b), best=best.cpu().numpy())
+                con=torch.stack(con).cpu().numpy().reshape(S, Tn, b), best=best.cpu().numpy(),
+                own_last=np.asarray(own_last))
+
+
+def _params():
+    out = []
+    for tag, case in LONG_CASES.items():
+        if case["arch"] == "PointNet":
+            out += [(tag, "f16x2", True), (tag, "f32", True), (tag, "f16x2", False)]
+        else:   # the PointNet++ kernels have one arithmetic mode
+            out += [(tag, "native", True), (tag, "native", False)]
+    return out
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("tag", list(LONG_CASES))
-@pytest.mark.parametrize("mode,deterministic", [("f16x2", True), ("f32", True), ("f16x2", False)])
+@pytest.mark.parametrize("tag,mode,deterministic", _params())
 def test_long_run_statistics_match_reference(long_golden, tag, mode, deterministic):
     g = long_golden
-    kw, b, n, _ = LONG_CASES[tag]
-    cfg = O.AttackCfg(**kw)
+    case = LONG_CASES[tag]
+    b = case["b"]
+    cfg = O.AttackCfg(**case["cfg"])
     pre = "long/%s/" % tag
-    hard = tag.endswith("hard")
-    out = _run(_net(mode), cfg, g, pre, deterministic, replay_last=hard)
+    targeted = case["target_rank"] > 0
+    hard = True     # every case: constants compared per instance, the reference's last labels replayed
+    out = _run(_net(mode, case), cfg, g, pre, deterministic, replay_last=True)
     S, Tn = cfg.binary_max_steps, cfg.iter_max_steps
-    gt = g[pre + "gt"]
-    ref_adv = (g[pre + "tr_pred"] != gt)                    # [S,T,b] adversarial at step t (batched forward)
-    got_adv = (out["pred"] != gt)
+    gt, tgt = g[pre + "gt"], g[pre + "tgt"]
+    ref_adv = adversarial(g[pre + "tr_pred"], gt, tgt, targeted)     # [S,T,b] adversarial at step t (batched forward)
+    got_adv = adversarial(out["pred"], gt, tgt, targeted)
     ref_n, got_n = ref_adv[:, 1:].sum(1), got_adv[:, 1:].sum(1)   # adversarial steps per (binary step, instance)
     report = {"tag": tag, "mode": mode, "deterministic": deterministic}
     fails = []
@@ -113,6 +140,13 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
         if not cond:
             fails.append(repr(msg))
 
+    # (0) the quirk's input: the run's own label of the last instance at the last step of every binary step, wherever
+    # the reference's top-2 margin there is not a near-tie (while the instance still follows the reference's constants)
+    ref_margin_last = g[pre + "tr_margin"][:, -1, -1]
+    robust_last = ref_margin_last > 0.05
+    report["last_label"] = [out["own_last"].tolist(), g[pre + "tr_pred"][:, -1, -1].tolist(), ref_margin_last.round(4).tolist()]
+    if robust_last[0]:
+        chk(out["own_last"][0] == g[pre + "tr_pred"][0, -1, -1], "last label of binary step 0", report["last_label"])
 
     # (1) success mask: equal for every instance the reference attacks robustly (or never)
     ref_succ = g[pre + "success"]
@@ -123,7 +157,7 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     # (2) fraction of adversarial steps per binary step (batch level)
     fa_ref, fa_got = ref_adv.mean((1, 2)), got_adv.mean((1, 2))
     report["adv_fraction"] = [fa_got.round(4).tolist(), fa_ref.round(4).tolist()]
-    chk(np.abs(fa_got - fa_ref).max() <= (0.02 if not hard else 0.05), "adversarial fraction", fa_got, fa_ref)
+    chk(np.abs(fa_got - fa_ref).max() <= 0.05, "adversarial fraction", fa_got, fa_ref)
 
     # (3) the binary search: trade-off constant at the start of every binary step, for instances whose success within
     # the previous binary steps is robust in BOTH runs (>= ROBUST_STEPS adversarial steps, or none)
@@ -146,10 +180,10 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     chk(np.median(np.abs(ratio - 1.0)) <= rt / 2, "best constrain (median)", ratio)
     chk((np.abs(ratio - 1.0) <= rt).mean() >= 0.75, "best constrain", ratio)
     # ... and it IS adversarial with that loss: re-evaluated by the oracle on the returned cloud
-    sd = O.make_pointnet_state_dict(40, seed=0)
+    onet = oracle_net(case)
     with torch.no_grad():
-        re_pred = O.pointnet_forward(sd, T(out["best"][both])).argmax(1).numpy()
-    chk((re_pred != gt[both]).mean() >= 0.85, "best clouds adversarial", re_pred, gt[both])
+        re_pred = onet(T(out["best"][both])).argmax(1).numpy()
+    chk(adversarial(re_pred, gt[both], tgt[both], targeted).mean() >= 0.85, "best clouds adversarial", re_pred, gt[both], tgt[both])
 
     # (5) level of the objective over time: 50-step windows of the batch mean of loss_n and of the constrain loss
     wr = WINDOW_RTOL[tag]

@@ -13,7 +13,7 @@ from geoa3_amd.pointnet import PointNet
 
 def main():
     dev = torch.device("cuda")
-    for B in (32, 250):
+    for B in [int(v) for v in sys.argv[1:]] or (32, 250):
         net = PointNet(40)
         net.load_state_dict(synthetic_state_dict(40, seed=0, device=dev))
         net = net.to(dev).eval()

@@ -83,9 +83,79 @@ static float* dev_random(size_t n, float scale, unsigned seed) {
   return d;
 }
 
+// bitwise comparison of a buffer of 32-bit words; bad[0]: words that differ, bad[1 + lane]: by word index mod 64
+__global__ void compare_words_kernel(const unsigned* __restrict__ got, const unsigned* __restrict__ want, size_t n,
+                                     unsigned long long* __restrict__ bad) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    if (got[i] != want[i]) {
+      atomicAdd(&bad[0], 1ull);
+      atomicAdd(&bad[1 + (i & 63)], 1ull);
+    }
+}
+
+// The forward chain x -> conv1 -> conv2 -> T-Net(64).conv1 -> T-Net(64).conv2 (conv_chain_kernel<3, true, .>, two
+// workgroups per CU as well) on random inputs, every output compared bit for bit with a device-synchronised first run.
+static int forward_chain_soak(int pairs, hipStream_t s) {
+  const int B = 250, N = 1024;
+  const size_t n64 = (N + 63) / 64;
+  ConvChainArgs a{};
+  a.x3 = dev_random((size_t)B * 3 * N, 1.f, 31);
+  a.T3 = dev_random((size_t)B * 9, 1.f, 32);
+  a.w1 = dev_random(64 * 3, 0.5f, 33);
+  a.b1 = dev_random(64, 0.1f, 34);
+  a.N = N; a.B = B; a.ns = 3;
+  float *h2, *c2, *h2r, *c2r;
+  unsigned long long *m[3], *mr[3];
+  CHECK(hipMalloc(&h2, (size_t)B * 64 * N * 4));
+  CHECK(hipMalloc(&c2, (size_t)B * 128 * N * 4));
+  CHECK(hipMalloc(&h2r, (size_t)B * 64 * N * 4));
+  CHECK(hipMalloc(&c2r, (size_t)B * 128 * N * 4));
+  const size_t msz[3] = {(size_t)B * 64 * n64 * 8, (size_t)B * 64 * n64 * 8, (size_t)B * 128 * n64 * 8};
+  for (int i = 0; i < 3; ++i) {
+    CHECK(hipMalloc(&m[i], msz[i]));
+    CHECK(hipMalloc(&mr[i], msz[i]));
+  }
+  a.st[0] = ChainStage{dev_random(64 * 64, 0.3f, 35), 0, dev_random(64, 0.1f, 36), h2, (long)64 * N, m[0], 64};
+  a.st[1] = ChainStage{dev_random(64 * 64, 0.3f, 37), 0, dev_random(64, 0.1f, 38), nullptr, 0, m[1], 64};
+  a.st[2] = ChainStage{dev_random(128 * 64, 0.3f, 39), 0, dev_random(128, 0.1f, 40), c2, (long)128 * N, m[2], 128};
+  unsigned long long* bad;
+  CHECK(hipMalloc(&bad, 5 * 65 * 8));
+  CHECK(hipMemset(bad, 0, 5 * 65 * 8));
+  if (launch_conv_chain(a, s) != GEOA3_OK) return 3;
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipMemcpy(h2r, h2, (size_t)B * 64 * N * 4, hipMemcpyDeviceToDevice));
+  CHECK(hipMemcpy(c2r, c2, (size_t)B * 128 * N * 4, hipMemcpyDeviceToDevice));
+  for (int i = 0; i < 3; ++i) CHECK(hipMemcpy(mr[i], m[i], msz[i], hipMemcpyDeviceToDevice));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0, s));
+  for (int it = 0; it < pairs; ++it) {
+    launch_conv_chain(a, s);
+    hipLaunchKernelGGL(compare_words_kernel, dim3(1024), dim3(256), 0, s, (const unsigned*)h2, (const unsigned*)h2r, (size_t)B * 64 * N, bad);
+    hipLaunchKernelGGL(compare_words_kernel, dim3(1024), dim3(256), 0, s, (const unsigned*)c2, (const unsigned*)c2r, (size_t)B * 128 * N, bad + 65);
+    for (int i = 0; i < 3; ++i)
+      hipLaunchKernelGGL(compare_words_kernel, dim3(256), dim3(256), 0, s, (const unsigned*)m[i], (const unsigned*)mr[i], msz[i] / 4, bad + 65 * (2 + i));
+  }
+  CHECK(hipEventRecord(e1, s));
+  CHECK(hipStreamSynchronize(s));
+  float ms;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  unsigned long long h[5 * 65];
+  CHECK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
+  printf("forward chain (3 stages): %d launches, %.1f us each incl. the checks: wrong words h2 %llu, c2 %llu, gate masks %llu %llu %llu\n",
+         pairs, ms * 1000.f / pairs, h[0], h[65], h[130], h[195], h[260]);
+  if (h[0] + h[65]) {
+    printf("        wrong h2 + c2 words by column mod 64:");
+    for (int l = 0; l < 64; ++l) printf("%s%llu", l % 16 == 0 ? " | " : " ", h[1 + l] + h[66 + l]);
+    printf("\n");
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const int pairs = argc > 1 ? atoi(argv[1]) : 20000;
-  const int mode = argc > 2 ? atoi(argv[2]) : 0;   // bit 0: a 256 MB streaming write in front of every producer
+  const int mode = argc > 2 ? atoi(argv[2]) : 0;   // bit 0: a 256 MB streaming write in front of every producer; bit 1: the forward chain kernel as well
   const int pitch = argc > 3 ? atoi(argv[3]) : 32;  // floats per partial row in the library under test (probe builds: 9)
   const int B = 250, N = 1024, nparts = (N + 255) / 256;
   ConvBwdChainArgs a[2] = {};
@@ -168,5 +238,6 @@ int main(int argc, char** argv) {
          h[132], h[133], h[134], h[135]);
   for (int l = 0; l < 64; ++l) printf("%s%llu", l % 16 == 0 ? " | " : " ", h[64 + l]);
   printf("\n");
+  if (mode & 2) return forward_chain_soak(pairs, s);
   return 0;
 }
