@@ -24,7 +24,7 @@ class GeoArgs(C.Structure):
                 ("B", C.c_int32), ("N", C.c_int32), ("k", C.c_int32), ("Nr", C.c_int32), ("dis_type", C.c_int32),
                 ("single_side", C.c_int32), ("w_dis", C.c_float), ("w_hd", C.c_float), ("w_curv", C.c_float),
                 ("dis_loss", vp), ("hd_loss", vp), ("curv_loss", vp), ("constrain", vp), ("kappa_adv", vp),
-                ("grad", vp), ("deterministic", C.c_int32)]
+                ("grad", vp), ("deterministic", C.c_int32), ("scratch", vp)]
 
 
 class TnetWeights(C.Structure):

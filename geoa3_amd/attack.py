@@ -156,6 +156,8 @@ class AttackRunner:
             t["proj_d"], t["proj_i"] = t["d_ao"], t["i_ao"]
         self.geo_out = {name: z(b) for name in ("dis_loss", "hd_loss", "curv_loss", "constrain")}
         self.geo_out["grad"] = t["g_geo"]
+        # clouds of 1025..4096 points: the records of the two-kernel objective (geoa3_geo_args.scratch)
+        self.geo_scratch = ops.geo_scratch(b, ne, device) if (1024 < ne <= 4096 and self.use_curv) else None
         if self.use_curv:
             t["knn"] = [torch.zeros(b, ne, self.k + 1, **i32) for _ in range(2)]
             t["knn_d"] = z(b, ne, self.k + 1)
@@ -399,7 +401,7 @@ class AttackRunner:
                                   knn_adv=knn_adv, k=self.k if self.use_curv else 0, dis_type=self.dis_type,
                                   single_side=bool(cfg.is_cd_single_side), w_dis=float(cfg.dis_loss_weight),
                                   w_hd=float(cfg.hd_loss_weight), w_curv=float(cfg.curv_loss_weight), out=self.geo_out,
-                                  deterministic=self.deterministic)
+                                  deterministic=self.deterministic, scratch=self.geo_scratch)
                 constrain = self.geo_out["constrain"]
         late = self.late_join and self.geo_stream is not None
         if self.geo_stream is not None:     # join: the bookkeeping needs the constrain loss, the update the gradient

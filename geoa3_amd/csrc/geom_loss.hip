@@ -930,6 +930,217 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// 1024 < N <= 4096 (BASELINE configs[4]: N = 4096, k = 32): the pair-parallel objective with the gradient accumulated in
+// FIXED POINT -- the cloud, its normals, coefficients and reverse-list rows no longer fit one workgroup's LDS together
+// (geo_fused_kernel), and the one-workgroup kernel with chunked reverse lists re-read table and normals ~14 times
+// (1.94 GB and 0.83 ms per launch at 250 instances).  geo_big_gather_kernel writes one 16-byte record per point
+// (normal of the nearest clean point, its kappa), geo_big_kernel<G> does the rest: one workgroup per instance, positions
+// (48 KB) and three planes of 64-bit sums (96 KB) in LDS, the table and the records streamed once.
+// HBM per launch: the table once (135 MB) + ~25 MB.  Measured: 15 + 120 us (round 4).
+// (Measured on the way: owner-range workgroups with reverse-list rows in LDS, four threads per owner -- 0.15 + 1.0 ms: the
+//  instance's sixteen workgroups each stage 112 KB of records and scan the whole table, and ranking rows of up to 91
+//  sources is VALU-bound on the one CU; rows split four ways overflow on the k-NN graph's hubs, 9 ms.)
+// ------------------------------------------------------------------------------------------
+constexpr int GB_T = 1024;
+
+// per adversarial point: (normal of its nearest clean point, kappa_ori of it) as one 16-byte record (coalesced for the
+// objective kernel, which would otherwise chain two gathers per centre and pass)
+__global__ __launch_bounds__(256) void geo_big_gather_kernel(geoa3_geo_args A, float4* __restrict__ ctr) {
+  const int N = A.N, Nr = A.Nr > 0 ? A.Nr : N, b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const size_t bN = (size_t)b * N, bNr = (size_t)b * Nr;
+  const int nn = A.i_ao[bN + i];
+  const float* Nm = A.normal_ori + bNr * 3;
+  ctr[bN + i] = make_float4(Nm[nn], Nm[Nr + nn], Nm[2 * Nr + nn], A.kappa_ori ? A.kappa_ori[bNr + nn] : 0.f);
+}
+
+constexpr float GB_FIX = 17592186044416.0f;        // 2^44
+__device__ __forceinline__ unsigned long long gb_fix(float v) {
+  v = fminf(fmaxf(v, -262144.0f), 262144.0f);
+  return (unsigned long long)__float2ll_rn(v * GB_FIX);
+}
+
+template <int G>
+__global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const float4* __restrict__ ctr) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = A.N, k = A.k, k1 = k + 1, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Nr = A.Nr > 0 ? A.Nr : N;
+  unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(sm);   // [3][N] fixed-point sums: own curvature term + pulls
+  float* s_pos = reinterpret_cast<float*>(s_acc + 3 * N);                  // [N][3]
+  float* s_red = s_pos + 3 * N;                                            // [16 * 5 + 4]
+  const size_t bN = (size_t)b * N, bNr = (size_t)b * Nr;
+  const float* adv = A.adv + bN * 3;
+  const float* ori = A.ori + bNr * 3;
+  const int32_t* tab = A.knn_adv + bN * (size_t)k1;
+  const bool do_cd = A.dis_type == 1, do_l2 = A.dis_type == 2;
+  const bool two_side = do_cd && !A.single_side && A.d_oa != nullptr;
+  const bool do_hd = A.w_hd != 0.f && A.d_ao != nullptr;
+  const bool want_grad = A.grad != nullptr;
+  for (int i = tid; i < N; i += GB_T) {
+    s_pos[3 * i] = adv[i];
+    s_pos[3 * i + 1] = adv[N + i];
+    s_pos[3 * i + 2] = adv[2 * N + i];
+    s_acc[i] = 0ull;
+    s_acc[N + i] = 0ull;
+    s_acc[2 * N + i] = 0ull;
+  }
+  __syncthreads();
+  const float invN = 1.0f / (float)N;
+  // ---- pairs: lane = (centre c, neighbour m); kappa_adv[c] and the centre's coefficient by a G-lane butterfly, then the
+  // pair's term goes to q's sums and its negative, summed over m, to c's (geo_fused_kernel's phase 1, same expressions)
+  float sum_e2 = 0.f;
+  {
+    constexpr int CPP = GB_T / G, U = 4;
+    const int m = tid % G, cl = tid / G;
+    const bool lane_on = m < k;
+    for (int c0 = 0; c0 < N; c0 += CPP * U) {
+      int q[U];
+      float4 cv[U];
+      float dkp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * CPP + cl;
+        const int cc = c < N ? c : N - 1;
+        q[u] = (c < N && lane_on) ? tab[(size_t)c * k1 + 1 + m] : cc;
+        cv[u] = ctr[bN + cc];
+        dkp[u] = A.dkappa ? A.dkappa[bN + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * CPP + cl;
+        const bool cvalid = c < N, active = cvalid && lane_on;
+        const int cc = cvalid ? c : N - 1;
+        const float cx = s_pos[3 * cc], cy = s_pos[3 * cc + 1], cz = s_pos[3 * cc + 2];
+        const float qx = s_pos[3 * q[u]], qy = s_pos[3 * q[u] + 1], qz = s_pos[3 * q[u] + 2];
+        const float4 nv = cv[u];
+        const float vx = qx - cx, vy = qy - cy, vz = qz - cz;
+        const float r = GEO_SQRT(vx * vx + vy * vy + vz * vz);
+        const float inv = GEO_RCP(fmaxf(r, NORM_EPS));
+        const float t = (vx * inv) * nv.x + (vy * inv) * nv.y + (vz * inv) * nv.z;
+        const float kap = group_sum<G>(active ? fabsf(t) : 0.f) / (float)k;
+        const float e = kap - nv.w;
+        const float dk = (A.dkappa ? dkp[u] : A.w_curv * invN * 2.0f * e) / (float)k;
+        float dvx, dvy, dvz, t2;
+        geo_pair_grad(cx, cy, cz, nv.x, nv.y, nv.z, dk, qx, qy, qz, dvx, dvy, dvz, t2);
+        const float sx = group_sum<G>(active ? dvx : 0.f), sy = group_sum<G>(active ? dvy : 0.f),
+                    sz = group_sum<G>(active ? dvz : 0.f);
+        if (active && want_grad) {
+          atomicAdd(&s_acc[q[u]], gb_fix(dvx));
+          atomicAdd(&s_acc[N + q[u]], gb_fix(dvy));
+          atomicAdd(&s_acc[2 * N + q[u]], gb_fix(dvz));
+        }
+        if (m == 0 && cvalid) {
+          sum_e2 += e * e;
+          if (A.kappa_adv) A.kappa_adv[bN + c] = kap;
+          if (want_grad) {
+            atomicAdd(&s_acc[c], gb_fix(-sx));
+            atomicAdd(&s_acc[N + c], gb_fix(-sy));
+            atomicAdd(&s_acc[2 * N + c], gb_fix(-sz));
+          }
+        }
+      }
+    }
+  }
+  const float c_cd = A.w_dis * invN * 2.0f;
+  const float cr = (Nr != N) ? A.w_dis * (1.0f / (float)Nr) * 2.0f : c_cd;
+  if (two_side && want_grad)          // clean point j pulls on its nearest adversarial point
+    for (int j = tid; j < Nr; j += GB_T) {
+      const int q = A.i_oa[bNr + j];
+      atomicAdd(&s_acc[q], gb_fix(cr * (s_pos[3 * q] - ori[j])));
+      atomicAdd(&s_acc[N + q], gb_fix(cr * (s_pos[3 * q + 1] - ori[Nr + j])));
+      atomicAdd(&s_acc[2 * N + q], gb_fix(cr * (s_pos[3 * q + 2] - ori[2 * Nr + j])));
+    }
+  // ---- loss values and the Hausdorff arg-max, fixed order
+  float sum_ao = 0.f, sum_oa = 0.f;
+  MaxIdx hd{-__builtin_inff(), 0x7fffffff};
+  for (int i = tid; i < N; i += GB_T) {
+    if (do_cd || do_hd) {
+      const float d = A.d_ao[bN + i];
+      if (do_cd) sum_ao += d;
+      if (do_hd) hd = better(hd, MaxIdx{d, i});
+    }
+    if (do_l2) {
+      const float dx = s_pos[3 * i] - ori[i], dy = s_pos[3 * i + 1] - ori[Nr + i], dz = s_pos[3 * i + 2] - ori[2 * Nr + i];
+      sum_ao += dx * dx + dy * dy + dz * dz;
+    }
+  }
+  if (two_side)
+    for (int i = tid; i < Nr; i += GB_T) sum_oa += A.d_oa[bNr + i];
+  sum_ao = wave_sum(sum_ao);
+  sum_oa = wave_sum(sum_oa);
+  sum_e2 = wave_sum(sum_e2);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxIdx other{__shfl_xor(hd.v, o, 64), __shfl_xor(hd.i, o, 64)};
+    hd = better(hd, other);
+  }
+  if (lane == 0) {
+    s_red[wave * 5 + 0] = sum_ao;
+    s_red[wave * 5 + 1] = sum_oa;
+    s_red[wave * 5 + 2] = sum_e2;
+    s_red[wave * 5 + 3] = hd.v;
+    s_red[wave * 5 + 4] = __int_as_float(hd.i);
+  }
+  __syncthreads();       // (also: every pull is in the sums)
+  {
+    float a = 0.f, o = 0.f, e2 = 0.f;
+    MaxIdx h{-__builtin_inff(), 0x7fffffff};
+#pragma unroll
+    for (int w = 0; w < GB_T / 64; ++w) {
+      a += s_red[w * 5 + 0];
+      o += s_red[w * 5 + 1];
+      e2 += s_red[w * 5 + 2];
+      h = better(h, MaxIdx{s_red[w * 5 + 3], __float_as_int(s_red[w * 5 + 4])});
+    }
+    hd = h;
+    if (tid == 0) {
+      float dis = 0.f;
+      if (do_cd) dis = a * invN + (two_side ? o * (1.0f / (float)Nr) : 0.f);
+      if (do_l2) dis = a;
+      const float hdv = do_hd ? h.v : 0.f;
+      const float curv = e2 * invN;
+      float con = 0.f;
+      if (A.dis_type != 0) con = A.w_dis * dis;
+      if (do_hd) con = con + A.w_hd * hdv;
+      con = con + A.w_curv * curv;
+      if (A.dis_loss) A.dis_loss[b] = dis;
+      if (A.hd_loss) A.hd_loss[b] = hdv;
+      if (A.curv_loss) A.curv_loss[b] = curv;
+      if (A.constrain) A.constrain[b] = con;
+    }
+  }
+  const int hd_arg = hd.i;
+  if (!want_grad) return;
+  // ---- every point: its Chamfer / Hausdorff / L2 terms, then its fixed-point sums (own curvature term + pulls)
+  float* Gd = A.grad + bN * 3;
+  for (int i = tid; i < N; i += GB_T) {
+    const float px = s_pos[3 * i], py = s_pos[3 * i + 1], pz = s_pos[3 * i + 2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (do_cd || do_hd) {
+      const int nn = A.i_ao[bN + i];
+      const float dx = px - ori[nn], dy = py - ori[Nr + nn], dz = pz - ori[2 * Nr + nn];
+      float c = do_cd ? c_cd : 0.f;
+      if (do_hd && i == hd_arg) c += A.w_hd * 2.0f;
+      gx += c * dx;
+      gy += c * dy;
+      gz += c * dz;
+    }
+    if (do_l2) {
+      const float c = A.w_dis * 2.0f;
+      gx += c * (px - ori[i]);
+      gy += c * (py - ori[Nr + i]);
+      gz += c * (pz - ori[2 * Nr + i]);
+    }
+    gx += __ll2float_rn((long long)s_acc[i]) * (1.0f / GB_FIX);
+    gy += __ll2float_rn((long long)s_acc[N + i]) * (1.0f / GB_FIX);
+    gz += __ll2float_rn((long long)s_acc[2 * N + i]) * (1.0f / GB_FIX);
+    Gd[i] = gx;
+    Gd[N + i] = gy;
+    Gd[2 * N + i] = gz;
+  }
+}
+
 }  // namespace
 
 extern "C" int geoa3_kappa(const float* pc, const float* normal, const int32_t* knn_idx, const int32_t* nn_idx,
@@ -991,6 +1202,35 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
       GEOA3_FUSED_CASE(32)
       GEOA3_FUSED_CASE(64)
 #undef GEOA3_FUSED_CASE
+      geoa3_prof_end(GEOA3_PROF_GEO, s);
+      GEOA3_CHECK_LAUNCH();
+      return GEOA3_OK;
+    }
+  }
+  if ((a->deterministic || !a->grad) && a->scratch && do_curv && a->N > GEO_T && a->N <= 4096 && a->k <= 64) {
+    // the pair-parallel kernel with fixed-point sums (see geo_big_kernel)
+    const int N = a->N, Nr = a->Nr > 0 ? a->Nr : a->N;
+    const bool two_side = a->dis_type == 1 && !a->single_side && a->d_oa != nullptr;
+    if (two_side && !a->i_oa) return GEOA3_EINVAL;
+    {
+      int G = 1;
+      while (G < a->k) G *= 2;
+      if (G < 16) G = 16;
+      float4* ctr = reinterpret_cast<float4*>(a->scratch);
+      hipStream_t s = geoa3_stream(stream);
+      const size_t lds2 = (size_t)36 * N + (16 * 5 + 4) * sizeof(float);
+      geoa3_prof_begin(GEOA3_PROF_GEO, s);
+      hipLaunchKernelGGL(geo_big_gather_kernel, dim3((N + 255) / 256, a->B), dim3(256), 0, s, *a, ctr);
+#define GEOA3_BIG_CASE(GG)                                                                                             \
+  if (G == GG) {                                                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geo_big_kernel<GG>),                                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                  \
+    hipLaunchKernelGGL(geo_big_kernel<GG>, dim3(a->B), dim3(GB_T), lds2, s, *a, ctr);                                  \
+  }
+      GEOA3_BIG_CASE(16)
+      GEOA3_BIG_CASE(32)
+      GEOA3_BIG_CASE(64)
+#undef GEOA3_BIG_CASE
       geoa3_prof_end(GEOA3_PROF_GEO, s);
       GEOA3_CHECK_LAUNCH();
       return GEOA3_OK;

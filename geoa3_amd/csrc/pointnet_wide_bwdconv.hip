@@ -60,10 +60,11 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   const int* argb = a.arg + (size_t)b * a.Co;
   if (tid <= COLS) s_off[tid] = 0;
   __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  {
   // (1) ordered compaction.  Wave w looks at channels [w Co/8, (w+1) Co/8) in chunks of 64; a hit's place in the flat
   // list follows (chunk, tap, channel): ballot + popcount, no ordering left to chance.
   const int cpw = (a.Co + BW2_WAVES - 1) / BW2_WAVES, c_lo = wave * cpw, c_hi = min(a.Co, c_lo + cpw);
-  const unsigned long long lt = (1ull << lane) - 1ull;
   // a wave's channels are at most two chunks of 64 for Co = 1024: their (gradient, arg-max) pairs are loaded ONCE, both
   // chunks in flight together, and serve the counting pass and the placement pass (they used to be re-read: two dependent
   // L2 round trips of the ~16 us a workgroup lives)
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     }
   }
   __syncthreads();
+  }
   // (2) stable placement by column: wave w owns columns 8 w .. 8 w + 7 and passes over the flat list in order, so
   // every column's list keeps the flat order
   const int total = s_off[COLS];

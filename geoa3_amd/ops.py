@@ -145,10 +145,16 @@ def kappa(pc: Tensor, normal: Tensor, knn_idx: Tensor, nn_idx: Optional[Tensor] 
     return out
 
 
+def geo_scratch(B: int, N: int, device) -> Tensor:
+    """geoa3_geo_args.scratch for B clouds of N points (16 bytes per point)."""
+    return torch.empty(B * N * 16, dtype=torch.uint8, device=device)
+
+
 def geo_loss_grad(adv: Tensor, ori: Tensor, *, normal_ori=None, kappa_ori=None, d_ao=None, i_ao=None, d_oa=None,
                   i_oa=None, knn_adv=None, dkappa=None, k: int = 0, dis_type: int = 1, single_side: bool = False,
                   w_dis: float = 1.0, w_hd: float = 0.0, w_curv: float = 0.0, want_grad: bool = True,
-                  want_kappa: bool = False, out: Optional[dict] = None, deterministic: bool = True) -> dict:
+                  want_kappa: bool = False, out: Optional[dict] = None, deterministic: bool = True,
+                  scratch: Optional[Tensor] = None) -> dict:
     """The fused geometric objective (Attacker/geoA3_attack.py:131-166) and d constrain / d adv.
     deterministic (default): every point's gradient is summed by its owner in a fixed order -- bit-for-bit reproducible
     and independent of the rest of the batch; False: LDS float atomics (free summation order)."""
@@ -162,6 +168,10 @@ def geo_loss_grad(adv: Tensor, ori: Tensor, *, normal_ori=None, kappa_ori=None, 
         o["grad"] = torch.empty(B, 3, N, device=dev, dtype=torch.float32)
     if want_kappa and "kappa_adv" not in o:
         o["kappa_adv"] = torch.empty(B, N, device=dev, dtype=torch.float32)
+    if scratch is None and (deterministic or not want_grad) and 1024 < N <= 4096 and knn_adv is not None:
+        scratch = geo_scratch(B, N, dev)      # (callers in a loop hand over their own: AttackRunner)
+    elif scratch is False:                    # tests: the one-workgroup kernel
+        scratch = None
     a = GeoArgs(adv=_p(adv, torch.float32), ori=_p(ori, torch.float32), normal_ori=_p(normal_ori),
                 kappa_ori=_p(kappa_ori), d_ao=_p(d_ao), i_ao=_p(i_ao, torch.int32) if i_ao is not None else None,
                 d_oa=_p(d_oa), i_oa=_p(i_oa, torch.int32) if i_oa is not None else None,
@@ -169,7 +179,8 @@ def geo_loss_grad(adv: Tensor, ori: Tensor, *, normal_ori=None, kappa_ori=None, 
                 B=B, N=N, k=k, Nr=int(ori.shape[2]), dis_type=dis_type, single_side=int(single_side), w_dis=w_dis, w_hd=w_hd,
                 w_curv=w_curv, dis_loss=_p(o["dis_loss"]), hd_loss=_p(o["hd_loss"]), curv_loss=_p(o["curv_loss"]),
                 constrain=_p(o["constrain"]), kappa_adv=_p(o.get("kappa_adv")) if want_kappa else None,
-                grad=_p(o["grad"]) if want_grad else None, deterministic=int(bool(deterministic)))
+                grad=_p(o["grad"]) if want_grad else None, deterministic=int(bool(deterministic)),
+                scratch=_p(scratch))
     check(_lib.load().geoa3_geo_loss_grad(C.byref(a), _stream()), "geoa3_geo_loss_grad")
     return o
 

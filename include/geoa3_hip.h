@@ -143,9 +143,14 @@ typedef struct geoa3_geo_args {
    * receives sorted by source) instead of with LDS float atomics: bit-for-bit reproducible and independent of the rest
    * of the batch (what the reference's scatter-adds -- knn_gather / index backward -- do not promise either).
    * Clouds of at most 1024 points take the pair-parallel kernel (a lane per (centre, neighbour) pair, reverse lists as
-   * fixed-capacity rows in LDS, rows sorted in registers); up to ~4800 points the one-workgroup kernel with LDS reverse
-   * lists; beyond (up to ~5800) the sums fall back to LDS float atomics (free order) whatever this flag says. */
+   * fixed-capacity rows in LDS, rows sorted in registers); 1025..4096 points with `scratch`: the pair-parallel kernel with
+   * fixed-point sums; otherwise up to ~4800 points the one-workgroup kernel with LDS reverse lists; beyond (up to ~5800)
+   * the sums fall back to LDS float atomics (free order) whatever this flag says. */
   int32_t deterministic;
+  /* optional workspace of 16 * B * N bytes (one float4 record per point).  Given, clouds of 1025..4096 points with the
+   * curvature term take the pair-parallel kernel with 64-bit fixed-point gradient sums (geo_big_kernel: order-free and
+   * therefore reproducible; the neighbour table is read once); NULL = the one-workgroup kernel.  Same values to rounding. */
+  void* scratch;
 } geoa3_geo_args;
 int geoa3_geo_loss_grad(const geoa3_geo_args* args, void* stream);
 
