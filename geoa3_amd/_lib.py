@@ -76,9 +76,6 @@ SIGNATURES = {
     "geoa3_knn": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "geoa3_knn_self_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "geoa3_knn_self": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
-    "geoa3_graph_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
-    "geoa3_graph_nn1_pair": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
-    "geoa3_graph_knn": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "geoa3_kappa": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_geo_loss_grad": (C.c_int, [C.POINTER(GeoArgs), vp]),
     "geoa3_pointnet_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

@@ -72,10 +72,6 @@ class AttackRunner:
         self.use_curv = cfg.curv_loss_weight != 0
         self.dis_type = {"CD": 1, "L2": 2, "None": 0}[cfg.dis_loss_type]
         self.need_nn = self.dis_type == 1 or cfg.hd_loss_weight != 0 or self.use_curv
-        # cfg.graph_search (opt-in, results bit-identical): answer the per-iteration searches from the clean cloud's
-        # neighbour table (geom_graph.hip).  It wins while offsets stay below the point spacing; measured on the
-        # synthetic workload (offsets of several spacings) it is 2 % SLOWER than brute force, hence off by default.
-        self.graph_search = bool(_cfg(cfg, "graph_search", False)) and self.need_nn
         self.iters = int(cfg.iter_max_steps)
         # the objective's gradient summed in a fixed order (geoa3_geo_args.deterministic): iterates are reproducible bit
         # for bit and shard rows equal the full batch's; cfg.deterministic / GEOA3_DETERMINISTIC=0 select the atomics
@@ -94,8 +90,6 @@ class AttackRunner:
             raise ValueError("eval_num must be in 1..64")
         # --is_pre_jitter_input (geoA3_attack.py:312-317): the objective is evaluated at x + tangent-plane noise
         self.jitter = bool(_cfg(cfg, "is_pre_jitter_input", False))
-        if self.sub:
-            self.graph_search = False
         self.hooks = {}
         # The geometry kernels of an iteration (1-NN, K-NN, losses: VALU / latency bound) do not depend on the victim's
         # forward (MFMA / HBM bound): they are enqueued on a second HIP stream between two events, so the hardware
@@ -208,14 +202,8 @@ class AttackRunner:
         t["best_bs"].fill_(-1)
         self.kappa_ori = None
         self.nn1_seeded = False
-        self.graph = None
-        if self.graph_search:
-            self.graph = ops.OriGraph(self.ori, 32 if (self.k + 1 if self.use_curv else 1) <= 24 else 64)
         if self.use_curv:  # _get_kappa_ori once per batch (geoA3_attack.py:216-217)
-            if self.graph is not None:
-                knn_ori = self.graph.idx[:, : self.k + 1].permute(0, 2, 1).contiguous()
-            else:
-                _, knn_ori = ops.knn_planar(self.ori, self.ori, self.k + 1)
+            _, knn_ori = ops.knn_planar(self.ori, self.ori, self.k + 1)
             self.kappa_ori = ops.kappa(self.ori, self.nrm, knn_ori)
             self.knn_cur = 0
             self.knn_seeded = not self.sub
@@ -361,34 +349,27 @@ class AttackRunner:
             constrain = None
             if self.need_nn:
                 both = self.dis_type == 1 and not cfg.is_cd_single_side
-                if self.graph is not None:
-                    self.graph.nn1_pair(xe, both, out=(t["d_ao"], t["i_ao"], t["d_oa"] if both else None,
-                                                       t["i_oa"] if both else None))
+                if self.grid_nn1:   # seeded with the tables of the previous iteration (in place)
+                    pa = t["i_ao"].data_ptr() if self.nn1_seeded else None
+                    pr = t["i_oa"].data_ptr() if self.nn1_seeded and both else None
+                    check(lib.geoa3_grid_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n, pa, pr,
+                                                  t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
+                                                  t["d_oa"].data_ptr() if both else None,
+                                                  t["i_oa"].data_ptr() if both else None, sg), "grid_nn1_pair")
+                    self.nn1_seeded = not self.sub
                 else:
-                    if self.grid_nn1:   # seeded with the tables of the previous iteration (in place)
-                        pa = t["i_ao"].data_ptr() if self.nn1_seeded else None
-                        pr = t["i_oa"].data_ptr() if self.nn1_seeded and both else None
-                        check(lib.geoa3_grid_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n, pa, pr,
-                                                      t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
-                                                      t["d_oa"].data_ptr() if both else None,
-                                                      t["i_oa"].data_ptr() if both else None, sg), "grid_nn1_pair")
-                        self.nn1_seeded = not self.sub
-                    else:
-                        check(lib.geoa3_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n,
-                                                 t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
-                                                 t["d_oa"].data_ptr() if both else None,
-                                                 t["i_oa"].data_ptr() if both else None, sg), "nn1_pair")
+                    check(lib.geoa3_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n,
+                                             t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
+                                             t["d_oa"].data_ptr() if both else None,
+                                             t["i_oa"].data_ptr() if both else None, sg), "nn1_pair")
             knn_adv = None
             if self.use_curv:
                 prior, out = t["knn"][self.knn_cur], t["knn"][1 - self.knn_cur]
-                if self.graph is not None:
-                    self.graph.knn_self(xe, self.k + 1, out=(t["knn_d"], out), prior=prior)
-                else:
-                    check(lib.geoa3_knn_self(xe.data_ptr(), self.b, ne, self.k + 1,
-                                             prior.data_ptr() if self.knn_seeded else None, t["knn_d"].data_ptr(),
-                                             out.data_ptr(), t["knn_scratch"].data_ptr() if self.knn_slab else None,
-                                             self.knn_method, sg),
-                          "knn_self")
+                check(lib.geoa3_knn_self(xe.data_ptr(), self.b, ne, self.k + 1,
+                                         prior.data_ptr() if self.knn_seeded else None, t["knn_d"].data_ptr(),
+                                         out.data_ptr(), t["knn_scratch"].data_ptr() if self.knn_slab else None,
+                                         self.knn_method, sg),
+                      "knn_self")
                 self.knn_seeded = True
                 self.knn_cur = 1 - self.knn_cur
                 knn_adv = out
@@ -559,7 +540,7 @@ class AttackRunner:
 # cfg fields that shape an AttackRunner's buffers / kernel choices at construction
 RUNNER_CFG_FIELDS = ("attack_label", "iter_max_steps", "curv_loss_knn", "curv_loss_weight", "dis_loss_type",
                      "hd_loss_weight", "cls_loss_type", "optim", "uniform_loss_weight", "npoint", "is_partial_var",
-                     "knn_range", "is_subsample_opt", "eval_num", "is_pre_jitter_input", "is_pro_grad", "graph_search",
+                     "knn_range", "is_subsample_opt", "eval_num", "is_pre_jitter_input", "is_pro_grad",
                      "brute_force_nn1", "classes", "deterministic")
 
 

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn1_pair_kernel(const float* __restr
                                                             int32_t* __restrict__ i_ra,
                                                             const uint8_t* __restrict__ only) {
   // `only` (optional, [2][B][max(Na,Nr)] bytes, direction-major): restrict the search to the flagged queries --
-  // the exact fallback of the graph-pruned search (geom_graph.hip); a block without a flagged query exits at once.
+  // the exact fallback of a pruned search; a block without a flagged query exits at once.
   __shared__ __attribute__((aligned(16))) float s_ref[3 * NN_CHUNK];
   const int b = blockIdx.y;
   const bool swap = blockIdx.z != 0;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
   const int tid = threadIdx.x;
   const int q = blockIdx.x * KNN_BLOCK + tid;
   bool live = q < Nq;
-  if (only) {  // exact fallback of the graph-pruned search: only the flagged queries, whole block skipped if none
+  if (only) {  // exact fallback of a pruned search: only the flagged queries, whole block skipped if none
     live = live && only[(size_t)b * Nq + q] != 0;
     if (!__syncthreads_or(live)) return;
   }

@@ -90,50 +90,6 @@ def knn_self_planar(pc: Tensor, K: int, prior: Optional[Tensor] = None, scratch:
     return d, i
 
 
-class OriGraph:
-    """Neighbour table of a CLEAN batch for the graph-pruned searches (include/geoa3_hip.h geoa3_graph_*):
-    built once per batch with the brute-force K-NN, stored neighbour-major [B,Kg,N]."""
-
-    def __init__(self, ori: Tensor, Kg: int):
-        B, _, N = ori.shape
-        self.Kg = int(min(Kg, N, 64))
-        d, i = knn_planar(ori, ori, self.Kg)
-        self.idx = i.permute(0, 2, 1).contiguous()
-        self.dist = d.permute(0, 2, 1).contiguous()
-        self.ori = ori
-        nbytes = _lib.load().geoa3_graph_scratch_bytes(B, N)
-        self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=ori.device)
-
-    def nn1_pair(self, adv: Tensor, both: bool = True, out=None):
-        """== nn1_pair(adv, ori, both) (bit-identical), O(N*few) while adv stays close to ori."""
-        B, _, N = adv.shape
-        if out is None:
-            d_ao = torch.empty(B, N, device=adv.device, dtype=torch.float32)
-            i_ao = torch.empty(B, N, device=adv.device, dtype=torch.int32)
-            d_oa = torch.empty_like(d_ao) if both else None
-            i_oa = torch.empty_like(i_ao) if both else None
-        else:
-            d_ao, i_ao, d_oa, i_oa = out
-        check(_lib.load().geoa3_graph_nn1_pair(_p(adv, torch.float32), _p(self.ori), _p(self.idx), _p(self.dist),
-                                               self.Kg, B, N, _p(d_ao), _p(i_ao), _p(d_oa), _p(i_oa),
-                                               _p(self.scratch), _stream()), "geoa3_graph_nn1_pair")
-        return d_ao, i_ao, d_oa, i_oa
-
-    def knn_self(self, adv: Tensor, K: int, out=None, prior: Optional[Tensor] = None):
-        """== knn_planar(adv, adv, K) (bit-identical).  prior (may be the output table itself, holding the previous
-        iteration's result) seeds the brute-force fallback of the queries the table cannot decide."""
-        B, _, N = adv.shape
-        if out is None:
-            d = torch.empty(B, N, K, device=adv.device, dtype=torch.float32)
-            i = torch.empty(B, N, K, device=adv.device, dtype=torch.int32)
-        else:
-            d, i = out
-        check(_lib.load().geoa3_graph_knn(_p(adv, torch.float32), _p(self.ori), _p(self.idx), _p(self.dist), self.Kg,
-                                          B, N, K, _p(prior, torch.int32) if prior is not None else None, _p(d), _p(i),
-                                          _p(self.scratch), _stream()), "geoa3_graph_knn")
-        return d, i
-
-
 def kappa(pc: Tensor, normal: Tensor, knn_idx: Tensor, nn_idx: Optional[Tensor] = None) -> Tensor:
     """pc/normal [B,3,N], knn_idx int32 [B,N,k+1] -> kappa [B,N] (Lib/loss_utils.py:52-62)."""
     B, _, N = pc.shape

@@ -86,18 +86,6 @@ int64_t geoa3_knn_self_scratch_bytes(int B, int N);
 int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_t* prior, float* dists, int32_t* idx,
                    void* scratch, int method, void* stream);
 
-/* Graph-pruned forms of the two searches for the attack loop, where the searched cloud is adv = ori + offset and
- * `ori` is fixed for the whole batch (Attacker/geoA3_attack.py:281).  (gidx, gdist): ori's own neighbour table,
- * NEIGHBOUR-MAJOR [B,Kg,N], row m = the m-th nearest clean point of every point (row 0 = the point itself), built once
- * per batch from geoa3_knn(ori, ori, Kg).  Results are bit-identical to geoa3_nn1_pair(adv, ori) /
- * geoa3_knn(adv, adv, K) for any offset: queries the table cannot decide are answered by the brute-force kernels.
- * scratch: geoa3_graph_scratch_bytes(B, N) bytes, contents irrelevant.  geoa3_graph_knn needs K <= Kg <= 64. */
-int64_t geoa3_graph_scratch_bytes(int B, int N);
-int geoa3_graph_nn1_pair(const float* adv, const float* ori, const int32_t* gidx, const float* gdist, int Kg, int B,
-                         int N, float* d_ao, int32_t* i_ao, float* d_oa, int32_t* i_oa, void* scratch, void* stream);
-int geoa3_graph_knn(const float* adv, const float* ori, const int32_t* gidx, const float* gdist, int Kg, int B, int N,
-                    int K, const int32_t* prior, float* dists, int32_t* idx, void* scratch, void* stream);
-/* prior: optional [B,N,K] table (e.g. last iteration's result; MAY ALIAS idx) that seeds the brute-force fallback. */
 
 /* _get_kappa_ori (Lib/loss_utils.py:52-62) given the self K-NN table knn_idx [B,N,k+1]
  * (column 0, the nearest hit, is dropped exactly as the reference's [:, :, :, 1:] slice):

@@ -83,8 +83,6 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--quiet", action="store_true", default=False)
     p.add_argument("--synthetic_npoint", type=int, default=0,
                    help="points per synthetic cloud when --synthetic writes the data file (default: --npoint)")
-    p.add_argument("--graph_search", action="store_true", default=False,
-                   help="answer the per-iteration NN searches from the clean cloud's neighbour table (same results)")
     return p
 
 

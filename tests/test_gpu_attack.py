@@ -1,5 +1,7 @@
 """The device-resident attack loop (geoa3_amd.attack) against the reference trajectories stored in the golden
 fixtures (produced by the reference's own attack()) and against the oracle on a fresh case."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -138,67 +140,31 @@ def test_shard_invariance_on_device(net, golden):
             assert (part[2] == full[2][lo:hi]).all() and list(part[3]) == list(full[3][lo:hi])
 
 
-@pytest.mark.parametrize("lr", [0.001, 0.02])
-def test_graph_search_in_the_loop(net, lr):
-    """cfg.graph_search answers the searches from the clean cloud's neighbour table (geom_graph.hip).  At every
-    iterate of a real attack run the tables it hands to the objective are bit-identical to the all-pairs search,
-    whether the table decides almost every query (small lr) or almost none (large lr); the run as a whole then
-    agrees with the brute-force run to float-summation noise (the objective's LDS float atomics are unordered)."""
-    import copy
-    from geoa3_amd import ops
-    from geoa3_amd.attack import AttackRunner, unpack_input
-    ori, nrm = O.make_synthetic_clouds(5, 700, seed=23)
-    with torch.no_grad():
-        gt = O.pointnet_forward(O.make_pointnet_state_dict(40, seed=0), ori).argmax(1)
-    cfg = O.AttackCfg(binary_max_steps=1, iter_max_steps=25, lr=lr, curv_loss_knn=16)
-    gcfg = copy.copy(cfg)
-    gcfg.graph_search = True
-    init = torch.randn(5, 3, 700, generator=torch.Generator().manual_seed(24)) * 1e-3
-    pc, nm, g, t = unpack_input(_loader_batch(ori, nrm, gt, None, False), False)
-    runs = []
-    for c in (cfg, gcfg):
-        r = AttackRunner(net, 5, 700, c, torch.device("cuda"))
-        r.setup(pc, nm, g, t)
-        r.begin_search_step(init.cuda())
-        runs.append(r)
-    brute, graph = runs
-    assert graph.graph is not None and brute.graph is None
-    assert torch.equal(brute.kappa_ori, graph.kappa_ori)
-    for step in range(cfg.iter_max_steps):
-        x = graph.t["x"].clone()
-        graph.step(step, 0)
-        brute.step(step, 0)
-        d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(x, graph.ori)
-        kd, ki = ops.knn_planar(x, x, cfg.curv_loss_knn + 1)
-        for got, want in ((graph.t["d_ao"], d_ao), (graph.t["i_ao"], i_ao), (graph.t["d_oa"], d_oa),
-                          (graph.t["i_oa"], i_oa), (graph.t["knn_d"], kd), (graph.t["knn"][graph.knn_cur], ki)):
-            assert torch.equal(got, want), step
-    diff = (graph.t["x"] - brute.t["x"]).abs()
-    # unordered float sums + Adam's sign-like steps on near-zero gradients: most coordinates agree to rounding,
-    # a few drift by whole steps (same behaviour between two brute-force runs).  At the large learning rate the two
-    # runs may part ways altogether once one such step changes a neighbourhood (seen once in ~10 runs): only the
-    # per-step tables above (bit-identical) and the step bound are asserted there.
-    assert diff.max().item() <= 2 * lr * cfg.iter_max_steps
-    if lr <= 0.001:
-        assert diff.median().item() < 2e-5
-
-
+@pytest.mark.timeout(1500)
 def test_config5_shape_n4096_k32(net):
-    """BASELINE configs[4]: N = 4096 points, curv_loss_knn = 32 (K-NN K = 33, 114 KB LDS objective kernel)."""
-    from geoa3_amd.attack import attack
-    cfg = O.AttackCfg(binary_max_steps=1, iter_max_steps=3, lr=0.002, curv_loss_knn=32)
+    """BASELINE configs[4]: N = 4096 points, curv_loss_knn = 32 (cell-grid K-NN with K = 33, the fixed-point objective kernel),
+    32 iterations against the oracle with the short-trajectory bars: iterates (>= 99 % of the coordinates within 5e-5, all
+    within 2 lr per step), labels, per-step losses, success flags."""
+    steps, lr = 32, 0.002
+    cfg = O.AttackCfg(binary_max_steps=1, iter_max_steps=steps, lr=lr, curv_loss_knn=32, initial_const=200.0)
     sd = O.make_pointnet_state_dict(40, seed=0)
     onet = lambda x: O.pointnet_forward(sd, x)
     ori, nrm = O.make_synthetic_clouds(2, 4096, seed=91)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))    # (torch's intra-op pool stops scaling long before 256 threads)
     with torch.no_grad():
         gt = onet(ori).argmax(1)
     inits = [torch.randn(2, 3, 4096, generator=torch.Generator().manual_seed(92)) * 1e-3]
     tr = {}
     _, _, osucc, _, oloss = O.attack(onet, ori, nrm, gt, None, cfg, inits, trace=tr)
-    best, target, succ, best_step, all_loss = attack(net, _loader_batch(ori, nrm, gt, None, False), cfg, 0, 1,
-                                                     init_offsets=[i.cuda() for i in inits], verbose=False)
-    np.testing.assert_allclose(np.asarray(all_loss, dtype=np.float32), np.asarray(oloss, dtype=np.float32),
+    r, (best, target, succ, best_step, all_loss), xs, labels = _run(net, cfg, ori, nrm, gt, gt, False, inits)
+    assert r.geo_scratch is not None                       # the two-kernel objective of the big clouds is the one in use
+    ref_x = torch.stack([ori + o for o in tr["offsets"]]).numpy()
+    _traj_close(xs, ref_x, tight=5e-5, frac=0.99, loose=2.0 * lr * steps)
+    assert (labels == np.asarray(tr["labels"])).mean() >= 0.95
+    np.testing.assert_allclose(np.asarray(all_loss, dtype=np.float32)[:8], np.asarray(oloss, dtype=np.float32)[:8],
                                rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(np.asarray(all_loss, dtype=np.float32), np.asarray(oloss, dtype=np.float32), rtol=2e-2, atol=2e-3)
+    assert (np.asarray(succ) == osucc).all()
 
 
 def test_pointnetpp_attack_matches_oracle():

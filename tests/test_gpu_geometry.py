@@ -228,38 +228,6 @@ def test_loss_utils_mirror_golden(golden, tag):
     np.testing.assert_allclose(adv.grad.cpu().numpy(), golden[pre + "g_curv"], rtol=2e-3, atol=2e-6)
 
 
-@pytest.mark.parametrize("N,K,Kg,scale", [(1024, 17, 32, 0.01), (1024, 17, 32, 0.08), (1024, 17, 32, 0.6),
-                                          (700, 9, 16, 0.02), (2048, 33, 64, 0.01), (300, 17, 32, 0.0),
-                                          (40, 17, 32, 0.05)])
-def test_graph_pruned_search_is_bit_identical_to_brute_force(ops, N, K, Kg, scale):
-    """Small offsets (pruned path), medium offsets (mixed) and huge offsets (every query falls back): the graph
-    search must reproduce the all-pairs kernels -- and the oracle -- bit for bit, including ties."""
-    B = 3
-    ori, _ = O.make_synthetic_clouds(B, N, seed=N + K)
-    g = torch.Generator().manual_seed(17)
-    off = scale * torch.randn(B, 3, N, generator=g)
-    off[:, :, : N // 2] *= 0.1                      # mixed magnitudes: dmax is set by a few points
-    adv = ori + off
-    if N > 12:
-        adv[:, :, 5] = adv[:, :, 4]                  # duplicate adversarial points: exact ties
-        adv[:, :, 9] = ori[:, :, 11]                 # an adversarial point sitting on another clean point
-    oriD, advD = dev(ori), dev(adv)
-    graph = ops.OriGraph(oriD, Kg)
-    d_ao, i_ao, d_oa, i_oa = graph.nn1_pair(advD)
-    b_ao, bi_ao, b_oa, bi_oa = ops.nn1_pair(advD, oriD)
-    assert torch.equal(i_ao, bi_ao) and torch.equal(d_ao, b_ao)
-    assert torch.equal(i_oa, bi_oa) and torch.equal(d_oa, b_oa)
-    kk = min(K, N)
-    d, i = graph.knn_self(advD, kk)
-    bd, bi = ops.knn_planar(advD, advD, kk)
-    assert torch.equal(i, bi) and torch.equal(d, bd)
-    od, oi = O.knn_points(adv.permute(0, 2, 1), adv.permute(0, 2, 1), kk)
-    assert torch.equal(i.cpu().long(), oi) and torch.equal(d.cpu(), od)
-    # single-sided form
-    d1, i1, n1, n2 = graph.nn1_pair(advD, both=False)
-    assert n1 is None and torch.equal(i1, bi_ao) and torch.equal(d1, b_ao)
-
-
 @pytest.mark.parametrize("N,K,scale", [(1024, 17, 0.002), (1024, 17, 0.05), (1024, 17, 0.6), (700, 9, 0.02),
                                        (4096, 33, 0.01), (2048, 64, 0.01), (300, 17, 0.0), (40, 17, 0.05),
                                        (8192, 5, 0.01), (9000, 5, 0.01)])

@@ -31,15 +31,22 @@ T = torch.from_numpy
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 # bars (relative unless noted); see DESIGN.md section 2, row "long run"
-BEST_RTOL = {"n256_b8_hard": 0.10, "n256_b8_tgt": 0.10, "n1024_b8_hard": 0.10, "n1024_b4_margin": 0.10,
-             "pn2_n1024_b4_tgt": 0.10}   # best constrain loss per instance
-# 50-step window means of loss_n (batch mean).  The bar is set by the chaos of the loop itself, measured with
-# tools/longrun_noise.py (profiles/round3_longrun_noise.txt): 13 deterministic runs whose start is perturbed by k*1e-7
-# spread over 0.2-0.5 % (median) / 1.1 % (max) of the reference's window means, 13 repeats of the atomics loop over
-# 0.3 % / 1.5 %; the CPU oracle under the same perturbation: 0.05-0.25 % (4 runs).  Constrain windows: 2 x this bar
-# (observed max 3.9 %).
-WINDOW_RTOL = {"n256_b8_hard": 0.025, "n256_b8_tgt": 0.025, "n1024_b8_hard": 0.025, "n1024_b4_margin": 0.025,
-               "pn2_n1024_b4_tgt": 0.025}
+# Bars per case; see DESIGN.md section 2, row "long run".  They come from the chaos of the loop itself, measured with
+# tools/longrun_noise.py (profiles/round4_longrun_noise.txt): 13 deterministic runs whose start is perturbed by k * 1e-7 and
+# 13 repeats of the atomics loop, first binary step, against the reference's window means.
+#   PointNet victim (four cases, both arithmetic modes): loss_n windows 0.02-0.16 % (median) / 0.34 % (max), constrain windows
+#   <= 3.9 %, adversarial fraction equal to 1e-3 -- and the CPU oracle under the same perturbation 0.05-0.25 % / <= 1.6 %.
+#   PointNet++ victim (farthest-point sampling and ball queries make the loss DISCONTINUOUS in the iterate; b = 4): loss_n
+#   windows 6.0 % (median) / 8.6 % (max), constrain 5.9 % / 8.3 %, adversarial fraction 0.03 / 0.10 -- and the CPU ORACLE
+#   perturbed the same way leaves the reference run by 4.1 % / 7.7 %, 4.7 % / 5.8 % and 0.045: the case is that chaotic on any
+#   implementation, its bars are wider by that much.
+BARS = {   # best: best constrain loss per instance; window: 50-step means of loss_n (constrain: twice that); adv: fraction
+    "n256_b8_hard": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
+    "n256_b8_tgt": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
+    "n1024_b8_hard": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
+    "n1024_b4_margin": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
+    "pn2_n1024_b4_tgt": dict(best=0.25, window=0.12, adv=0.15, last_margin=1.0, first=5e-3, first_steps=4),
+}
 ROBUST_STEPS = 3         # an instance counts as robustly (un)successful in a binary step with >= 3 / 0 adversarial steps
 
 
@@ -143,7 +150,8 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     # (0) the quirk's input: the run's own label of the last instance at the last step of every binary step, wherever
     # the reference's top-2 margin there is not a near-tie (while the instance still follows the reference's constants)
     ref_margin_last = g[pre + "tr_margin"][:, -1, -1]
-    robust_last = ref_margin_last > 0.05
+    bars = BARS[tag]
+    robust_last = ref_margin_last > bars["last_margin"]
     report["last_label"] = [out["own_last"].tolist(), g[pre + "tr_pred"][:, -1, -1].tolist(), ref_margin_last.round(4).tolist()]
     if robust_last[0]:
         chk(out["own_last"][0] == g[pre + "tr_pred"][0, -1, -1], "last label of binary step 0", report["last_label"])
@@ -157,7 +165,7 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     # (2) fraction of adversarial steps per binary step (batch level)
     fa_ref, fa_got = ref_adv.mean((1, 2)), got_adv.mean((1, 2))
     report["adv_fraction"] = [fa_got.round(4).tolist(), fa_ref.round(4).tolist()]
-    chk(np.abs(fa_got - fa_ref).max() <= 0.05, "adversarial fraction", fa_got, fa_ref)
+    chk(np.abs(fa_got - fa_ref).max() <= bars["adv"], "adversarial fraction", fa_got, fa_ref)
 
     # (3) the binary search: trade-off constant at the start of every binary step, for instances whose success within
     # the previous binary steps is robust in BOTH runs (>= ROBUST_STEPS adversarial steps, or none)
@@ -176,7 +184,7 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     both = out["succ"] & ref_succ
     ratio = out["best_loss"][both] / g[pre + "best_constrain"][both]
     report["best_constrain_ratio"] = ratio.round(4).tolist()
-    rt = BEST_RTOL[tag]
+    rt = bars["best"]
     chk(np.median(np.abs(ratio - 1.0)) <= rt / 2, "best constrain (median)", ratio)
     chk((np.abs(ratio - 1.0) <= rt).mean() >= 0.75, "best constrain", ratio)
     # ... and it IS adversarial with that loss: re-evaluated by the oracle on the returned cloud
@@ -186,7 +194,7 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     chk(adversarial(re_pred, gt[both], tgt[both], targeted).mean() >= 0.85, "best clouds adversarial", re_pred, gt[both], tgt[both])
 
     # (5) level of the objective over time: 50-step windows of the batch mean of loss_n and of the constrain loss
-    wr = WINDOW_RTOL[tag]
+    wr = bars["window"]
     ref_ln, got_ln = g[pre + "tr_loss_n"].mean(2), out["loss_n"].mean(2)     # [S,T]
     ref_con, got_con = g[pre + "tr_constrain"].mean(2), out["con"].mean(2)
     rows = []
@@ -206,7 +214,10 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     # the first iterations are still a shared trajectory: tight
     dev = np.abs(out["loss_n"][0, :12] - g[pre + "tr_loss_n"][0, :12]) / (np.abs(g[pre + "tr_loss_n"][0, :12]) + 0.1)
     report["first_steps_max_rel_dev"] = dev.max(1).round(6).tolist()
-    chk(dev[:6].max() <= 5e-3, "first six steps", dev.max(1))
+    # (per instance; the median over the instances: one sign flip of Adam's first step on a near-zero gradient moves a
+    # coordinate by 2 lr, which a PointNet++ victim turns into another farthest-point sample for THAT instance)
+    nfirst = bars.get("first_steps", 6)      # (PointNet++: the median instance leaves the shared trajectory at step 5)
+    chk(np.median(dev[:nfirst], axis=1).max() <= bars["first"], "first steps", dev.max(1), np.median(dev, axis=1))
     report["fails"] = fails
     outdir = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(outdir):

@@ -1,0 +1,37 @@
+"""Every cross-kernel hand-over of the loop, soaked: ONE attack iteration replayed thousands of times from the
+same device state (tools/iteration_replay_soak.py); after every replay every tensor the iteration writes -- logits,
+losses, 1-NN / K-NN tables, both gradient parts, Adam moments, the iterate, and every buffer of the victim's workspace
+(activations, gate masks, arg-max keys, FC k-split partials, Gram partials, the dT3 partial sums, ...) -- is compared bit
+for bit with the first replay.  This is the test that would have caught round 3's `conv_bwd_chain_kernel` hazard (wrong
+values in lanes 48-63 with two wavefronts per SIMD, ~1e-3 of the launches) by the name of the buffer: `ws.dTpart`, `g_cls`.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+
+# buffers whose CONTENT may legitimately differ between runs while every result is bit-identical: the K-NN scratch holds the
+# cloud counting-sorted into slabs / cells with atomic cursors (the order inside a bin is free; the searches are exact)
+FREE = {"knn_scratch"}
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("b,n,k,arch,mode,iters", [
+    (250, 1024, 16, "PointNet", None, 10000),      # configs[1]
+    (32, 1024, 16, "PointNet", None, 3000),        # one rank's shard of configs[2] (other tile shapes, split head)
+    (64, 1024, 16, "PointNet", "f32", 1000),       # the fp32-MFMA kernels
+    (16, 4096, 32, "PointNet", None, 300),         # configs[4]: cell-grid K-NN, fixed-point objective
+    (32, 1024, 16, "PointNetPP", None, 500),       # configs[3]
+])
+def test_one_iteration_replayed_is_bit_stable(b, n, k, arch, mode, iters):
+    import iteration_replay_soak as S
+    iters = max(50, int(iters * float(os.environ.get("GEOA3_SOAK_SCALE", "1"))))
+    r = S.make_runner(b, n, k, arch, mode, presteps=20)
+    differing, by = S.replay(r, iters, 20)
+    by = {name: cnt for name, cnt in by.items() if name not in FREE}
+    assert not by, "%d of %d replays differ: %s" % (differing, iters, by)
