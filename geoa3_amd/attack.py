@@ -104,9 +104,9 @@ class AttackRunner:
         # Small shards (the 32-instance regime of an 8-GPU split) are latency bound: there the geometry chain is as long
         # as the forward, so the head is split (geoa3_attack_head_classify / _finish) and the geometry stream is joined
         # only AFTER the victim's backward.  At 250 instances the kernels are throughput bound and the late join gains
-        # nothing (measured), so it is taken for b <= 96 unless GEOA3_LATE_JOIN says otherwise.  Same results.
-        lj = os.environ.get("GEOA3_LATE_JOIN", "auto")
-        self.late_join = (b <= 96) if lj == "auto" else lj == "1"
+        # nothing (measured), so it is taken for b <= 96 (cfg.late_join overrides).  Same results.
+        lj = _cfg(cfg, "late_join", None)           # (tests: cfg.late_join = True / False)
+        self.late_join = (b <= 96) if lj is None else bool(lj)
         # the 1-NN tables through the uniform-grid search (geom_grid.hip; same bits as the all-pairs kernel, which
         # stays the path for clouds beyond 4096 points or when cfg.brute_force_nn1 is set)
         self.grid_nn1 = max(n, self.ne) <= 4096 and not _cfg(cfg, "brute_force_nn1", False)
@@ -155,8 +155,8 @@ class AttackRunner:
         if self.use_curv:
             t["knn"] = [torch.zeros(b, ne, self.k + 1, **i32) for _ in range(2)]
             t["knn_d"] = z(b, ne, self.k + 1)
-            self.knn_slab = os.environ.get("GEOA3_KNN_SLAB", "1") != "0"
-            self.knn_method = int(os.environ.get("GEOA3_KNN_METHOD", "0"))   # 0 = by (K, N), 1 = slab, 2 = cell grid
+            self.knn_slab = True
+            self.knn_method = int(_cfg(cfg, "knn_method", 0))   # geoa3_knn_self: 0 = by (K, N), 1 = slab, 2 = cell grid
             t["knn_scratch"] = ops.knn_self_scratch(b, ne, device)
         if self.native:
             bw = b * self.eval_num if self.sub else b

@@ -223,16 +223,16 @@ _NEXT_HANDLE = itertools.count(1)
 
 def register_net(net) -> int:
     """A handle for `net` (a geoa3_amd.pointnet.PointNet in eval mode) to pass to geoa3::pointnet_forward.  Handles
-    come from a counter (never reused); a copy of a module (copy.deepcopy / pickle carry the integer along) registers
-    itself again through net_handle()."""
+    come from a counter (never reused); a copy of a module (copy.deepcopy / pickle) registers itself again in
+    PointNet.__setstate__."""
     h = next(_NEXT_HANDLE)
     _NETS[h] = net
     return h
 
 
-@torch.compiler.assume_constant_result
 def net_handle(net) -> int:
-    """The handle under which `net` itself is registered (re-registered if the stored one belongs to another module)."""
+    """The handle under which `net` itself is registered (re-registered if the stored one belongs to another module).
+    Eager callers; a traced forward reads net._handle, which PointNet.__setstate__ keeps its own for copies."""
     h = getattr(net, "_handle", None)
     if h is None or _NETS.get(h) is not net:
         h = net._handle = register_net(net)

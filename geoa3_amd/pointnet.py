@@ -78,10 +78,8 @@ def wide_shape(layer: str = "conv5") -> int:
     """MFMA shape of a split 1024-wide layer: 16 = v_mfma_f32_16x16x32_f16 (pointnet_wide16.hip), 32 =
     v_mfma_f32_32x32x16_f16 (pointnet_wide_split.hip).  Measured on MI355X: conv5 (K = 384 per group) 0.495 -> 0.444 ms on
     the 16x16x32 shape, the T-Nets' conv3 (K = 128 per group: a third of the MFMAs between two epilogues) 0.182 -> 0.292 ms
-    -- so conv5 defaults to 16, the T-Nets to 32.  GEOA3_WIDE_SHAPE / GEOA3_WIDE_SHAPE_TNET override."""
-    if layer == "conv5":
-        return int(os.environ.get("GEOA3_WIDE_SHAPE", "16"))
-    return int(os.environ.get("GEOA3_WIDE_SHAPE_TNET", "32"))
+    -- so conv5 takes 16, the T-Nets 32."""
+    return 16 if layer == "conv5" else 32
 
 
 def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
@@ -103,7 +101,7 @@ def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     out["w3h"], out["w3h_unscale"] = pack_wide_split(out["w3"], 1)
     out["w2h"], out["w2h_unscale"] = pack_wide_split(out["w2"], 1)
     out["w3h16"], _ = pack_wide_split16(out["w3"])
-    out["w2t_amax"] = float(out["w2t"].abs().max()) if os.environ.get("GEOA3_W2T_AMAX", "1") != "0" else 0.0
+    out["w2t_amax"] = float(out["w2t"].abs().max())
     return out
 
 
@@ -129,7 +127,7 @@ def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
     out["w5h"], out["w5h_unscale"] = pack_wide_split(out["w5"], 3)
     out["w4h"], out["w4h_unscale"] = pack_wide_split(out["w4"], 1)
     out["w5h16"], _ = pack_wide_split16(out["w5"])
-    out["w4t_amax"] = float(out["w4t"].abs().max()) if os.environ.get("GEOA3_W2T_AMAX", "1") != "0" else 0.0
+    out["w4t_amax"] = float(out["w4t"].abs().max())
     return out
 
 
@@ -149,20 +147,19 @@ def default_wide_mode() -> str:
 
 
 def fuse_front() -> bool:
-    """GEOA3_FUSE_FRONT=1 (opt-in): the 64 -> 128 layers in front of the three 1024-wide layers (T-Net conv2, trunk conv4)
-    are evaluated inside the wide kernels' staging pass (split mode only) and their [B,128,N] activations never
-    written.  Same results to rounding, all tests pass -- but measured SLOWER on MI355X (conv5 0.50 -> 0.71 ms, T-Net
-    conv3 0.186 -> 0.238 ms against 52-60 us per convolution saved: 2.26 -> 2.45 ms/iteration): the staging pass of a
-    unit grows from two dependent phases to six (loads, split, four rounds of weight-fragment loads + MFMAs +
-    epilogue) and the co-resident workgroup's MFMAs no longer cover it.  Off by default; DESIGN.md."""
-    return os.environ.get("GEOA3_FUSE_FRONT", "0") == "1"
+    """The 64 -> 128 layers in front of the three 1024-wide layers evaluated inside the wide kernels' staging pass (the
+    library supports it: geoa3_tnet_weights.w2h / geoa3_pointnet_weights.w4h).  Same results to rounding, but measured
+    SLOWER on MI355X (conv5 0.50 -> 0.71 ms against 52-60 us per convolution saved): never handed over by this host."""
+    return False
+
+
+# A/B switches of the library (geoa3_pointnet_weights.flags; the library itself reads no environment): bit 0 / bit 1 select
+# the unfused sparse backward / the one-layer-per-launch trunk (same bits either way, tests/test_gpu_pointnet.py)
+AB_FLAGS = 0
 
 
 def ab_flags() -> int:
-    """geoa3_pointnet_weights.flags from the A/B switches of the environment (read HERE, by the host side: the library
-    itself reads no environment): GEOA3_FUSE_BWD=0 / GEOA3_FUSE_CHAIN=0 select the unfused kernels (same bits)."""
-    return ((1 if os.environ.get("GEOA3_FUSE_BWD", "1") == "0" else 0) |
-            (2 if os.environ.get("GEOA3_FUSE_CHAIN", "1") == "0" else 0))
+    return int(AB_FLAGS)
 
 
 class PackedPointNet:
@@ -287,6 +284,13 @@ class PointNet(nn.Module):
         from . import library
         self._handle = library.register_net(self)  # the scalar the custom op geoa3::pointnet_forward takes for this module
 
+    def __setstate__(self, state):
+        """copy.deepcopy / pickle: the copy is a module of its own -- its own handle, packed weights and workspace."""
+        super().__setstate__(state)
+        from . import library
+        self._packed, self._packed_key, self._ws_cache = None, None, {}
+        self._handle = library.register_net(self)
+
     def _weights_key(self, device):
         return (str(device), self.wide_mode or default_wide_mode(), fuse_front(), wide_shape("conv5"), wide_shape("tnet")) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
@@ -302,8 +306,7 @@ class PointNet(nn.Module):
         if self.training:
             raise NotImplementedError("only the eval-mode forward (the attack's victim) is implemented")
         if torch.compiler.is_compiling():   # traced: the registered custom op (geoa3_amd/library.py), same kernels
-            from . import library
-            return torch.ops.geoa3.pointnet_forward(pc, library.net_handle(self))
+            return torch.ops.geoa3.pointnet_forward(pc, self._handle)
         return _PointNetFn.apply(pc, self.packed(pc.device), self._ws_cache)
 
     @property

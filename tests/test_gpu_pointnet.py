@@ -73,7 +73,7 @@ def test_batch_independence(net):
 @pytest.mark.parametrize("B,N", [(3, 256), (5, 1000), (2, 77), (9, 1024)])
 def test_chain_kernels_same_bits_as_layer_by_layer(B, N, monkeypatch):
     """The chain kernels of the trunk (pointnet_conv_chain.hip: conv2 -> T-Net conv1 -> conv2, conv3 -> conv4, and the
-    backward of the front) against the one-layer-per-launch path (GEOA3_FUSE_CHAIN=0, read per call): logits and input
+    backward of the front) against the one-layer-per-launch path (geoa3_amd.pointnet.AB_FLAGS bit 1, read per call): logits and input
     gradient bit for bit, ragged N (partly dead wavefronts) included."""
     from geoa3_amd.pointnet import PointNet
     n = PointNet(40)
@@ -83,8 +83,9 @@ def test_chain_kernels_same_bits_as_layer_by_layer(B, N, monkeypatch):
     pc, _ = O.make_synthetic_clouds(B, N, seed=17 * B + N)
     w = torch.randn(B, 40, generator=torch.Generator().manual_seed(2)).cuda()
     out = {}
+    from geoa3_amd import pointnet as PN
     for flag in ("0", "1"):
-        monkeypatch.setenv("GEOA3_FUSE_CHAIN", flag)
+        monkeypatch.setattr(PN, "AB_FLAGS", 2 if flag == "0" else 0)
         x = pc.cuda().requires_grad_()
         lg = n(x)
         (lg * w).sum().backward()

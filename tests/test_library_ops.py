@@ -56,17 +56,18 @@ def test_fake_kernels_cover_optional_arguments():
 
 
 def test_net_handles_are_per_module_and_survive_deepcopy():
-    """A copied module carries the original's integer along; net_handle() registers the copy under its own handle, so the
-    custom op resolves each module to ITS weights and workspace (handles come from a counter, never from id())."""
+    """A copied module gets its own handle, packed weights and workspace (PointNet.__setstate__), so the custom op
+    resolves each module to ITS weights; handles come from a counter, never from id(), and are never reused."""
     import copy
+    import gc
     from geoa3_amd.pointnet import PointNet
     a = PointNet(40)
     b = copy.deepcopy(a)
-    assert b._handle == a._handle and library._NETS[a._handle] is a
-    hb = library.net_handle(b)
-    assert hb != a._handle and library._NETS[hb] is b and library.net_handle(a) == a._handle
-    assert library.net_handle(b) == hb
+    assert b._handle != a._handle and library._NETS[a._handle] is a and library._NETS[b._handle] is b
+    assert b._ws_cache is not a._ws_cache and library.net_handle(b) == b._handle
+    hb, ha = b._handle, a._handle
     del a
-    import gc
     gc.collect()
-    assert library.net_handle(b) == hb and PointNet(40)._handle not in (hb,)
+    assert ha not in library._NETS and library.net_handle(b) == hb and PointNet(40)._handle not in (ha, hb)
+    b._handle = 10 ** 9                       # a stale integer (e.g. restored by hand): net_handle() repairs it
+    assert library.net_handle(b) != 10 ** 9 and library._NETS[b._handle] is b
