@@ -385,17 +385,16 @@ __device__ __forceinline__ void sp_count_less(int& r, unsigned long long kj, uns
   asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r) : "v"(kj), "v"(ki) : "vcc");
 }
 
-#ifndef GEOA3_SLAB_CAP
-#define GEOA3_SLAB_CAP 40
-#define GEOA3_SLAB_WAVES 3
-#endif
-// Three waves per SIMD (168 VGPRs): at four (128) the 40-slot ranking spilled 35 registers -- 140 bytes of scratch per lane,
-// 36 MB each way per launch at 250 instances (round 3's PMC: 141 MB moved against 55 MB algorithmic); the kernel's own time
-// is the same or a little lower (143 vs 144-155 us in the bench's one-stream figure), the iteration unchanged.
+// Lists of 32 slots at four waves per SIMD (round 4).  With 40 slots the final ranking's keys (80 registers) spilled 35
+// registers at the 128 of four waves -- 140 bytes of scratch per lane, 36 MB each way per launch at 250 instances; at three
+// waves (168 VGPRs) nothing spilled but the kernel alone took 116 instead of 101 us.  32 slots: 8 bytes of scratch, the list
+// is compacted when a lane passes 28 candidates instead of 36 (seeded lists hold K = 17 + the few points inside the old
+// radius: p99 21), and the kernel takes 127 instead of 142 us in the bench's one-stream figure, the iteration 1.740 instead
+// of 1.755 ms (three interleaved runs, profiles/round4_ab_slab_waves.txt).
 // MULTI: a cloud of more than one staging chunk (N <= 65535) and / or longer lists (K <= SP_CAP - 16): the positions are
 // those of the whole sorted cloud and the ranking gathers the coordinates from memory (L2) instead of the staged chunk.
 template <int SP_CAP, bool MULTI>
-__global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI ? 3 : GEOA3_SLAB_WAVES, MULTI ? 3 : GEOA3_SLAB_WAVES))) void knn_slabp_kernel(const float* __restrict__ R, int N, int K,
+__global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI ? 3 : 4, MULTI ? 3 : 4))) void knn_slabp_kernel(const float* __restrict__ R, int N, int K,
                                                              const int32_t* __restrict__ prior,
                                                              const float* __restrict__ sorted,
                                                              const int32_t* __restrict__ sidx,
@@ -1071,7 +1070,7 @@ extern "C" int geoa3_knn_self(const float* pc, int B, int N, int K, const int32_
     // hold at once (two workgroups per CU); a small shard's launch runs beside the victim's kernels, where the denser
     // kernel cost more than it saved (32 instances: 0.500 -> 0.506 ms per iteration)
     if (K <= 20 && N <= SK_CHUNK && slabp && ((size_t)grid.x * grid.y > 512 || slabp_always))
-      hipLaunchKernelGGL((knn_slabp_kernel<GEOA3_SLAB_CAP, false>), grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx,
+      hipLaunchKernelGGL((knn_slabp_kernel<32, false>), grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx,
                          sc.bstart, sc.geo, dists, idx);
     else if (K <= 40 && N <= 65535 && slabp && ((size_t)grid.x * grid.y > 512 || slabp_always))
       hipLaunchKernelGGL((knn_slabp_kernel<56, true>), grid, dim3(SK_BLOCK), 0, s, pc, N, K, prior, sc.sorted, sc.sidx,
