@@ -45,7 +45,7 @@ BARS = {   # best: best constrain loss per instance; window: 50-step means of lo
     "n256_b8_tgt": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
     "n1024_b8_hard": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
     "n1024_b4_margin": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
-    "pn2_n1024_b4_tgt": dict(best=0.25, window=0.18, adv=0.15, last_margin=1.0, first=5e-3, first_steps=4),
+    "pn2_n1024_b4_tgt": dict(best=0.25, window=0.18, adv=0.15, last_margin=1.0, first=5e-3, first_steps=3),
 }
 ROBUST_STEPS = 3         # an instance counts as robustly (un)successful in a binary step with >= 3 / 0 adversarial steps
 
@@ -216,7 +216,7 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     report["first_steps_max_rel_dev"] = dev.max(1).round(6).tolist()
     # (per instance; the median over the instances: one sign flip of Adam's first step on a near-zero gradient moves a
     # coordinate by 2 lr, which a PointNet++ victim turns into another farthest-point sample for THAT instance)
-    nfirst = bars.get("first_steps", 6)      # (PointNet++: the median instance leaves the shared trajectory at step 5)
+    nfirst = bars.get("first_steps", 6)      # (PointNet++: the median instance leaves the shared trajectory at step 4-6; with float atomics at step 3)
     chk(np.median(dev[:nfirst], axis=1).max() <= bars["first"], "first steps", dev.max(1), np.median(dev, axis=1))
     report["fails"] = fails
     outdir = os.path.join(REPO, "gpurun_out")
