@@ -150,8 +150,8 @@ class AttackRunner:
             t["proj_d"], t["proj_i"] = t["d_ao"], t["i_ao"]
         self.geo_out = {name: z(b) for name in ("dis_loss", "hd_loss", "curv_loss", "constrain")}
         self.geo_out["grad"] = t["g_geo"]
-        # clouds of 1025..4096 points: the records of the two-kernel objective (geoa3_geo_args.scratch)
-        self.geo_scratch = ops.geo_scratch(b, ne, device) if (1024 < ne <= 4096 and self.use_curv) else None
+        # clouds of 1025..4096 points (or k > 32): the records of the fixed-point objective kernel (geoa3_geo_args.scratch)
+        self.geo_scratch = ops.geo_scratch(b, ne, device) if ((1024 < ne or self.k > 32) and ne <= 4096 and self.use_curv) else None
         if self.use_curv:
             t["knn"] = [torch.zeros(b, ne, self.k + 1, **i32) for _ in range(2)]
             t["knn_d"] = z(b, ne, self.k + 1)

@@ -1164,7 +1164,8 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
     return GEOA3_EINVAL;
   if (a->w_curv != 0.f && !a->dkappa && !a->kappa_ori) return GEOA3_EINVAL;
   const bool do_curv = (a->w_curv != 0.f || a->dkappa) && a->knn_adv;
-  if ((a->deterministic || !a->grad) && a->N <= GEO_T && a->k <= 64) {
+  // (k > 32 with a scratch buffer: the fixed-point kernel below -- geo_fused_kernel<64> carries 272 bytes of scratch per lane)
+  if ((a->deterministic || !a->grad) && a->N <= GEO_T && a->k <= 64 && !(a->k > 32 && a->scratch && do_curv)) {
     // the pair-parallel kernel: the cloud, its normals, coefficients and own terms (10 N floats), row lengths, and one row
     // of C source ids per point; rows of 2 (k + clean points per point) + 16 ids (in-degrees of a k-NN graph concentrate
     // around k), at least 32, at most what fits
@@ -1207,7 +1208,7 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
       return GEOA3_OK;
     }
   }
-  if ((a->deterministic || !a->grad) && a->scratch && do_curv && a->N > GEO_T && a->N <= 4096 && a->k <= 64) {
+  if ((a->deterministic || !a->grad) && a->scratch && do_curv && (a->N > GEO_T || a->k > 32) && a->N <= 4096 && a->k <= 64) {
     // the pair-parallel kernel with fixed-point sums (see geo_big_kernel)
     const int N = a->N, Nr = a->Nr > 0 ? a->Nr : a->N;
     const bool two_side = a->dis_type == 1 && !a->single_side && a->d_oa != nullptr;

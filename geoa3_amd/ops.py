@@ -124,7 +124,7 @@ def geo_loss_grad(adv: Tensor, ori: Tensor, *, normal_ori=None, kappa_ori=None, 
         o["grad"] = torch.empty(B, 3, N, device=dev, dtype=torch.float32)
     if want_kappa and "kappa_adv" not in o:
         o["kappa_adv"] = torch.empty(B, N, device=dev, dtype=torch.float32)
-    if scratch is None and (deterministic or not want_grad) and 1024 < N <= 4096 and knn_adv is not None:
+    if scratch is None and (deterministic or not want_grad) and (1024 < N or k > 32) and N <= 4096 and knn_adv is not None:
         scratch = geo_scratch(B, N, dev)      # (callers in a loop hand over their own: AttackRunner)
     elif scratch is False:                    # tests: the one-workgroup kernel
         scratch = None

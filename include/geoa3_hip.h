@@ -135,8 +135,8 @@ typedef struct geoa3_geo_args {
    * fixed-point sums; otherwise up to ~4800 points the one-workgroup kernel with LDS reverse lists; beyond (up to ~5800)
    * the sums fall back to LDS float atomics (free order) whatever this flag says. */
   int32_t deterministic;
-  /* optional workspace of 16 * B * N bytes (one float4 record per point).  Given, clouds of 1025..4096 points with the
-   * curvature term take the pair-parallel kernel with 64-bit fixed-point gradient sums (geo_big_kernel: order-free and
+  /* optional workspace of 16 * B * N bytes (one float4 record per point).  Given, clouds of 1025..4096 points (and smaller
+   * ones with k > 32) with the curvature term take the pair-parallel kernel with 64-bit fixed-point gradient sums (geo_big_kernel: order-free and
    * therefore reproducible; the neighbour table is read once); NULL = the one-workgroup kernel.  Same values to rounding. */
   void* scratch;
 } geoa3_geo_args;

@@ -425,12 +425,14 @@ def test_pair_parallel_objective_special_paths(ops, N, k, kind):
 
 @pytest.mark.parametrize("N,Nr,k,kind", [(1500, 1500, 16, "plain"), (2048, 2048, 32, "plain"), (4096, 4096, 32, "plain"),
                                          (4096, 4096, 32, "coincident130"), (2048, 2048, 16, "coincident40"),
-                                         (1500, 3000, 16, "plain"), (1100, 1100, 40, "plain")])
+                                         (1500, 3000, 16, "plain"), (1100, 1100, 40, "plain"), (1024, 1024, 40, "plain"),
+                                         (600, 600, 48, "coincident40")])
 def test_fixed_point_objective_for_big_clouds(ops, N, Nr, k, kind):
     """Clouds of 1025..4096 points (BASELINE configs[4]): geo_big_gather_kernel + geo_big_kernel (a 16-byte record per point in a
     scratch buffer, the gradient as 64-bit fixed-point sums in LDS).  Against the oracle's autograd and the one-workgroup
     kernel it replaces; 130 / 40 coincident points (zero-length pairs, hubs of the neighbour graph);
-    a clean cloud larger than the sample (Nr > N); k = 40 on 64 lanes per centre.  Reproducible bit for bit and
+    a clean cloud larger than the sample (Nr > N); k = 40 / 48 on 64 lanes per centre, also for clouds of at most 1024
+    points (where k > 32 takes this kernel instead of geo_fused_kernel<64> and its spills).  Reproducible bit for bit and
     independent of the batch (alone / inside a batch of 19 copies: other XCDs, other workgroup ids)."""
     B = 3
     ori, nrm = O.make_synthetic_clouds(B, Nr, seed=N + k)
