@@ -6,11 +6,11 @@
 #      wrong dx / dT3 in lanes 48-63 of ~1e-4 of the workgroups) and against the product build (expected: 0);
 #   3. the loop soak (80 runs of 30 iterations of configs[1]) on both builds.
 # Build the two binaries first (in the container):
-#   cd tools/ub && hipcc --offload-arch=gfx950 -O3 -o xcd_visibility xcd_visibility.hip
+#   cd tools/ub && hipcc --offload-arch=gfx950 -O3 -o xcd_visibility xcd_visibility.hip && hipcc --offload-arch=gfx950 -O3 -o regstress regstress.hip
 #               && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o dtpart_pair dtpart_pair.hip -L ../../geoa3_amd/lib -lgeoa3_hip
 cd $GRAFT_REPO_ROOT
 N=${1:-100000}
-( cd tools/ub && timeout 600 ./xcd_visibility $N 1000 )
+( cd tools/ub && timeout 600 ./xcd_visibility $N 1000; [ -x ./regstress ] && timeout 600 ./regstress 20000 )
 for L in tools/ub/lib_two_wave geoa3_amd/lib; do
   echo "== dtpart_pair against $L"
   LD_LIBRARY_PATH=$PWD/$L:$LD_LIBRARY_PATH timeout 600 tools/ub/dtpart_pair $N 0 32
