@@ -29,6 +29,15 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP library cannot be built")
 
 
+# per-file flags.  pointnet_conv_chain.hip: no SLP vectorisation = no packed-FP32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with
+# SGPR-pair operands) in conv_bwd_chain_kernel, which with two wavefronts per SIMD computed wrong values in lanes 48-63
+# (found with tools/ub/dtpart_pair.hip; the same source with the packed instructions: ~1e-4 of the workgroups).
+# pointnet_conv_split.hip: the one-layer-per-launch kernels the chains are held to BIT FOR BIT (tests/test_gpu_pointnet.py)
+# must contract their multiply-adds the same way (no cost: configs[1] does not run them, configs[3] +0.2 %).
+# (pointnet_gemm.hip -- the FC heads -- loses 4 % of the iteration without SLP and is left alone.)
+FILE_FLAGS = {"pointnet_conv_chain.hip": ["-fno-slp-vectorize"], "pointnet_conv_split.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -44,7 +53,11 @@ def _digest(path: str, flags=None) -> str:
 
 
 def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
-    flags = flags or FLAGS
+    flags = list(flags or FLAGS)
+    if "--no-file-flags" in flags:     # (tools: the build WITHOUT the per-file flags, e.g. the faulty one of DESIGN 5a)
+        flags.remove("--no-file-flags")
+    else:
+        flags += FILE_FLAGS.get(os.path.basename(src), [])
     obj = os.path.join(objdir, os.path.basename(src) + ".o")
     stamp = obj + ".sha1"
     dig = _digest(src, flags)
@@ -86,6 +99,6 @@ if __name__ == "__main__":
     if "--variant" in sys.argv:
         i = sys.argv.index("--variant")
         build(force="--force" in sys.argv, libdir=os.path.abspath(sys.argv[i + 1]),
-              extra_flags=[f for f in sys.argv[i + 2:] if f.startswith("-D")])
+              extra_flags=[f for f in sys.argv[i + 2:] if f.startswith("-") and f != "--force"])
     else:
         build(force="--force" in sys.argv)

@@ -13,12 +13,6 @@
     if (e__ != hipSuccess) return GEOA3_ELAUNCH;     \
   } while (0)
 
-// GEOA3_HAZARD_PROBE=1 (tools/ub/dtpart_pair.hip only; never set for the product build) restores the round-2/3 build of
-// conv_bwd_chain_kernel with two wavefronts per SIMD, the configuration DESIGN 5a's hazard was found on.
-#ifndef GEOA3_HAZARD_PROBE
-#define GEOA3_HAZARD_PROBE 0
-#endif
-
 static inline hipStream_t geoa3_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Squared distance, un-fused: fl(fl(fl(dx*dx)+fl(dy*dy))+fl(dz*dz)) -- the evaluation order the

@@ -250,16 +250,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   dh2 = gate_h2( W3eff^T Ga + Wc1^T Gb )          Ga = d/d(pre-activation of h3), Gb = that of the T-Net's c1
 //   g1  = gate_first( W2^T dh2 ),  q = w1^T g1,  dx = T q,  dTpart = per-workgroup sums of x q^T
 // dh2 and g1 never leave the registers.
-// ONE wave per SIMD: with two workgroups of this kernel resident on a CU (amdgpu_waves_per_eu(2, 2), the
-// round-2/3 build) lanes 48-63 of an occasional wavefront came out wrong -- dx and the dT3 partial sums of ~1e-4 of the
-// workgroups on random inputs (tools/ub/dtpart_pair.hip: the kernel alone, device-synchronised launches included), ~1e-3
-// of the launches in the loop.  The same machine code with one workgroup per CU: 0 of 3e7 workgroups.
-// GEOA3_HAZARD_PROBE=1 (tools only) restores the two-wave build.
-#if GEOA3_HAZARD_PROBE
+// Two waves per SIMD -- and NO packed-FP32 instructions.  Compiled with SLP vectorisation (604 v_pk_mul_f32 /
+// v_pk_fma_f32 / v_pk_add_f32, among them the 3x3 transform with SGPR-pair operands) this kernel computed wrong values in
+// lanes 48-63 of ~1e-4 of its workgroups whenever two of its wavefronts shared a SIMD: p = T3^T x came out wrong at the start,
+// d = T q and the dx stores at the end (stage checksums of tools/ub/conv_bwd_chain_probe.patch in tools/ub/dtpart_pair.hip);
+// with the transform through vector loads the rate falls 1000-fold, without packed instructions altogether
+// (geoa3_amd/build.py FILE_FLAGS: -fno-slp-vectorize for this file) it is 0 of 1e8 workgroups at the same 48 us.
+// The faulty build for the harness: `python -m geoa3_amd.build --variant tools/ub/lib_two_wave --no-file-flags`.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_bwd_chain_kernel(ConvBwdChainArgs a) {
-#else
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_bwd_chain_kernel(ConvBwdChainArgs a) {
-#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
   float4* s_w1 = reinterpret_cast<float4*>(cc_smem + 3 * CC_BLK);   // [64] (w1 row, b1)
   float* s_red = reinterpret_cast<float*>(s_w1 + 64);               // [3][4 waves]

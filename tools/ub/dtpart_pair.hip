@@ -3,9 +3,11 @@
 // per workgroup) followed by reduce_dT_kernel (9 workgroups; its first instructions read them), on random inputs, the two
 // input sets alternating so that a stale partial row shows as the OTHER set's value.
 //
-//   hipcc --offload-arch=gfx950 -O3 -o dtpart_pair dtpart_pair.hip -L<dir of a libgeoa3_hip.so build> -lgeoa3_hip
+//   hipcc --offload-arch=gfx950 -O3 -o dtpart_pair dtpart_pair.hip -L<dir of a libgeoa3_hip.so build> -lgeoa3_hip -ldl
 //   LD_LIBRARY_PATH=<that dir> ./dtpart_pair [pairs] [mode]
-// Run against tools/ub/lib_probe3 (36-byte rows, no release: the round-2 layout) and against the product library.
+// Run against tools/ub/lib_two_wave (`python -m geoa3_amd.build --variant tools/ub/lib_two_wave --no-file-flags`: the chain
+// kernels compiled WITH packed-FP32 instructions, the faulty build) and against the product library.  A build of
+// tools/ub/conv_bwd_chain_probe.patch (stage checksums inside the kernel) adds the per-stage report.
 #include "../../geoa3_amd/csrc/pointnet_kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +66,16 @@ __global__ void compare_dx_kernel(const float* __restrict__ got, const float* __
       atomicAdd(&bad[132 + ((col >> 6) & 3)], 1ull);
       const float rel = fabsf(got[i] - want[i]) / fmaxf(fabsf(want[i]), 1e-20f);
       atomicAdd(&bad[rel < 1e-6f ? 41 : rel < 1e-4f ? 42 : rel < 1e-2f ? 43 : 44], 1ull);
+    }
+}
+// stage checksums of the probe build: [5][B * N]; bad[48 + stage]: columns whose checksum differs, bad[56 + stage]: of those in lanes 48-63
+__global__ void compare_stages_kernel(const unsigned* __restrict__ got, const unsigned* __restrict__ want, size_t bn,
+                                      unsigned long long* __restrict__ bad) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 5 * bn; i += (size_t)gridDim.x * 256)
+    if (got[i] != want[i]) {
+      const int st = (int)(i / bn);
+      atomicAdd(&bad[48 + st], 1ull);
+      if (((i % bn) & 63) >= 48) atomicAdd(&bad[56 + st], 1ull);
     }
 }
 __global__ void dirty_kernel(float* __restrict__ buf, size_t n, float v) {
@@ -153,6 +165,8 @@ static int forward_chain_soak(int pairs, hipStream_t s) {
   return 0;
 }
 
+#include <dlfcn.h>
+
 int main(int argc, char** argv) {
   const int pairs = argc > 1 ? atoi(argv[1]) : 20000;
   const int mode = argc > 2 ? atoi(argv[2]) : 0;   // bit 0: a 256 MB streaming write in front of every producer; bit 1: the forward chain kernel as well
@@ -188,12 +202,22 @@ int main(int argc, char** argv) {
   }
   hipStream_t s;
   CHECK(hipStreamCreate(&s));
+  typedef int (*setbuf_fn)(unsigned*);
+  setbuf_fn set_buf = (setbuf_fn)dlsym(RTLD_DEFAULT, "geoa3_probe_set_buf");
+  unsigned *stg = nullptr, *stg_ref[2] = {nullptr, nullptr};
+  const size_t bn = (size_t)B * N;
+  if (set_buf) {
+    CHECK(hipMalloc(&stg, 5 * bn * 4));
+    for (int p = 0; p < 2; ++p) CHECK(hipMalloc(&stg_ref[p], 5 * bn * 4));
+    set_buf(stg);
+  }
   // references: every launch fenced by a device synchronisation, twice (they must agree)
   for (int rep = 0; rep < 2; ++rep)
     for (int p = 0; p < 2; ++p) {
       CHECK(hipMemsetAsync(bad, 0, 2048, s));
       if (launch_conv_bwd_chain(a[p], s) != GEOA3_OK) return 3;
       CHECK(hipDeviceSynchronize());
+      if (rep == 0 && stg) CHECK(hipMemcpy(stg_ref[p], stg, 5 * bn * 4, hipMemcpyDeviceToDevice));
       if (rep == 0) CHECK(hipMemcpy(refdx[p], dx, (size_t)B * 3 * N * 4, hipMemcpyDeviceToDevice));
       if (rep == 0) CHECK(hipMemcpy(refpart[p], dTpart, (size_t)B * nparts * 32 * 4, hipMemcpyDeviceToDevice));
       if (launch_reduce_dT(dTpart, nparts, rep == 0 ? ref[p] : gT3, B, s) != GEOA3_OK) return 3;
@@ -215,6 +239,7 @@ int main(int argc, char** argv) {
     if (mode & 1) hipLaunchKernelGGL(dirty_kernel, dim3(2048), dim3(256), 0, s, big, bign, (float)it);
     launch_conv_bwd_chain(a[p], s);
     launch_reduce_dT(dTpart, nparts, gT3, B, s);
+    if (stg) hipLaunchKernelGGL(compare_stages_kernel, dim3(512), dim3(256), 0, s, stg, stg_ref[p], bn, bad);
     hipLaunchKernelGGL(compare_dx_kernel, dim3(512), dim3(256), 0, s, dx, refdx[p], (size_t)B * 3 * N, bad);
     hipLaunchKernelGGL(compare_rows_kernel, dim3((B * nparts + 255) / 256), dim3(256), 0, s, dTpart, refpart[p], refpart[1 - p],
                        B * nparts, pitch, bad);
@@ -238,6 +263,19 @@ int main(int argc, char** argv) {
          h[132], h[133], h[134], h[135]);
   for (int l = 0; l < 64; ++l) printf("%s%llu", l % 16 == 0 ? " | " : " ", h[64 + l]);
   printf("\n");
+  if (stg) {
+    printf("        probe: columns whose stage checksum differs from the reference run (of which lanes 48-63):");
+    const char* nm[5] = {"W2^T dh2 from the accumulators", "after W3eff^T Ga", "first-layer rows from LDS (broadcast ds_read_b128)", "p = T3^T x at its use", "q"};
+    for (int st = 0; st < 5; ++st) printf("  %s %llu (%llu)", nm[st], h[48 + st], h[56 + st]);
+    printf("\n");
+  }
+  typedef int (*probe_fn)(unsigned long long*);
+  if (probe_fn geoa3_probe_read = (probe_fn)dlsym(RTLD_DEFAULT, "geoa3_probe_read")) {   // builds with -DGEOA3_HAZARD_PROBE=3 only
+    unsigned long long pc[4] = {0, 0, 0, 0};
+    geoa3_probe_read(pc);
+    printf("        probe: gate words parked in SGPRs that differ from a fresh v_readlane at the point of use: %llu (bits: lo %08llx hi %08llx)\n",
+           pc[0], pc[1] & 0xffffffffull, pc[1] >> 32);
+  }
   if (mode & 2) return forward_chain_soak(pairs, s);
   return 0;
 }

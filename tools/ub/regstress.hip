@@ -105,6 +105,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// The instruction pattern of conv_bwd_chain_kernel's 3x3 transform as the compiler emitted it: an SGPR PAIR assembled with
+// s_mov_b32 right in front of a packed-FP32 instruction that reads it, one half overwritten right behind it.
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int VARIANT>   // 0: s_mov, s_mov, v_pk_mul, s_mov (as compiled); 1: the same with s_nop 3 in front of the packed op;
+                         // 2: no trailing overwrite
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pkstress(unsigned long long* bad, int rounds,
+                                                                                            const float* __restrict__ tab) {
+  extern __shared__ float lds[];
+  const unsigned lane = threadIdx.x & 63;
+  float2v x = {1.0f + 0.001f * (float)(threadIdx.x & 255), 2.0f + 0.003f * (float)(threadIdx.x & 127)};
+  float busy[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) busy[i] = 1.0f + (float)i + (float)lane;
+  for (int it = 0; it < rounds; ++it) {
+    const float a = tab[(blockIdx.x * 7 + it) & 1023], b = tab[(blockIdx.x * 13 + it * 3 + 5) & 1023], c = tab[(it * 11 + 9) & 1023];
+    float2v r;
+    if (VARIANT == 0)
+      asm volatile("s_mov_b32 s40, %2\n\ts_mov_b32 s41, %3\n\tv_pk_mul_f32 %0, %1, s[40:41]\n\ts_mov_b32 s41, %4\n\ts_mov_b32 s40, %4"
+                   : "=v"(r) : "v"(x), "s"(a), "s"(b), "s"(c) : "s40", "s41");
+    else if (VARIANT == 1)
+      asm volatile("s_mov_b32 s40, %2\n\ts_mov_b32 s41, %3\n\ts_nop 3\n\tv_pk_mul_f32 %0, %1, s[40:41]\n\ts_nop 3\n\ts_mov_b32 s41, %4\n\ts_mov_b32 s40, %4"
+                   : "=v"(r) : "v"(x), "s"(a), "s"(b), "s"(c) : "s40", "s41");
+    else
+      asm volatile("s_mov_b32 s40, %2\n\ts_mov_b32 s41, %3\n\tv_pk_mul_f32 %0, %1, s[40:41]"
+                   : "=v"(r) : "v"(x), "s"(a), "s"(b), "s"(c) : "s40", "s41");
+    const float e0 = x[0] * a, e1 = x[1] * b;
+    if (__float_as_uint(r[0]) != __float_as_uint(e0) || __float_as_uint(r[1]) != __float_as_uint(e1)) {
+      atomicAdd(&bad[0], 1ull);
+      atomicAdd(&bad[1 + (lane >> 4)], 1ull);
+      if (__float_as_uint(r[0]) == __float_as_uint(x[0] * c) || __float_as_uint(r[1]) == __float_as_uint(x[1] * c)) atomicAdd(&bad[9], 1ull);
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) busy[i] = busy[i] * 1.0001f + r[i & 1];     // VALU traffic between the probes
+    x[0] += 0.25f;
+    x[1] -= 0.125f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) s += busy[i];
+  if (s == 12345.678f) lds[threadIdx.x] = s;
+}
+
+template <int VARIANT>
+static void run_pk(const char* name, int launches, unsigned long long* bad, const float* tab) {
+  CHECK(hipMemset(bad, 0, 128));
+  const size_t lds = 56 * 1024;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pkstress<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int i = 0; i < launches; ++i) hipLaunchKernelGGL((pkstress<VARIANT>), dim3(1000), dim3(256), lds, 0, bad, 200, tab);
+  CHECK(hipDeviceSynchronize());
+  unsigned long long h[16];
+  CHECK(hipMemcpy(h, bad, 128, hipMemcpyDeviceToHost));
+  printf("%-58s %d launches x 256000 lanes x 200 probes: wrong products %llu (lanes 0-15: %llu, 16-31: %llu, 32-47: %llu, 48-63: %llu; "
+         "equal to the product with the OVERWRITING value: %llu)\n", name, launches, h[0], h[1], h[2], h[3], h[4], h[9]);
+  fflush(stdout);
+}
+
 template <int R, int MODE>
 static void run(const char* name, int launches, unsigned long long* bad, float* sink) {
   CHECK(hipMemset(bad, 0, 128));
@@ -133,6 +189,17 @@ int main(int argc, char** argv) {
   float* sink;
   CHECK(hipMalloc(&bad, 128));
   CHECK(hipMalloc(&sink, 1000 * 256 * 4));
+  {
+    float htab[1024];
+    for (int i = 0; i < 1024; ++i) htab[i] = 0.5f + 0.001f * (float)((i * 7919) % 1000);
+    float* tab;
+    CHECK(hipMalloc(&tab, sizeof(htab)));
+    CHECK(hipMemcpy(tab, htab, sizeof(htab), hipMemcpyHostToDevice));
+    const int pl = launches / 10 > 0 ? launches / 10 : 1;
+    run_pk<0>("s_mov pair -> v_pk_mul_f32 s[40:41] -> s_mov (as compiled)", pl, bad, tab);
+    run_pk<1>("the same with s_nop 3 around the packed instruction", pl, bad, tab);
+    run_pk<2>("without the trailing overwrite", pl, bad, tab);
+  }
   run<200, 0>("200 live registers, integer updates only", launches, bad, sink);
   run<184, 1>("184 registers + MFMA 32x32x16 f16 between the rounds", launches, bad, sink);
   run<200, 2>("200 registers + v_permlane32_swap pairs", launches, bad, sink);
