@@ -21,6 +21,9 @@ struct Ws {  // workspace carve-up; every buffer starts on a 256-byte boundary
   float *G128, *G64a, *P64, *dh2, *g1024, *g512, *g256, *gT64, *gT3, *dTpart;   // P64 [B][64][64] = h2 G64a^T
   // relu gates of the stored activations as bit masks [B][ceil(N/64)][C] x 64 bit (ConvArgs::Ymask / Zmask)
   unsigned long long *m_a2, *m_h2, *m_c1, *m_c2, *m_h3, *m_h4;
+  // the sparse backward's hit lists, built by the forward's finalize passes (WideArgs::hits / hoff): lists [B][1024 taps],
+  // column offsets [B][N + 1] -- T-Net 3, T-Net 64, conv5
+  int *hl3, *ho3, *hlq, *hoq, *hl5, *ho5;
   size_t total;
 };
 
@@ -73,6 +76,12 @@ Ws carve(void* base, int B, int N, int classes) {
   w.m_c2 = (unsigned long long*)take(b * 128 * n64 * 2);
   w.m_h3 = (unsigned long long*)take(b * 64 * n64 * 2);
   w.m_h4 = (unsigned long long*)take(b * 128 * n64 * 2);
+  w.hl3 = (int*)take(b * 1024);
+  w.ho3 = (int*)take(b * ((size_t)N + 1));
+  w.hlq = (int*)take(b * 1024);
+  w.hoq = (int*)take(b * ((size_t)N + 1));
+  w.hl5 = (int*)take(b * 3072);
+  w.ho5 = (int*)take(b * ((size_t)N + 1));
   w.total = off;
   (void)classes;
   return w;
@@ -95,6 +104,9 @@ thread_local int tl_split = 0;
 thread_local int tl_flags = 0;
 bool fuse_bwd() { return !(tl_flags & GEOA3_PN_NO_FUSE_BWD); }
 bool fuse_chain() { return !(tl_flags & GEOA3_PN_NO_CHAIN); }
+// the sparse backward's hit lists come from the forward's finalize pass (GEOA3_PN_NO_PRE_LISTS: every backward workgroup
+// builds its own, as before round 4; same bits)
+bool pre_lists(int N) { return tl_split && fuse_bwd() && N <= 4096 && !(tl_flags & GEOA3_PN_NO_PRE_LISTS); }
 
 // Y = act(W X + bias) over [B][K][N] -> [B][Co][N]; shared weights [Co][K]
 int conv(const float* X, int K, const float* W, const float* bias, float* Y, int Co, int B, int N, bool relu,
@@ -168,9 +180,10 @@ struct FrontLayer {
 };
 int wide(const float* X, const float* W, const void* Wh, float unscale, const float* bias, float* out, int* arg,
          unsigned long long* keys, int taps, int B, int N, hipStream_t s, const FrontLayer* f = nullptr,
-         const void* Wh16 = nullptr) {
+         const void* Wh16 = nullptr, int* hits = nullptr, int* hoff = nullptr) {
   WideArgs a{};
   a.Wh16 = Wh16;
+  if (pre_lists(N)) { a.hits = hits; a.hoff = hoff; }
   if (f) {
     a.W2h = f->w2h; a.w2_unscale = f->w2_unscale; a.W2f = f->w2; a.b2 = f->b2;
     a.Xin = f->h64; a.sXinb = (long)64 * N; a.ldXin = N;
@@ -199,8 +212,10 @@ int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, con
 
 // sparse backward of a 1024-wide layer + the gated 128 -> 64 layer behind it in one kernel (split mode: bit gates)
 int wide_bwd_conv(const float* g, const int* arg, const float* W, const unsigned long long* Zmask, const float* W2t,
-                  const unsigned long long* Zmask2, float* dY, int taps, int B, int N, hipStream_t s, float w2t_amax) {
+                  const unsigned long long* Zmask2, float* dY, int taps, int B, int N, hipStream_t s, float w2t_amax,
+                  const int* hits, const int* hoff) {
   WideBwdArgs a{};
+  if (pre_lists(N)) { a.hits = hits; a.hoff = hoff; }
   a.w2t_amax = w2t_amax;
   a.Zmask = Zmask;
   a.g = g; a.arg = arg; a.W = W;
@@ -215,12 +230,12 @@ int wide_bwd_conv(const float* g, const int* arg, const float* W, const unsigned
 int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* x3, float* act128,
                   unsigned long long* m128, float* pooled,
                   int* arg, float* f4, float* f5, float* T, unsigned long long* keys, int B, int N, hipStream_t s,
-                  bool have128 = false) {
+                  int* hits, int* hoff, bool have128 = false) {
   if (have128) {   // act128 (and m128) already produced by the trunk's chain kernel
-    TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, nullptr, t.w3h16));
+    TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, nullptr, t.w3h16, hits, hoff));
   } else if (tl_split && t.w2h) {   // conv2 (behind conv1 for the 3-channel T-Net) inside the wide kernel: act128 is never written
     FrontLayer f{t.w2h, t.w2h_unscale, t.w2, t.b2, act64, act64 ? nullptr : x3, t.w1, t.b1, m128};
-    TRY(wide(nullptr, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, &f));
+    TRY(wide(nullptr, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, &f, nullptr, hits, hoff));
   } else {
     if (act64) TRY(conv(act64, 64, t.w2, t.b2, act128, 128, B, N, true, nullptr, false, s, m128));
     else if (tl_split && fuse_chain()) {   // conv1 + conv2 of the 3-channel T-Net: the chain kernel with one stage
@@ -230,7 +245,7 @@ int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* 
       a.st[0] = ChainStage{t.w2, 0, t.b2, act128, (long)128 * N, m128, 128};
       TRY(launch_conv_chain(a, s));
     } else TRY(conv_first(x3, nullptr, t.w1, t.b1, t.w2, t.b2, act128, 128, B, N, s, m128));
-    TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, nullptr, t.w3h16));
+    TRY(wide(act128, t.w3p, t.w3h, t.w3h_unscale, t.b3, pooled, arg, keys, 1, B, N, s, nullptr, t.w3h16, hits, hoff));
   }
   TRY(fc(pooled, 1024, t.f1, t.fb1, f4, 512, B, true, nullptr, s));
   TRY(fc(f4, 512, t.f2, t.fb2, f5, 256, B, true, nullptr, s));
@@ -242,7 +257,7 @@ int tnet_tail_fwd(const geoa3_tnet_weights& t, const float* act64, const float* 
 int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, const unsigned long long* m64,
              const float* x3, const float* act128, const unsigned long long* m128,
              const float* pooled, const int* arg, const float* f4, const float* f5, Ws& w, float* G64out, int B, int N,
-             hipStream_t s) {
+             hipStream_t s, const int* hits, const int* hoff) {
   // (K = 4096 for the feature transform: split over four workgroups per tile through G128, which is written only below,
   //  when its B * 128 * N floats hold the ceil(B / 16) * 16 tiles x 4096 partial values)
   const bool ks = (size_t)((B + 15) / 16) * 16 * 4096 <= (size_t)B * 128 * N;
@@ -250,11 +265,12 @@ int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, c
   TRY(fc(w.g256, 256, t.f2t, nullptr, w.g512, 512, B, false, f4, s));
   TRY(fc(w.g512, 512, t.f1t, nullptr, w.g1024, 1024, B, false, pooled, s));
   if (act64 && tl_split && m128 && m64 && fuse_bwd()) {
-    TRY(wide_bwd_conv(w.g1024, arg, t.w3, m128, t.w2t, m64, G64out, 1, B, N, s, t.w2t_amax));
+    TRY(wide_bwd_conv(w.g1024, arg, t.w3, m128, t.w2t, m64, G64out, 1, B, N, s, t.w2t_amax, hits, hoff));
     return 0;
   }
   if (!act64 && tl_split && m128 && fuse_bwd()) {   // the 3-channel T-Net: ... and its first layer's backward: dx += w1^T (..)
     WideBwdArgs a{};
+    if (pre_lists(N)) { a.hits = hits; a.hoff = hoff; }
     a.Zmask = m128;
     a.g = w.g1024; a.arg = arg; a.W = t.w3;
     a.W2t = t.w2t; a.w2t_amax = t.w2t_amax;
@@ -287,7 +303,8 @@ extern "C" int geoa3_debug_pointnet_workspace_layout(int B, int N, int classes, 
       {"T64", w.T64}, {"W3eff", w.W3eff}, {"h3", w.h3}, {"h4", w.h4}, {"p5", w.p5}, {"i5", w.i5}, {"f6", w.f6},
       {"f7", w.f7}, {"G128", w.G128}, {"G64a", w.G64a}, {"P64", w.P64}, {"dh2", w.dh2}, {"g1024", w.g1024},
       {"g512", w.g512}, {"g256", w.g256}, {"gT64", w.gT64}, {"gT3", w.gT3}, {"dTpart", w.dTpart}, {"m_a2", w.m_a2},
-      {"m_h2", w.m_h2}, {"m_c1", w.m_c1}, {"m_c2", w.m_c2}, {"m_h3", w.m_h3}, {"m_h4", w.m_h4}};
+      {"m_h2", w.m_h2}, {"m_c1", w.m_c1}, {"m_c2", w.m_c2}, {"m_h3", w.m_h3}, {"m_h4", w.m_h4},
+      {"hl3", w.hl3}, {"ho3", w.ho3}, {"hlq", w.hlq}, {"hoq", w.hoq}, {"hl5", w.hl5}, {"ho5", w.ho5}};
   const int n = (int)(sizeof(f) / sizeof(f[0]));
   for (int i = 0; i < n && i < cap; ++i) {
     names[i] = f[i].name;
@@ -310,7 +327,7 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
       hipMemsetAsync(w.keys, 0, (size_t)B * 1024 * sizeof(unsigned long long), s) != hipSuccess)
     return GEOA3_ELAUNCH;
   // input transform (Model/PointNet.py:137-138)
-  TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s));
+  TRY(tnet_tail_fwd(p.t3, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w.T3, w.keys, B, N, s, w.hl3, w.ho3));
   const bool chain = tl_split && fuse_chain();
   if (chain && !p.t64.w2h) {
     // trunk conv1, conv2 (:139-140) and the feature transform's conv1, conv2 (:78-80) in one kernel: h2 is written (the
@@ -322,13 +339,13 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
     a.st[1] = ChainStage{p.t64.w1, 0, p.t64.b1, nullptr, 0, w.m_c1, 64};
     a.st[2] = ChainStage{p.t64.w2, 0, p.t64.b2, w.c2, (long)128 * N, w.m_c2, 128};
     TRY(launch_conv_chain(a, s));
-    TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s, true));
+    TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s, w.hlq, w.hoq, true));
   } else {
     // trunk conv1, conv2 (:139-140)
     TRY(conv_first(x, w.T3, p.w1, p.b1, p.w2, p.b2, w.h2, 64, B, N, s, w.m_h2));
     // feature transform (:142-143)
     TRY(conv(w.h2, 64, p.t64.w1, p.t64.b1, w.c1, 64, B, N, true, nullptr, false, s, w.m_c1));
-    TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s));
+    TRY(tnet_tail_fwd(p.t64, w.c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w.T64, w.keys, B, N, s, w.hlq, w.hoq));
   }
   // feature transform folded into conv3 (:143-144): W3 (T64^T h2) = (W3 T64^T) h2 -- one 64^3 product per instance
   // instead of a pass over [B,64,N]
@@ -361,13 +378,13 @@ extern "C" int geoa3_pointnet_forward(const geoa3_pointnet_weights* pw, const fl
   }
   // conv4, conv5 + max (:145-147)
   if (chain34) {
-    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16));
+    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16, w.hl5, w.ho5));
   } else if (tl_split && p.w4h) {   // conv4 inside conv5's staging pass: h4 is never written
     FrontLayer f{p.w4h, p.w4h_unscale, p.w4, p.b4, w.h3, nullptr, nullptr, nullptr, w.m_h4};
-    TRY(wide(nullptr, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, &f));
+    TRY(wide(nullptr, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, &f, nullptr, w.hl5, w.ho5));
   } else {
     TRY(conv(w.h3, 64, p.w4, p.b4, w.h4, 128, B, N, true, nullptr, false, s, w.m_h4));
-    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16));
+    TRY(wide(w.h4, p.w5p, p.w5h, p.w5h_unscale, p.b5, w.p5, w.i5, w.keys, 3, B, N, s, nullptr, p.w5h16, w.hl5, w.ho5));
   }
   // classifier head (:150-152), dropout is the identity in eval mode
   TRY(fc(w.p5, 1024, p.f1, p.fb1, w.f6, 512, B, true, nullptr, s));
@@ -390,7 +407,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, 1024, B, false, w.p5, s));
   // max + conv5 (sparse), conv4, conv3
   if (tl_split && fuse_bwd()) {
-    TRY(wide_bwd_conv(w.g1024, w.i5, p.w5, w.m_h4, p.w4t, w.m_h3, w.G64a, 3, B, N, s, p.w4t_amax));
+    TRY(wide_bwd_conv(w.g1024, w.i5, p.w5, w.m_h4, p.w4t, w.m_h3, w.G64a, 3, B, N, s, p.w4t_amax, w.hl5, w.ho5));
   } else {
     TRY(wide_bwd(w.g1024, w.i5, p.w5, w.h4, w.m_h4, w.G128, 3, B, N, s));
     TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, nullptr, false, s, nullptr, w.m_h3));
@@ -428,7 +445,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     // the T-Net branch's gradient goes to the dh2 buffer (the Gram kernel's scratch is consumed by now); then ONE kernel:
     // dh2 = gate_h2(W3eff^T G64a + W_t64.conv1^T G), conv2's backward, trunk conv1 + input transform backward (dx, dT3
     // partials) -- dh2 is never written
-    TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.m_c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.dh2, B, N, s));
+    TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.m_c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.dh2, B, N, s, w.hlq, w.hoq));
     ConvBwdChainArgs a{};
     a.Xa = w.G64a; a.Wa = w.W3eff; a.sWa = 4096;
     a.Xb = w.dh2; a.Wb = p.t64.w1;
@@ -439,7 +456,7 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
     a.N = N; a.B = B;
     TRY(launch_conv_bwd_chain(a, s));
   } else {
-  TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.m_c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s));
+  TRY(tnet_bwd(p.t64, w.gT64, w.c1, w.m_c1, nullptr, w.c2, w.m_c2, w.q3, w.iq3, w.qf4, w.qf5, w, w.G64a, B, N, s, w.hlq, w.hoq));
   // dh2 += W_t64.conv1^T G64a, then the relu gate of h2
   {
     ConvArgs a{};
@@ -456,6 +473,6 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   }
   TRY(launch_reduce_dT(w.dTpart, nparts, w.gT3, B, s));
   // T-Net(3) backward; its last kernel adds the T-Net branch into dx
-  TRY(tnet_bwd(p.t3, w.gT3, nullptr, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w, dx, B, N, s));
+  TRY(tnet_bwd(p.t3, w.gT3, nullptr, nullptr, x, w.a2, w.m_a2, w.p3, w.i3, w.tf4, w.tf5, w, dx, B, N, s, w.hl3, w.ho3));
   return GEOA3_OK;
 }

@@ -131,6 +131,10 @@ struct WideArgs {
   const float* x3; const float* w1; const float* b1;   // [B][3][N], [64][3], [64]
   unsigned long long* Ymask;
   unsigned long long* stamps;                 // diagnostics (tools/bench_wide.py --stamps): s_memtime trace of workgroup 0
+  // with both (Co = 1024, N <= 4096): the finalize pass also builds the sparse backward's hit lists -- hits [B][Co taps]
+  // = (co * taps + tap) | (column << 16) sorted by (column, chunk of 64 channels, tap, channel), hoff [B][N + 1] the
+  // columns' start offsets (WideBwdArgs::hits / hoff)
+  int* hits; int* hoff;
 };
 int launch_wide_max(const WideArgs& a, hipStream_t s);          // dispatches on a.Wh
 int launch_wide_max_split(const WideArgs& a, hipStream_t s);    // pointnet_wide_split.hip
@@ -163,6 +167,8 @@ struct WideBwdArgs {
   // ... or, with dx3: that layer is the one behind the 3-channel first layer (gate recomputed from x3 [B][3][N] with
   // w1 [64][3], b1 [64]) and the first layer's backward finishes in the same kernel: dx3[b][d][n] += sum_o w1[o][d] dY[o][n]
   const float* x3; const float* w1; const float* b1; float* dx3;
+  const int* hits; const int* hoff;           // launch_wide_bwd_conv: the lists built by the forward's finalize pass (or null:
+                                              // every workgroup builds its tile's lists from g / arg)
   int form;                                   // 0 = register accumulation over per-column lists (default), 1 = the first
                                               // form (LDS accumulation); same sums in the same order
 };

@@ -164,6 +164,115 @@ __global__ __launch_bounds__(256) void wide_finalize_kernel(unsigned long long* 
   arg[e] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
 }
 
+// The same, and the backward's hit lists with it (Co = 1024, N <= WIDE_HITS_MAXN): one 1024-thread workgroup per instance,
+// thread = channel.  The sparse backward (pointnet_wide_bwdconv.hip) needs, per 64-point tile, the (channel, tap) pairs whose
+// arg-max column falls into the tile, by column, each column's list in (chunk of 64 channels, tap, channel) order.  It used
+// to build them in every workgroup (250 x 16 workgroups each scanning the instance's 1024 channels); here they are built
+// once per instance, all columns: hits [B][1024 TAPS] sorted by (column, chunk, tap, channel) and the columns' start
+// offsets [B][N + 1], so that a tile's lists are ONE contiguous segment.  A channel is listed when its pooled value is
+// positive -- the upstream gradient is gated by exactly that (zero elsewhere; a zero gradient that slips in adds +0).
+//   rank of a hit among the lanes of its wave with the same column: ballots over the column's bits;
+//   per-(chunk, column) counts in LDS (each wave owns its chunk's row: no atomics), prefix over the chunks per column,
+//   block scan over the columns, placement.
+constexpr int WIDE_HITS_MAXN = 4096;
+template <int TAPS>
+__global__ __launch_bounds__(1024) void wide_finalize_hits_kernel(unsigned long long* __restrict__ keys,
+                                                                  const float* __restrict__ bias, int N,
+                                                                  float* __restrict__ out, int* __restrict__ arg,
+                                                                  int* __restrict__ hits, int* __restrict__ hoff) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const int NP = (N + 1) & ~1;
+  uint16_t* s_cnt = reinterpret_cast<uint16_t*>(fsm);               // [16][NP]
+  int* s_off = reinterpret_cast<int*>(fsm + (size_t)32 * NP);       // [N + 1]
+  int* s_wsum = s_off + N + 1;                                      // [17]
+  const int b = blockIdx.x, co = threadIdx.x, lane = co & 63, chunk = co >> 6;
+  const size_t e = (size_t)b * 1024 + co;
+  const unsigned long long k = keys[e];
+  keys[e] = 0ull;
+  const unsigned u = (unsigned)(k >> 32);
+  const float v = __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+  const float o = v != v ? v : fmaxf(v + bias[co], 0.f);
+  const int ar = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+  out[e] = o;
+  arg[e] = ar;
+  for (int i = co; i < 8 * NP; i += 1024) reinterpret_cast<int*>(s_cnt)[i] = 0;
+  __syncthreads();
+  const bool live = !(o <= 0.f);   // (NaN counts: the poison must reach the gradient)
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint16_t* my = s_cnt + (size_t)chunk * NP;
+  int local[TAPS], colm[TAPS];
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+    const int m = ar - TAPS / 2 + tap;
+    const bool valid = live && m >= 0 && m < N;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 12; ++bit) {
+      const bool one = (m >> bit) & 1;
+      const unsigned long long bb = __ballot(one);
+      peers &= one ? bb : ~bb;
+    }
+    const int base = valid ? (int)my[m] : 0;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (peers & lt) == 0ull) my[m] = (uint16_t)(base + __popcll(peers));
+    __builtin_amdgcn_wave_barrier();
+    local[tap] = base + __popcll(peers & lt);
+    colm[tap] = valid ? m : -1;
+  }
+  __syncthreads();
+  for (int m = co; m < N; m += 1024) {   // counts of the chunks -> exclusive prefixes; the column's total
+    int run = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int t = s_cnt[(size_t)c * NP + m];
+      s_cnt[(size_t)c * NP + m] = (uint16_t)run;
+      run += t;
+    }
+    s_off[m] = run;
+  }
+  __syncthreads();
+  {   // exclusive scan of the N totals: thread t owns columns [t per, (t + 1) per)
+    const int per = (N + 1023) >> 10, m_lo = co * per;
+    int sum = 0;
+    for (int j = 0; j < per; ++j) sum += m_lo + j < N ? s_off[m_lo + j] : 0;
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wsum[chunk] = incl;
+    __syncthreads();
+    if (co == 0) {
+      int run = 0;
+      for (int w = 0; w < 16; ++w) {
+        const int t = s_wsum[w];
+        s_wsum[w] = run;
+        run += t;
+      }
+      s_wsum[16] = run;
+    }
+    __syncthreads();
+    int run = s_wsum[chunk] + incl - sum;
+    for (int j = 0; j < per; ++j)
+      if (m_lo + j < N) {
+        const int t = s_off[m_lo + j];
+        s_off[m_lo + j] = run;
+        run += t;
+      }
+    if (co == 0) s_off[N] = s_wsum[16];
+  }
+  __syncthreads();
+  int* ho = hoff + (size_t)b * (N + 1);
+  for (int m = co; m <= N; m += 1024) ho[m] = s_off[m];
+  int* hl = hits + (size_t)b * 1024 * TAPS;
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+    const int m = colm[tap];
+    if (m >= 0) hl[s_off[m] + s_cnt[(size_t)chunk * NP + m] + local[tap]] = (co * TAPS + tap) | (m << 16);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Sparse backward.  One workgroup per (instance, WB_COLS-point tile), split in NP parts of WB_COLS/NP columns with 128
 // threads each; thread (ci, part) owns row ci of its part, so no two threads ever touch the same accumulator
@@ -518,6 +627,22 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_max_bwd2_kernel(WideBwdArgs 
 }  // namespace
 
 void launch_wide_finalize(const WideArgs& a, hipStream_t s) {
+  if (a.hits && a.hoff && a.Co == 1024 && a.N <= WIDE_HITS_MAXN && (a.taps == 1 || a.taps == 3)) {
+    const int NP = (a.N + 1) & ~1;
+    const size_t lds = (size_t)32 * NP + ((size_t)a.N + 1 + 17) * sizeof(int);
+    if (a.taps == 1) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_finalize_hits_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(wide_finalize_hits_kernel<1>, dim3(a.B), dim3(1024), lds, s, a.keys, a.bias, a.N, a.out, a.arg,
+                         a.hits, a.hoff);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_finalize_hits_kernel<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(wide_finalize_hits_kernel<3>, dim3(a.B), dim3(1024), lds, s, a.keys, a.bias, a.N, a.out, a.arg,
+                         a.hits, a.hoff);
+    }
+    return;
+  }
   const int total = a.B * a.Co;
   hipLaunchKernelGGL(wide_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a.keys, a.bias, a.Co, total,
                      a.out, a.arg);

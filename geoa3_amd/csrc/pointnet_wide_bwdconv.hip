@@ -21,7 +21,7 @@ __device__ __forceinline__ float bc_unscale(unsigned E) { return __uint_as_float
 
 constexpr int BW2_WAVES = 8, BW2_THREADS = 64 * BW2_WAVES;
 constexpr int BC_PT = WM_CI + 4;   // floats per column of the tile (column-major here: the B operand reads 8 consecutive ci)
-template <int TAPS, bool GF = false>   // GF: the 64-channel activation is the 3-channel first layer (recomputed gate) and its
+template <int TAPS, bool GF = false, bool PRE = false>   // PRE: the hit lists come from the forward (WideBwdArgs::hits); GF: the 64-channel activation is the 3-channel first layer (recomputed gate) and its
                                        // backward finishes here: dx3 += w1^T (gated result), no [B,64,N] output
 __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -58,9 +58,23 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   if (GF && tid < 64) w1row = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
   const float* gb = a.g + (size_t)b * a.Co;
   const int* argb = a.arg + (size_t)b * a.Co;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  if constexpr (PRE) {
+    // the tile's lists are one contiguous segment of the instance's sorted hits (wide_finalize_hits_kernel)
+    const int* ho = a.hoff + (size_t)b * (a.N + 1);
+    const int h0 = ho[m0];
+    if (tid <= COLS) s_off[tid] = ho[min(m0 + tid, a.N)] - h0;
+    const int total = ho[min(m0 + COLS, a.N)] - h0;
+    const int* seg = a.hits + (size_t)b * a.Co * TAPS + h0;
+    for (int i = tid; i < total; i += BW2_THREADS) {
+      const int e = seg[i];
+      s_list[i] = (list_t)((e & 0xffff) | (((e >> 16) - m0) << LSH));
+    }
+    for (int e = tid; e < COLS * BC_PT; e += BW2_THREADS) s_acc[e] = 0.f;
+    __syncthreads();
+  } else {
   if (tid <= COLS) s_off[tid] = 0;
   __syncthreads();
-  const unsigned long long lt = (1ull << lane) - 1ull;
   {
   // (1) ordered compaction.  Wave w looks at channels [w Co/8, (w+1) Co/8) in chunks of 64; a hit's place in the flat
   // list follows (chunk, tap, channel): ballot + popcount, no ordering left to chance.
@@ -169,6 +183,8 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
   __syncthreads();
   for (int e = tid; e < COLS * BC_PT; e += BW2_THREADS) s_acc[e] = 0.f;   // the flat list is done with: the tile
   __syncthreads();
+  }
+  const int total = s_off[COLS];
   // (3) walk: the flat list is cut into equal shares, one per wave -- arg-max columns cluster on a few "critical" points,
   // so a split by columns leaves most waves idle.  A column that continues from the previous wave's share is summed
   // into the wave's side row and added to the tile afterwards, in wave order (fixed order: deterministic).
@@ -370,19 +386,14 @@ int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s) {
   dim3 grid((a.N + 63) / 64, a.B);
   const size_t region = (size_t)64 * BC_PT > 2 * (size_t)a.Co * a.taps ? (size_t)64 * BC_PT : 2 * (size_t)a.Co * a.taps;
   const size_t lds = (region + (a.taps == 1 ? (size_t)a.Co / 2 : (size_t)a.Co * a.taps) + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 16 + 3 + 4) * sizeof(float);
-  if (a.taps == 1 && a.dx3) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_conv_kernel<1, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((wide_bwd_conv_kernel<1, true>), grid, dim3(BW2_THREADS), lds, s, a);
-  } else if (a.taps == 1) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_conv_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wide_bwd_conv_kernel<1>, grid, dim3(BW2_THREADS), lds, s, a);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_bwd_conv_kernel<3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wide_bwd_conv_kernel<3>, grid, dim3(BW2_THREADS), lds, s, a);
-  }
+  const bool pre = a.hits && a.hoff;
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(BW2_THREADS), lds, s, a);
+  };
+  if (a.taps == 1 && a.dx3) pre ? go(wide_bwd_conv_kernel<1, true, true>) : go(wide_bwd_conv_kernel<1, true, false>);
+  else if (a.taps == 1) pre ? go(wide_bwd_conv_kernel<1, false, true>) : go(wide_bwd_conv_kernel<1, false, false>);
+  else pre ? go(wide_bwd_conv_kernel<3, false, true>) : go(wide_bwd_conv_kernel<3, false, false>);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

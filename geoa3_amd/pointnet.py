@@ -154,7 +154,8 @@ def fuse_front() -> bool:
 
 
 # A/B switches of the library (geoa3_pointnet_weights.flags; the library itself reads no environment): bit 0 / bit 1 select
-# the unfused sparse backward / the one-layer-per-launch trunk (same bits either way, tests/test_gpu_pointnet.py)
+# the unfused sparse backward / the one-layer-per-launch trunk, bit 3 (8) the sparse backward that builds its hit lists per
+# workgroup instead of reading the forward's (same bits either way, tests/test_gpu_pointnet.py)
 AB_FLAGS = 0
 
 

@@ -174,6 +174,7 @@ typedef struct geoa3_tnet_weights {   /* transform_net, Model/PointNet.py:56-94 
 
 #define GEOA3_PN_NO_FUSE_BWD 1 /* sparse backward and the 128 -> 64 layer behind it as two kernels (same bits) */
 #define GEOA3_PN_NO_CHAIN 2    /* the 64-input layers one kernel each instead of chains (same bits) */
+#define GEOA3_PN_NO_PRE_LISTS 8 /* the sparse backward builds its hit lists per workgroup instead of reading the forward's (same bits) */
 #define GEOA3_PN_KEYS_CLEAN 4  /* geoa3_pointnet_forward: the caller vouches that the LAST call that used `workspace` was a
                                   geoa3_pointnet_forward with the same (B, N) (backward calls in between are fine) -- the
                                   arg-max keys in it are then zero already (every layer's finalize leaves them so) and the

@@ -94,6 +94,33 @@ def test_chain_kernels_same_bits_as_layer_by_layer(B, N, monkeypatch):
     assert torch.equal(out["0"][1], out["1"][1])
 
 
+@pytest.mark.parametrize("B,N", [(3, 256), (5, 1000), (2, 77), (9, 1024), (2, 1500), (1, 4096), (2, 4100)])
+def test_forward_built_hit_lists_same_bits(B, N, monkeypatch):
+    """The sparse backward reading the hit lists the forward's finalize pass built once per instance
+    (wide_finalize_hits_kernel: by column, (chunk, tap, channel) order inside a column) against every workgroup building
+    its tile's lists itself (AB_FLAGS bit 3): logits and input gradient bit for bit -- also with a cloud whose points
+    coincide (all channels' maxima on few columns: long lists), ragged N, and N > 4096 where the forward builds none."""
+    from geoa3_amd.pointnet import PointNet
+    from geoa3_amd import pointnet as PN
+    n = PointNet(40)
+    n.load_state_dict(O.make_pointnet_state_dict(40, seed=0))
+    n.wide_mode = "f16x2"
+    n = n.cuda().eval()
+    pc, _ = O.make_synthetic_clouds(B, N, seed=3 * B + N)
+    pc[0, :, N // 2:] = pc[0, :, :1]      # half of the first cloud is one point: ties -> the lowest index takes every maximum
+    w = torch.randn(B, 40, generator=torch.Generator().manual_seed(2)).cuda()
+    out = {}
+    for flag in (8, 0):
+        monkeypatch.setattr(PN, "AB_FLAGS", flag)
+        x = pc.cuda().requires_grad_()
+        lg = n(x)
+        (lg * w).sum().backward()
+        out[flag] = (lg.detach().clone(), x.grad.clone())
+    assert torch.equal(out[0][0], out[8][0])
+    assert torch.equal(out[0][1], out[8][1])
+    assert torch.isfinite(out[0][1]).all() and float(out[0][1].abs().max()) > 0
+
+
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 300.0, 1e6])
 def test_wide_split_operand_range(scale):
     """f16x2 mode carries every fp32 operand of the 1024-wide layers as two fp16 values after a power-of-two scaling
