@@ -20,10 +20,20 @@ __device__ __forceinline__ float bc_scale(unsigned E) { return __uint_as_float((
 __device__ __forceinline__ float bc_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
 
 constexpr int BW2_WAVES = 8, BW2_THREADS = 64 * BW2_WAVES;
+#ifdef GEOA3_BC_STAMPS   // probe build: s_memtime at the phase boundaries of a few workgroups (tools/bc_stamps.py)
+__device__ unsigned long long g_bc_stamps[3 * 8 * 16];
+#define BC_STAMP(i)                                                                                          \
+  do {                                                                                                       \
+    if (tid == 0 && blockIdx.x == 5 && (blockIdx.y & 31) == 7 && blockIdx.y < 256)                            \
+      g_bc_stamps[((TAPS == 3 ? 2 : (GF ? 1 : 0)) * 8 + (blockIdx.y >> 5)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define BC_STAMP(i)
+#endif
 constexpr int BC_PT = WM_CI + 4;   // floats per column of the tile (column-major here: the B operand reads 8 consecutive ci)
 template <int TAPS, bool GF = false, bool PRE = false>   // PRE: the hit lists come from the forward (WideBwdArgs::hits); GF: the 64-channel activation is the 3-channel first layer (recomputed gate) and its
                                        // backward finishes here: dx3 += w1^T (gated result), no [B,64,N] output
-__global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs a) {
+__device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int COLS = 64;
   float* s_acc = smem;                                                  // [64 columns][BC_PT]; before the walk: the flat list
@@ -54,24 +64,25 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
 
   // GF: [64] (w1 row, b1), then [2][32] partial d x -- in the side rows, once the walk is done with them
   float4* s_w1 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s_side) + 15) & ~(uintptr_t)15);
-  float4 w1row = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (GF && tid < 64) w1row = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);
   const float* gb = a.g + (size_t)b * a.Co;
   const int* argb = a.arg + (size_t)b * a.Co;
   const unsigned long long lt = (1ull << lane) - 1ull;
+  BC_STAMP(0);
   if constexpr (PRE) {
     // the tile's lists are one contiguous segment of the instance's sorted hits (wide_finalize_hits_kernel)
     const int* ho = a.hoff + (size_t)b * (a.N + 1);
-    const int h0 = ho[m0];
-    if (tid <= COLS) s_off[tid] = ho[min(m0 + tid, a.N)] - h0;
-    const int total = ho[min(m0 + COLS, a.N)] - h0;
+    const int h0 = ho[m0], h1 = ho[min(m0 + COLS, a.N)], hv = ho[min(m0 + min(tid, COLS), a.N)];
+    for (int e = tid; e < COLS * BC_PT; e += BW2_THREADS) s_acc[e] = 0.f;   // (while the offsets are on their way)
+    if (tid <= COLS) s_off[tid] = hv - h0;
+    const int total = h1 - h0;
     const int* seg = a.hits + (size_t)b * a.Co * TAPS + h0;
+    if (total >= 0) BC_STAMP(1);
     for (int i = tid; i < total; i += BW2_THREADS) {
       const int e = seg[i];
       s_list[i] = (list_t)((e & 0xffff) | (((e >> 16) - m0) << LSH));
     }
-    for (int e = tid; e < COLS * BC_PT; e += BW2_THREADS) s_acc[e] = 0.f;
     __syncthreads();
+    BC_STAMP(2);
   } else {
   if (tid <= COLS) s_off[tid] = 0;
   __syncthreads();
@@ -212,6 +223,9 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
         *reinterpret_cast<float2*>(s_acc + cur * BC_PT + 2 * lane) = make_float2(acc0, acc1);
       }
     };
+#ifdef GEOA3_BC_SKIP_WALK
+    if (total == 12345)
+#endif
     for (int h0 = lo; h0 < hi; h0 += U) {
       float2 w[U];
       float gg[U];
@@ -240,8 +254,10 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     }
     flush();
     if (lane == 0) s_sidecol[wave] = side_col;
+    BC_STAMP(3);
   }
   __syncthreads();
+  BC_STAMP(4);
   if (tid < WM_CI) {
     for (int w = 1; w < BW2_WAVES; ++w) {
       const int c = s_sidecol[w];
@@ -249,26 +265,31 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     }
   }
   __syncthreads();
-  if (GF && tid < 64) s_w1[tid] = w1row;    // (read behind the next barriers)
+  BC_STAMP(5);
+  if (GF && tid < 64) s_w1[tid] = make_float4(a.w1[3 * tid], a.w1[3 * tid + 1], a.w1[3 * tid + 2], a.b1[tid]);    // (read behind the next barriers)
   // (4) the 128 -> 64 layer behind it, on the tile while it is in LDS: gate by the relu bits of the 128-channel
-  // activation, tile maximum -> power-of-two scale; four waves take one 32 x 32 quadrant of W2^T tile each on the f16
-  // matrix core (a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi as in pointnet_conv_split.hip; W2^T's fragments were requested
-  // as fp32 at kernel start and are split here); the result leaves gated by the bits of the 64-channel activation.
+  // activation, tile maximum -> power-of-two scale, and the tile is split ONCE, by all eight waves, into fp16 hi / lo
+  // images written over it (row c: 128 hi halves, 128 lo halves, in the 528 bytes its 132 floats had); four waves then
+  // take one 32 x 32 quadrant of W2^T tile each on the f16 matrix core with ready operands (a*w = a_hi*w_hi + a_hi*w_lo +
+  // a_lo*w_hi as in pointnet_conv_split.hip; W2^T's fragments come split from the host -- W2th -- or as fp32, split
+  // here); the result leaves gated by the bits of the 64-channel activation.  (The waves used to split their B operand
+  // themselves, two waves the same columns, and every workgroup W2^T: 40 % of the kernel's cycles, tools/bc_stamps.py.)
+  float tv[16];
   {
     const int ci = tid & 127, c0 = (tid >> 7) * 16;
     float mx = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int c = c0 + j;
-      float v = s_acc[c * BC_PT + ci];
-      v = ((mkw >> c) & 1ull) && m0 + c < a.N ? v : 0.f;
-      s_acc[c * BC_PT + ci] = v;
-      mx = fmaxf(mx, __builtin_fabsf(v));
+      const float v = s_acc[c * BC_PT + ci];
+      tv[j] = ((mkw >> c) & 1ull) && m0 + c < a.N ? v : 0.f;
+      mx = fmaxf(mx, __builtin_fabsf(tv[j]));
     }
     mx = wave_max(mx);
     if (lane == 0) s_mx[wave] = mx;
   }
-  if (a.w2t_amax > 0.f) {   // max |W2^T| handed over by the caller (a property of the weights)
+  if (a.W2th) {
+  } else if (a.w2t_amax > 0.f) {   // max |W2^T| handed over by the caller (a property of the weights)
     if (lane == 0) s_mx[8 + wave] = a.w2t_amax;
   } else {   // maximum of W2^T [64][128] (every workgroup reads the 32 KB from L2: sixteen values per thread)
     float wmax = 0.f;
@@ -281,55 +302,98 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     wmax = wave_max(wmax);
     if (lane == 0) s_mx[8 + wave] = wmax;
   }
-  __syncthreads();
-  if (wave >= 4) return;
+  __syncthreads();   // every thread holds its sixteen values: the rows may be overwritten
+  BC_STAMP(6);
   float tm = s_mx[0];
 #pragma unroll
   for (int w = 1; w < BW2_WAVES; ++w) tm = fmaxf(tm, s_mx[w]);
-  float wm = s_mx[8];
+  const unsigned Ex = bc_exp(tm);
+  const float sx = bc_scale(Ex);
+  constexpr int BC_PH = 2 * BC_PT;   // halves per column of the images
+  _Float16* s_img = reinterpret_cast<_Float16*>(s_acc);
+  {
+    const int ci = tid & 127, c0 = (tid >> 7) * 16;
 #pragma unroll
-  for (int w = 1; w < BW2_WAVES; ++w) wm = fmaxf(wm, s_mx[8 + w]);
-  const unsigned Ex = bc_exp(tm), Ew = bc_exp(wm);
-  const float sx = bc_scale(Ex), sw = bc_scale(Ew);
+    for (int j = 0; j < 16; ++j) {
+      const float xv = tv[j] * sx;
+      const _Float16 h = (_Float16)xv;
+      s_img[(c0 + j) * BC_PH + ci] = h;
+      s_img[(c0 + j) * BC_PH + WM_CI + ci] = (_Float16)(xv - (float)h);
+    }
+  }
+  __syncthreads();
+  if (wave >= 4) return;
+  float un_w;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const float* brow = s_acc + (32 * qc + (lane & 31)) * BC_PT + (lane >> 5) * 8;
-  // this wave's fragments of W2^T (rows 32 qt + (lane & 31), k = 16 c + 8 (lane >> 5) .. + 7) stream from L2 one k-step ahead
-  // (requested here, not at kernel start: fragments in flight across the list phases made the kernel 10-15 % slower)
-  constexpr int WQ = 2;   // k-steps of fragments in flight
-  float4 wq[WQ][2];
+  const _Float16* brow = s_img + (32 * qc + (lane & 31)) * BC_PH + (lane >> 5) * 8;
+  if (a.W2th) {
+    un_w = a.w2th_unscale;
+    const half8* wf = reinterpret_cast<const half8*>(a.W2th) + (size_t)qt * 8 * 2 * 64 + lane;   // [qt][c][hi / lo][lane]
+    constexpr int WQ = 2;   // k-steps of fragments in flight
+    half8 wq[WQ][2];
 #pragma unroll
-  for (int c = 0; c + 1 < WQ; ++c) {
-    wq[c][0] = *reinterpret_cast<const float4*>(wr + 16 * c);
-    wq[c][1] = *reinterpret_cast<const float4*>(wr + 16 * c + 4);
-  }
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    if (c + WQ - 1 < 8) {
-      wq[(c + WQ - 1) % WQ][0] = *reinterpret_cast<const float4*>(wr + 16 * (c + WQ - 1));
-      wq[(c + WQ - 1) % WQ][1] = *reinterpret_cast<const float4*>(wr + 16 * (c + WQ - 1) + 4);
+    for (int c = 0; c + 1 < WQ; ++c) {
+      wq[c][0] = wf[(2 * c) * 64];
+      wq[c][1] = wf[(2 * c + 1) * 64];
     }
-    const float4 wa = wq[c % WQ][0], wb = wq[c % WQ][1];
-    const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-    const float4 b0 = *reinterpret_cast<const float4*>(brow + c * 16);
-    const float4 b1 = *reinterpret_cast<const float4*>(brow + c * 16 + 4);
-    const float x8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    half8 wh, wl, xh, xl;
+#ifdef GEOA3_BC_SKIP_MFMA
+    if (total == 12345)
+#endif
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float wv = w8[j] * sw, xv = x8[j] * sx;
-      const _Float16 a0 = (_Float16)wv, a1 = (_Float16)xv;
-      wh[j] = a0;
-      wl[j] = (_Float16)(wv - (float)a0);
-      xh[j] = a1;
-      xl[j] = (_Float16)(xv - (float)a1);
+    for (int c = 0; c < 8; ++c) {
+      if (c + WQ - 1 < 8) {
+        wq[(c + WQ - 1) % WQ][0] = wf[(2 * (c + WQ - 1)) * 64];
+        wq[(c + WQ - 1) % WQ][1] = wf[(2 * (c + WQ - 1) + 1) * 64];
+      }
+      const half8 wh = wq[c % WQ][0], wl = wq[c % WQ][1];
+      const half8 xh = *reinterpret_cast<const half8*>(brow + c * 16);
+      const half8 xl = *reinterpret_cast<const half8*>(brow + WM_CI + c * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+  } else {
+    float wm = s_mx[8];
+#pragma unroll
+    for (int w = 1; w < BW2_WAVES; ++w) wm = fmaxf(wm, s_mx[8 + w]);
+    const unsigned Ew = bc_exp(wm);
+    const float sw = bc_scale(Ew);
+    un_w = bc_unscale(Ew);
+    // this wave's fragments of W2^T (rows 32 qt + (lane & 31), k = 16 c + 8 (lane >> 5) .. + 7) stream from L2 one k-step ahead
+    constexpr int WQ = 2;
+    float4 wq[WQ][2];
+#pragma unroll
+    for (int c = 0; c + 1 < WQ; ++c) {
+      wq[c][0] = *reinterpret_cast<const float4*>(wr + 16 * c);
+      wq[c][1] = *reinterpret_cast<const float4*>(wr + 16 * c + 4);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c + WQ - 1 < 8) {
+        wq[(c + WQ - 1) % WQ][0] = *reinterpret_cast<const float4*>(wr + 16 * (c + WQ - 1));
+        wq[(c + WQ - 1) % WQ][1] = *reinterpret_cast<const float4*>(wr + 16 * (c + WQ - 1) + 4);
+      }
+      const float4 wa = wq[c % WQ][0], wb = wq[c % WQ][1];
+      const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+      half8 wh, wl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float wv = w8[j] * sw;
+        const _Float16 a0 = (_Float16)wv;
+        wh[j] = a0;
+        wl[j] = (_Float16)(wv - (float)a0);
+      }
+      const half8 xh = *reinterpret_cast<const half8*>(brow + c * 16);
+      const half8 xl = *reinterpret_cast<const half8*>(brow + WM_CI + c * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+    }
   }
-  const float un = bc_unscale(Ex) * bc_unscale(Ew);
+  if (acc[0] != 12345.f) BC_STAMP(7);
+  const float un = bc_unscale(Ex) * un_w;
   // acc[r]: row 32 qt + (r&3) + 8 (r>>2) + 4 (lane>>5), column 32 qc + (lane&31); gate word of row l in lane l of gw2
   const int col = 32 * qc + (lane & 31), m = m0 + col;
   if constexpr (GF) {
@@ -360,6 +424,7 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
       dxp[a.N] += q1 + o.y;
       dxp[2 * (size_t)a.N] += q2 + o.z;
     }
+    BC_STAMP(8);
     return;
   }
   float* Y = a.dY + (size_t)b * a.sYb + m;
@@ -374,10 +439,26 @@ __global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs 
     const int row = rr + 4 * (lane >> 5);
     if (m < a.N) Y[(size_t)row * a.ldY] = (gsel >> (lane & 31)) & 1u ? acc[r] * un : 0.f;
   }
+  BC_STAMP(8);
+}
+
+template <int TAPS, bool PRE>
+__global__ __launch_bounds__(BW2_THREADS) void wide_bwd_conv_kernel(WideBwdArgs a) {
+  wide_bwd_conv_body<TAPS, false, PRE>(a);
+}
+// the first-layer form: its epilogue would take 72-74 registers (seven waves per SIMD = three workgroups per CU); held at 64
+template <bool PRE>
+__global__ __launch_bounds__(BW2_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void wide_bwd_conv_first_kernel(WideBwdArgs a) {
+  wide_bwd_conv_body<1, true, PRE>(a);
 }
 
 }  // namespace
 
+#ifdef GEOA3_BC_STAMPS
+extern "C" int geoa3_debug_bc_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc_stamps), sizeof(g_bc_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s) {
   const bool gf = a.dx3 != nullptr;   // first-layer form: x3, w1, b1, dx3 instead of Zmask2 / dY
   if ((a.taps != 1 && a.taps != 3) || !a.Zmask || !a.W2t || a.Co * a.taps > 0xffff || (a.taps == 1 && a.Co > 1024) ||
@@ -391,9 +472,9 @@ int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(BW2_THREADS), lds, s, a);
   };
-  if (a.taps == 1 && a.dx3) pre ? go(wide_bwd_conv_kernel<1, true, true>) : go(wide_bwd_conv_kernel<1, true, false>);
-  else if (a.taps == 1) pre ? go(wide_bwd_conv_kernel<1, false, true>) : go(wide_bwd_conv_kernel<1, false, false>);
-  else pre ? go(wide_bwd_conv_kernel<3, false, true>) : go(wide_bwd_conv_kernel<3, false, false>);
+  if (a.taps == 1 && a.dx3) pre ? go(wide_bwd_conv_first_kernel<true>) : go(wide_bwd_conv_first_kernel<false>);
+  else if (a.taps == 1) pre ? go(wide_bwd_conv_kernel<1, true>) : go(wide_bwd_conv_kernel<1, false>);
+  else pre ? go(wide_bwd_conv_kernel<3, true>) : go(wide_bwd_conv_kernel<3, false>);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -102,6 +102,7 @@ def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     out["w2h"], out["w2h_unscale"] = pack_wide_split(out["w2"], 1)
     out["w3h16"], _ = pack_wide_split16(out["w3"])
     out["w2t_amax"] = float(out["w2t"].abs().max())
+    out["w2th"], out["w2th_unscale"] = pack_wide_split(out["w2t"], 1)
     return out
 
 
@@ -128,6 +129,7 @@ def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
     out["w4h"], out["w4h_unscale"] = pack_wide_split(out["w4"], 1)
     out["w5h16"], _ = pack_wide_split16(out["w5"])
     out["w4t_amax"] = float(out["w4t"].abs().max())
+    out["w4th"], out["w4th_unscale"] = pack_wide_split(out["w4t"], 1)
     return out
 
 
@@ -182,6 +184,8 @@ class PackedPointNet:
 
         def pick(p: Dict[str, object], name: str):
             if name in ("w3h", "w5h", "w2h", "w4h") and (not split or (name in ("w2h", "w4h") and not fuse_front())):
+                return None
+            if name in ("w2th", "w4th") and not split:
                 return None
             if name == "w5h16" and (not split or wide_shape("conv5") != 16):
                 return None
