@@ -32,7 +32,7 @@ class TnetWeights(C.Structure):
     _fields_ = [("K", C.c_int32)] + [(n, vp) for n in (
         "w1", "b1", "w2", "b2", "w3", "b3", "w3p", "w2t", "f1", "fb1", "f2", "fb2", "f3", "fb3",
         "f1t", "f2t", "f3t", "w3h")] + [("w3h_unscale", C.c_float), ("w2h", vp), ("w2h_unscale", C.c_float), ("w3h16", vp),
-                                      ("w2t_amax", C.c_float), ("w2th", vp), ("w2th_unscale", C.c_float)]
+                                      ("w2th", vp), ("w2th_unscale", C.c_float)]
 
 
 class PointNetWeights(C.Structure):
@@ -41,7 +41,7 @@ class PointNetWeights(C.Structure):
         "w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "w5", "b5", "w5p", "w4t", "w3t", "w2t",
         "f1", "fb1", "f2", "fb2", "f3", "fb3", "f1t", "f2t", "f3t", "w5h")] + [("w5h_unscale", C.c_float), ("w4h", vp),
                                                                                  ("w4h_unscale", C.c_float), ("w5h16", vp),
-                                                                                 ("w4t_amax", C.c_float), ("w4th", vp), ("w4th_unscale", C.c_float),
+                                                                                 ("w4th", vp), ("w4th_unscale", C.c_float),
                                                                                  ("flags", C.c_int32)]
 
 

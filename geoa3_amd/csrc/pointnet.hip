@@ -212,12 +212,11 @@ int wide_bwd(const float* g, const int* arg, const float* W, const float* Z, con
 
 // sparse backward of a 1024-wide layer + the gated 128 -> 64 layer behind it in one kernel (split mode: bit gates)
 int wide_bwd_conv(const float* g, const int* arg, const float* W, const unsigned long long* Zmask, const float* W2t,
-                  const unsigned long long* Zmask2, float* dY, int taps, int B, int N, hipStream_t s, float w2t_amax,
+                  const unsigned long long* Zmask2, float* dY, int taps, int B, int N, hipStream_t s,
                   const int* hits, const int* hoff, const void* W2th, float w2th_unscale) {
   WideBwdArgs a{};
   a.W2th = W2th; a.w2th_unscale = w2th_unscale;
   if (pre_lists(N)) { a.hits = hits; a.hoff = hoff; }
-  a.w2t_amax = w2t_amax;
   a.Zmask = Zmask;
   a.g = g; a.arg = arg; a.W = W;
   a.W2t = W2t; a.Zmask2 = Zmask2;
@@ -265,16 +264,15 @@ int tnet_bwd(const geoa3_tnet_weights& t, const float* gT, const float* act64, c
   TRY(fc(gT, t.K * t.K, t.f3t, nullptr, w.g256, 256, B, false, f5, s, ks ? w.G128 : nullptr));
   TRY(fc(w.g256, 256, t.f2t, nullptr, w.g512, 512, B, false, f4, s));
   TRY(fc(w.g512, 512, t.f1t, nullptr, w.g1024, 1024, B, false, pooled, s));
-  if (act64 && tl_split && m128 && m64 && fuse_bwd()) {
-    TRY(wide_bwd_conv(w.g1024, arg, t.w3, m128, t.w2t, m64, G64out, 1, B, N, s, t.w2t_amax, hits, hoff, t.w2th, t.w2th_unscale));
+  if (act64 && tl_split && m128 && m64 && fuse_bwd() && t.w2th) {
+    TRY(wide_bwd_conv(w.g1024, arg, t.w3, m128, t.w2t, m64, G64out, 1, B, N, s, hits, hoff, t.w2th, t.w2th_unscale));
     return 0;
   }
-  if (!act64 && tl_split && m128 && fuse_bwd()) {   // the 3-channel T-Net: ... and its first layer's backward: dx += w1^T (..)
+  if (!act64 && tl_split && m128 && fuse_bwd() && t.w2th) {   // the 3-channel T-Net: ... and its first layer's backward: dx += w1^T (..)
     WideBwdArgs a{};
     if (pre_lists(N)) { a.hits = hits; a.hoff = hoff; }
     a.Zmask = m128;
     a.g = w.g1024; a.arg = arg; a.W = t.w3;
-    a.W2t = t.w2t; a.w2t_amax = t.w2t_amax;
     a.W2th = t.w2th; a.w2th_unscale = t.w2th_unscale;
     a.x3 = x3; a.w1 = t.w1; a.b1 = t.b1; a.dx3 = G64out;
     a.Co = 1024; a.N = N; a.B = B; a.taps = 1;
@@ -408,8 +406,8 @@ extern "C" int geoa3_pointnet_backward(const geoa3_pointnet_weights* pw, const f
   TRY(fc(w.g256, 256, p.f2t, nullptr, w.g512, 512, B, false, w.f6, s));
   TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, 1024, B, false, w.p5, s));
   // max + conv5 (sparse), conv4, conv3
-  if (tl_split && fuse_bwd()) {
-    TRY(wide_bwd_conv(w.g1024, w.i5, p.w5, w.m_h4, p.w4t, w.m_h3, w.G64a, 3, B, N, s, p.w4t_amax, w.hl5, w.ho5, p.w4th, p.w4th_unscale));
+  if (tl_split && fuse_bwd() && p.w4th) {
+    TRY(wide_bwd_conv(w.g1024, w.i5, p.w5, w.m_h4, p.w4t, w.m_h3, w.G64a, 3, B, N, s, w.hl5, w.ho5, p.w4th, p.w4th_unscale));
   } else {
     TRY(wide_bwd(w.g1024, w.i5, p.w5, w.h4, w.m_h4, w.G128, 3, B, N, s));
     TRY(conv(w.G128, 128, p.w4t, nullptr, w.G64a, 64, B, N, false, nullptr, false, s, nullptr, w.m_h3));

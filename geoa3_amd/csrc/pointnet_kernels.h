@@ -162,9 +162,8 @@ struct WideBwdArgs {
   // kernel: dY[b][o][n] = gate2 . sum_ci W2t[o][ci] dX[b][ci][n] (dX stays in LDS; needs Zmask).  W2t [64][128];
   // Zmask2: relu bits of the 64-channel activation, [B][ceil(N/64)][64] words (ConvArgs::Ymask layout)
   const float* W2t; const unsigned long long* Zmask2;
-  float w2t_amax;                             // max |W2t| if the caller knows it (> 0), else 0: every workgroup computes it
   const void* W2th; float w2th_unscale;       // W2t as split-fp16 fragments (pack_wide_split: [row >> 5][k >> 4][hi / lo][lane][8])
-                                              // and 1 / their scale: ready A operands, or null: split from W2t in the kernel
+                                              // and 1 / their scale: the A operands (required)
   float* dY; long sYb; int ldY;
   // ... or, with dx3: that layer is the one behind the 3-channel first layer (gate recomputed from x3 [B][3][N] with
   // w1 [64][3], b1 [64]) and the first layer's backward finishes in the same kernel: dx3[b][d][n] += sum_o w1[o][d] dY[o][n]

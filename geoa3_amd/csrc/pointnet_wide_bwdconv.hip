@@ -52,15 +52,15 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   int* s_sidecol = s_wcnt + BW2_WAVES + 1;                              // [BW2_WAVES]
   float* s_side = reinterpret_cast<float*>(s_sidecol + BW2_WAVES);      // [BW2_WAVES][128]
   float* s_mx = s_side + BW2_WAVES * WM_CI;                             // [8] tile maxima of the waves, [8] weight maxima
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, m0 = blockIdx.x * COLS;
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y, m0 = blockIdx.x * COLS;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the walk's list entries, rows and columns stay in SGPRs)
   // requested now, used at the very end: the gate word of output row `lane`
   unsigned long long gw2 = 0ull;
   if (!GF && wave < 4) gw2 = a.Zmask2[((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * 64 + lane];
   // ... and the gate word of tile row (tid & 127) of the 128-channel activation
   const int tiles = (a.N + 63) >> 6;
-  const unsigned long long mkw = a.Zmask[((size_t)b * tiles + blockIdx.x) * WM_CI + (tid & 127)];
+  const ulonglong2 mkw = reinterpret_cast<const ulonglong2*>(a.Zmask + ((size_t)b * tiles + blockIdx.x) * WM_CI)[lane];   // rows 2 lane, 2 lane + 1
   const int qt = wave & 1, qc = (wave >> 1) & 1;     // waves 0-3: output rows 32 qt .., columns 32 qc ..
-  const float* wr = a.W2t + (size_t)(32 * qt + (lane & 31)) * WM_CI + 8 * (lane >> 5);
 
   // GF: [64] (w1 row, b1), then [2][32] partial d x -- in the side rows, once the walk is done with them
   float4* s_w1 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(s_side) + 15) & ~(uintptr_t)15);
@@ -230,10 +230,13 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
       float2 w[U];
       float gg[U];
       int cc[U];
+      // lane u reads entry h0 + u; the entries then travel through SGPRs (v_readlane): the row address, the gradient's
+      // address and the column are scalar -- the walk was a quarter of the kernel's VALU instructions
+      const int ev = (int)s_list[min(h0 + (lane & (U - 1)), hi - 1)];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const bool ok = h0 + u < hi;
-        const int e = (int)s_list[ok ? h0 + u : hi - 1];
+        const int e = __builtin_amdgcn_readlane(ev, u);
         const int er = e & ((1 << LSH) - 1);
         w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)er * ldW + 2 * lane);
         gg[u] = ok ? gb[er / TAPS] : 0.f;
@@ -274,33 +277,21 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   // a_lo*w_hi as in pointnet_conv_split.hip; W2^T's fragments come split from the host -- W2th -- or as fp32, split
   // here); the result leaves gated by the bits of the 64-channel activation.  (The waves used to split their B operand
   // themselves, two waves the same columns, and every workgroup W2^T: 40 % of the kernel's cycles, tools/bc_stamps.py.)
+  // thread = (pair of rows 2 lane, 2 lane + 1; the wave's eight columns): a column is touched by ONE wave
   float tv[16];
   {
-    const int ci = tid & 127, c0 = (tid >> 7) * 16;
     float mx = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int c = c0 + j;
-      const float v = s_acc[c * BC_PT + ci];
-      tv[j] = ((mkw >> c) & 1ull) && m0 + c < a.N ? v : 0.f;
-      mx = fmaxf(mx, __builtin_fabsf(tv[j]));
+    for (int j = 0; j < 8; ++j) {
+      const int c = 8 * wave + j;
+      const float2 v = *reinterpret_cast<const float2*>(s_acc + c * BC_PT + 2 * lane);
+      const bool in = m0 + c < a.N;
+      tv[2 * j] = ((mkw.x >> c) & 1ull) && in ? v.x : 0.f;
+      tv[2 * j + 1] = ((mkw.y >> c) & 1ull) && in ? v.y : 0.f;
+      mx = fmaxf(mx, fmaxf(__builtin_fabsf(tv[2 * j]), __builtin_fabsf(tv[2 * j + 1])));
     }
     mx = wave_max(mx);
     if (lane == 0) s_mx[wave] = mx;
-  }
-  if (a.W2th) {
-  } else if (a.w2t_amax > 0.f) {   // max |W2^T| handed over by the caller (a property of the weights)
-    if (lane == 0) s_mx[8 + wave] = a.w2t_amax;
-  } else {   // maximum of W2^T [64][128] (every workgroup reads the 32 KB from L2: sixteen values per thread)
-    float wmax = 0.f;
-    const float4* w4 = reinterpret_cast<const float4*>(a.W2t) + tid;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 v = w4[i * BW2_THREADS];
-      wmax = fmaxf(wmax, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
-    }
-    wmax = wave_max(wmax);
-    if (lane == 0) s_mx[8 + wave] = wmax;
   }
   __syncthreads();   // every thread holds its sixteen values: the rows may be overwritten
   BC_STAMP(6);
@@ -311,25 +302,22 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   const float sx = bc_scale(Ex);
   constexpr int BC_PH = 2 * BC_PT;   // halves per column of the images
   _Float16* s_img = reinterpret_cast<_Float16*>(s_acc);
-  {
-    const int ci = tid & 127, c0 = (tid >> 7) * 16;
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float xv = tv[j] * sx;
-      const _Float16 h = (_Float16)xv;
-      s_img[(c0 + j) * BC_PH + ci] = h;
-      s_img[(c0 + j) * BC_PH + WM_CI + ci] = (_Float16)(xv - (float)h);
-    }
+  for (int j = 0; j < 8; ++j) {
+    const float x0 = tv[2 * j] * sx, x1 = tv[2 * j + 1] * sx;
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    _Float16* row = s_img + (8 * wave + j) * BC_PH + 2 * lane;
+    *reinterpret_cast<half2v*>(row) = half2v{h0, h1};
+    *reinterpret_cast<half2v*>(row + WM_CI) = half2v{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};
   }
   __syncthreads();
   if (wave >= 4) return;
-  float un_w;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const _Float16* brow = s_img + (32 * qc + (lane & 31)) * BC_PH + (lane >> 5) * 8;
-  if (a.W2th) {
-    un_w = a.w2th_unscale;
+  {
     const half8* wf = reinterpret_cast<const half8*>(a.W2th) + (size_t)qt * 8 * 2 * 64 + lane;   // [qt][c][hi / lo][lane]
     constexpr int WQ = 2;   // k-steps of fragments in flight
     half8 wq[WQ][2];
@@ -354,57 +342,23 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
     }
-  } else {
-    float wm = s_mx[8];
-#pragma unroll
-    for (int w = 1; w < BW2_WAVES; ++w) wm = fmaxf(wm, s_mx[8 + w]);
-    const unsigned Ew = bc_exp(wm);
-    const float sw = bc_scale(Ew);
-    un_w = bc_unscale(Ew);
-    // this wave's fragments of W2^T (rows 32 qt + (lane & 31), k = 16 c + 8 (lane >> 5) .. + 7) stream from L2 one k-step ahead
-    constexpr int WQ = 2;
-    float4 wq[WQ][2];
-#pragma unroll
-    for (int c = 0; c + 1 < WQ; ++c) {
-      wq[c][0] = *reinterpret_cast<const float4*>(wr + 16 * c);
-      wq[c][1] = *reinterpret_cast<const float4*>(wr + 16 * c + 4);
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      if (c + WQ - 1 < 8) {
-        wq[(c + WQ - 1) % WQ][0] = *reinterpret_cast<const float4*>(wr + 16 * (c + WQ - 1));
-        wq[(c + WQ - 1) % WQ][1] = *reinterpret_cast<const float4*>(wr + 16 * (c + WQ - 1) + 4);
-      }
-      const float4 wa = wq[c % WQ][0], wb = wq[c % WQ][1];
-      const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-      half8 wh, wl;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float wv = w8[j] * sw;
-        const _Float16 a0 = (_Float16)wv;
-        wh[j] = a0;
-        wl[j] = (_Float16)(wv - (float)a0);
-      }
-      const half8 xh = *reinterpret_cast<const half8*>(brow + c * 16);
-      const half8 xl = *reinterpret_cast<const half8*>(brow + WM_CI + c * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
-    }
   }
   if (acc[0] != 12345.f) BC_STAMP(7);
-  const float un = bc_unscale(Ex) * un_w;
+  const float un = bc_unscale(Ex) * a.w2th_unscale;
   // acc[r]: row 32 qt + (r&3) + 8 (r>>2) + 4 (lane>>5), column 32 qc + (lane&31); gate word of row l in lane l of gw2
   const int col = 32 * qc + (lane & 31), m = m0 + col;
   if constexpr (GF) {
     // gate = sign of the first layer, recomputed from the point (Model/PointNet.py:79 behind relu); q = w1^T (gated rows)
-    const bool in = m < a.N;
-    const float* xp = a.x3 + (size_t)b * 3 * a.N + (in ? m : a.N - 1);
+    // (lane and column are formed again here: kept alive across the matrix product they cost a spilled register pair)
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int mq = m0 + 32 * qc + (ln & 31);
+    const bool in = mq < a.N;
+    const float* xp = a.x3 + (size_t)b * 3 * a.N + (in ? mq : a.N - 1);
     const float x0 = xp[0], x1 = xp[a.N], x2 = xp[2 * (size_t)a.N];
     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float4 w = s_w1[32 * qt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+      const float4 w = s_w1[32 * qt + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5)];
       const float o = (w.x * x0 + w.y * x1 + w.z * x2 + w.w) > 0.f ? acc[r] * un : 0.f;
       q0 += w.x * o;
       q1 += w.y * o;
@@ -415,11 +369,11 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
     q2 += __shfl_xor(q2, 32, 64);
     float4* s_q = s_w1 + 64;          // [2 column blocks][32]: the partial sums of row tile 1
     __syncthreads();                  // (waves 4-7 have left: the barrier counts the four that remain) s_w1 is read
-    if (qt == 1 && lane < 32) s_q[qc * 32 + lane] = make_float4(q0, q1, q2, 0.f);
+    if (qt == 1 && ln < 32) s_q[qc * 32 + ln] = make_float4(q0, q1, q2, 0.f);
     __syncthreads();
-    if (qt == 0 && lane < 32 && in) {
-      const float4 o = s_q[qc * 32 + lane];
-      float* dxp = a.dx3 + (size_t)b * 3 * a.N + m;    // += : the trunk's gradient is there already
+    if (qt == 0 && ln < 32 && in) {
+      const float4 o = s_q[qc * 32 + ln];
+      float* dxp = a.dx3 + (size_t)b * 3 * a.N + mq;    // += : the trunk's gradient is there already
       dxp[0] += q0 + o.x;
       dxp[a.N] += q1 + o.y;
       dxp[2 * (size_t)a.N] += q2 + o.z;
@@ -461,7 +415,7 @@ extern "C" int geoa3_debug_bc_stamps(unsigned long long* out) {
 #endif
 int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s) {
   const bool gf = a.dx3 != nullptr;   // first-layer form: x3, w1, b1, dx3 instead of Zmask2 / dY
-  if ((a.taps != 1 && a.taps != 3) || !a.Zmask || !a.W2t || a.Co * a.taps > 0xffff || (a.taps == 1 && a.Co > 1024) ||
+  if ((a.taps != 1 && a.taps != 3) || !a.Zmask || !a.W2th || a.Co * a.taps > 0xffff || (a.taps == 1 && a.Co > 1024) ||
       (gf ? (!a.x3 || !a.w1 || !a.b1 || a.taps != 1) : (!a.Zmask2 || !a.dY)))
     return GEOA3_ENOSUPPORT;
   dim3 grid((a.N + 63) / 64, a.B);

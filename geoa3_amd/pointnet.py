@@ -101,7 +101,6 @@ def pack_tnet(sd: Dict[str, Tensor], prefix: str, K: int) -> Dict[str, Tensor]:
     out["w3h"], out["w3h_unscale"] = pack_wide_split(out["w3"], 1)
     out["w2h"], out["w2h_unscale"] = pack_wide_split(out["w2"], 1)
     out["w3h16"], _ = pack_wide_split16(out["w3"])
-    out["w2t_amax"] = float(out["w2t"].abs().max())
     out["w2th"], out["w2th_unscale"] = pack_wide_split(out["w2t"], 1)
     return out
 
@@ -128,7 +127,6 @@ def pack_pointnet(sd: Dict[str, Tensor]) -> Dict[str, object]:
     out["w5h"], out["w5h_unscale"] = pack_wide_split(out["w5"], 3)
     out["w4h"], out["w4h_unscale"] = pack_wide_split(out["w4"], 1)
     out["w5h16"], _ = pack_wide_split16(out["w5"])
-    out["w4t_amax"] = float(out["w4t"].abs().max())
     out["w4th"], out["w4th_unscale"] = pack_wide_split(out["w4t"], 1)
     return out
 
