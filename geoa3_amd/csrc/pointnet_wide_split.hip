@@ -504,12 +504,16 @@ int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
     switch (a.variant) {
       case 1: launch_variant<1, 2, 8, 1, 2, true>(a, s); break;
       case 2: launch_variant<1, 2, 8, 1, 0, false>(a, s); break;
+      case 3: launch_variant<1, 2, 8, 2, 0, true>(a, s); break;
+      case 4: launch_variant<1, 2, 8, 2, 2, true>(a, s); break;
       default: launch_variant<1, 2, 8, 1, 0, true>(a, s);
     }
   } else {
     switch (a.variant) {
       case 1: launch_variant<3, 2, 4, 1, 0, true>(a, s); break;
       case 2: launch_variant<3, 2, 4, 1, 2, false>(a, s); break;
+      case 3: launch_variant<3, 2, 4, 2, 0, true>(a, s); break;
+      case 4: launch_variant<3, 2, 4, 2, 2, true>(a, s); break;
       default: launch_variant<3, 2, 4, 1, 2, true>(a, s);
     }
   }
