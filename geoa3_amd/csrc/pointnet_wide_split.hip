@@ -495,6 +495,8 @@ int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
       hipMemsetAsync(a.keys, 0, (size_t)a.B * a.Co * sizeof(unsigned long long), s) != hipSuccess)
     return GEOA3_ELAUNCH;
   // variants measured on hardware (tools/bench_wide.py 0 1 2): within +-5 % of each other and of run-to-run noise
+  // (round 4 again: two channel tiles per wave, CB = 2 -- half the LDS reads per MFMA -- 186.2 against 185.2 us at one
+  //  tap, 542 against 508 us at three: LDS bandwidth is not what holds these kernels at ~1.1-1.2 PF on the f16 pipe)
   if (a.W2h) {   // the 64 -> 128 layer in front is computed while the tile is staged
     if (!a.b2 || (a.x3 ? (!a.w1 || !a.b1 || a.taps != 1) : !a.Xin) || (a.taps == 3 && !a.W2f)) return GEOA3_EINVAL;
     if (a.taps == 1 && a.x3) launch_variant<1, 2, 8, 1, 0, true, 2>(a, s);
@@ -504,16 +506,12 @@ int launch_wide_max_split(const WideArgs& a, hipStream_t s) {
     switch (a.variant) {
       case 1: launch_variant<1, 2, 8, 1, 2, true>(a, s); break;
       case 2: launch_variant<1, 2, 8, 1, 0, false>(a, s); break;
-      case 3: launch_variant<1, 2, 8, 2, 0, true>(a, s); break;
-      case 4: launch_variant<1, 2, 8, 2, 2, true>(a, s); break;
       default: launch_variant<1, 2, 8, 1, 0, true>(a, s);
     }
   } else {
     switch (a.variant) {
       case 1: launch_variant<3, 2, 4, 1, 0, true>(a, s); break;
       case 2: launch_variant<3, 2, 4, 1, 2, false>(a, s); break;
-      case 3: launch_variant<3, 2, 4, 2, 0, true>(a, s); break;
-      case 4: launch_variant<3, 2, 4, 2, 2, true>(a, s); break;
       default: launch_variant<3, 2, 4, 1, 2, true>(a, s);
     }
   }
