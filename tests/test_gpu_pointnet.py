@@ -121,6 +121,36 @@ def test_forward_built_hit_lists_same_bits(B, N, monkeypatch):
     assert torch.isfinite(out[0][1]).all() and float(out[0][1].abs().max()) > 0
 
 
+def test_without_transposed_fragments_same_bits():
+    """geoa3_tnet_weights.w2th / geoa3_pointnet_weights.w4th are optional (include/geoa3_hip.h): a caller that does not
+    hand them over gets the sparse backward and the 128 -> 64 layer behind it as two kernels -- the same gradient, bit
+    for bit."""
+    from geoa3_amd.pointnet import PointNet
+    n = PointNet(40)
+    n.load_state_dict(O.make_pointnet_state_dict(40, seed=0))
+    n.wide_mode = "f16x2"
+    n = n.cuda().eval()
+    pc, _ = O.make_synthetic_clouds(4, 700, seed=21)
+    w = torch.randn(4, 40, generator=torch.Generator().manual_seed(5)).cuda()
+    out = []
+    st = n.packed(torch.device("cuda")).struct
+    keep = (st.t3.w2th, st.t64.w2th, st.w4th)
+    assert all(keep)
+    try:
+        for drop in (False, True):
+            if drop:
+                st.t3.w2th = st.t64.w2th = st.w4th = None
+            x = pc.cuda().requires_grad_()
+            lg = n(x)
+            (lg * w).sum().backward()
+            out.append((lg.detach().clone(), x.grad.clone()))
+    finally:
+        st.t3.w2th, st.t64.w2th, st.w4th = keep
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert float(out[0][1].abs().max()) > 0
+
+
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 300.0, 1e6])
 def test_wide_split_operand_range(scale):
     """f16x2 mode carries every fp32 operand of the 1024-wide layers as two fp16 values after a power-of-two scaling
