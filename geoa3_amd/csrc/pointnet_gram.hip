@@ -6,7 +6,8 @@
 // in LDS (row-major in n: exactly the k-contiguous fragment both MFMA operands need, one ds_read_b128 each), each
 // wave multiplies one 32 x 32 quadrant on the f16 matrix pipe (a*g = a_hi*g_hi + a_hi*g_lo + a_lo*g_hi, fp32
 // accumulation), and the chunk's sum is scaled back and added in fp32.  The next chunk's rows are in flight in
-// registers meanwhile.  One workgroup per instance is latency bound (4 waves per CU: 90 us); four workgroups per
+// registers meanwhile.  A chunk passes through the LDS images in two 64-column halves (same scales, same order of the
+// k-steps: same bits): 35 KB per workgroup, four workgroups per CU -- 51 -> 30.5 us at B = 250, N = 1024 (5.3 TB/s).  One workgroup per instance is latency bound (4 waves per CU: 90 us); four workgroups per
 // instance take every fourth chunk and a second kernel adds their partial sums in a fixed order.  Deterministic.
 #include "pointnet_kernels.h"
 
@@ -14,8 +15,11 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-constexpr int GR_CHK = 128;                  // columns per chunk
-constexpr int GR_PITCH = GR_CHK * 2 + 16;    // bytes per LDS row (conflict-free 16-byte reads: 68 banks = 4 mod 64)
+constexpr int GR_CHK = 128;                  // columns per chunk (one power-of-two scale per matrix and chunk)
+constexpr int GR_HALF = GR_CHK / 2;          // columns in LDS at a time: a chunk goes through the images in two halves --
+                                             // 35 KB per workgroup instead of 70, four workgroups per CU instead of two
+                                             // (the kernel is bound by HBM latency: 51 -> 30.5 us at B = 250, N = 1024)
+constexpr int GR_PITCH = GR_HALF * 2 + 16;   // bytes per LDS row (conflict-free 16-byte reads: 36 banks = 4 mod 32)
 constexpr int GR_IMG = 64 * GR_PITCH;        // one piece of one matrix
 
 __device__ __forceinline__ unsigned gr_exp(float m) {
@@ -32,23 +36,17 @@ __global__ __launch_bounds__(256) void gram64_kernel(const float* __restrict__ A
   const float* Gb = G + (size_t)b * 64 * N;
   const int chunks = (N + GR_CHK - 1) / GR_CHK;
   const int part = blockIdx.y;   // this workgroup: chunks part, part + parts, .. (partial sums: gram64_reduce_kernel)
-  // wave w stages rows 16w .. 16w+15 of both matrices; a lane two adjacent columns
+  // wave w stages rows 16w .. 16w+15 of both matrices; a lane the columns `lane` and 64 + `lane` of the chunk (.x / .y)
   float2 ra[16], rg[16];
   auto load_chunk = [&](int c) {
-    const int n = c * GR_CHK + 2 * lane;
-    const bool vec = (N & 1) == 0 && n + 1 < N;
+    const int n = c * GR_CHK + lane;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const size_t off = (size_t)(16 * wave + r) * N + n;
-      if (vec) {
-        ra[r] = *reinterpret_cast<const float2*>(Ab + off);
-        rg[r] = *reinterpret_cast<const float2*>(Gb + off);
-      } else {
-        ra[r].x = n < N ? Ab[off] : 0.f;
-        ra[r].y = n + 1 < N ? Ab[off + 1] : 0.f;
-        rg[r].x = n < N ? Gb[off] : 0.f;
-        rg[r].y = n + 1 < N ? Gb[off + 1] : 0.f;
-      }
+      ra[r].x = n < N ? Ab[off] : 0.f;
+      ra[r].y = n + GR_HALF < N ? Ab[off + GR_HALF] : 0.f;
+      rg[r].x = n < N ? Gb[off] : 0.f;
+      rg[r].y = n + GR_HALF < N ? Gb[off + GR_HALF] : 0.f;
     }
   };
   load_chunk(part);
@@ -76,31 +74,34 @@ __global__ __launch_bounds__(256) void gram64_kernel(const float* __restrict__ A
     const unsigned Ea = gr_exp(fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3])));
     const unsigned Eg = gr_exp(fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3])));
     const float sa = __uint_as_float((267u - Ea) << 23), sg = __uint_as_float((267u - Eg) << 23);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      unsigned char* d = gr_smem + (16 * wave + r) * GR_PITCH + lane * 4;   // columns 2 lane, 2 lane + 1
-      const float a0 = ra[r].x * sa, a1 = ra[r].y * sa, g0 = rg[r].x * sg, g1 = rg[r].y * sg;
-      const _Float16 ah0 = (_Float16)a0, ah1 = (_Float16)a1, gh0 = (_Float16)g0, gh1 = (_Float16)g1;
-      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<half2v*>(d) = half2v{ah0, ah1};
-      *reinterpret_cast<half2v*>(d + GR_IMG) = half2v{(_Float16)(a0 - (float)ah0), (_Float16)(a1 - (float)ah1)};
-      *reinterpret_cast<half2v*>(d + 2 * GR_IMG) = half2v{gh0, gh1};
-      *reinterpret_cast<half2v*>(d + 3 * GR_IMG) = half2v{(_Float16)(g0 - (float)gh0), (_Float16)(g1 - (float)gh1)};
-    }
-    if (c + parts < chunks) load_chunk(c + parts);   // in flight under the MFMAs
-    __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < GR_CHK / 16; ++s) {
-      const half8 ah = *reinterpret_cast<const half8*>(pa + s * 32);
-      const half8 al = *reinterpret_cast<const half8*>(pa + s * 32 + GR_IMG);
-      const half8 gh = *reinterpret_cast<const half8*>(pg + s * 32);
-      const half8 gl = *reinterpret_cast<const half8*>(pg + s * 32 + GR_IMG);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh, acc, 0, 0, 0);
+    for (int hf = 0; hf < 2; ++hf) {
+      if (hf) __syncthreads();   // the first half's images have been consumed
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        unsigned char* d = gr_smem + (16 * wave + r) * GR_PITCH + lane * 2;   // column `lane` of this half
+        const float a0 = (hf ? ra[r].y : ra[r].x) * sa, g0 = (hf ? rg[r].y : rg[r].x) * sg;
+        const _Float16 ah0 = (_Float16)a0, gh0 = (_Float16)g0;
+        *reinterpret_cast<_Float16*>(d) = ah0;
+        *reinterpret_cast<_Float16*>(d + GR_IMG) = (_Float16)(a0 - (float)ah0);
+        *reinterpret_cast<_Float16*>(d + 2 * GR_IMG) = gh0;
+        *reinterpret_cast<_Float16*>(d + 3 * GR_IMG) = (_Float16)(g0 - (float)gh0);
+      }
+      if (hf && c + parts < chunks) load_chunk(c + parts);   // in flight under the MFMAs (the registers are free now)
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < GR_HALF / 16; ++s) {
+        const half8 ah = *reinterpret_cast<const half8*>(pa + s * 32);
+        const half8 al = *reinterpret_cast<const half8*>(pa + s * 32 + GR_IMG);
+        const half8 gh = *reinterpret_cast<const half8*>(pg + s * 32);
+        const half8 gl = *reinterpret_cast<const half8*>(pg + s * 32 + GR_IMG);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh, acc, 0, 0, 0);
+      }
     }
     const float un = __uint_as_float((Ea - 13u) << 23) * __uint_as_float((Eg - 13u) << 23);
 #pragma unroll
