@@ -47,7 +47,8 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   list_t* s_list = reinterpret_cast<list_t*>(smem + region);            // [Co * TAPS]
   // (a hit's upstream gradient is read again from g in the walk -- an L2 hit beside the weight row it multiplies --
   //  instead of being carried in a second list: 12 KB of LDS less at three taps, one more workgroup per CU)
-  int* s_off = reinterpret_cast<int*>(smem + region) + (TAPS == 1 ? a.Co / 2 : a.Co * TAPS);   // [COLS + 1] column counts -> start offsets
+  // (PRE: no list in LDS -- the walk reads the forward's segment itself: 12 KB less at three taps, four workgroups per CU)
+  int* s_off = reinterpret_cast<int*>(smem + region) + (PRE ? 0 : (TAPS == 1 ? a.Co / 2 : a.Co * TAPS));   // [COLS + 1] column counts -> start offsets
   int* s_wcnt = s_off + COLS + 1;                                       // [BW2_WAVES + 1] hits found by each wave -> offsets
   int* s_sidecol = s_wcnt + BW2_WAVES + 1;                              // [BW2_WAVES]
   float* s_side = reinterpret_cast<float*>(s_sidecol + BW2_WAVES);      // [BW2_WAVES][128]
@@ -68,19 +69,22 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   const int* argb = a.arg + (size_t)b * a.Co;
   const unsigned long long lt = (1ull << lane) - 1ull;
   BC_STAMP(0);
+  constexpr int U = 8;            // list entries (weight rows) in flight per wave in the walk
+  const int* seg = nullptr;       // PRE: the tile's segment of the instance's sorted hits
+  int ev0 = 0;                    // PRE: the wave's first U entries, requested before the tile is cleared
   if constexpr (PRE) {
     // the tile's lists are one contiguous segment of the instance's sorted hits (wide_finalize_hits_kernel)
     const int* ho = a.hoff + (size_t)b * (a.N + 1);
     const int h0 = ho[m0], h1 = ho[min(m0 + COLS, a.N)], hv = ho[min(m0 + min(tid, COLS), a.N)];
+    seg = a.hits + (size_t)b * a.Co * TAPS + h0;
+    {
+      const int tot = h1 - h0, per = (tot + BW2_WAVES - 1) / BW2_WAVES;
+      const int lo = min(tot, wave * per), hi = min(tot, lo + per);
+      if (lo < hi) ev0 = seg[min(lo + (lane & (U - 1)), hi - 1)];
+    }
     for (int e = tid; e < COLS * BC_PT; e += BW2_THREADS) s_acc[e] = 0.f;   // (while the offsets are on their way)
     if (tid <= COLS) s_off[tid] = hv - h0;
-    const int total = h1 - h0;
-    const int* seg = a.hits + (size_t)b * a.Co * TAPS + h0;
-    if (total >= 0) BC_STAMP(1);
-    for (int i = tid; i < total; i += BW2_THREADS) {
-      const int e = seg[i];
-      s_list[i] = (list_t)((e & 0xffff) | (((e >> 16) - m0) << LSH));
-    }
+    BC_STAMP(1);
     __syncthreads();
     BC_STAMP(2);
   } else {
@@ -202,14 +206,26 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   {
     const int per = (total + BW2_WAVES - 1) / BW2_WAVES;
     const int lo = min(total, wave * per), hi = min(total, lo + per);
-    constexpr int U = 8;
     const int ldW = a.ldW ? a.ldW : WM_CI;   // (co * TAPS + tap) -th row of 128 input channels
     int cur = -1;
     float acc0 = 0.f, acc1 = 0.f;
+    // lane u holds entry h0 + u of the batch at h0 (PRE: as the forward wrote it, (co TAPS + tap) | column << 16, read from
+    // global one batch ahead; else the tile's own list in LDS, row | tile column << LSH); the entries travel through SGPRs
+    auto load_ev = [&](int h0) -> int {
+      const int i = min(h0 + (lane & (U - 1)), hi - 1);
+      if constexpr (PRE) return seg[i];
+      else return (int)s_list[i];
+    };
+    auto dec = [&](int e) -> int {
+      if constexpr (PRE) return (e & 0xffff) | (((e >> 16) - m0) << LSH);
+      else return e;
+    };
+    int evn = 0;
+    if (lo < hi) evn = PRE ? ev0 : load_ev(lo);
     // the column of hit lo started in an earlier share <=> lo is not the first entry of that column's list
     int side_col = -1;
     if (lo < hi) {
-      const int c0 = (int)s_list[lo] >> LSH;
+      const int c0 = dec(__builtin_amdgcn_readlane(evn, 0)) >> LSH;
       if (lo > s_off[c0]) side_col = c0;
     }
     bool in_side = side_col >= 0;
@@ -230,13 +246,14 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
       float2 w[U];
       float gg[U];
       int cc[U];
-      // lane u reads entry h0 + u; the entries then travel through SGPRs (v_readlane): the row address, the gradient's
-      // address and the column are scalar -- the walk was a quarter of the kernel's VALU instructions
-      const int ev = (int)s_list[min(h0 + (lane & (U - 1)), hi - 1)];
+      // (v_readlane: the row address, the gradient's address and the column are scalar -- the walk was a quarter of the
+      //  kernel's VALU instructions)
+      const int ev = evn;
+      if (h0 + U < hi) evn = load_ev(h0 + U);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const bool ok = h0 + u < hi;
-        const int e = __builtin_amdgcn_readlane(ev, u);
+        const int e = dec(__builtin_amdgcn_readlane(ev, u));
         const int er = e & ((1 << LSH) - 1);
         w[u] = *reinterpret_cast<const float2*>(a.W + (size_t)er * ldW + 2 * lane);
         gg[u] = ok ? gb[er / TAPS] : 0.f;
@@ -420,8 +437,8 @@ int launch_wide_bwd_conv(const WideBwdArgs& a, hipStream_t s) {
     return GEOA3_ENOSUPPORT;
   dim3 grid((a.N + 63) / 64, a.B);
   const size_t region = (size_t)64 * BC_PT > 2 * (size_t)a.Co * a.taps ? (size_t)64 * BC_PT : 2 * (size_t)a.Co * a.taps;
-  const size_t lds = (region + (a.taps == 1 ? (size_t)a.Co / 2 : (size_t)a.Co * a.taps) + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 16 + 3 + 4) * sizeof(float);
   const bool pre = a.hits && a.hoff;
+  const size_t lds = (region + (pre ? 0 : (a.taps == 1 ? (size_t)a.Co / 2 : (size_t)a.Co * a.taps)) + 65 + 2 * BW2_WAVES + 1 + BW2_WAVES * WM_CI + 16 + 3 + 4) * sizeof(float);
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(BW2_THREADS), lds, s, a);
