@@ -2,7 +2,19 @@
 // wide_max_bwd2_kernel (pointnet_wide.hip) writes out -- the [B,128,N] gradient, 131 MB at B = 250 -- is consumed by a
 // gated 128 -> 64 convolution that reads it back.  Here the 64-column tile stays in LDS (column-major), is gated, and
 // goes through W2^T on the matrix core; only the [B,64,N] result leaves (a third of the bytes of the two kernels, one
-// launch).  Phases (1)-(3) are those of wide_max_bwd2_kernel: same hit lists, same sums in the same order.
+// launch).  One workgroup per (instance, 64-point tile):
+//   lists   the (channel, tap) pairs whose arg-max column falls into the tile, by column, in (chunk of 64 channels, tap,
+//           channel) order inside a column.  PRE: one contiguous segment of the lists the FORWARD's finalize pass built
+//           per instance (wide_finalize_hits_kernel, pointnet_wide.hip), read in place; else built here, phases (1)-(2)
+//           of wide_max_bwd2_kernel (N > 4096, or the caller opted out: GEOA3_PN_NO_PRE_LISTS) -- same lists either way;
+//   walk    (3) the list cut into eight equal shares, one per wave; a column's sum in registers, list entries through
+//           SGPRs (scalar row / gradient addresses), eight weight rows in flight; shares that start inside a column go
+//           through side rows and are added in wave order;
+//   product (4) tile gated by relu bits, scaled by a power of two from its own maximum and split ONCE into fp16 hi / lo
+//           images written over it; W2^T's fragments arrive split from the host (WideBwdArgs::W2th); four waves take one
+//           32 x 32 quadrant each on the f16 matrix core; the result leaves gated (or, first-layer form, is contracted
+//           with w1 into dx in the same kernel).
+// Same sums in the same order as wide_max_bwd2_kernel + the 128 -> 64 convolution: bit-identical to the two-kernel path.
 // Reference: the autograd of Model/PointNet.py:80-82,146-147 (conv3 / conv5 + max, conv2 / conv4 + relu).
 #include "pointnet_kernels.h"
 #include <type_traits>
@@ -31,8 +43,9 @@ __device__ unsigned long long g_bc_stamps[3 * 8 * 16];
 #define BC_STAMP(i)
 #endif
 constexpr int BC_PT = WM_CI + 4;   // floats per column of the tile (column-major here: the B operand reads 8 consecutive ci)
-template <int TAPS, bool GF = false, bool PRE = false>   // PRE: the hit lists come from the forward (WideBwdArgs::hits); GF: the 64-channel activation is the 3-channel first layer (recomputed gate) and its
-                                       // backward finishes here: dx3 += w1^T (gated result), no [B,64,N] output
+// PRE: the hit lists come from the forward (WideBwdArgs::hits / hoff); GF: the 64-channel activation is the 3-channel first
+// layer (recomputed gate) and its backward finishes here: dx3 += w1^T (gated result), no [B,64,N] output
+template <int TAPS, bool GF = false, bool PRE = false>
 __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int COLS = 64;
@@ -52,13 +65,13 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
   int* s_wcnt = s_off + COLS + 1;                                       // [BW2_WAVES + 1] hits found by each wave -> offsets
   int* s_sidecol = s_wcnt + BW2_WAVES + 1;                              // [BW2_WAVES]
   float* s_side = reinterpret_cast<float*>(s_sidecol + BW2_WAVES);      // [BW2_WAVES][128]
-  float* s_mx = s_side + BW2_WAVES * WM_CI;                             // [8] tile maxima of the waves, [8] weight maxima
+  float* s_mx = s_side + BW2_WAVES * WM_CI;                             // [8] tile maxima of the waves
   const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y, m0 = blockIdx.x * COLS;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the walk's list entries, rows and columns stay in SGPRs)
   // requested now, used at the very end: the gate word of output row `lane`
   unsigned long long gw2 = 0ull;
   if (!GF && wave < 4) gw2 = a.Zmask2[((size_t)b * ((a.N + 63) >> 6) + blockIdx.x) * 64 + lane];
-  // ... and the gate word of tile row (tid & 127) of the 128-channel activation
+  // ... and the gate words of tile rows 2 lane, 2 lane + 1 of the 128-channel activation
   const int tiles = (a.N + 63) >> 6;
   const ulonglong2 mkw = reinterpret_cast<const ulonglong2*>(a.Zmask + ((size_t)b * tiles + blockIdx.x) * WM_CI)[lane];   // rows 2 lane, 2 lane + 1
   const int qt = wave & 1, qc = (wave >> 1) & 1;     // waves 0-3: output rows 32 qt .., columns 32 qc ..
