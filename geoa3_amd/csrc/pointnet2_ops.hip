@@ -255,28 +255,30 @@ __device__ __forceinline__ float gpg_row_sum(float v) {            // sum over t
   v += dpp_f32<0x140, 0xF>(v, 0.f);
   return v;
 }
-template <bool PRIV, int MODE = 0, int GPG_PF = 8>   // MODE != 0, GPG_PF: variants for tools/ub/gpg_ub.hip
+template <bool PRIV, int MODE = 0, int GPG_PF = 8, int CT = GPG_CT>   // MODE != 0, GPG_PF: variants for tools/ub/gpg_ub.hip;
+                                                                 // CT: channels per workgroup (4 or 8: the same sums, bit for bit --
+                                                                 // every value goes through the same reduction tree)
 __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* __restrict__ grad_out,
                                                                   const int32_t* __restrict__ idx,
                                                                   float* __restrict__ grad_points, int C, int N, int M,
                                                                   float* __restrict__ rowsum) {
-  extern __shared__ __attribute__((aligned(16))) float s_all[];   // [PRIV ? 4 : 1][GPG_CT][N]
-  const int b = blockIdx.y, c0 = blockIdx.x * GPG_CT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nc = min(GPG_CT, C - c0);
-  float* s_acc = s_all + (PRIV ? wave * GPG_CT * N : 0);
+  extern __shared__ __attribute__((aligned(16))) float s_all[];   // [PRIV ? 4 : 1][CT][N]
+  const int b = blockIdx.y, c0 = blockIdx.x * CT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nc = min(CT, C - c0);
+  float* s_acc = s_all + (PRIV ? wave * CT * N : 0);
   const float* G = grad_out + ((size_t)b * C + c0) * M * 64;
   const int32_t* I = idx + (size_t)b * M * 64;
-  float v[GPG_PF][GPG_CT];
+  float v[GPG_PF][CT];
   int iv[GPG_PF];
-  auto load_row = [&](int j, float (&d)[GPG_CT], int& i) {
+  auto load_row = [&](int j, float (&d)[CT], int& i) {
     const int jj = j < M ? j : M - 1;
     i = I[(size_t)jj * 64 + lane];
 #pragma unroll
-    for (int c = 0; c < GPG_CT; ++c) d[c] = c < nc ? G[((size_t)c * M + jj) * 64 + lane] : 0.f;
+    for (int c = 0; c < CT; ++c) d[c] = c < nc ? G[((size_t)c * M + jj) * 64 + lane] : 0.f;
   };
 #pragma unroll
   for (int p = 0; p < GPG_PF; ++p) load_row(wave + 4 * p, v[p], iv[p]);   // in flight while the accumulators are cleared
-  for (int e = tid; e < (PRIV ? 4 : 1) * GPG_CT * N; e += 256) s_all[e] = 0.f;
+  for (int e = tid; e < (PRIV ? 4 : 1) * CT * N; e += 256) s_all[e] = 0.f;
   __syncthreads();
   for (int j0 = wave; j0 < M; j0 += 4 * GPG_PF) {
 #pragma unroll
@@ -293,33 +295,33 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
         const bool dprev = __shfl_up((int)dup, 1, 64) != 0;
         const bool distinct = __all(lane == 0 || dup || (i > iprev && !dprev)) != 0;
         // r[0..7]: the row totals, r[8..15]: the sums over the padded entries -- reduced transposed
-        float r[2 * GPG_CT];
+        float r[2 * CT];
 #pragma unroll
-        for (int c = 0; c < GPG_CT; ++c) {
+        for (int c = 0; c < CT; ++c) {
           r[c] = v[p][c];
-          r[GPG_CT + c] = dup ? v[p][c] : 0.f;
+          r[CT + c] = dup ? v[p][c] : 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < GPG_CT; ++c) {      // lanes 0-31 keep value c, lanes 32-63 value 8 + c
-          gpg_swap32(r[c], r[GPG_CT + c]);
-          r[c] += r[GPG_CT + c];
+        for (int c = 0; c < CT; ++c) {      // lanes 0-31 keep value c, lanes 32-63 value 8 + c
+          gpg_swap32(r[c], r[CT + c]);
+          r[c] += r[CT + c];
         }
 #pragma unroll
-        for (int c = 0; c < GPG_CT / 2; ++c) {  // even rows keep value c, odd rows value 4 + c (of their half's eight)
-          gpg_swap16(r[c], r[GPG_CT / 2 + c]);
-          r[c] += r[GPG_CT / 2 + c];
+        for (int c = 0; c < CT / 2; ++c) {  // even rows keep value c, odd rows value 4 + c (of their half's eight)
+          gpg_swap16(r[c], r[CT / 2 + c]);
+          r[c] += r[CT / 2 + c];
         }
 #pragma unroll
-        for (int c = 0; c < GPG_CT / 2; ++c) r[c] = gpg_row_sum(r[c]);
+        for (int c = 0; c < CT / 2; ++c) r[c] = gpg_row_sum(r[c]);
         // row 0 (lane 0): totals 0-3, row 1 (lane 16): totals 4-7, row 2 (lane 32): padded sums 0-3, row 3 (lane 48): 4-7
-        float dsum[GPG_CT];
+        float dsum[CT];
 #pragma unroll
-        for (int c = 0; c < GPG_CT / 2; ++c) {
+        for (int c = 0; c < CT / 2; ++c) {
           dsum[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[c]), 32));
-          dsum[GPG_CT / 2 + c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[c]), 48));
+          dsum[CT / 2 + c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r[c]), 48));
         }
 #pragma unroll
-        for (int c = 0; c < GPG_CT; ++c) {
+        for (int c = 0; c < CT; ++c) {
           if (c >= nc) break;
           // (plain updates only on a wave's OWN copy: with one shared copy other waves' rows hit the same points)
           if (MODE == 1 || (MODE == 0 && PRIV && distinct)) {
@@ -332,9 +334,9 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
           }
         }
         if (rowsum && (lane == 0 || lane == 16)) {   // d shift of the pre-transformed first layer: the row totals
-          const int cb = lane ? GPG_CT / 2 : 0;
+          const int cb = lane ? CT / 2 : 0;
 #pragma unroll
-          for (int c = 0; c < GPG_CT / 2; ++c)
+          for (int c = 0; c < CT / 2; ++c)
             if (cb + c < nc) rowsum[((size_t)b * C + c0 + cb + c) * M + j] = r[c];
         }
       }
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
   }
   __syncthreads();
   float* dst = grad_points + ((size_t)b * C + c0) * N;
-  const int P = GPG_CT * N;
+  const int P = CT * N;
   for (int e = tid; e < nc * N; e += 256)
     dst[e] = PRIV ? ((s_all[e] + s_all[P + e]) + s_all[2 * P + e]) + s_all[3 * P + e] : s_all[e];
 }
@@ -452,10 +454,19 @@ static int group_points_grad_impl(const float* grad_out, const int32_t* idx, int
   const int MS = M * nsample;
   const size_t lds = (size_t)GPG_CT * N * sizeof(float);
   if (nsample == 64 && 4 * lds <= 128 * 1024) {          // per-wave accumulators: deterministic
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_points_grad64_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds));
-    hipLaunchKernelGGL(group_points_grad64_kernel<true>, dim3((C + GPG_CT - 1) / GPG_CT, B), dim3(256), 4 * lds,
-                       geoa3_stream(stream), grad_out, idx, grad_points, C, N, M, rowsum);
+#ifndef GEOA3_GPG_CT
+#define GEOA3_GPG_CT 4
+#endif
+    // four channels per workgroup: a wave's accumulators are 8 KB instead of 16 (N = 512), 16 waves per CU instead of 8 --
+    // the kernel streams 1.1 GB at configs[3] and is bound by the latency of those reads; the index rows are read twice as
+    // often (from L2).  Same bits as eight channels per workgroup (-DGEOA3_GPG_CT=8); configs[3] 5.26 -> 5.10 ms; two channels
+    // or sixteen rows in flight give nothing more.
+    constexpr int CT = GEOA3_GPG_CT;
+    auto kern = group_points_grad64_kernel<true, 0, 8, CT>;
+    const size_t l4 = (size_t)4 * CT * N * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+    hipLaunchKernelGGL(kern, dim3((C + CT - 1) / CT, B), dim3(256), l4, geoa3_stream(stream), grad_out, idx, grad_points, C,
+                       N, M, rowsum);
   } else if (nsample == 64 && lds <= 128 * 1024) {
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_points_grad64_kernel<false>),

@@ -22,4 +22,17 @@ for mode in ("f16x2", "f32"):
         (lg * w).sum().backward()
         h.update(lg.detach().cpu().numpy().tobytes())
         h.update(x.grad.cpu().numpy().tobytes())
-print(h.hexdigest())
+print("PointNet", h.hexdigest())
+from geoa3_amd.pointnet2 import PointNet2ClassificationSSG
+h = hashlib.sha256()
+torch.manual_seed(0)
+net = PointNet2ClassificationSSG(use_xyz=True, use_normal=False).to(dev).eval()
+for B, N in ((3, 1024), (2, 700), (16, 1024)):
+    ori, _ = synthetic_clouds(B, N, seed=B + N)
+    x = ori.to(dev).requires_grad_()
+    w = torch.randn(B, 40, generator=torch.Generator().manual_seed(1)).to(dev)
+    lg = net(x)
+    (lg * w).sum().backward()
+    h.update(lg.detach().cpu().numpy().tobytes())
+    h.update(x.grad.cpu().numpy().tobytes())
+print("PointNet++", h.hexdigest())

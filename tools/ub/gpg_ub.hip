@@ -7,7 +7,7 @@
 template <int MODE, int PF = 8>
 float run(const float* G, const int* I, float* out, float* rs, int B, int C, int N, int M, int iters) {
   const size_t lds = (size_t)4 * GPG_CT * N * sizeof(float);
-  auto k = group_points_grad64_kernel<true, MODE, PF>;
+  auto k = group_points_grad64_kernel<true, MODE, PF, GPG_CT>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
