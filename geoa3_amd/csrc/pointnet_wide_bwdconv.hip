@@ -252,9 +252,6 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
         *reinterpret_cast<float2*>(s_acc + cur * BC_PT + 2 * lane) = make_float2(acc0, acc1);
       }
     };
-#ifdef GEOA3_BC_SKIP_WALK
-    if (total == 12345)
-#endif
     for (int h0 = lo; h0 < hi; h0 += U) {
       float2 w[U];
       float gg[U];
@@ -356,9 +353,6 @@ __device__ __forceinline__ void wide_bwd_conv_body(const WideBwdArgs& a) {
       wq[c][0] = wf[(2 * c) * 64];
       wq[c][1] = wf[(2 * c + 1) * 64];
     }
-#ifdef GEOA3_BC_SKIP_MFMA
-    if (total == 12345)
-#endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       if (c + WQ - 1 < 8) {
