@@ -881,12 +881,14 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
       z0 = kg_cell(qz - r, g.loz, g.inv_h); z1 = kg_cell(qz + r, g.loz, g.inv_h);
     }
     const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    const float inv_ny = 1.f / (float)ny;     // row / ny below, exact for row < 256, ny <= 16 (no integer division: ~40 instructions)
     cnt = 0;
     for (int rb = 0; rb < nrows; rb += 64) {
       const int row = rb + lane;
       int s = 0, len = 0;
       if (row < nrows) {
-        const int zz = z0 + row / ny, yy = y0 + row - (row / ny) * ny;
+        const int rz = (int)(((float)row + 0.5f) * inv_ny);
+        const int zz = z0 + rz, yy = y0 + row - rz * ny;
         const int c0 = (zz * KG_G + yy) * KG_G;
         s = cs[c0 + x0];
         len = cs[c0 + x1 + 1] - s;
@@ -902,19 +904,38 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
       const int T = __builtin_amdgcn_readlane(incl, 63);
       P[lane] = incl - len;      // this wave's own slots: LDS operations of a wave execute in order
       Sr[lane] = s;
-      for (int t0 = 0; t0 < T; t0 += 64) {
-        const int c = t0 + lane;
-        float d = S_INF;
-        int oi = 0;
+#ifndef GEOA3_KG_U
+#define GEOA3_KG_U 3
+#endif
+      constexpr int KG_U = GEOA3_KG_U;   // batches of 64 candidates whose loads are in flight together (a query's ~150 candidates
+                                         // used to cost one dependent L2 round trip per 64)
+      for (int tb = 0; tb < T; tb += 64 * KG_U) {
+      float fx[KG_U], fy[KG_U], fz[KG_U];
+      int fo[KG_U];
+#pragma unroll
+      for (int u = 0; u < KG_U; ++u) {
+        const int c = tb + 64 * u + lane;
+        fx[u] = fy[u] = fz[u] = 0.f;
+        fo[u] = 0;
         if (c < T) {
           int r = 0;             // the last row whose range starts at or before candidate c
 #pragma unroll
           for (int st = 32; st > 0; st >>= 1)
             if (P[r + st] <= c) r += st;
           const int j = Sr[r] + (c - P[r]);
-          d = geoa3_sqdist(qx, qy, qz, Sb[j], Sb[N + j], Sb[2 * N + j]);
-          oi = Ib[j];
+          fx[u] = Sb[j];
+          fy[u] = Sb[N + j];
+          fz[u] = Sb[2 * N + j];
+          fo[u] = Ib[j];
         }
+      }
+#pragma unroll
+      for (int u = 0; u < KG_U; ++u) {
+        const int t0 = tb + 64 * u;
+        if (t0 >= T) break;      // wave-uniform
+        const int c = t0 + lane;
+        const float d = c < T ? geoa3_sqdist(qx, qy, qz, fx[u], fy[u], fz[u]) : S_INF;
+        const int oi = fo[u];
         const bool pass = c < T && d <= tau;
         const unsigned long long mask = __ballot(pass);
         if (pass) L[cnt + __popcll(mask & lt)] = kg_key(d, oi);
@@ -942,33 +963,44 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
           if (keep == K) tau = __uint_as_float((unsigned)(L[K - 1] >> 32));
         }
       }
+      }
     }
     if (cnt >= K || K > N || !(tau < S_INF)) break;
     tau = S_INF;
     }
-    // the K smallest of the list by (distance, index): every lane ranks its own entries
+    // the K smallest of the list by (distance, index): every lane ranks its own entries -- ONE per lane when the list holds
+    // at most 64 (the usual case: the K old neighbours + the few points that moved inside their radius), so the rank loop
+    // is a broadcast read, a compare and an add per entry instead of four compares (the kernel is bound by VALU issue:
+    // ~700 instructions per query, 250 of them here)
     {
-      unsigned long long mine[KG_CAP / 64];
-      int rk[KG_CAP / 64];
-#pragma unroll
-      for (int u = 0; u < KG_CAP / 64; ++u) {
-        const int c = lane + 64 * u;
-        mine[u] = c < cnt ? L[c] : ~0ull;
-        rk[u] = 0;
-      }
-      for (int j2 = 0; j2 < cnt; ++j2) {
-        const unsigned long long kj = L[j2];
-#pragma unroll
-        for (int u = 0; u < KG_CAP / 64; ++u) rk[u] += kj < mine[u] ? 1 : 0;
-      }
       float* od = dists + ((size_t)b * N + qo) * K;
       int32_t* oi = idx + ((size_t)b * N + qo) * K;
+      auto rank_emit = [&](auto ul) {
+        constexpr int UL = decltype(ul)::value;
+        unsigned long long mine[UL];
+        int rk[UL];
 #pragma unroll
-      for (int u = 0; u < KG_CAP / 64; ++u)
-        if (lane + 64 * u < cnt && rk[u] < K) {
-          od[rk[u]] = __uint_as_float((unsigned)(mine[u] >> 32));
-          oi[rk[u]] = (int32_t)(unsigned)(mine[u] & 0xffffffffull);
+        for (int u = 0; u < UL; ++u) {
+          const int c = lane + 64 * u;
+          mine[u] = c < cnt ? L[c] : ~0ull;
+          rk[u] = 0;
         }
+#pragma unroll 4
+        for (int j2 = 0; j2 < cnt; ++j2) {
+          const unsigned long long kj = L[j2];
+#pragma unroll
+          for (int u = 0; u < UL; ++u) rk[u] += kj < mine[u] ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u)
+          if (lane + 64 * u < cnt && rk[u] < K) {
+            od[rk[u]] = __uint_as_float((unsigned)(mine[u] >> 32));
+            oi[rk[u]] = (int32_t)(unsigned)(mine[u] & 0xffffffffull);
+          }
+      };
+      if (cnt <= 64) rank_emit(std::integral_constant<int, 1>{});
+      else if (cnt <= 128) rank_emit(std::integral_constant<int, 2>{});
+      else rank_emit(std::integral_constant<int, KG_CAP / 64>{});
       for (int m = cnt + lane; m < K; m += 64) {   // fewer than K candidates (K > N): the all-pairs kernel's padding
         od[m] = S_INF;
         oi[m] = -1;
