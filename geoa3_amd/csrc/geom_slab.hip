@@ -797,6 +797,17 @@ __device__ __forceinline__ unsigned long long kg_key(float d, int i) {   // d >=
   return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
 }
 
+// element idx of a UNIFORM array through a 32-bit byte offset (idx < 2^30): `global_load v, voffset, s[base]` -- no 64-bit
+// address arithmetic per lane
+template <class T>
+__device__ __forceinline__ T kg_ld(const T* base, unsigned idx) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(T));
+}
+template <class T>
+__device__ __forceinline__ void kg_st(T* base, unsigned idx, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(T)) = v;
+}
+
 __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__ R, int N, int K,
                                                        const int32_t* __restrict__ prior,
                                                        const float* __restrict__ sorted, const int32_t* __restrict__ sidx,
@@ -805,8 +816,11 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
   __shared__ unsigned long long s_key[4][KG_CAP];
   __shared__ int s_rowp[4][64], s_rows[4][64];   // per wave: exclusive prefix of the rows' lengths, their first positions
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (uniform row bases + UNSIGNED 32-bit indices everywhere below: scalar-base addressing, no 64-bit address arithmetic per
+  //  lane -- the kernel is bound by VALU issue)
   const float* Rb = R + (size_t)b * 3 * N;
   const float* Sb = sorted + (size_t)b * 3 * N;
+  const float *Sy = Sb + N, *Sz = Sb + 2 * (size_t)N, *Ry = Rb + N, *Rz = Rb + 2 * (size_t)N;
   const int32_t* Ib = sidx + (size_t)b * N;
   const int32_t* cs = cstart + (size_t)b * KG_PITCH;
   const GridGeo g = geo[b];
@@ -822,25 +836,27 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
   float vqx = 0.f, vqy = 0.f, vqz = 0.f;
   int vqo = 0;
   if (lane < KG_QPW && q0 + lane < N) {
-    vqx = Sb[q0 + lane];
-    vqy = Sb[N + q0 + lane];
-    vqz = Sb[2 * N + q0 + lane];
-    vqo = Ib[q0 + lane];
+    const unsigned ql = (unsigned)(q0 + lane);
+    vqx = kg_ld(Sb, ql);
+    vqy = kg_ld(Sy, ql);
+    vqz = kg_ld(Sz, ql);
+    vqo = kg_ld(Ib, ql);
   }
   const bool pipe = K <= 64;
   auto load_prior = [&](int qi) {     // neighbour `lane` of query qi (or -1)
     if (qi >= KG_QPW || q0 + qi >= N || lane >= K) return -1;
-    return (int)prior[((size_t)b * N + __builtin_amdgcn_readlane(vqo, qi)) * K + lane];
+    const int32_t* pr = prior + ((size_t)b * N + __builtin_amdgcn_readlane(vqo, qi)) * K;   // uniform
+    return (int)kg_ld(pr, (unsigned)lane);
   };
   int jn = pipe ? load_prior(0) : -1;           // indices whose coordinates are requested next
   float cx = 0.f, cy = 0.f, cz = 0.f;            // coordinates of the CURRENT query's neighbour
   bool cok = true;
   auto load_coords = [&](int j) {
     cok = lane >= K || (j >= 0 && j < N);
-    const int jj = j >= 0 && j < N ? j : 0;
-    cx = Rb[jj];
-    cy = Rb[N + jj];
-    cz = Rb[2 * N + jj];
+    const unsigned jj = j >= 0 && j < N ? (unsigned)j : 0u;
+    cx = kg_ld(Rb, jj);
+    cy = kg_ld(Ry, jj);
+    cz = kg_ld(Rz, jj);
   };
   if (pipe) {
     load_coords(jn);
@@ -890,8 +906,8 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
         const int rz = (int)(((float)row + 0.5f) * inv_ny);
         const int zz = z0 + rz, yy = y0 + row - rz * ny;
         const int c0 = (zz * KG_G + yy) * KG_G;
-        s = cs[c0 + x0];
-        len = cs[c0 + x1 + 1] - s;
+        s = kg_ld(cs, (unsigned)(c0 + x0));
+        len = kg_ld(cs, (unsigned)(c0 + x1 + 1)) - s;
       }
       // The rows' point ranges, concatenated, are walked 64 candidates at a time (lane = candidate): a lane per ROW left a
       // quarter of the lanes busy and made the loop as long as the longest row -- one L2 round trip per iteration.
@@ -922,11 +938,11 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
 #pragma unroll
           for (int st = 32; st > 0; st >>= 1)
             if (P[r + st] <= c) r += st;
-          const int j = Sr[r] + (c - P[r]);
-          fx[u] = Sb[j];
-          fy[u] = Sb[N + j];
-          fz[u] = Sb[2 * N + j];
-          fo[u] = Ib[j];
+          const unsigned j = (unsigned)(Sr[r] + (c - P[r]));
+          fx[u] = kg_ld(Sb, j);
+          fy[u] = kg_ld(Sy, j);
+          fz[u] = kg_ld(Sz, j);
+          fo[u] = kg_ld(Ib, j);
         }
       }
 #pragma unroll
@@ -994,8 +1010,8 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < UL; ++u)
           if (lane + 64 * u < cnt && rk[u] < K) {
-            od[rk[u]] = __uint_as_float((unsigned)(mine[u] >> 32));
-            oi[rk[u]] = (int32_t)(unsigned)(mine[u] & 0xffffffffull);
+            kg_st(od, (unsigned)rk[u], __uint_as_float((unsigned)(mine[u] >> 32)));
+            kg_st(oi, (unsigned)rk[u], (int32_t)(unsigned)(mine[u] & 0xffffffffull));
           }
       };
       if (cnt <= 64) rank_emit(std::integral_constant<int, 1>{});
