@@ -998,6 +998,7 @@ __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const f
       int q[U];
       float4 cv[U];
       float dkp[U];
+      float csx[U], csy[U], csz[U];   // the group sums of the U centres' pair terms (the same in every lane of a group)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = c0 + u * CPP + cl;
@@ -1033,11 +1034,27 @@ __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const f
         if (m == 0 && cvalid) {
           sum_e2 += e * e;
           if (A.kappa_adv) A.kappa_adv[bN + c] = kap;
-          if (want_grad) {
-            atomicAdd(&s_acc[c], gb_fix(-sx));
-            atomicAdd(&s_acc[N + c], gb_fix(-sy));
-            atomicAdd(&s_acc[2 * N + c], gb_fix(-sz));
+        }
+        csx[u] = sx;
+        csy[u] = sy;
+        csz[u] = sz;
+      }
+      // the centres' own terms: lane m < U of a group takes centre m of the U just done -- one conversion + atomic pass
+      // with U lanes per group instead of U passes with one (the kernel is bound by VALU issue; the sums are integers:
+      // who adds them does not matter)
+      if (want_grad && m < U) {
+        const int c = c0 + m * CPP + cl;
+        if (c < N) {
+          float sx = csx[0], sy = csy[0], sz = csz[0];
+#pragma unroll
+          for (int u = 1; u < U; ++u) {
+            sx = m == u ? csx[u] : sx;
+            sy = m == u ? csy[u] : sy;
+            sz = m == u ? csz[u] : sz;
           }
+          atomicAdd(&s_acc[c], gb_fix(-sx));
+          atomicAdd(&s_acc[N + c], gb_fix(-sy));
+          atomicAdd(&s_acc[2 * N + c], gb_fix(-sz));
         }
       }
     }
