@@ -4,48 +4,57 @@
 // PointNetPP_ssg.py:58-66 (npoint 512, radius 0.2, nsample 64, mlp [0(+3), 64, 64, 128]).
 //
 // The reference materialises [B,64,512,64] and [B,128,512,64] activations (2.1 + 2.1 + 4.2 GB at B = 250) and walks
-// them once per layer and once more per layer in backward.  Here ONE WAVEFRONT owns one centroid: lane = sample.
-//   layer 1 (K = 3) on the VALU, lane-local; layers 2 and 3 on the f16 matrix core with SPLIT fp32 operands (the
-//   arithmetic of pointnet_wide_split.hip: v = hi + lo, a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulation;
-//   per-wave power-of-two activation scales, weights scaled and split into fp16 LDS images when they are staged):
-//   * layer 2: a chunk of 16 layer-1 channels is one k-step; v_permlane32_swap of rows (j, 8 + j) yields the B operands
-//     of both 32-sample column blocks (as in pointnet_conv_split.hip);
+// them once per layer and once more per layer in backward.  Here ONE WAVEFRONT owns one centroid and takes its two
+// 32-sample column blocks one after the other; EVERY layer runs on the f16 matrix core with SPLIT fp32 operands (the
+// arithmetic of pointnet_wide_split.hip: v = hi + lo, a*w = a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulation;
+// per-block power-of-two activation scales, weights scaled and split into fp16 LDS images when they are staged):
+//   * layer 1 (K = 3 + bias) is ONE k-step: the hi / lo pieces of the point and of the weights share the K dimension
+//     (round 5; on the VALU it and its relu masks were 700 of the backward's 3300 vector instructions per centroid);
+//   * its accumulator registers 8s..8s+7 ARE the B operand of a k-step of layer 2 -- channels in the accumulator's row
+//     order, which the W2 image in LDS follows (position ks*16 + 8h + j <-> channel 32(ks>>1) + 16(ks&1) + 4h + (j&3) +
+//     8(j>>2)); the bias of layer 2 enters as the accumulators' initial value, so the relu gate is their sign;
 //   * layer 3 TRANSPOSED (activations as A: rows = samples; weights as B: columns = channels), so a lane ends with ONE
-//     channel and 32 of its samples: the max over samples is lane-local + one exchange.  The layer-2 accumulator
-//     registers 8s..8s+7 of a lane ARE its A fragment of a k-step -- channels in the accumulator's row order, which
-//     the weight image in LDS follows (position ks*16 + 8h + j <-> channel 32(ks>>1) + 16(ks&1) + 4h + (j&3) + 8(j>>2));
-//   no activation ever leaves the registers.
-// Backward recomputes the two hidden layers (cheaper than reading 6 GB), routes the pooled gradient through a one-hot
-// B operand against a W3^T image, chains the accumulator registers again as B operands against a W2^T image (same
-// row-order trick), and finishes with the K = 3 contraction and the scatter to the points.
-// The fp32-MFMA form of this file ran 1.67 ms forward / 2.61 ms backward at B = 250 (MFMA floors 1.4 / 1.9 ms).
+//     channel and 16 of the block's samples: the max over samples is lane-local + one exchange;
+//   no activation ever leaves the registers, an operand split is two v_fma_mix per element.
+// Backward recomputes the two hidden layers (cheaper than reading 6 GB; the gates are the signs of the recomputed
+// accumulators: no masks), routes the pooled gradient through a one-hot B operand against a W3^T image, chains the
+// accumulator registers again as B operands against a W2^T image, and finishes with the K = 3 contraction and the
+// scatter to the points.
+// History: fp32 MFMA 1.67 / 2.61 ms (forward / backward, B = 250); split fp16 with layer 1 on the VALU 0.68 / 1.13 ms.
 #include "pointnet_kernels.h"
 #include "profile.h"
 
 namespace {
 
-constexpr int SA_TF = 256;         // forward: 4 wavefronts per workgroup (6 waves / 3 per SIMD measured slower)
-constexpr int SA_TB = 256;         // backward: 4 wavefronts (256 VGPRs: 2 waves/SIMD)
+// One 8-wave workgroup per CU = two waves per SIMD, forward and backward.  Measured (tools/bench_sa1.py, B = 250): three
+// and four waves per SIMD (12-wave workgroups at 168 VGPRs, two 8-wave workgroups at 128) are SLOWER (backward 0.81 ->
+// 0.93 ms, forward 0.65 -> 0.75 ms), one wave per SIMD much slower (1.10 / 0.71 ms); s_setprio around the matrix phases
+// and sched_barrier-pinned LDS prefetch do not help either.
+constexpr int SA_WF = 8;
+constexpr int SA_WB = 8;
 constexpr int SA_S = 64;           // samples per centroid
 constexpr int SA_PH = 64 * 2 + 16;    // bytes per row of a 64-k fp16 image (conflict-free 16-byte reads)
 constexpr int SA_PH2 = 128 * 2 + 16;  // bytes per row of the 128-k image (W3^T)
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
 struct Sa1Lds {
-  float* w1;            // [64][4]  (w0, w1, w2, shift)
+  float* w1;            // backward: [64][3] fp32 rows for the K = 3 contraction
   float* b2;            // [64]
-  float* b3;            // [128]
-  float* scal;          // [2] 1 / scale of the w2 and w3 images; [2..9] reduction scratch
-  unsigned char* w2h;   // [64 out][64 k] hi, lo at + 64 * SA_PH       (A operand of layer 2)
+  float* b3;            // forward: [128]
+  float* red;           // [48] reduction scratch of the staging pass
+  int* kw;              // [3]: log2 of the power-of-two scales of the W1 / W2 / W3 images
+  unsigned char* w1a;   // [64 out][16 k] layer 1 as ONE k-step: (wh.xyz, bh | wh.xyz, bl | wl.xyz, 0 | wl.xyz, 0)
+  unsigned char* w2h;   // [64 out][64 positions] hi, lo at + 64 * SA_PH          (A operand of layer 2)
   unsigned char* w3h;   // forward: [128 out][64 positions] hi, lo at + 128 * SA_PH   (B operand of layer 3)
                         // backward: W3^T [64 i][128 ch] hi, lo at + 64 * SA_PH2      (A operand of d h2)
   unsigned char* w2t;   // backward: W2^T [64 i][64 positions] hi, lo at + 64 * SA_PH (A operand of d h1)
-  float* scratch;       // [waves][256]
+  unsigned* pa;         // backward: [waves][384] one-hot records of the wave's centroid (below)
 };
-constexpr int sa1_lds_bytes(int threads, bool bwd) {
-  return (64 * 4 + 64 + 128 + 16) * 4 + 2 * 64 * SA_PH + (bwd ? 2 * 64 * SA_PH2 + 2 * 64 * SA_PH : 2 * 128 * SA_PH) +
-         (threads / 64) * 256 * 4;
+constexpr int sa1_lds_bytes(int waves, bool bwd) {
+  return (64 * 4 + 64 + 128 + 48 + 16) * 4 + 64 * 32 + 2 * 64 * SA_PH +
+         (bwd ? 2 * 64 * SA_PH2 + 2 * 64 * SA_PH + waves * 1536 : 2 * 128 * SA_PH);
 }
 
 __device__ __forceinline__ Sa1Lds sa1_carve(float* sm, bool bwd) {
@@ -53,11 +62,13 @@ __device__ __forceinline__ Sa1Lds sa1_carve(float* sm, bool bwd) {
   L.w1 = sm;
   L.b2 = L.w1 + 64 * 4;
   L.b3 = L.b2 + 64;
-  L.scal = L.b3 + 128;
-  L.w2h = reinterpret_cast<unsigned char*>(L.scal + 16);
+  L.red = L.b3 + 128;
+  L.kw = reinterpret_cast<int*>(L.red + 48);
+  L.w1a = reinterpret_cast<unsigned char*>(L.kw + 16);
+  L.w2h = L.w1a + 64 * 32;
   L.w3h = L.w2h + 2 * 64 * SA_PH;
   L.w2t = L.w3h + (bwd ? 2 * 64 * SA_PH2 : 2 * 128 * SA_PH);
-  L.scratch = reinterpret_cast<float*>(bwd ? L.w2t + 2 * 64 * SA_PH : L.w2t);
+  L.pa = reinterpret_cast<unsigned*>(L.w2t + 2 * 64 * SA_PH);
   return L;
 }
 
@@ -66,53 +77,80 @@ __device__ __forceinline__ int sa_perm(int p) {
   const int ks = p >> 4, h = (p >> 3) & 1, j = p & 7;
   return 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h + (j & 3) + 8 * (j >> 2);
 }
-__device__ __forceinline__ unsigned sa_exp(float m) {
-  const unsigned E = (__float_as_uint(m) >> 23) & 0xffu;
-  return E < 14u ? 14u : (E > 254u ? 254u : E);
+// Every scale of this file is a power of two 2^k carried as its integer k (wave-uniform: SALU arithmetic):
+// sa_k(m) puts a maximum m into [2^13, 2^14); lo / hi clamp the biased exponent (tiny maxima keep a finite scale).
+__device__ __forceinline__ int sa_k(float m, int lo = 110, int hi = 254) {
+  int E = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  E = E < lo ? lo : (E > hi ? hi : E);
+  return 140 - E;
 }
-__device__ __forceinline__ float sa_scale(unsigned E) { return __uint_as_float((267u - E) << 23); }     // max -> [2^13, 2^14)
-__device__ __forceinline__ float sa_unscale(unsigned E) { return __uint_as_float((E - 13u) << 23); }
+__device__ __forceinline__ float sa_pow2(int k) {
+  k = k < -126 ? -126 : (k > 127 ? 127 : k);
+  return __uint_as_float((unsigned)(k + 127) << 23);
+}
 __device__ __forceinline__ void sa_put(unsigned char* img, int lo_off, int off, float v) {
   const _Float16 h = (_Float16)v;
   *reinterpret_cast<_Float16*>(img + off) = h;
   *reinterpret_cast<_Float16*>(img + lo_off + off) = (_Float16)(v - (float)h);
 }
+__device__ __forceinline__ float sa_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_huge_valf()); }
 
 template <int SA_T, bool BWD>
 __device__ __forceinline__ void sa1_stage(const geoa3_sa1_weights& w, const Sa1Lds& L) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < 64; e += SA_T) {
-    L.w1[4 * e + 0] = w.w1[3 * e + 0];
-    L.w1[4 * e + 1] = w.w1[3 * e + 1];
-    L.w1[4 * e + 2] = w.w1[3 * e + 2];
-    L.w1[4 * e + 3] = w.b1[e];
-    L.b2[e] = w.b2[e];
-  }
-  for (int e = tid; e < 128; e += SA_T) L.b3[e] = w.b3[e];
-  float m2 = 0.f, m3 = 0.f;
+  float m1 = 0.f, m2 = 0.f, m3 = 0.f;
+  for (int e = tid; e < 64 * 3; e += SA_T) m1 = fmaxf(m1, __builtin_fabsf(w.w1[e]));
+  for (int e = tid; e < 64; e += SA_T) m1 = fmaxf(m1, __builtin_fabsf(w.b1[e]));
   for (int e = tid; e < 64 * 64; e += SA_T) m2 = fmaxf(m2, __builtin_fabsf(w.w2[e]));
   for (int e = tid; e < 128 * 64; e += SA_T) m3 = fmaxf(m3, __builtin_fabsf(w.w3[e]));
+  m1 = wave_max(m1);
   m2 = wave_max(m2);
   m3 = wave_max(m3);
   if (lane == 0) {
-    L.scal[2 + wave] = m2;
-    L.scal[6 + wave] = m3;
+    L.red[wave] = m1;
+    L.red[16 + wave] = m2;
+    L.red[32 + wave] = m3;
   }
   __syncthreads();
-  float t2 = 0.f, t3 = 0.f;
+  float t1 = 0.f, t2 = 0.f, t3 = 0.f;
   for (int i = 0; i < SA_T / 64; ++i) {
-    t2 = fmaxf(t2, L.scal[2 + i]);
-    t3 = fmaxf(t3, L.scal[6 + i]);
+    t1 = fmaxf(t1, L.red[i]);
+    t2 = fmaxf(t2, L.red[16 + i]);
+    t3 = fmaxf(t3, L.red[32 + i]);
   }
-  const unsigned E2 = sa_exp(t2), E3 = sa_exp(t3);
-  const float s2 = sa_scale(E2), s3 = sa_scale(E3);
+  const int k1 = sa_k(t1), k2 = sa_k(t2), k3 = sa_k(t3);
+  const float s1 = sa_pow2(k1), s2 = sa_pow2(k2), s3 = sa_pow2(k3);
   if (tid == 0) {
-    L.scal[0] = sa_unscale(E2);
-    L.scal[1] = sa_unscale(E3);
+    L.kw[0] = k1;
+    L.kw[1] = k2;
+    L.kw[2] = k3;
   }
-  for (int e = tid; e < 64 * 64; e += SA_T) {   // W2 [out][k]: A operand of layer 2
-    const int o = e >> 6, k = e & 63;
-    sa_put(L.w2h, 64 * SA_PH, o * SA_PH + k * 2, w.w2[e] * s2);
+  for (int e = tid; e < 64; e += SA_T) {
+    // layer 1 as one k-step of the matrix core (K = 16): against the operand (ph.xyz, one | pl.xyz, one) of the lanes of k
+    // half 0 and (ph.xyz, 0 | pl.xyz, 0) of k half 1 -- wh.ph + bh.one + wh.pl + bl.one + wl.ph + wl.pl, fp32 accumulation
+    _Float16 hh[4], ll[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float v = (d < 3 ? w.w1[3 * e + d] : w.b1[e]) * s1;
+      hh[d] = (_Float16)v;
+      ll[d] = (_Float16)(v - (float)hh[d]);
+    }
+    const half8 r0 = {hh[0], hh[1], hh[2], hh[3], hh[0], hh[1], hh[2], ll[3]};
+    const half8 r1 = {ll[0], ll[1], ll[2], (_Float16)0.f, ll[0], ll[1], ll[2], (_Float16)0.f};
+    *reinterpret_cast<half8*>(L.w1a + e * 32) = r0;
+    *reinterpret_cast<half8*>(L.w1a + e * 32 + 16) = r1;
+    L.b2[e] = w.b2[e];
+    if (BWD) {
+      L.w1[3 * e + 0] = w.w1[3 * e + 0];
+      L.w1[3 * e + 1] = w.w1[3 * e + 1];
+      L.w1[3 * e + 2] = w.w1[3 * e + 2];
+    }
+  }
+  if (!BWD)
+    for (int e = tid; e < 128; e += SA_T) L.b3[e] = w.b3[e];
+  for (int e = tid; e < 64 * 64; e += SA_T) {   // W2 [out][position]: A operand of layer 2; the positions follow the
+    const int o = e >> 6, p = e & 63;           // row order of the layer-1 accumulators, which ARE its B operand
+    sa_put(L.w2h, 64 * SA_PH, o * SA_PH + p * 2, w.w2[o * 64 + sa_perm(p)] * s2);
   }
   if (!BWD) {
     for (int e = tid; e < 128 * 64; e += SA_T) {   // W3 [out][position]: B operand of the transposed layer 3
@@ -132,170 +170,209 @@ __device__ __forceinline__ void sa1_stage(const geoa3_sa1_weights& w, const Sa1L
   __syncthreads();
 }
 
-__device__ __forceinline__ void sa_swap32(float& a, float& b) {   // a[32..63] <-> b[0..31]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]);
-  b = __uint_as_float(r[1]);
+// (hi, lo) fp16 images of x0 * s and x1 * s, packed: two v_fma_mix per element (the scale, the conversion and the packing
+// in one instruction; the residual x * s - hi is one exact fma).  The inputs are results of VALU instructions the compiler
+// sees (never matrix-core results: the hazard recogniser does not look into inline assembly).
+__device__ __forceinline__ void sa_split2(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+#ifdef GEOA3_SA1_PLAIN_SPLIT
+  const float v0 = x0 * s, v1 = x1 * s;
+  const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+  const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+  hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | (unsigned)__builtin_bit_cast(unsigned short, h1) << 16;
+  lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | (unsigned)__builtin_bit_cast(unsigned short, l1) << 16;
+#else
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "s"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "s"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "s"(s), "v"(hi));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "s"(s), "v"(hi));
+#endif
+}
+// two accumulator tiles (rows 32 t + mfma_row(r, lane)) -> the operands of the four k-steps that consume them: registers
+// 8 s .. 8 s + 7 of tile t are k-step 2 t + s in the accumulator's row order (the weight images follow it: sa_perm)
+__device__ __forceinline__ void sa_split_tiles(const f32x16 (&v)[2], float s, half8 (&oh)[4], half8 (&ol)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4v H, Lw;
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+      unsigned a, b;
+      sa_split2(v[ks >> 1][8 * (ks & 1) + 2 * j2], v[ks >> 1][8 * (ks & 1) + 2 * j2 + 1], s, a, b);
+      H[j2] = a;
+      Lw[j2] = b;
+    }
+    oh[ks] = __builtin_bit_cast(half8, H);
+    ol[ks] = __builtin_bit_cast(half8, Lw);
+  }
 }
 
-// Layers 1 and 2 for the wave's 64 samples (lane = sample, p = xyz[sample] - centroid).
-// h2[cb][t][r]: relu'd layer-2 output, MFMA D layout: channel t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), sample cb*32 + (lane&31).
-// m1lo / m1hi: bit k set = layer-1 channel k of THIS LANE'S sample is active (z > 0).
-// TWICE (the backward kernel): layer 1 is evaluated a first time for the relu masks and the wave's maximum (the power-of-
-// two scale of the fp16 split needs it before any operand is formed), then sixteen channels at a time right in front of
-// the k-step that consumes them -- 48 live registers less than holding all of h1, for 192 more FMAs against ~3500 vector
-// instructions per centroid (the backward spilled at its 256-register budget).  Same values, same scale, same bits.
-template <bool TWICE = false>
-__device__ __forceinline__ void sa1_hidden(const Sa1Lds& L, float px, float py, float pz, int lane, f32x16 (&h2)[2][2],
-                                           unsigned& m1lo, unsigned& m1hi) {
-  float h1[TWICE ? 16 : 64];
-  m1lo = 0u;
-  m1hi = 0u;
+#define SA_ZERO16 f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
+
+// the B operand of layer 1 for one column block: p * 2^kp split, `one` = 2^kp in the lanes of k half 0 (bias), 0 in k half 1
+__device__ __forceinline__ half8 sa1_bop(float px, float py, float pz, float sp, _Float16 one) {
+  const float x = px * sp, y = py * sp, z = pz * sp;
+  const _Float16 hx = (_Float16)x, hy = (_Float16)y, hz = (_Float16)z;
+  const half8 b = {hx, hy, hz, one, (_Float16)(x - (float)hx), (_Float16)(y - (float)hy), (_Float16)(z - (float)hz), one};
+  return b;
+}
+// layer 1 of one column block on the matrix core: z[t][r] = 2^(k1 + kp) (w1 p + b1), channel 32 t + mfma_row(r, lane),
+// sample = lane & 31 of the block
+__device__ __forceinline__ void sa1_layer1(const Sa1Lds& L, half8 bop, int lane, f32x16 (&z)[2]) {
+  const unsigned char* ar = L.w1a + (lane & 31) * 32 + (lane >> 5) * 16;
+  const half8 a0 = *reinterpret_cast<const half8*>(ar), a1 = *reinterpret_cast<const half8*>(ar + 32 * 32);
+  z[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bop, SA_ZERO16, 0, 0, 0);
+  z[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bop, SA_ZERO16, 0, 0, 0);
+}
+// relu in place, k of the block's maximum
+__device__ __forceinline__ int sa_relu_k(f32x16 (&z)[2]) {
   float m = 0.f;
-#pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    const float4 w = *reinterpret_cast<const float4*>(L.w1 + 4 * k);
-    const float z = w.x * px + w.y * py + w.z * pz + w.w;
-    if (!TWICE) h1[k] = fmaxf(z, 0.f);
-    m = fmaxf(m, z);
-    if (k < 32) m1lo |= (z > 0.f ? 1u : 0u) << k;
-    else m1hi |= (z > 0.f ? 1u : 0u) << (k - 32);
-    if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-  }
-  m = fmaxf(m, 0.f);                                          // max of relu(z)
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) h2[c][t][r] = 0.f;
-  const unsigned E = sa_exp(wave_max(m));
-  const float sx = sa_scale(E);
-  const unsigned char* wr = L.w2h + (lane & 31) * SA_PH + (lane >> 5) * 16;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {                                // 16 layer-1 channels = one k-step
-    if (TWICE) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const float4 w = *reinterpret_cast<const float4*>(L.w1 + 4 * (16 * c + k));
-        h1[k] = fmaxf(w.x * px + w.y * py + w.z * pz + w.w, 0.f);
-      }
-    }
-    half8 xh[2], xl[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v0 = h1[(TWICE ? 0 : 16 * c) + j] * sx, v1 = h1[(TWICE ? 0 : 16 * c) + 8 + j] * sx;
-      sa_swap32(v0, v1);                                       // v0: samples 0..31, v1: 32..63; lanes (sample, k half)
-      const _Float16 a0 = (_Float16)v0, a1 = (_Float16)v1;
-      xh[0][j] = a0;
-      xl[0][j] = (_Float16)(v0 - (float)a0);
-      xh[1][j] = a1;
-      xl[1][j] = (_Float16)(v1 - (float)a1);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + c * 32);
-      const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + c * 32 + 64 * SA_PH);
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        h2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[cb], h2[cb][t], 0, 0, 0);
-        h2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[cb], h2[cb][t], 0, 0, 0);
-        h2[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[cb], h2[cb][t], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const float un = sa_unscale(E) * L.scal[0];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float bias = L.b2[t * 32 + mfma_row(r, lane)];
-      h2[0][t][r] = fmaxf(h2[0][t][r] * un + bias, 0.f);
-      h2[1][t][r] = fmaxf(h2[1][t][r] * un + bias, 0.f);
+      z[t][r] = sa_relu(z[t][r]);
+      m = fmaxf(m, z[t][r]);
     }
+  return sa_k(wave_max(m));
+}
+// layer 2 of one column block: acc[t][r] = 2^kacc (W2 h1 + b2), rows 32 t + mfma_row(r, lane); the bias enters as the
+// accumulators' initial value (b2 * 2^kacc: exact), so the relu gate of the backward is the accumulator's sign
+__device__ __forceinline__ void sa1_layer2(const Sa1Lds& L, const half8 (&xh)[4], const half8 (&xl)[4], float bscale, int lane,
+                                           f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *reinterpret_cast<const float4*>(L.b2 + 32 * t + 8 * g + 4 * (lane >> 5));
+      acc[t][4 * g + 0] = b.x * bscale;
+      acc[t][4 * g + 1] = b.y * bscale;
+      acc[t][4 * g + 2] = b.z * bscale;
+      acc[t][4 * g + 3] = b.w * bscale;
+    }
+  const unsigned char* wr = L.w2h + (lane & 31) * SA_PH + (lane >> 5) * 16;
+  half8 fr[2][4];
+  auto fetch = [&](int ks, half8 (&f)[4]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f[2 * t] = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32);
+      f[2 * t + 1] = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32 + 64 * SA_PH);
+    }
+  };
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    fetch(ks, fr[ks & 1]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const half8 wh = fr[ks & 1][2 * t], wl = fr[ks & 1][2 * t + 1];
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acc[t], 0, 0, 0);
+    }
+  }
 }
 
-__global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) void sa1_fwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
-                                                       const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
-                                                       int M, float* __restrict__ out, uint8_t* __restrict__ arg) {
+// a centroid's gather for the lane (n, h) = (lane & 31, lane >> 5): the points of samples n and 32 + n relative to the
+// centroid (both halves of the wave hold both column blocks' operands), requested one centroid ahead
+struct Sa1Pts {
+  int ia, ib;
+  float ax, ay, az, bx, by, bz;
+};
+__device__ __forceinline__ void sa1_load(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                         const int32_t* __restrict__ idx, int c, int M, int N, int lane, Sa1Pts& P) {
+  const int b = c / M;   // (wave-uniform: scalar arithmetic)
+  P.ia = idx[(size_t)c * SA_S + (lane & 31)];
+  P.ib = idx[(size_t)c * SA_S + 32 + (lane & 31)];
+  const float* qa = xyz + ((size_t)b * N + P.ia) * 3;
+  const float* qb = xyz + ((size_t)b * N + P.ib) * 3;
+  const float* ctr = new_xyz + (size_t)c * 3;
+  const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+  P.ax = qa[0] - cx;
+  P.ay = qa[1] - cy;
+  P.az = qa[2] - cz;
+  P.bx = qb[0] - cx;
+  P.by = qb[1] - cy;
+  P.bz = qb[2] - cz;
+}
+__device__ __forceinline__ int sa1_kp(const Sa1Pts& P) {   // 2^kp |p| < 2^14 for both blocks; 2^kp itself an fp16 normal
+  const float m = fmaxf(fmaxf(fmaxf(__builtin_fabsf(P.ax), __builtin_fabsf(P.ay)), fmaxf(__builtin_fabsf(P.az), __builtin_fabsf(P.bx))),
+                        fmaxf(__builtin_fabsf(P.by), __builtin_fabsf(P.bz)));
+  return sa_k(wave_max(m), 126, 154);
+}
+
+template <int SA_T>
+__global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                      const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
+                                                      int M, float* __restrict__ out, uint8_t* __restrict__ arg) {
   extern __shared__ __attribute__((aligned(16))) float sa_sm[];
   const Sa1Lds L = sa1_carve(sa_sm, false);
-  sa1_stage<SA_TF, false>(w, L);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long total = (long)B * M;
-  for (long c = (long)blockIdx.x * (SA_TF / 64) + wave; c < total; c += (long)gridDim.x * (SA_TF / 64)) {
+  sa1_stage<SA_T, false>(w, L);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, l31 = lane & 31;
+  const int k1 = __builtin_amdgcn_readfirstlane(L.kw[0]), k2 = __builtin_amdgcn_readfirstlane(L.kw[1]),
+            k3 = __builtin_amdgcn_readfirstlane(L.kw[2]);
+  const int total = B * M, stride = (int)gridDim.x * (SA_T / 64);   // B * M < 2^31 / 128 (checked by the launcher)
+  int c = (int)blockIdx.x * (SA_T / 64) + wave;
+  Sa1Pts P;
+  if (c < total) sa1_load(xyz, new_xyz, idx, c, M, N, lane, P);
+  for (; c < total; c += stride) {
     asm volatile("" ::: "memory");   // the weights stay in LDS: no hoisting of their loads out of the centroid loop
-    const int b = (int)(c / M);
-    const int i = idx[c * SA_S + lane];
-    const float* q = xyz + ((size_t)b * N + i) * 3;
-    const float* ctr = new_xyz + (size_t)c * 3;
-    const float px = q[0] - ctr[0], py = q[1] - ctr[1], pz = q[2] - ctr[2];
-    f32x16 h2[2][2];
-    unsigned m1lo, m1hi;
-    sa1_hidden(L, px, py, pz, lane, h2, m1lo, m1hi);
-    // layer-2 activations -> the A fragments of the transposed layer 3: registers 8s..8s+7 of tile t are k-step
-    // ks = 2t + s (channels in the accumulator's row order, which the W3 image follows); one scale for the wave
-    half8 ah[2][4], al[2][4];
-    float un3;
-    {
-      float m = 0.f;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, h2[cb][t][r]);     // h2 >= 0
-      const unsigned E = sa_exp(wave_max(m));
-      const float sx = sa_scale(E);
-      un3 = sa_unscale(E) * L.scal[1];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float v = h2[cb][ks >> 1][8 * (ks & 1) + j] * sx;
-            const _Float16 a = (_Float16)v;
-            ah[cb][ks][j] = a;
-            al[cb][ks][j] = (_Float16)(v - (float)a);
-          }
-    }
+    const Sa1Pts Q = P;
+    if (c + stride < total) sa1_load(xyz, new_xyz, idx, c + stride, M, N, lane, P);
+    const int kp = sa1_kp(Q);
+    const float sp = sa_pow2(kp);
+    const _Float16 one = h ? (_Float16)0.f : (_Float16)sp;
+    float bv[4];   // best (value, sample) of channel 32 t3 + l31 over this lane's samples
+    int bs[4];
 #pragma unroll 1
+    for (int cb = 0; cb < 2; ++cb) {
+      asm volatile("" ::: "memory");   // (the weight fragments are re-read per block: no hoisting out of this loop)
+      f32x16 z[2];
+      sa1_layer1(L, cb ? sa1_bop(Q.bx, Q.by, Q.bz, sp, one) : sa1_bop(Q.ax, Q.ay, Q.az, sp, one), lane, z);
+      half8 xh[4], xl[4];
+      const int kx = sa_relu_k(z);
+      sa_split_tiles(z, sa_pow2(kx), xh, xl);
+      const int ka = k1 + kp + kx + k2;
+      sa1_layer2(L, xh, xl, sa_pow2(ka), lane, z);
+      // layer-2 activations -> the A fragments of the transposed layer 3 (rows = samples, the weights as B: columns =
+      // channels): a lane ends with ONE channel and 16 of the block's samples, the max over samples is lane-local
+      const int kx2 = sa_relu_k(z);
+      sa_split_tiles(z, sa_pow2(kx2), xh, xl);
+      const float un3 = sa_pow2(-(ka + kx2 + k3));
+      const unsigned char* wr = L.w3h + l31 * SA_PH + h * 16;
+      half8 fr[2][2];
+      auto fetch = [&](int st, half8 (&f)[2]) {
+        f[0] = *reinterpret_cast<const half8*>(wr + (st >> 2) * 32 * SA_PH + (st & 3) * 32);
+        f[1] = *reinterpret_cast<const half8*>(wr + (st >> 2) * 32 * SA_PH + (st & 3) * 32 + 128 * SA_PH);
+      };
+#pragma unroll
+      for (int t3 = 0; t3 < 4; ++t3) {
+        f32x16 a3;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int st = 4 * t3 + ks;
+          fetch(st, fr[st & 1]);
+          const half8 bh = fr[st & 1][0], bl = fr[st & 1][1];
+          a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], bh, ks == 0 ? SA_ZERO16 : a3, 0, 0, 0);
+          a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], bl, a3, 0, 0, 0);
+          a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[ks], bh, a3, 0, 0, 0);
+        }
+        // a3[r]: channel t3*32 + l31, sample cb*32 + mfma_row(r, lane); ascending sample order, strict > : the first
+        // maximal sample wins, as F.max_pool2d
+        float v = a3[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v = fmaxf(v, a3[r]);
+        int smp = 3 + 8 * 3;                                     // mfma_row(r, lane) - 4 h
+#pragma unroll
+        for (int r = 14; r >= 0; --r) smp = a3[r] == v ? (r & 3) + 8 * (r >> 2) : smp;
+        v *= un3;   // the blocks carry their own power-of-two scales: compared unscaled (exact)
+        if (cb == 0 || v > bv[t3]) {
+          bv[t3] = v;
+          bs[t3] = cb * 32 + 4 * h + smp;
+        }
+      }
+    }
+#pragma unroll
     for (int t3 = 0; t3 < 4; ++t3) {
-      // layer 3 TRANSPOSED: the layer-2 registers go in as the A operand (rows = samples), the weights as B (columns =
-      // channels), so a lane ends up with ONE channel and 32 of its samples in registers: the max over samples is
-      // lane-local plus one exchange between the register halves instead of a 32-lane shuffle reduction per register
-      f32x16 a3[2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        a3[0][r] = 0.f;
-        a3[1][r] = 0.f;
-      }
-      const unsigned char* wr = L.w3h + (t3 * 32 + (lane & 31)) * SA_PH + (lane >> 5) * 16;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const half8 bh = *reinterpret_cast<const half8*>(wr + ks * 32);
-        const half8 bl = *reinterpret_cast<const half8*>(wr + ks * 32 + 128 * SA_PH);
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          a3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][ks], bh, a3[cb], 0, 0, 0);
-          a3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][ks], bl, a3[cb], 0, 0, 0);
-          a3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][ks], bh, a3[cb], 0, 0, 0);
-        }
-      }
-      // a3[cb][r]: channel t3*32 + (lane&31), sample cb*32 + (r&3) + 8*(r>>2) + 4*(lane>>5); ascending sample order,
-      // strict > : the first maximal sample wins, as F.max_pool2d
-      float v = -__builtin_inff();
-      int smp = 0;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool gt = a3[cb][r] > v;
-          v = gt ? a3[cb][r] : v;
-          smp = gt ? cb * 32 + mfma_row(r, lane) : smp;
-        }
+      float v = bv[t3];
+      int smp = bs[t3];
       const float ov = __shfl_xor(v, 32, 64);
       const int os = __shfl_xor(smp, 32, 64);
       const bool take = ov > v || (ov == v && os < smp);
@@ -303,188 +380,201 @@ __global__ __launch_bounds__(SA_TF) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       smp = take ? os : smp;
       if (lane < 32) {   // 128 contiguous bytes of the centroid's row of out_t [B,M,128]
         const int ch = t3 * 32 + lane;
-        out[(size_t)c * 128 + ch] = fmaxf(v * un3 + L.b3[ch], 0.f);   // the (positive) scale commutes with the max
+        out[(size_t)c * 128 + ch] = fmaxf(v + L.b3[ch], 0.f);
         arg[(size_t)c * 128 + ch] = (uint8_t)smp;
       }
     }
   }
 }
 
-__global__ __launch_bounds__(SA_TB) __attribute__((amdgpu_waves_per_eu(2, 2))) void sa1_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
-                                                       const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
-                                                       int M, const float* __restrict__ out,
-                                                       const uint8_t* __restrict__ arg, const float* __restrict__ g,
-                                                       float* __restrict__ dxyz, float* __restrict__ dnew,
-                                                       float* __restrict__ dpbuf) {
+template <int SA_T>
+__global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4, SA_WB / 4))) void sa1_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                      const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
+                                                      int M, const float* __restrict__ out,
+                                                      const uint8_t* __restrict__ arg, const float* __restrict__ g,
+                                                      float* __restrict__ dxyz, float* __restrict__ dnew,
+                                                      float* __restrict__ dpbuf) {
   extern __shared__ __attribute__((aligned(16))) float sa_sm[];
   const Sa1Lds L = sa1_carve(sa_sm, true);
-  sa1_stage<SA_TB, true>(w, L);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
-  float* s_gz = L.scratch + wave * 256;                       // [128] pooled gradient through the output relu
-  int* s_arg = reinterpret_cast<int*>(s_gz + 128);            // [128] arg-max sample of every channel
-  const long total = (long)B * M;
-  for (long c = (long)blockIdx.x * (SA_TB / 64) + wave; c < total; c += (long)gridDim.x * (SA_TB / 64)) {
+  sa1_stage<SA_T, true>(w, L);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, l31 = lane & 31;
+  const int k1 = __builtin_amdgcn_readfirstlane(L.kw[0]), k2 = __builtin_amdgcn_readfirstlane(L.kw[1]),
+            k3 = __builtin_amdgcn_readfirstlane(L.kw[2]);
+  // one-hot records of the wave's centroid: channel PAIRS (2 q, 2 q + 1) as packed fp16 images of the scaled pooled gradient
+  // (hi pieces | lo pieces), and per channel the arg-max sample as a one-hot bit over samples 0-31 | 32-63
+  unsigned* s_hp = L.pa + wave * 384;   // [64]
+  unsigned* s_lp = s_hp + 64;           // [64]
+  unsigned* s_m = s_lp + 64;            // [2 blocks][128]
+  const int total = B * M, stride = (int)gridDim.x * (SA_T / 64);   // B * M < 2^31 / 128 (checked by the launcher)
+  int c = (int)blockIdx.x * (SA_T / 64) + wave;
+  Sa1Pts P;
+  if (c < total) sa1_load(xyz, new_xyz, idx, c, M, N, lane, P);
+  for (; c < total; c += stride) {
     asm volatile("" ::: "memory");   // the weights stay in LDS: no hoisting of their loads out of the centroid loop
-    const int b = (int)(c / M);
-    const int i = idx[c * SA_S + lane];
-    const float* q = xyz + ((size_t)b * N + i) * 3;
-    const float* ctr = new_xyz + (size_t)c * 3;
-    const float px = q[0] - ctr[0], py = q[1] - ctr[1], pz = q[2] - ctr[2];
+    const Sa1Pts Q = P;
+    int kg;
     {
+      // every channel's scaled gradient (through the output relu) is split ONCE by the lane that loads it; the one-hot
+      // operand construction below is then a bit-field extract per channel (0 / -1: is this lane's sample the channel's
+      // arg-max?), one byte permute per pair to join two of them, and an AND per packed pair -- no compare through an SGPR
+      // (two wait states between a v_cmp and the v_cndmask that reads it on this chip)
       const float2 ov = *reinterpret_cast<const float2*>(out + (size_t)c * 128 + 2 * lane);
       const float2 gv = *reinterpret_cast<const float2*>(g + (size_t)c * 128 + 2 * lane);
-      s_gz[2 * lane] = ov.x > 0.f ? gv.x : 0.f;
-      s_gz[2 * lane + 1] = ov.y > 0.f ? gv.y : 0.f;
-      s_arg[2 * lane] = arg[(size_t)c * 128 + 2 * lane];
-      s_arg[2 * lane + 1] = arg[(size_t)c * 128 + 2 * lane + 1];
+      const unsigned av = *reinterpret_cast<const unsigned short*>(arg + (size_t)c * 128 + 2 * lane);
+      const float g0 = ov.x > 0.f ? gv.x : 0.f, g1 = ov.y > 0.f ? gv.y : 0.f;
+      kg = sa_k(wave_max(fmaxf(__builtin_fabsf(g0), __builtin_fabsf(g1))));
+      const float sg = sa_pow2(kg);
+      const float z0 = g0 * sg, z1 = g1 * sg;
+      const _Float16 h0 = (_Float16)z0, h1 = (_Float16)z1;
+      const _Float16 l0 = (_Float16)(z0 - (float)h0), l1 = (_Float16)(z1 - (float)h1);
+      s_hp[lane] = (unsigned)__builtin_bit_cast(unsigned short, h0) | (unsigned)__builtin_bit_cast(unsigned short, h1) << 16;
+      s_lp[lane] = (unsigned)__builtin_bit_cast(unsigned short, l0) | (unsigned)__builtin_bit_cast(unsigned short, l1) << 16;
+      const unsigned a0 = av & 0x3fu, a1 = (av >> 8) & 0x3fu;
+      const unsigned b0 = 1u << (a0 & 31u), b1 = 1u << (a1 & 31u);
+      *reinterpret_cast<uint2*>(s_m + 2 * lane) = make_uint2(a0 < 32u ? b0 : 0u, a1 < 32u ? b1 : 0u);
+      *reinterpret_cast<uint2*>(s_m + 128 + 2 * lane) = make_uint2(a0 < 32u ? 0u : b0, a1 < 32u ? 0u : b1);
     }
-    unsigned m1lo, m1hi, m2[2] = {0u, 0u};   // m2[cb] bit t*16 + r: layer-2 activation (D layout) is positive
-    {
-      f32x16 h2[2][2];
-      sa1_hidden<true>(L, px, py, pz, lane, h2, m1lo, m1hi);
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m2[cb] |= (h2[cb][t][r] > 0.f ? 1u : 0u) << (t * 16 + r);
-    }
-    float dpx_, dpy_, dpz_;
-    // d h2 [64 x 64 samples] = W3^T dz3, dz3 one-hot per channel (only the arg-max sample carries gradient).
-    // The two column blocks (samples 0-31, 32-63) go through the three backward products ONE AFTER THE OTHER: with both
-    // in flight the accumulators alone are 128 registers (d2, d1: 2 x 2 x 16 each) and the kernel spilled 61 dwords per
-    // lane at its 256-register budget -- 1.7 GB of scratch traffic per launch (PMC: 1.97 GB against 0.28 GB algorithmic).
-    // Sequentially the weight fragments are read from LDS twice and each block takes its own power-of-two scales.
-    {
-      // every channel's scaled gradient is split ONCE (by the lane that staged it) and kept with its arg-max sample as
-      // {hi | lo << 16, sample}: the operand construction below is then one 8-byte LDS read, a compare and a select
-      // per (channel, lane half) plus byte permutes
-      const float g0 = s_gz[2 * lane], g1 = s_gz[2 * lane + 1];
-      const int a0 = s_arg[2 * lane], a1 = s_arg[2 * lane + 1];
-      const unsigned E = sa_exp(wave_max(fmaxf(__builtin_fabsf(g0), __builtin_fabsf(g1))));
-      const float sg = sa_scale(E);
-      const float f2 = sa_unscale(E) * L.scal[1];     // d2 holds (d h2) / f2
-      unsigned* s_pa = reinterpret_cast<unsigned*>(s_gz);   // [128][2], over s_gz / s_arg (this wave's own 1 KB)
-      {
-        const float z0 = g0 * sg, z1 = g1 * sg;
-        const _Float16 h0 = (_Float16)z0, h1 = (_Float16)z1;
-        const _Float16 l0 = (_Float16)(z0 - (float)h0), l1 = (_Float16)(z1 - (float)h1);
-        const unsigned p0 = (unsigned)__builtin_bit_cast(unsigned short, h0) | (unsigned)__builtin_bit_cast(unsigned short, l0) << 16;
-        const unsigned p1 = (unsigned)__builtin_bit_cast(unsigned short, h1) | (unsigned)__builtin_bit_cast(unsigned short, l1) << 16;
-        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<uint4v*>(s_pa + 4 * lane) = uint4v{p0, (unsigned)a0, p1, (unsigned)a1};
-      }
-      float part[2][3];
+    if (c + stride < total) sa1_load(xyz, new_xyz, idx, c + stride, M, N, lane, P);
+    const int kp = sa1_kp(Q);
+    const float sp = sa_pow2(kp);
+    const _Float16 one = h ? (_Float16)0.f : (_Float16)sp;
+    float dpx = 0.f, dpy = 0.f, dpz = 0.f;   // of sample `lane`
+    // The two column blocks (samples 0-31, 32-63) go through the forward recomputation and the three backward products ONE
+    // AFTER THE OTHER, each with its own power-of-two scales: half the live accumulators, three waves per SIMD.
 #pragma unroll 1
-      for (int cb = 0; cb < 2; ++cb) {
-        asm volatile("" ::: "memory");   // (the weight fragments are re-read per block: no hoisting out of this loop)
-        f32x16 d2[2];
+    for (int cb = 0; cb < 2; ++cb) {
+      asm volatile("" ::: "memory");   // (the weight fragments are re-read per block: no hoisting out of this loop)
+      // d h2 [64 x 32 samples] = W3^T dz3, dz3 one-hot per channel (only the arg-max sample carries gradient): element j
+      // of lane (sample, k half) for k-step ks is channel ch = 16 ks + 8 h + j, non-zero only in the lane of the channel's
+      // arg-max sample; the A operand is the W3^T image.  FIRST (it needs nothing of the forward): the recomputed layers'
+      // registers are not live beside the k-steps' operands, which are read from LDS one k-step ahead.
+      f32x16 d2[2];
+      {
+        const unsigned char* wr = L.w3h + l31 * SA_PH2 + h * 16;
+        const unsigned* mrow = s_m + cb * 128 + 8 * h;
+        uint4v rec[2][4];   // (hi pairs, lo pairs, 2 x 4 masks) of a k-step
+        half8 fr[2][4];
+        auto fetch = [&](int ks, uint4v (&r)[4], half8 (&f)[4]) {
+          r[0] = *reinterpret_cast<const uint4v*>(s_hp + 8 * ks + 4 * h);
+          r[1] = *reinterpret_cast<const uint4v*>(s_lp + 8 * ks + 4 * h);
+          r[2] = *reinterpret_cast<const uint4v*>(mrow + 16 * ks);
+          r[3] = *reinterpret_cast<const uint4v*>(mrow + 16 * ks + 4);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) d2[t][r] = 0.f;
-        {
-          // one-hot B operand: element j of lane (sample, k half) for k-step ks is channel ch = 16 ks + 8h + j, non-zero
-          // only in the lane of the channel's arg-max sample; the A operand is the W3^T image
-          const unsigned char* wr = L.w3h + l31 * SA_PH2 + h * 16;
-          const int mysample = cb * 32 + l31;
-#pragma unroll 2
-          for (int ks = 0; ks < 8; ++ks) {
-            unsigned s0[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int ch = 16 * ks + 8 * h + j;
-              const uint2 pa = *reinterpret_cast<const uint2*>(s_pa + 2 * ch);
-              s0[j] = (int)pa.y == mysample ? pa.x : 0u;
-            }
-            typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-            uint4v vh0, vl0;
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-              vh0[j2] = __builtin_amdgcn_perm(s0[2 * j2 + 1], s0[2 * j2], 0x05040100u);   // low halves: hi pieces
-              vl0[j2] = __builtin_amdgcn_perm(s0[2 * j2 + 1], s0[2 * j2], 0x07060302u);   // high halves: lo pieces
-            }
-            const half8 bh = __builtin_bit_cast(half8, vh0), bl = __builtin_bit_cast(half8, vl0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32);
-              const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32 + 64 * SA_PH2);
-              d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, d2[t], 0, 0, 0);
-              d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, d2[t], 0, 0, 0);
-              d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, d2[t], 0, 0, 0);
-            }
+          for (int t = 0; t < 2; ++t) {
+            f[2 * t] = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32);
+            f[2 * t + 1] = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH2 + ks * 32 + 64 * SA_PH2);
           }
-        }
-        // through relu 2, then d h1 = W2^T dz2 with the accumulator registers as B operands (registers 8s..8s+7 of tile
-        // t = k-step 2t + s in the accumulator's row order; the W2^T image follows it)
-        f32x16 d1[2];
+        };
+        fetch(0, rec[0], fr[0]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks + 1 < 8) fetch(ks + 1, rec[(ks + 1) & 1], fr[(ks + 1) & 1]);
+          uint4v vh0, vl0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) d1[t][r] = 0.f;
-        float f1;   // d1 holds (d h1) / f1
-        {
-          const unsigned mm = cb ? m2[1] : m2[0];
-          float m = 0.f;
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              d2[t][r] = ((mm >> (t * 16 + r)) & 1u) ? d2[t][r] : 0.f;
-              m = fmaxf(m, __builtin_fabsf(d2[t][r]));
-            }
-          const unsigned E1 = sa_exp(wave_max(m));
-          const float sx = sa_scale(E1);
-          f1 = f2 * sa_unscale(E1) * L.scal[0];
-          const unsigned char* wr = L.w2t + l31 * SA_PH + h * 16;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            half8 bh, bl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float v = d2[ks >> 1][8 * (ks & 1) + j] * sx;
-              const _Float16 a = (_Float16)v;
-              bh[j] = a;
-              bl[j] = (_Float16)(v - (float)a);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const half8 wh = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32);
-              const half8 wl = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32 + 64 * SA_PH);
-              d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, d1[t], 0, 0, 0);
-              d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, d1[t], 0, 0, 0);
-              d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, d1[t], 0, 0, 0);
-            }
+          for (int j2 = 0; j2 < 4; ++j2) {
+            const unsigned ma = (unsigned)__builtin_amdgcn_sbfe((int)rec[ks & 1][2 + (j2 >> 1)][2 * (j2 & 1)], (unsigned)l31, 1u);
+            const unsigned mb = (unsigned)__builtin_amdgcn_sbfe((int)rec[ks & 1][2 + (j2 >> 1)][2 * (j2 & 1) + 1], (unsigned)l31, 1u);
+            const unsigned mp = __builtin_amdgcn_perm(mb, ma, 0x07060100u);   // ma's low half | mb's high half
+            vh0[j2] = rec[ks & 1][0][j2] & mp;
+            vl0[j2] = rec[ks & 1][1][j2] & mp;
           }
-        }
-        // through relu 1 (mask of sample cb*32 + l31 lives in that lane) and the K = 3 layer
-        {
-          const unsigned mlo = __shfl(m1lo, cb * 32 + l31, 64), mhi = __shfl(m1hi, cb * 32 + l31, 64);
-          float sx = 0.f, sy = 0.f, sz = 0.f;
+          const half8 bh = __builtin_bit_cast(half8, vh0), bl = __builtin_bit_cast(half8, vl0);
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int kk = (r & 3) + 8 * (r >> 2) + 4 * h;     // bit within the word of tile t
-              const bool on = (((t == 0 ? mlo : mhi) >> kk) & 1u) != 0u;
-              const float z = on ? d1[t][r] * f1 : 0.f;
-              const float4 wv = *reinterpret_cast<const float4*>(L.w1 + 4 * (t * 32 + kk));
-              sx += wv.x * z;
-              sy += wv.y * z;
-              sz += wv.z * z;
-            }
-          part[cb][0] = sx + __shfl_xor(sx, 32, 64);
-          part[cb][1] = sy + __shfl_xor(sy, 32, 64);
-          part[cb][2] = sz + __shfl_xor(sz, 32, 64);
+          for (int t = 0; t < 2; ++t) {
+            const half8 wh = fr[ks & 1][2 * t], wl = fr[ks & 1][2 * t + 1];
+            d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, ks == 0 ? SA_ZERO16 : d2[t], 0, 0, 0);
+            d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, d2[t], 0, 0, 0);
+            d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, d2[t], 0, 0, 0);
+          }
         }
       }
-      dpx_ = h ? part[1][0] : part[0][0];
-      dpy_ = h ? part[1][1] : part[0][1];
-      dpz_ = h ? part[1][2] : part[0][2];
+      // the forward of the block: layers 1 and 2; the sign of the layer-2 accumulators (bias included) is the relu gate
+      const half8 bop = sa1_bop(cb ? Q.bx : Q.ax, cb ? Q.by : Q.ay, cb ? Q.bz : Q.az, sp, one);
+      int kd;
+      half8 bh[4], bl[4];
+      {
+        f32x16 a2[2];
+        {
+          f32x16 z[2];
+          sa1_layer1(L, bop, lane, z);
+          half8 xh[4], xl[4];
+          const int kx = sa_relu_k(z);
+          sa_split_tiles(z, sa_pow2(kx), xh, xl);
+          sa1_layer2(L, xh, xl, sa_pow2(k1 + kp + kx + k2), lane, a2);
+        }
+        // through relu 2; the gated accumulator registers are the B operands of d h1 = W2^T dz2 (the W2^T image follows
+        // their row order)
+        float m = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            d2[t][r] = a2[t][r] > 0.f ? d2[t][r] : 0.f;
+            m = fmaxf(m, __builtin_fabsf(d2[t][r]));
+          }
+        kd = sa_k(wave_max(m));
+        sa_split_tiles(d2, sa_pow2(kd), bh, bl);
+      }
+      f32x16 d1[2];
+      {
+        const unsigned char* wr = L.w2t + l31 * SA_PH + h * 16;
+        half8 fr[2][4];
+        auto fetch = [&](int ks, half8 (&f)[4]) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            f[2 * t] = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32);
+            f[2 * t + 1] = *reinterpret_cast<const half8*>(wr + t * 32 * SA_PH + ks * 32 + 64 * SA_PH);
+          }
+        };
+        fetch(0, fr[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks + 1 < 4) fetch(ks + 1, fr[(ks + 1) & 1]);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const half8 wh = fr[ks & 1][2 * t], wl = fr[ks & 1][2 * t + 1];
+            d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[ks], ks == 0 ? SA_ZERO16 : d1[t], 0, 0, 0);
+            d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[ks], d1[t], 0, 0, 0);
+            d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[ks], d1[t], 0, 0, 0);
+          }
+        }
+      }
+      // through relu 1 (layer 1 once more on the matrix core: its sign is the gate, in the layout of d1) and the K = 3 layer
+      {
+        f32x16 z[2];
+        sa1_layer1(L, bop, lane, z);
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            // rows 32 t + 8 g4 + 4 h + (0..3): twelve consecutive floats of the [64][3] image, three 16-byte reads
+            const float4* wq = reinterpret_cast<const float4*>(L.w1 + 3 * (32 * t + 8 * g4 + 4 * h));
+            const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2];
+            const float wr3[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float v = z[t][4 * g4 + i] > 0.f ? d1[t][4 * g4 + i] : 0.f;
+              sx = __builtin_fmaf(wr3[3 * i], v, sx);
+              sy = __builtin_fmaf(wr3[3 * i + 1], v, sy);
+              sz = __builtin_fmaf(wr3[3 * i + 2], v, sz);
+            }
+          }
+        const float f1 = sa_pow2(-(k2 + kd + k3 + kg));
+        sx = (sx + __shfl_xor(sx, 32, 64)) * f1;
+        sy = (sy + __shfl_xor(sy, 32, 64)) * f1;
+        sz = (sz + __shfl_xor(sz, 32, 64)) * f1;
+        if (h == cb) {
+          dpx = sx;
+          dpy = sy;
+          dpz = sz;
+        }
+      }
     }
-    const float dpx = dpx_, dpy = dpy_, dpz = dpz_;
     // scatter to the gathered points (entries repeating the row's first index -- the ball query's padding -- leave as
     // one add) and minus the sum to the centroid
+    const int b = c / M;
+    const int i = h ? Q.ib : Q.ia;
     const int i0 = __shfl(i, 0, 64);
     const bool dup = lane > 0 && i == i0;
     const float ex = wave_sum(dup ? dpx : 0.f), ey = wave_sum(dup ? dpy : 0.f), ez = wave_sum(dup ? dpz : 0.f);
@@ -616,9 +706,9 @@ __global__ __launch_bounds__(SCAT_BLOCK) void sa1_scatter_kernel(const float* __
   for (int i = tid; i < 3 * N; i += SCAT_BLOCK) G[i] = s_g[i];
 }
 
-int sa1_grid(int B, int M, int waves) {
+int sa1_grid(int B, int M, int waves, int per_cu) {   // persistent workgroups
   const long groups = ((long)B * M + waves - 1) / waves;
-  return (int)(groups < 256 * 2 ? groups : 256 * 2);   // persistent: 2 workgroups per CU (62 / 78 KB LDS each)
+  return (int)(groups < 256 * per_cu ? groups : 256 * per_cu);
 }
 
 }  // namespace
@@ -627,11 +717,12 @@ extern "C" int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, con
                                      const geoa3_sa1_weights* w, int B, int N, int M, float* out, uint8_t* arg,
                                      void* stream) {
   if (!xyz || !new_xyz || !idx || !w || !out || !arg || B <= 0 || N <= 0 || M <= 0) return GEOA3_EINVAL;
-  const size_t lds = (size_t)sa1_lds_bytes(SA_TF, false);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if ((long)B * M > (1L << 24)) return GEOA3_ENOSUPPORT;
+  const size_t lds = (size_t)sa1_lds_bytes(SA_WF, false);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_fwd_kernel<SA_WF * 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   geoa3_prof_begin(GEOA3_PROF_SA1_FWD, geoa3_stream(stream));
-  hipLaunchKernelGGL(sa1_fwd_kernel, dim3(sa1_grid(B, M, SA_TF / 64)), dim3(SA_TF), lds, geoa3_stream(stream), xyz, new_xyz, idx, *w,
+  hipLaunchKernelGGL(sa1_fwd_kernel<SA_WF * 64>, dim3(sa1_grid(B, M, SA_WF, 1)), dim3(SA_WF * 64), lds, geoa3_stream(stream), xyz, new_xyz, idx, *w,
                      B, N, M, out, arg);
   geoa3_prof_end(GEOA3_PROF_SA1_FWD, geoa3_stream(stream));
   GEOA3_CHECK_LAUNCH();
@@ -650,16 +741,17 @@ extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, co
   if (!xyz || !new_xyz || !idx || !w || !out || !arg || !grad_out || !grad_xyz || !grad_new_xyz || B <= 0 || N <= 0 ||
       M <= 0)
     return GEOA3_EINVAL;
+  if ((long)B * M > (1L << 24)) return GEOA3_ENOSUPPORT;
   hipStream_t s = geoa3_stream(stream);
   // deterministic scatter (scratch given and the owner's accumulators + at least one centroid's lists fit LDS)
   const size_t fixed = ((size_t)N + 1) * sizeof(int) + (size_t)3 * N * sizeof(float), cap = 160 * 1024 - 512;
   const bool det = scratch && fixed + SA_S * sizeof(int) <= cap;
   if (!det && hipMemsetAsync(grad_xyz, 0, (size_t)B * N * 3 * sizeof(float), s) != hipSuccess) return GEOA3_ELAUNCH;
-  const size_t lds = (size_t)sa1_lds_bytes(SA_TB, true);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  const size_t lds = (size_t)sa1_lds_bytes(SA_WB, true);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_bwd_kernel<SA_WB * 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   geoa3_prof_begin(GEOA3_PROF_SA1_BWD, s);
-  hipLaunchKernelGGL(sa1_bwd_kernel, dim3(sa1_grid(B, M, SA_TB / 64)), dim3(SA_TB), lds, s, xyz, new_xyz, idx, *w, B, N, M, out, arg,
+  hipLaunchKernelGGL(sa1_bwd_kernel<SA_WB * 64>, dim3(sa1_grid(B, M, SA_WB, 1)), dim3(SA_WB * 64), lds, s, xyz, new_xyz, idx, *w, B, N, M, out, arg,
                      grad_out, grad_xyz, grad_new_xyz, det ? scratch : nullptr);
   geoa3_prof_end(GEOA3_PROF_SA1_BWD, s);
   if (det) {
