@@ -170,22 +170,19 @@ __device__ __forceinline__ void sa1_stage(const geoa3_sa1_weights& w, const Sa1L
   __syncthreads();
 }
 
-// (hi, lo) fp16 images of x0 * s and x1 * s, packed: two v_fma_mix per element (the scale, the conversion and the packing
-// in one instruction; the residual x * s - hi is one exact fma).  The inputs are results of VALU instructions the compiler
-// sees (never matrix-core results: the hazard recogniser does not look into inline assembly).
+// (hi, lo) fp16 images of x0 * s and x1 * s, packed: v_pk_mul_f32 + v_cvt_pk_f16_f32 for the pair of hi pieces, one
+// v_fma_mixlo / mixhi_f16 per lo piece (the residual x * s - hi as ONE exact fma, converted and packed by the same
+// instruction): two instructions per element, all of them visible to the compiler's scheduler and hazard recogniser.
+// The file is compiled with -fno-slp-vectorize (geoa3_amd/build.py): the SLP vectoriser turns the pair of residuals into
+// v_cvt_f32_f16 x 2 + v_pk_fma_f32 + v_cvt_pk_f16_f32 (three per element).
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void sa_split2(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
-#ifdef GEOA3_SA1_PLAIN_SPLIT
-  const float v0 = x0 * s, v1 = x1 * s;
-  const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-  const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
-  hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | (unsigned)__builtin_bit_cast(unsigned short, h1) << 16;
-  lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | (unsigned)__builtin_bit_cast(unsigned short, l1) << 16;
-#else
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "s"(s));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "s"(s));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "s"(s), "v"(hi));
-  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "s"(s), "v"(hi));
-#endif
+  const float2v x = {x0, x1};
+  const half2v h = __builtin_convertvector(x * s, half2v);
+  const half2v l = {(_Float16)__builtin_fmaf(x0, s, -(float)h[0]), (_Float16)__builtin_fmaf(x1, s, -(float)h[1])};
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
 }
 // two accumulator tiles (rows 32 t + mfma_row(r, lane)) -> the operands of the four k-steps that consume them: registers
 // 8 s .. 8 s + 7 of tile t are k-step 2 t + s in the accumulator's row order (the weight images follow it: sa_perm)
@@ -204,6 +201,15 @@ __device__ __forceinline__ void sa_split_tiles(const f32x16 (&v)[2], float s, ha
     ol[ks] = __builtin_bit_cast(half8, Lw);
   }
 }
+
+// instruction-stream shaping: a matrix instruction holds the SIMD's issue port for 8 of its 32 cycles; five plain vector
+// instructions fit into the rest (MI355X_MICROARCH.md, cycle constants).  SA_MIX(n): n x {1 MFMA, 5 VALU} in this order.
+#define SA_SB() __builtin_amdgcn_sched_barrier(0)
+#define SA_MIX(n, v)                                         \
+  _Pragma("unroll") for (int sg_ = 0; sg_ < (n); ++sg_) {     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       \
+    __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);     \
+  }
 
 #define SA_ZERO16 f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
 
@@ -321,53 +327,83 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
     const _Float16 one = h ? (_Float16)0.f : (_Float16)sp;
     float bv[4];   // best (value, sample) of channel 32 t3 + l31 over this lane's samples
     int bs[4];
-#pragma unroll 1
-    for (int cb = 0; cb < 2; ++cb) {
-      asm volatile("" ::: "memory");   // (the weight fragments are re-read per block: no hoisting out of this loop)
-      f32x16 z[2];
-      sa1_layer1(L, cb ? sa1_bop(Q.bx, Q.by, Q.bz, sp, one) : sa1_bop(Q.ax, Q.ay, Q.az, sp, one), lane, z);
-      half8 xh[4], xl[4];
-      const int kx = sa_relu_k(z);
-      sa_split_tiles(z, sa_pow2(kx), xh, xl);
-      const int ka = k1 + kp + kx + k2;
-      sa1_layer2(L, xh, xl, sa_pow2(ka), lane, z);
-      // layer-2 activations -> the A fragments of the transposed layer 3 (rows = samples, the weights as B: columns =
-      // channels): a lane ends with ONE channel and 16 of the block's samples, the max over samples is lane-local
-      const int kx2 = sa_relu_k(z);
-      sa_split_tiles(z, sa_pow2(kx2), xh, xl);
-      const float un3 = sa_pow2(-(ka + kx2 + k3));
-      const unsigned char* wr = L.w3h + l31 * SA_PH + h * 16;
-      half8 fr[2][2];
-      auto fetch = [&](int st, half8 (&f)[2]) {
-        f[0] = *reinterpret_cast<const half8*>(wr + (st >> 2) * 32 * SA_PH + (st & 3) * 32);
-        f[1] = *reinterpret_cast<const half8*>(wr + (st >> 2) * 32 * SA_PH + (st & 3) * 32 + 128 * SA_PH);
-      };
+    // The two 32-sample column blocks A and B go through the layers SKEWED by one stage, so that every matrix phase of one
+    // block has the other block's vector phase (relu, maximum, operand split, arg-max) beside it in ONE wave's instruction
+    // stream -- an in-order wave cannot fill its own dependent MFMA chain's gaps otherwise, and two waves per SIMD running
+    // the same program overlapped only 17 % of the matrix pipe's busy cycles (SQ_VALU_MFMA_COEXEC_CYCLES):
+    //   L1(A) L1(B) | split(A) | L2(A) + split(B) | L2(B) + split2(A) | L3(A) + split2(B) + argmax(A) | L3(B) + argmax | tail
+    half8 xhA[4], xlA[4], xhB[4], xlB[4];
+    f32x16 zA[2], zB[2];
+    sa1_layer1(L, sa1_bop(Q.ax, Q.ay, Q.az, sp, one), lane, zA);
+    sa1_layer1(L, sa1_bop(Q.bx, Q.by, Q.bz, sp, one), lane, zB);
+    SA_SB();
+    const int kxA = sa_relu_k(zA);
+    sa_split_tiles(zA, sa_pow2(kxA), xhA, xlA);
+    SA_SB();
+    const int kaA = k1 + kp + kxA + k2;
+    sa1_layer2(L, xhA, xlA, sa_pow2(kaA), lane, zA);            // (zA: layer-2 accumulators of A from here)
+    const int kxB = sa_relu_k(zB);
+    sa_split_tiles(zB, sa_pow2(kxB), xhB, xlB);
+    SA_MIX(24, 5)
+    SA_SB();
+    const int kaB = k1 + kp + kxB + k2;
+    sa1_layer2(L, xhB, xlB, sa_pow2(kaB), lane, zB);
+    const int kyA = sa_relu_k(zA);
+    sa_split_tiles(zA, sa_pow2(kyA), xhA, xlA);                // the A fragments of the transposed layer 3
+    SA_MIX(24, 5)
+    SA_SB();
+    auto tile = [&](const half8 (&xh)[4], const half8 (&xl)[4], int t3, f32x16& a3) {
+      const unsigned char* wr = L.w3h + (t3 * 32 + l31) * SA_PH + h * 16;
 #pragma unroll
-      for (int t3 = 0; t3 < 4; ++t3) {
-        f32x16 a3;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int st = 4 * t3 + ks;
-          fetch(st, fr[st & 1]);
-          const half8 bh = fr[st & 1][0], bl = fr[st & 1][1];
-          a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], bh, ks == 0 ? SA_ZERO16 : a3, 0, 0, 0);
-          a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], bl, a3, 0, 0, 0);
-          a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[ks], bh, a3, 0, 0, 0);
-        }
-        // a3[r]: channel t3*32 + l31, sample cb*32 + mfma_row(r, lane); ascending sample order, strict > : the first
-        // maximal sample wins, as F.max_pool2d
-        float v = a3[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) v = fmaxf(v, a3[r]);
-        int smp = 3 + 8 * 3;                                     // mfma_row(r, lane) - 4 h
-#pragma unroll
-        for (int r = 14; r >= 0; --r) smp = a3[r] == v ? (r & 3) + 8 * (r >> 2) : smp;
-        v *= un3;   // the blocks carry their own power-of-two scales: compared unscaled (exact)
-        if (cb == 0 || v > bv[t3]) {
-          bv[t3] = v;
-          bs[t3] = cb * 32 + 4 * h + smp;
-        }
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 bh = *reinterpret_cast<const half8*>(wr + ks * 32);
+        const half8 bl = *reinterpret_cast<const half8*>(wr + ks * 32 + 128 * SA_PH);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], bh, ks == 0 ? SA_ZERO16 : a3, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], bl, a3, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[ks], bh, a3, 0, 0, 0);
       }
+    };
+    // a3[r]: channel t3*32 + l31, sample cb*32 + mfma_row(r, lane); ascending sample order: the first maximal sample wins,
+    // as F.max_pool2d.  The blocks carry their own power-of-two scales: compared unscaled (exact).
+    auto argmax = [&](const f32x16& a3, float un3, int cb, int t3) {
+      float v = a3[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) v = fmaxf(v, a3[r]);
+      int smp = 3 + 8 * 3;                                     // mfma_row(r, lane) - 4 h
+#pragma unroll
+      for (int r = 14; r >= 0; --r) smp = a3[r] == v ? (r & 3) + 8 * (r >> 2) : smp;
+      v *= un3;
+      if (cb == 0 || v > bv[t3]) {
+        bv[t3] = v;
+        bs[t3] = cb * 32 + 4 * h + smp;
+      }
+    };
+    f32x16 t0, t1;
+    {
+      const float un3 = sa_pow2(-(kaA + kyA + k3));
+      tile(xhA, xlA, 0, t0);
+      const int kyB = sa_relu_k(zB);
+      sa_split_tiles(zB, sa_pow2(kyB), xhB, xlB);
+      tile(xhA, xlA, 1, t1);
+      argmax(t0, un3, 0, 0);
+      tile(xhA, xlA, 2, t0);
+      argmax(t1, un3, 0, 1);
+      tile(xhA, xlA, 3, t1);
+      argmax(t0, un3, 0, 2);
+      SA_MIX(48, 5)
+      SA_SB();
+      const float un3b = sa_pow2(-(kaB + kyB + k3));
+      tile(xhB, xlB, 0, t0);
+      argmax(t1, un3, 0, 3);
+      tile(xhB, xlB, 1, t1);
+      argmax(t0, un3b, 1, 0);
+      tile(xhB, xlB, 2, t0);
+      argmax(t1, un3b, 1, 1);
+      tile(xhB, xlB, 3, t1);
+      argmax(t0, un3b, 1, 2);
+      SA_MIX(48, 4)
+      SA_SB();
+      argmax(t1, un3b, 1, 3);
     }
 #pragma unroll
     for (int t3 = 0; t3 < 4; ++t3) {
@@ -441,9 +477,15 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4,
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;   // of sample `lane`
     // The two column blocks (samples 0-31, 32-63) go through the forward recomputation and the three backward products ONE
     // AFTER THE OTHER, each with its own power-of-two scales: half the live accumulators, three waves per SIMD.
+#ifdef GEOA3_SA1_UNROLL_CB
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int cb = 0; cb < 2; ++cb) {
+#ifndef GEOA3_SA1_UNROLL_CB
       asm volatile("" ::: "memory");   // (the weight fragments are re-read per block: no hoisting out of this loop)
+#endif
       // d h2 [64 x 32 samples] = W3^T dz3, dz3 one-hot per channel (only the arg-max sample carries gradient): element j
       // of lane (sample, k half) for k-step ks is channel ch = 16 ks + 8 h + j, non-zero only in the lane of the channel's
       // arg-max sample; the A operand is the W3^T image.  FIRST (it needs nothing of the forward): the recomputed layers'
