@@ -35,11 +35,12 @@ def _hipcc() -> str:
 # pointnet_conv_split.hip: the one-layer-per-launch kernels the chains are held to BIT FOR BIT (tests/test_gpu_pointnet.py)
 # must contract their multiply-adds the same way (no cost: configs[1] does not run them, configs[3] +0.2 %).
 # (pointnet_gemm.hip -- the FC heads -- loses 4 % of the iteration without SLP and is left alone.)
-# pointnet2_sa.hip: relu / max of matrix-core results without the canonicalising v_max x, x the IEEE maxnum semantics put in front
+# pointnet2_sa.hip, pointnet2_sa2.hip: relu / max of matrix-core results without the canonicalising v_max x, x the IEEE maxnum semantics put in front
 # of every one of them (a sixth of the level-1 kernels' vector instructions); NaNs still propagate through the products.
 # -fno-slp-vectorize there: the operand split stays at two instructions per element (sa_split2).
 FILE_FLAGS = {"pointnet_conv_chain.hip": ["-fno-slp-vectorize"], "pointnet_conv_split.hip": ["-fno-slp-vectorize"],
-              "pointnet2_sa.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+              "pointnet2_sa.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+              "pointnet2_sa2.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 
 
 def sources():

@@ -39,6 +39,32 @@ __device__ __forceinline__ void s2_swap32(float& a, float& b) {   // a[32..63] <
   a = __uint_as_float(r[0]);
   b = __uint_as_float(r[1]);
 }
+// (hi, lo) fp16 images of x0 * s and x1 * s, packed: v_pk_mul_f32 + v_cvt_pk_f16_f32 for the hi pieces, one v_fma_mixlo /
+// mixhi_f16 per lo piece (the residual x * s - hi as one exact fma): two instructions per element where the scalar form
+// took five (the file is compiled with -fno-slp-vectorize: the SLP vectoriser turns the residual pair into three).  The
+// same bits as hi = rn16(x s), lo = rn16(x s - hi): s is a power of two.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s2_split2(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+  const float2v x = {x0, x1};
+  const half2v h = __builtin_convertvector(x * s, half2v);
+  const half2v l = {(_Float16)__builtin_fmaf(x0, s, -(float)h[0]), (_Float16)__builtin_fmaf(x1, s, -(float)h[1])};
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void s2_split8(const float (&x)[8], float s, half8& oh, half8& ol) {
+  uint4v H, Lw;
+#pragma unroll
+  for (int j2 = 0; j2 < 4; ++j2) {
+    unsigned a, b;
+    s2_split2(x[2 * j2], x[2 * j2 + 1], s, a, b);
+    H[j2] = a;
+    Lw[j2] = b;
+  }
+  oh = __builtin_bit_cast(half8, H);
+  ol = __builtin_bit_cast(half8, Lw);
+}
 __device__ __forceinline__ int s2_rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float s2_rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
@@ -174,7 +200,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (__builtin_expect(cw < 0, 0)) {   // wave-uniform: the sample's last channel
           const int col = (cw >> 16) & 63;
-          const float val = (cur.mk >> col) & 1ull ? acc : 0.f;
+          // a1 > 0 of (row k, sample col): bit col of the lane's gate word -> 0 / -1 by a bit-field extract, AND
+          const int gbit = __builtin_amdgcn_sbfe(col < 32 ? (int)(unsigned)cur.mk : (int)(unsigned)(cur.mk >> 32), (unsigned)(col & 31), 1u);
+          const float val = __int_as_float(__float_as_int(acc) & gbit);
           tile[col * S2_PT + k] = val;
           mx = fmaxf(mx, __builtin_fabsf(val));
           acc = 0.f;
@@ -211,13 +239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const float4 b0 = *reinterpret_cast<const float4*>(brow + cb * 32 * S2_PT + c * 16);
           const float4 b1 = *reinterpret_cast<const float4*>(brow + cb * 32 * S2_PT + c * 16 + 4);
           const float x[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float v = x[j] * sx;
-            const _Float16 h = (_Float16)v;
-            xh[cb][j] = h;
-            xl[cb][j] = (_Float16)(v - (float)h);
-          }
+          s2_split8(x, sx, xh[cb], xl[cb]);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -411,12 +433,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int j8 = 0; j8 < 8; ++j8) {
         half8 hh, ll;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x = v[8 * j8 + j] * sa;
-          const _Float16 hi = (_Float16)x;
-          hh[j] = hi;
-          ll[j] = (_Float16)(x - (float)hi);
+        {
+          const float x8[8] = {v[8 * j8], v[8 * j8 + 1], v[8 * j8 + 2], v[8 * j8 + 3], v[8 * j8 + 4], v[8 * j8 + 5], v[8 * j8 + 6], v[8 * j8 + 7]};
+          s2_split8(x8, sa, hh, ll);
         }
         *reinterpret_cast<half8*>(thi + lane * S2_PH + (64 * hf + 8 * j8) * 2) = hh;
         *reinterpret_cast<half8*>(tlo + lane * S2_PH + (64 * hf + 8 * j8) * 2) = ll;
@@ -492,12 +511,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int g4 = 0; g4 < 4; ++g4) {
             typedef _Float16 half4 __attribute__((ext_vector_type(4)));
             half4 hh, ll;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float x = acc[cb][t][4 * g4 + i] * sh;
-              const _Float16 hi = (_Float16)x;
-              hh[i] = hi;
-              ll[i] = (_Float16)(x - (float)hi);
+            {
+              unsigned h0, l0, h1, l1;
+              s2_split2(acc[cb][t][4 * g4], acc[cb][t][4 * g4 + 1], sh, h0, l0);
+              s2_split2(acc[cb][t][4 * g4 + 2], acc[cb][t][4 * g4 + 3], sh, h1, l1);
+              typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+              hh = __builtin_bit_cast(half4, uint2v{h0, h1});
+              ll = __builtin_bit_cast(half4, uint2v{l0, l1});
             }
             const int k0 = 64 * hf + 32 * t + 8 * g4 + 4 * h;
             *reinterpret_cast<half4*>(thi + (32 * cb + l31) * S2_PH + k0 * 2) = hh;
@@ -667,12 +687,9 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
 #pragma unroll
       for (int j8 = 0; j8 < 4; ++j8) {
         half8 hh, ll;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x = v[8 * j8 + j] * sa;
-          const _Float16 hi = (_Float16)x;
-          hh[j] = hi;
-          ll[j] = (_Float16)(x - (float)hi);
+        {
+          const float x8[8] = {v[8 * j8], v[8 * j8 + 1], v[8 * j8 + 2], v[8 * j8 + 3], v[8 * j8 + 4], v[8 * j8 + 5], v[8 * j8 + 6], v[8 * j8 + 7]};
+          s2_split8(x8, sa, hh, ll);
         }
         *reinterpret_cast<half8*>(thi + lane * S2_PH + (32 * qt + 8 * j8) * 2) = hh;
         *reinterpret_cast<half8*>(tlo + lane * S2_PH + (32 * qt + 8 * j8) * 2) = ll;
@@ -748,12 +765,13 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
         for (int g4 = 0; g4 < 4; ++g4) {
           typedef _Float16 half4 __attribute__((ext_vector_type(4)));
           half4 hh, ll;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float x = acc[cb][4 * g4 + i] * sh;
-            const _Float16 hi = (_Float16)x;
-            hh[i] = hi;
-            ll[i] = (_Float16)(x - (float)hi);
+          {
+            unsigned h0, l0, h1, l1;
+            s2_split2(acc[cb][4 * g4], acc[cb][4 * g4 + 1], sh, h0, l0);
+            s2_split2(acc[cb][4 * g4 + 2], acc[cb][4 * g4 + 3], sh, h1, l1);
+            typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+            hh = __builtin_bit_cast(half4, uint2v{h0, h1});
+            ll = __builtin_bit_cast(half4, uint2v{l0, l1});
           }
           const int k0 = 32 * qt + 8 * g4 + 4 * h;
           *reinterpret_cast<half4*>(thi + (32 * cb + l31) * S2_PH + k0 * 2) = hh;

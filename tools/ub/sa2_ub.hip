@@ -1,4 +1,4 @@
-// micro-benchmark of sa2_bwd_kernel (which phase bounds it?): hipcc --offload-arch=gfx950 -O3 -o sa2_ub sa2_ub.hip
+// micro-benchmark of sa2_bwd_kernel (which phase bounds it?): hipcc --offload-arch=gfx950 -O3 -fno-honor-nans -fno-slp-vectorize -I../../include -o sa2_ub sa2_ub.hip
 #include "../../geoa3_amd/csrc/pointnet2_sa2.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -42,7 +42,7 @@ int main() {
   hipMemcpy(m1, mk.data(), mk.size() * 8, hipMemcpyHostToDevice);
   launch_sa2_sort(dg, darg, eg, ec, centres, 0);
   char* scr; hipMalloc(&scr, 65536 + 256);
-  hipLaunchKernelGGL(sa2_prep_kernel, dim3(1), dim3(256), 0, 0, dw1, (_Float16*)scr, (float*)(scr + 65536));
+  launch_frag_image(dw1, 128, 128, scr, (float*)(scr + 65536), 0);
   Sa2BwdArgs a{eg, ec, dw2, (_Float16*)scr, (float*)(scr + 65536), m1, m0, da0, B, M};
   printf("mode0 (all)        %.1f us\n", run<0>(a, 5));
   printf("mode1 (no phase 1) %.1f us\n", run<1>(a, 5));
