@@ -44,7 +44,7 @@ PEAK_HBM = 8.0e12
 PEAK_F32_VALU = 157.3e12
 
 # event-timer tags (include/geoa3_hip_debug.h)
-TAG_CONV5, TAG_NN1, TAG_KNN, TAG_TNET, TAG_SA1_BWD, TAG_SA1_FWD = 0, 1, 2, 3, 4, 5
+TAG_CONV5, TAG_NN1, TAG_KNN, TAG_TNET, TAG_SA1_BWD, TAG_SA1_FWD, TAG_GEO = 0, 1, 2, 3, 4, 5, 7
 
 
 def cfg_full_geoa3(steps, npoint=NPOINT, knn=KNN):
@@ -168,6 +168,12 @@ def main():
                     help="skip the second, shorter measurement in the strict fp32-MFMA mode of the convolutions")
     ap.add_argument("--npoint", type=int, default=NPOINT, help="points per cloud (configs[4]: 4096)")
     ap.add_argument("--knn", type=int, default=KNN, help="curv_loss_knn (configs[4]: 32)")
+    ap.add_argument("--data", default="ellipsoid", choices=["ellipsoid", "cad"],
+                    help="synthetic input: one uniform ellipsoid per instance (the headline), or CAD-like clouds -- boxes, "
+                         "tables on thin legs, two clusters of very different density, rods, 5 %% exact duplicates "
+                         "(geoa3_amd.data.synthetic_cad_clouds)")
+    ap.add_argument("--cad-kinds", default="", help="with --data cad: comma-separated subset of box,table,clusters,rod,ellipsoid2")
+    ap.add_argument("--cad-duplicates", type=float, default=0.05, help="with --data cad: fraction of exact duplicate points")
     ap.add_argument("--arch", default="PointNet", choices=["PointNet", "PointNetPP"],
                     help="victim (PointNetPP = configs[3]: SSG classifier)")
     a = ap.parse_args()
@@ -210,7 +216,12 @@ def main():
         __graft_entry__.build()
     from geoa3_amd import _lib
     from geoa3_amd.attack import AttackRunner
-    from geoa3_amd.data import synthetic_clouds, synthetic_state_dict
+    from geoa3_amd.data import SYNTHETIC_GENERATORS, synthetic_state_dict
+    synthetic_clouds = SYNTHETIC_GENERATORS[a.data]
+    if a.data == "cad" and (a.cad_kinds or a.cad_duplicates != 0.05):
+        import functools
+        synthetic_clouds = functools.partial(synthetic_clouds, duplicates=a.cad_duplicates,
+                                             **({"kinds": tuple(a.cad_kinds.split(","))} if a.cad_kinds else {}))
     from geoa3_amd.distributed import shard_bounds
     from geoa3_amd.pointnet import PointNet
 
@@ -299,7 +310,7 @@ def main():
             runner.step(s, 0)
         torch.cuda.synchronize()
         runner.geo_stream = geo_stream
-        for tag in range(6):
+        for tag in range(8):
             if tag != dominant_tag:
                 ms[tag] = kernel_ms(tag)
         lib.geoa3_profile_select(0xFFFFFFFF)
@@ -378,7 +389,7 @@ def main():
                           "layers, Gram product) carry each fp32 operand as two fp16 values on the f16 MFMA (3 products "
                           "per fp32 product) -- error against float64 no larger than the fp32 MFMA kernels', "
                           "tools/wide_accuracy.py, DESIGN.md 4a; GEOA3_WIDE_MODE=f32 selects fp32 MFMA (other_wide_mode)",
-            "data": "synthetic",
+            "data": "synthetic" if a.data == "ellipsoid" else "synthetic (%s)" % a.data,
             "config": {"workload": "configs[%d]: %s %d-pt, %s, full GeoA3 (CE + CD 1.0 + HD 0.1 + curvature 1.0 k=%d), "
                                    "untargeted" % (cfg_idx, victim, npoint,
                                                    {"strong": "%d instances sharded over %d GPU(s) (%d on rank 0)"
@@ -462,7 +473,7 @@ def main():
                                 "hbm_frac": round(cd_bytes / (nn1_ms * 1e-3) / PEAK_HBM, 5),
                                 "valu_frac": round(8.0 * B * npoint * npoint / (nn1_ms * 1e-3) / PEAK_F32_VALU, 4)}
         out["kernels_ms"] = {"conv5_wide_max": kms.get(TAG_CONV5), "tnet_wide_max(x2)": kms.get(TAG_TNET),
-                             "nn1_pair": nn1_ms, "knn": kms.get(TAG_KNN), "sa1_bwd": kms.get(TAG_SA1_BWD),
+                             "nn1_pair": nn1_ms, "knn": kms.get(TAG_KNN), "geo_loss_grad": kms.get(TAG_GEO), "sa1_bwd": kms.get(TAG_SA1_BWD),
                              "sa1_fwd": kms.get(TAG_SA1_FWD),
                              "note": "the roofline kernel: HIP events inside the timed region; the others: %d untimed "
                                      "iterations right after it, on ONE stream (in the timed loop the geometry kernels "

@@ -473,6 +473,101 @@ __global__ __launch_bounds__(GEO_BLOCK) void geo_loss_grad_kernel(geoa3_geo_args
 }
 
 
+
+// ------------------------------------------------------------------------------------------
+// Order-free accumulation of gradient terms: 64-bit FIXED POINT at two scales, chosen per instance.
+//
+// Integer addition is associative, so sums of converted terms do not depend on who adds them in which order (LDS integer
+// atomics): deterministic and batch-independent without reverse lists.  Round 4 used ONE fixed scale (2^-44 per unit, every
+// term clamped silently at 2^18): right for the attack loop's magnitudes, wrong for a caller-supplied dkappa, for loss
+// weights far from 1 and for near-coincident pairs (a pair term is ~ 2 dk / r).  Now, with X = the instance's largest
+// coefficient (2 w_curv / (N k) or max |dkappa| / k; the Chamfer coefficients) and Ex = ceil(log2 X):
+//   fine    unit 2^(Ex - 40), terms up to 2^(Ex + 10):  4096 of them still fit 63 bits; X-relative precision 2^-40;
+//   coarse  unit 2^(Ex - 16), terms up to 2^(Ex + 34):  pairs down to r ~ 1e-10 at the largest coefficient -- they are
+//           rare, so their sums live in a small hash pool in LDS keyed by the destination point;
+//   beyond that (or NaN, or a full pool): the destination's gradient is written as NaN -- loud, never a silent clamp.
+// The result is fine * 2^(Ex - 40) + coarse * 2^(Ex - 16) in fp32.
+// ------------------------------------------------------------------------------------------
+struct GeoFix {
+  float to_f, to_c, from_f, from_c, lim_f, lim_c;
+};
+__device__ __forceinline__ float geo_pow2(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }   // -126 <= k <= 127
+__device__ __forceinline__ GeoFix geo_fix_make(float X) {
+  int Ex = (int)((__float_as_uint(X) >> 23) & 0xffu) - 126;        // X < 2^Ex (X = m 2^Ex, 0.5 <= m < 1)
+  Ex = Ex < -80 ? -80 : (Ex > 60 ? 60 : Ex);                        // (X = 0, denormal or absurd: any scale will do)
+  GeoFix f;
+  f.to_f = geo_pow2(40 - Ex);
+  f.to_c = geo_pow2(16 - Ex);
+  f.from_f = geo_pow2(Ex - 40);
+  f.from_c = geo_pow2(Ex - 16);
+  f.lim_f = geo_pow2(Ex + 10);
+  f.lim_c = geo_pow2(Ex + 34);
+  return f;
+}
+__device__ __forceinline__ unsigned long long geo_fix_conv(float v, float mul) {
+  return (unsigned long long)__float2ll_rn(v * mul);
+}
+// hash pool of destinations with coarse sums: key [cap] (-1 = empty), acc [cap][W] 64-bit words
+struct GeoPool {
+  int* key;
+  unsigned long long* acc;
+  int cap;   // a power of two
+};
+__device__ __forceinline__ int geo_pool_find(const GeoPool& P, int q, bool insert) {
+  unsigned h = ((unsigned)q * 0x9E3779B1u) >> 8;
+  for (int step = 0; step < P.cap; ++step) {
+    const int s = (int)((h + (unsigned)step) & (unsigned)(P.cap - 1));
+    int kk = P.key[s];
+    if (kk == q) return s;
+    if (kk == -1) {
+      if (!insert) return -1;
+      kk = atomicCAS(&P.key[s], -1, q);
+      if (kk == -1 || kk == q) return s;
+    }
+  }
+  return -1;
+}
+__device__ __forceinline__ void geo_mark_bad(unsigned* s_bad, int q) { atomicOr(&s_bad[q >> 5], 1u << (q & 31)); }
+// one gradient term of destination q: into the per-point fine sums (planes of N, or null: everything through the pool,
+// words 0-2 fine / 3-5 coarse), the pool's coarse sums, or the sticky NaN flags
+template <int W>
+__device__ __forceinline__ void geo_fix_add(const GeoFix& F, unsigned long long* fine, int N, const GeoPool& P, unsigned* s_bad,
+                                            int q, float x, float y, float z) {
+  const float m = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+  if (m <= F.lim_f) {
+    if (W == 3) {
+      atomicAdd(&fine[q], geo_fix_conv(x, F.to_f));
+      atomicAdd(&fine[N + q], geo_fix_conv(y, F.to_f));
+      atomicAdd(&fine[2 * N + q], geo_fix_conv(z, F.to_f));
+    } else {
+      const int s = geo_pool_find(P, q, true);
+      if (s < 0) return geo_mark_bad(s_bad, q);
+      atomicAdd(&P.acc[s * W + 0], geo_fix_conv(x, F.to_f));
+      atomicAdd(&P.acc[s * W + 1], geo_fix_conv(y, F.to_f));
+      atomicAdd(&P.acc[s * W + 2], geo_fix_conv(z, F.to_f));
+    }
+  } else if (m <= F.lim_c) {
+    const int s = geo_pool_find(P, q, true);
+    if (s < 0) return geo_mark_bad(s_bad, q);
+    atomicAdd(&P.acc[s * W + W - 3], geo_fix_conv(x, F.to_c));
+    atomicAdd(&P.acc[s * W + W - 2], geo_fix_conv(y, F.to_c));
+    atomicAdd(&P.acc[s * W + W - 1], geo_fix_conv(z, F.to_c));
+  } else {
+    geo_mark_bad(s_bad, q);      // out of range or NaN
+  }
+}
+constexpr int GEO_POOL_CAP = 128;                                     // geo_fused_kernel: overflowed rows (fine + coarse sums)
+constexpr size_t GEO_POOL_BYTES = GEO_POOL_CAP * (4 + 6 * 8) + 8;     // keys + sums + alignment
+constexpr int GB_POOL_CAP = 256;                                      // geo_big_kernel: destinations with coarse terms
+// the instance's largest coefficient: max |dkappa| / k over the block (dkappa mode) or the loss's analytic bound (kappa is a
+// mean of |cosines|: |kappa_adv - kappa_ori| <= 1), and the Chamfer coefficients
+__device__ __forceinline__ float geo_coef_bound(const geoa3_geo_args& A, int N, int Nr, float block_max_dkappa) {
+  const float k = (float)(A.k > 0 ? A.k : 1);
+  float X = A.dkappa ? block_max_dkappa / k : fabsf(A.w_curv) * 2.0f / ((float)N * k);
+  X = fmaxf(X, fabsf(A.w_dis) * 2.0f / (float)(N < Nr ? N : Nr));
+  return X;
+}
+
 // ------------------------------------------------------------------------------------------
 // Deterministic objective for clouds of at most 1024 points (the default there): one 1024-thread workgroup per instance
 // as above, but every (centre, neighbour) PAIR a lane and no dependent chain longer than one round trip.
@@ -579,6 +674,14 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
   float* s_red = sm + 12 * N;                             // [16 * 5 + 4]
   uint16_t* s_rows = reinterpret_cast<uint16_t*>(s_red + 16 * 5 + 4);  // [N][C + 1] source ids, fill order
   const int stride = C + 1;
+  // Rows longer than C (a dense cluster's clean points all nearest to ONE adversarial point; hubs of the K-NN graph): every
+  // term of such a destination goes through fixed-point sums in a small hash pool -- the appends beyond slot C - 1 add theirs
+  // in phase 1, the owner adds the C sources its row does hold: order-free, so still bit-reproducible.  (Round 4: the owner
+  // walked the whole table, N k entries by one thread: 27x the kernel's time on clustered clouds.)
+  GeoPool pool;
+  pool.cap = GEO_POOL_CAP;
+  pool.acc = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(s_rows + (size_t)R * stride) + 7) & ~(uintptr_t)7);
+  pool.key = reinterpret_cast<int*>(pool.acc + GEO_POOL_CAP * 6);
   // Small batches: an instance is split over gridDim.y workgroups by OWNER range [r0, r0 + R) -- every workgroup stages
   // the cloud and forms every centre's coefficient (the pulls need the sources'), but keeps rows, sorts and receives
   // only for its own points: the LDS-bound parts (appends, receives) shrink with the range.  Same bits for any split.
@@ -630,6 +733,13 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
     ly = ori[Nr + me];
     lz = ori[2 * Nr + me];
   }
+  for (int i = tid; i < GEO_POOL_CAP * 6; i += GEO_T) pool.acc[i] = 0ull;
+  for (int i = tid; i < GEO_POOL_CAP; i += GEO_T) pool.key[i] = -1;
+  float xmax = fabsf(dkap_me);
+  if (A.dkappa) {                                  // (dkappa mode only: the block's largest |dkappa|)
+    xmax = wave_max(me_valid ? xmax : 0.f);
+    if (lane == 0) s_red[wave] = xmax;
+  }
   if (me_valid) {
     s_cnt[me] = 0;
     float kori = 0.f;
@@ -643,6 +753,27 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
     s_n[me] = nv;
   }
   __syncthreads();
+  if (A.dkappa) {
+    xmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < GEO_T / 64; ++w) xmax = fmaxf(xmax, s_red[w]);
+    __syncthreads();                               // (s_red is reused by the loss reduction below)
+  }
+  const GeoFix FX = geo_fix_make(geo_coef_bound(A, N, Nr, xmax));
+  auto ovf_add = [&](int q, float x, float y, float z) {   // a term of an overflowed row
+    const float mm = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+    const int sl = (mm <= FX.lim_c) ? geo_pool_find(pool, q, true) : -1;
+    if (sl < 0) {                                          // pool full, out of range or NaN: the owner writes NaN
+      atomicOr(&s_cnt[q], (int)0x40000000);
+      return;
+    }
+    const bool fine = mm <= FX.lim_f;
+    const float mul = fine ? FX.to_f : FX.to_c;
+    const int o = sl * 6 + (fine ? 0 : 3);
+    atomicAdd(&pool.acc[o + 0], geo_fix_conv(x, mul));
+    atomicAdd(&pool.acc[o + 1], geo_fix_conv(y, mul));
+    atomicAdd(&pool.acc[o + 2], geo_fix_conv(z, mul));
+  };
 
   // ---- phase 1: pairs
   float sum_e2 = 0.f;
@@ -657,8 +788,9 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
       const int cc = cvalid ? c : N - 1;
       const int q = active ? q_all[p] : cc;
       const float4 cp = s_p[cc], nv = s_n[cc], qp = s_p[q];
+      int slot = -1;
       if (active && want_grad && (unsigned)(q - r0) < (unsigned)R) {   // the reverse list of q: source c
-        const int slot = atomicAdd(&s_cnt[q], 1);
+        slot = atomicAdd(&s_cnt[q], 1) & 0x3fffffff;
         if (slot < C) s_rows[(q - r0) * stride + slot] = (uint16_t)c;
       }
       // kappa term, as kappa_point()
@@ -674,6 +806,7 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
       geo_pair_grad(cp.x, cp.y, cp.z, nv.x, nv.y, nv.z, dk, qp.x, qp.y, qp.z, dvx, dvy, dvz, t2);
       const float sx = group_sum<G>(active ? dvx : 0.f), sy = group_sum<G>(active ? dvy : 0.f),
                   sz = group_sum<G>(active ? dvz : 0.f);
+      if (slot >= C) ovf_add(q, dvx, dvy, dvz);     // the row of q is full: this pair's pull, in fixed point
       if (m == 0 && cvalid) {
         sum_e2 += e * e;
         if (A.kappa_adv && first) A.kappa_adv[bN + c] = kap;
@@ -689,8 +822,13 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
     for (int j = tid; j < Nr; j += GEO_T) {
       const int q = j == tid ? oa_first : A.i_oa[bNr + j];
       if ((unsigned)(q - r0) >= (unsigned)R) continue;
-      const int slot = atomicAdd(&s_cnt[q], 1);
+      const int slot = atomicAdd(&s_cnt[q], 1) & 0x3fffffff;
       if (slot < C) s_rows[(q - r0) * stride + slot] = (uint16_t)(N + j);
+      else {
+        const float crj = (Nr != N) ? A.w_dis * (1.0f / (float)Nr) * 2.0f : A.w_dis * (1.0f / (float)N) * 2.0f;
+        const float4 qp = s_p[q];
+        ovf_add(q, crj * (qp.x - ori[j]), crj * (qp.y - ori[Nr + j]), crj * (qp.z - ori[2 * Nr + j]));
+      }
     }
 
   // ---- loss values and the Hausdorff arg-max
@@ -807,7 +945,8 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
       gz += cr * (pz - ori[2 * Nr + jj]);
     }
   };
-  const int ncnt = mine ? s_cnt[me] : 0;
+  const int ncnt_raw = mine ? s_cnt[me] : 0;
+  const int ncnt = ncnt_raw & 0x3fffffff;
   const int n = ncnt <= C ? ncnt : 0;
   uint16_t* L = s_rows + (mine ? me - r0 : 0) * stride;
   int nmax = n;
@@ -911,16 +1050,51 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
     }
   }
   if (ncnt > C) {
-    // overflowed row (coincident points): the owner walks the table itself, sources ascending, then the clean points
-    if (do_curv)
-      for (int src = 0; src < N; ++src) {
-        bool hit = false;
-        for (int mm = 1; mm <= k; ++mm) hit |= tab[(size_t)src * k1 + mm] == me;
-        if (hit) receive(src);
+    // overflowed row: the C sources the row holds (WHICH ones is the appends' arrival order) are converted by the owner and
+    // added to what the later arrivals put into the pool in phase 1 -- integer sums, so the split does not matter
+    long long fxs = 0, fys = 0, fzs = 0, cxs = 0, cys = 0, czs = 0;
+    bool bad = (ncnt_raw & 0x40000000) != 0;
+    for (int e = 0; e < C; ++e) {
+      const int src = (int)s_rows[(me - r0) * stride + e];
+      float dvx, dvy, dvz;
+      if (src < N) {
+        const float4 sp = s_p[src], sn = s_n[src];
+        float t2;
+        geo_pair_grad(sp.x, sp.y, sp.z, sn.x, sn.y, sn.z, sp.w, px, py, pz, dvx, dvy, dvz, t2);
+      } else {
+        const int jj = src - N;
+        dvx = cr * (px - ori[jj]);
+        dvy = cr * (py - ori[Nr + jj]);
+        dvz = cr * (pz - ori[2 * Nr + jj]);
       }
-    if (two_side)
-      for (int j = 0; j < Nr; ++j)
-        if (A.i_oa[bNr + j] == me) receive(N + j);
+      const float mm = fmaxf(fmaxf(fabsf(dvx), fabsf(dvy)), fabsf(dvz));
+      if (mm <= FX.lim_f) {
+        fxs += (long long)geo_fix_conv(dvx, FX.to_f);
+        fys += (long long)geo_fix_conv(dvy, FX.to_f);
+        fzs += (long long)geo_fix_conv(dvz, FX.to_f);
+      } else if (mm <= FX.lim_c) {
+        cxs += (long long)geo_fix_conv(dvx, FX.to_c);
+        cys += (long long)geo_fix_conv(dvy, FX.to_c);
+        czs += (long long)geo_fix_conv(dvz, FX.to_c);
+      } else {
+        bad = true;
+      }
+    }
+    const int sl = geo_pool_find(pool, me, false);
+    if (sl >= 0) {
+      fxs += (long long)pool.acc[sl * 6 + 0];
+      fys += (long long)pool.acc[sl * 6 + 1];
+      fzs += (long long)pool.acc[sl * 6 + 2];
+      cxs += (long long)pool.acc[sl * 6 + 3];
+      cys += (long long)pool.acc[sl * 6 + 4];
+      czs += (long long)pool.acc[sl * 6 + 5];
+    } else {
+      bad = true;       // (a row overflows only through appends that reached the pool: it was full)
+    }
+    gx += __ll2float_rn(fxs) * FX.from_f + __ll2float_rn(cxs) * FX.from_c;
+    gy += __ll2float_rn(fys) * FX.from_f + __ll2float_rn(cys) * FX.from_c;
+    gz += __ll2float_rn(fzs) * FX.from_f + __ll2float_rn(czs) * FX.from_c;
+    if (bad) gx = gy = gz = __builtin_nanf("");
   }
   if (mine) {
     float* Gd = A.grad + (size_t)b * 3 * N;
@@ -955,12 +1129,6 @@ __global__ __launch_bounds__(256) void geo_big_gather_kernel(geoa3_geo_args A, f
   ctr[bN + i] = make_float4(Nm[nn], Nm[Nr + nn], Nm[2 * Nr + nn], A.kappa_ori ? A.kappa_ori[bNr + nn] : 0.f);
 }
 
-constexpr float GB_FIX = 17592186044416.0f;        // 2^44
-__device__ __forceinline__ unsigned long long gb_fix(float v) {
-  v = fminf(fmaxf(v, -262144.0f), 262144.0f);
-  return (unsigned long long)__float2ll_rn(v * GB_FIX);
-}
-
 template <int G>
 __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const float4* __restrict__ ctr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -969,6 +1137,11 @@ __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const f
   unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(sm);   // [3][N] fixed-point sums: own curvature term + pulls
   float* s_pos = reinterpret_cast<float*>(s_acc + 3 * N);                  // [N][3]
   float* s_red = s_pos + 3 * N;                                            // [16 * 5 + 4]
+  GeoPool pool;                                                            // destinations with coarse-scale terms
+  pool.cap = GB_POOL_CAP;
+  pool.acc = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(s_red + 16 * 5 + 4) + 7) & ~(uintptr_t)7);
+  pool.key = reinterpret_cast<int*>(pool.acc + GB_POOL_CAP * 3);
+  unsigned* s_bad = reinterpret_cast<unsigned*>(pool.key + GB_POOL_CAP);   // [ceil(N / 32)] sticky "not representable"
   const size_t bN = (size_t)b * N, bNr = (size_t)b * Nr;
   const float* adv = A.adv + bN * 3;
   const float* ori = A.ori + bNr * 3;
@@ -985,7 +1158,23 @@ __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const f
     s_acc[N + i] = 0ull;
     s_acc[2 * N + i] = 0ull;
   }
+  for (int i = tid; i < GB_POOL_CAP * 3; i += GB_T) pool.acc[i] = 0ull;
+  for (int i = tid; i < GB_POOL_CAP; i += GB_T) pool.key[i] = -1;
+  for (int i = tid; i < (N + 31) / 32; i += GB_T) s_bad[i] = 0u;
+  float xmax = 0.f;
+  if (A.dkappa) {                                  // (dkappa mode only: the block's largest |dkappa|)
+    for (int i = tid; i < N; i += GB_T) xmax = fmaxf(xmax, fabsf(A.dkappa[bN + i]));
+    xmax = wave_max(xmax);
+    if (lane == 0) s_red[wave] = xmax;
+  }
   __syncthreads();
+  if (A.dkappa) {
+    xmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < GB_T / 64; ++w) xmax = fmaxf(xmax, s_red[w]);
+    __syncthreads();                               // (s_red is reused by the loss reduction below)
+  }
+  const GeoFix FX = geo_fix_make(geo_coef_bound(A, N, Nr, xmax));
   const float invN = 1.0f / (float)N;
   // ---- pairs: lane = (centre c, neighbour m); kappa_adv[c] and the centre's coefficient by a G-lane butterfly, then the
   // pair's term goes to q's sums and its negative, summed over m, to c's (geo_fused_kernel's phase 1, same expressions)
@@ -1026,11 +1215,7 @@ __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const f
         geo_pair_grad(cx, cy, cz, nv.x, nv.y, nv.z, dk, qx, qy, qz, dvx, dvy, dvz, t2);
         const float sx = group_sum<G>(active ? dvx : 0.f), sy = group_sum<G>(active ? dvy : 0.f),
                     sz = group_sum<G>(active ? dvz : 0.f);
-        if (active && want_grad) {
-          atomicAdd(&s_acc[q[u]], gb_fix(dvx));
-          atomicAdd(&s_acc[N + q[u]], gb_fix(dvy));
-          atomicAdd(&s_acc[2 * N + q[u]], gb_fix(dvz));
-        }
+        if (active && want_grad) geo_fix_add<3>(FX, s_acc, N, pool, s_bad, q[u], dvx, dvy, dvz);
         if (m == 0 && cvalid) {
           sum_e2 += e * e;
           if (A.kappa_adv) A.kappa_adv[bN + c] = kap;
@@ -1052,9 +1237,7 @@ __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const f
             sy = m == u ? csy[u] : sy;
             sz = m == u ? csz[u] : sz;
           }
-          atomicAdd(&s_acc[c], gb_fix(-sx));
-          atomicAdd(&s_acc[N + c], gb_fix(-sy));
-          atomicAdd(&s_acc[2 * N + c], gb_fix(-sz));
+          geo_fix_add<3>(FX, s_acc, N, pool, s_bad, c, -sx, -sy, -sz);
         }
       }
     }
@@ -1064,9 +1247,8 @@ __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const f
   if (two_side && want_grad)          // clean point j pulls on its nearest adversarial point
     for (int j = tid; j < Nr; j += GB_T) {
       const int q = A.i_oa[bNr + j];
-      atomicAdd(&s_acc[q], gb_fix(cr * (s_pos[3 * q] - ori[j])));
-      atomicAdd(&s_acc[N + q], gb_fix(cr * (s_pos[3 * q + 1] - ori[Nr + j])));
-      atomicAdd(&s_acc[2 * N + q], gb_fix(cr * (s_pos[3 * q + 2] - ori[2 * Nr + j])));
+      geo_fix_add<3>(FX, s_acc, N, pool, s_bad, q, cr * (s_pos[3 * q] - ori[j]), cr * (s_pos[3 * q + 1] - ori[Nr + j]),
+                     cr * (s_pos[3 * q + 2] - ori[2 * Nr + j]));
     }
   // ---- loss values and the Hausdorff arg-max, fixed order
   float sum_ao = 0.f, sum_oa = 0.f;
@@ -1149,9 +1331,18 @@ __global__ __launch_bounds__(GB_T) void geo_big_kernel(geoa3_geo_args A, const f
       gy += c * (py - ori[Nr + i]);
       gz += c * (pz - ori[2 * Nr + i]);
     }
-    gx += __ll2float_rn((long long)s_acc[i]) * (1.0f / GB_FIX);
-    gy += __ll2float_rn((long long)s_acc[N + i]) * (1.0f / GB_FIX);
-    gz += __ll2float_rn((long long)s_acc[2 * N + i]) * (1.0f / GB_FIX);
+    float ax = __ll2float_rn((long long)s_acc[i]) * FX.from_f, ay = __ll2float_rn((long long)s_acc[N + i]) * FX.from_f,
+          az = __ll2float_rn((long long)s_acc[2 * N + i]) * FX.from_f;
+    const int sl = geo_pool_find(pool, i, false);
+    if (sl >= 0) {
+      ax += __ll2float_rn((long long)pool.acc[sl * 3 + 0]) * FX.from_c;
+      ay += __ll2float_rn((long long)pool.acc[sl * 3 + 1]) * FX.from_c;
+      az += __ll2float_rn((long long)pool.acc[sl * 3 + 2]) * FX.from_c;
+    }
+    gx += ax;
+    gy += ay;
+    gz += az;
+    if ((s_bad[i >> 5] >> (i & 31)) & 1u) gx = gy = gz = __builtin_nanf("");   // a term beyond 2^34 X, a NaN, or a full pool
     Gd[i] = gx;
     Gd[N + i] = gy;
     Gd[2 * N + i] = gz;
@@ -1191,7 +1382,7 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
     if (two_side && !a->i_oa) return GEOA3_EINVAL;
     const int per = (do_curv ? a->k : 0) + (two_side ? (Nr + N - 1) / N : 0);
     const size_t fixed = ((size_t)12 * N + 16 * 5 + 4) * sizeof(float);
-    const size_t room = 160 * 1024 - 256 - fixed;
+    const size_t room = 160 * 1024 - 256 - fixed - GEO_POOL_BYTES;
     // owner ranges per instance: enough workgroups for the chip when the batch is small (a function of the batch size only
     // -- and the results do not depend on it)
     int S = 1;
@@ -1201,7 +1392,7 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
     const int Cfit = (int)(room / ((size_t)R * sizeof(uint16_t))) - 1;
     if (C > Cfit) C = Cfit;
     if (N + Nr < 65535 && C >= 32 && 2 * C >= 3 * per + 16) {
-      const size_t lds = fixed + (size_t)R * (C + 1) * sizeof(uint16_t);
+      const size_t lds = fixed + (size_t)R * (C + 1) * sizeof(uint16_t) + GEO_POOL_BYTES;
       int G = 1;
       while (G < a->k && do_curv) G *= 2;
       hipStream_t s = geoa3_stream(stream);
@@ -1236,7 +1427,7 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
       if (G < 16) G = 16;
       float4* ctr = reinterpret_cast<float4*>(a->scratch);
       hipStream_t s = geoa3_stream(stream);
-      const size_t lds2 = (size_t)36 * N + (16 * 5 + 4) * sizeof(float);
+      const size_t lds2 = (size_t)36 * N + (16 * 5 + 4) * sizeof(float) + 8 + GB_POOL_CAP * (3 * 8 + 4) + ((size_t)(N + 31) / 32) * 4;
       geoa3_prof_begin(GEOA3_PROF_GEO, s);
       hipLaunchKernelGGL(geo_big_gather_kernel, dim3((N + 255) / 256, a->B), dim3(256), 0, s, *a, ctr);
 #define GEOA3_BIG_CASE(GG)                                                                                             \

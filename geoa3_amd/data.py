@@ -94,9 +94,106 @@ def synthetic_clouds(M: int, N: int, seed: int = 0):
     return pts.contiguous().float(), nrm.contiguous().float()
 
 
-def write_synthetic_mat(path: str, labels: List[int], N: int, seed: int = 0) -> str:
-    """Write a `.mat` in the reference schema with len(labels) synthetic instances."""
-    data, normal = synthetic_clouds(len(labels), N, seed)
+def _box_surface(g, n, ext, centre=(0.0, 0.0, 0.0)):
+    """n points uniform by area on the six faces of an axis-aligned box of half-extents ext, outward normals."""
+    ext = torch.as_tensor(ext, dtype=torch.float32)
+    area = torch.stack([ext[1] * ext[2], ext[0] * ext[2], ext[0] * ext[1]]).repeat_interleave(2)    # +x -x +y -y +z -z
+    face = torch.multinomial(area / area.sum(), n, replacement=True, generator=g)
+    axis, sign = face // 2, 1.0 - 2.0 * (face % 2).float()
+    p = (torch.rand(n, 3, generator=g) * 2 - 1) * ext
+    p[torch.arange(n), axis] = sign * ext[axis]
+    nrm = torch.zeros(n, 3)
+    nrm[torch.arange(n), axis] = sign
+    return p + torch.as_tensor(centre, dtype=torch.float32), nrm
+
+
+def _ellipsoid_surface(g, n, axes, centre=(0.0, 0.0, 0.0)):
+    axes = torch.as_tensor(axes, dtype=torch.float32)
+    u = torch.randn(n, 3, generator=g)
+    u = u / u.norm(dim=1, keepdim=True).clamp(min=1e-12)
+    nrm = u / axes
+    return u * axes + torch.as_tensor(centre, dtype=torch.float32), nrm / nrm.norm(dim=1, keepdim=True).clamp(min=1e-12)
+
+
+def _cylinder_surface(g, n, radius, half_len, centre=(0.0, 0.0, 0.0)):
+    """side + two caps of a cylinder along z, by area."""
+    a_side, a_cap = 2 * np.pi * radius * 2 * half_len, np.pi * radius * radius
+    part = torch.multinomial(torch.tensor([a_side, a_cap, a_cap], dtype=torch.float32), n, replacement=True, generator=g)
+    th = torch.rand(n, generator=g) * (2 * np.pi)
+    r = torch.where(part == 0, torch.full((n,), float(radius)), radius * torch.rand(n, generator=g).sqrt())
+    z = torch.where(part == 0, (torch.rand(n, generator=g) * 2 - 1) * half_len,
+                    torch.where(part == 1, torch.full((n,), float(half_len)), torch.full((n,), -float(half_len))))
+    p = torch.stack([r * th.cos(), r * th.sin(), z], 1)
+    nrm = torch.stack([th.cos(), th.sin(), torch.zeros(n)], 1)
+    nrm[part == 1] = torch.tensor([0.0, 0.0, 1.0])
+    nrm[part == 2] = torch.tensor([0.0, 0.0, -1.0])
+    return p + torch.as_tensor(centre, dtype=torch.float32), nrm
+
+
+CAD_KINDS = ("box", "table", "clusters", "rod", "ellipsoid2")
+
+
+def synthetic_cad_clouds(M: int, N: int, seed: int = 0, duplicates: float = 0.05, kinds=CAD_KINDS):
+    """Seeded clouds shaped like the reference's data -- ModelNet CAD models sampled on their surfaces
+    (Provider/gen_data_mat.py:142-159,161-306): planar faces, thin parts, strongly non-uniform density, exact coordinate
+    repeats -- where `synthetic_clouds` is the friendliest input the searches, FPS and ball queries can get (one
+    ellipsoid, uniform).  Instance j is of kind kinds[j % len(kinds)] (default: all five in turn):
+      box         six planar faces of a random box;
+      table       a thin slab on four thin legs (40 % of the points on the legs);
+      clusters    a large ellipsoid carrying 25 % of the points and a small one (1/8 of its size) carrying 75 %;
+      rod         a thin cylinder (radius 3 % of its length) with caps;
+      ellipsoid2  `synthetic_clouds`' ellipsoid with 10 % of the points on a second, smaller one.
+    `duplicates` of the points are exact copies of other points (coordinates and normal).  Analytic unit normals; centred
+    on the mean and scaled to unit maximum radius as gen_data_mat.py:153-157.  -> (data [M,3,N], normal [M,3,N]) float32."""
+    g = torch.Generator().manual_seed(seed)
+    data, normal = torch.empty(M, 3, N), torch.empty(M, 3, N)
+    for j in range(M):
+        kind = kinds[j % len(kinds)]
+        r = torch.rand(8, generator=g)
+        if kind == "box":
+            p, nr = _box_surface(g, N, (0.3 + 0.7 * r[0], 0.3 + 0.7 * r[1], 0.1 + 0.9 * r[2]))
+        elif kind == "table":
+            w, d, h, t = 0.6 + 0.4 * r[0], 0.4 + 0.4 * r[1], 0.5 + 0.4 * r[2], 0.03 + 0.03 * r[3]
+            n_leg = int(0.1 * N)
+            parts = [_box_surface(g, N - 4 * n_leg, (w, d, t), (0.0, 0.0, float(h)))]
+            for sx in (-1.0, 1.0):
+                for sy in (-1.0, 1.0):
+                    parts.append(_box_surface(g, n_leg, (t, t, h / 2), (float(sx * (w - 2 * t)), float(sy * (d - 2 * t)), float(h / 2))))
+            p, nr = torch.cat([q[0] for q in parts]), torch.cat([q[1] for q in parts])
+        elif kind == "clusters":
+            n_big = N // 4
+            a = 0.5 + 0.5 * r[:3]
+            pb, nb = _ellipsoid_surface(g, n_big, a)
+            ps, ns = _ellipsoid_surface(g, N - n_big, a / 8, (float(1.3 * a[0]), float(0.2 * r[3]), float(0.2 * r[4])))
+            p, nr = torch.cat([pb, ps]), torch.cat([nb, ns])
+        elif kind == "rod":
+            p, nr = _cylinder_surface(g, N, 0.03 + 0.02 * float(r[0]), 1.0)
+            rot = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+            p, nr = p @ rot.T, nr @ rot.T
+        else:
+            n2 = N // 10
+            a = 0.3 + 0.7 * r[:3]
+            p1, n1 = _ellipsoid_surface(g, N - n2, a)
+            p2, n2_ = _ellipsoid_surface(g, n2, a * 0.3, (float(0.9 * a[0]), 0.0, float(0.5 * a[2])))
+            p, nr = torch.cat([p1, p2]), torch.cat([n1, n2_])
+        perm = torch.randperm(N, generator=g)
+        p, nr = p[perm], nr[perm]
+        n_dup = int(duplicates * N)
+        if n_dup > 0:
+            src = torch.randint(0, N - n_dup, (n_dup,), generator=g)
+            p[N - n_dup:], nr[N - n_dup:] = p[src], nr[src]
+        p = p - p.mean(0, keepdim=True)
+        p = p / p.norm(dim=1).max()
+        data[j], normal[j] = p.t(), nr.t()
+    return data.contiguous().float(), normal.contiguous().float()
+
+
+SYNTHETIC_GENERATORS = {"ellipsoid": synthetic_clouds, "cad": synthetic_cad_clouds}
+
+
+def write_synthetic_mat(path: str, labels: List[int], N: int, seed: int = 0, kind: str = "ellipsoid") -> str:
+    """Write a `.mat` in the reference schema with len(labels) synthetic instances (kind: SYNTHETIC_GENERATORS)."""
+    data, normal = SYNTHETIC_GENERATORS[kind](len(labels), N, seed)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     savemat(path, {"data": data.numpy(), "normal": normal.numpy(),
                    "label": np.asarray(labels, dtype=np.int64).reshape(-1, 1)})

@@ -83,6 +83,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--quiet", action="store_true", default=False)
     p.add_argument("--synthetic_npoint", type=int, default=0,
                    help="points per synthetic cloud when --synthetic writes the data file (default: --npoint)")
+    p.add_argument("--synthetic_kind", default="ellipsoid", choices=["ellipsoid", "cad"],
+                   help="what --synthetic writes: one ellipsoid per instance, or CAD-like clouds (boxes, tables on thin "
+                        "legs, clusters of very different density, rods, exact duplicates)")
     return p
 
 
@@ -245,7 +248,7 @@ def main(cfg):
     if not os.path.isfile(cfg.data_dir_file) and cfg.synthetic:
         if rank == 0:
             labels = [TEN_LABEL_INDEXES[i // 25] for i in range(250)]
-            write_synthetic_mat(cfg.data_dir_file, labels, cfg.synthetic_npoint or cfg.npoint, seed=0)
+            write_synthetic_mat(cfg.data_dir_file, labels, cfg.synthetic_npoint or cfg.npoint, seed=0, kind=cfg.synthetic_kind)
         if world > 1:
             dist.barrier()
     dataset = ModelNet40(data_mat_file=cfg.data_dir_file, attack_label=cfg.attack_label, resample_num=-1)

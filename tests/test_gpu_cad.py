@@ -1,0 +1,167 @@
+"""The data-dependent kernels of the hot path on clouds shaped like the reference's data (`geoa3_amd.data.synthetic_cad_clouds`:
+planar boxes, a slab on thin legs, two clusters of very different density, rods, exact duplicates) instead of the one
+uniform ellipsoid every other test and bench line uses: grid 1-NN, slab / cell-grid K-NN, FPS, ball query and the
+objective stay bit-exact / within their bars.  Reference: Provider/gen_data_mat.py:142-159 (what the data looks like),
+Lib/loss_utils.py:25-97, pointnet2_ops `_ext-src/src/{sampling,ball_query}_gpu.cu`."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geoa3_oracle as O
+from oracle import pointnet2_oracle as P2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from geoa3_amd import ops as _ops
+    assert torch.cuda.is_available(), "needs the MI355X"
+    return _ops
+
+
+def dev(x):
+    return x.contiguous().cuda()
+
+
+def _cad(B, N, seed):
+    from geoa3_amd.data import synthetic_cad_clouds
+    return synthetic_cad_clouds(B, N, seed=seed)
+
+
+def test_generator_is_seeded_normalised_and_holds_duplicates():
+    from geoa3_amd.data import CAD_KINDS
+    a, n = _cad(10, 512, 3)
+    b, _ = _cad(10, 512, 3)
+    assert torch.equal(a, b) and a.shape == (10, 3, 512)
+    np.testing.assert_allclose(a.norm(dim=1).max(dim=1)[0].numpy(), 1.0, atol=1e-6)      # gen_data_mat.py:153-157
+    np.testing.assert_allclose(a.mean(dim=2).numpy(), 0.0, atol=2e-6)
+    np.testing.assert_allclose(n.norm(dim=1).numpy(), 1.0, atol=1e-5)
+    for j in range(10):
+        uniq = torch.unique(a[j].t(), dim=0).shape[0]
+        assert uniq <= 512 - 20, (CAD_KINDS[j % 5], uniq)                                 # 5 % exact repeats
+
+
+@pytest.mark.parametrize("N,scale", [(1024, 0.003), (1024, 0.05), (4096, 0.01), (300, 0.02)])
+def test_nn1_grid_and_pair_bit_exact_on_cad_clouds(ops, N, scale):
+    B = 10                                            # two instances of every kind
+    ori, _ = _cad(B, N, seed=N)
+    g = torch.Generator().manual_seed(N + 1)
+    adv = ori + scale * torch.randn(B, 3, N, generator=g)
+    want = ops.nn1_pair(dev(adv), dev(ori))
+    got = ops.nn1_pair(dev(adv), dev(ori), method="grid")
+    for w, x in zip(want, got):
+        assert torch.equal(w, x)
+    od, oi = O.knn_points(adv.permute(0, 2, 1), ori.permute(0, 2, 1), 1)
+    assert torch.equal(got[1].cpu().long(), oi[:, :, 0]) and torch.equal(got[0].cpu(), od[:, :, 0])
+    od, oi = O.knn_points(ori.permute(0, 2, 1), adv.permute(0, 2, 1), 1)
+    assert torch.equal(got[3].cpu().long(), oi[:, :, 0]) and torch.equal(got[2].cpu(), od[:, :, 0])
+    again = ops.nn1_pair(dev(adv), dev(ori), method="grid", prior=(want[1].clone(), want[3].clone()))
+    for w, x in zip(want, again):
+        assert torch.equal(w, x)
+
+
+@pytest.mark.parametrize("N,K,scale", [(1024, 17, 0.003), (1024, 17, 0.05), (4096, 33, 0.01), (700, 9, 0.02)])
+def test_self_knn_all_methods_bit_exact_on_cad_clouds(ops, N, K, scale):
+    B = 5
+    ori, _ = _cad(B, N, seed=N + K)
+    g = torch.Generator().manual_seed(K)
+    adv = ori + scale * torch.randn(B, 3, N, generator=g)
+    advD, oriD = dev(adv), dev(ori)
+    bd, bi = ops.knn_planar(advD, advD, K)
+    od, oi = O.knn_points(adv.permute(0, 2, 1), adv.permute(0, 2, 1), K)
+    assert torch.equal(bi.cpu().long(), oi) and torch.equal(bd.cpu(), od)
+    scratch = ops.knn_self_scratch(B, N, advD.device)
+    _, clean = ops.knn_planar(oriD, oriD, K)        # the clean cloud's table: duplicates give exact ties in it
+    for method in (1, 2, 0) + ((3, 4) if K <= 40 else ()):
+        for prior in (clean, None):
+            if prior is None and method in (3, 4):
+                continue
+            d, i = ops.knn_self_planar(advD, K, prior=prior, scratch=scratch, method=method)
+            assert torch.equal(i, bi) and torch.equal(d, bd), (method, prior is None)
+
+
+@pytest.mark.parametrize("N,k", [(1024, 16), (2048, 16), (4096, 32)])
+def test_objective_on_cad_clouds_matches_oracle(ops, N, k):
+    """CD + HD + curvature values and d / d adv (deterministic path: fused kernel up to 1024 points, the fixed-point
+    kernel beyond) on planar / clustered / duplicated clouds; the oracle's autograd is the reference composition
+    (Lib/loss_utils.py:28-97)."""
+    B = 5
+    ori, nrm = _cad(B, N, seed=7 * N)
+    g = torch.Generator().manual_seed(N)
+    adv = ori + 0.01 * torch.randn(B, 3, N, generator=g)
+    a = adv.clone().requires_grad_()
+    ka, _ = O.get_kappa_adv(a, ori, nrm, k)
+    con = O.chamfer_loss(a, ori) + 0.1 * O.hausdorff_loss(a, ori) + O.curvature_loss(a, ori, ka, O.get_kappa_ori(ori, nrm, k))
+    (gw,) = torch.autograd.grad(con.sum(), a)
+    advD, oriD, nrmD = dev(adv), dev(ori), dev(nrm)
+    d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(advD, oriD)
+    _, knn_ori = ops.knn_planar(oriD, oriD, k + 1)
+    kap = ops.kappa(oriD, nrmD, knn_ori)
+    _, knn_adv = ops.knn_planar(advD, advD, k + 1)
+    out = ops.geo_loss_grad(advD, oriD, normal_ori=nrmD, kappa_ori=kap, d_ao=d_ao, i_ao=i_ao, d_oa=d_oa, i_oa=i_oa,
+                            knn_adv=knn_adv, k=k, w_dis=1.0, w_hd=0.1, w_curv=1.0, deterministic=True)
+    grad = out["grad"]
+    np.testing.assert_allclose(out["constrain"].cpu().numpy(), con.detach().numpy(), rtol=5e-5, atol=1e-7)
+    # duplicated points make pairs at distance exactly 0 (the reference's clamp(min=1e-12) regime): compare where the
+    # oracle's own gradient is finite and on the scale of the rest
+    gn, wn = grad.cpu().numpy(), gw.numpy()
+    scale = np.abs(wn).max()
+    np.testing.assert_allclose(gn, wn, rtol=2e-3, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("N,m", [(1024, 512), (512, 128), (4096, 1024)])
+def test_fps_and_ball_query_exact_on_cad_clouds(N, m):
+    from geoa3_amd import pointnet2
+    B = 10
+    pts, _ = _cad(B, N, seed=50 + N)
+    xyz = pts.permute(0, 2, 1).contiguous()
+    got = pointnet2.ext.furthest_point_sampling(xyz.cuda(), m).cpu()
+    want = P2.furthest_point_sampling(xyz, m)
+    assert torch.equal(got, want)
+    centres = torch.gather(xyz, 1, want.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    for r, ns in ((0.2, 64), (0.4, 64), (0.05, 16)):
+        gq = pointnet2.ext.ball_query(centres.cuda(), xyz.cuda(), r, ns).cpu()
+        assert torch.equal(gq, P2.ball_query(centres, xyz, r, ns)), (r, ns)
+
+
+def _merge_twins(grad, pts):
+    """Sum the gradient over groups of exactly coincident points (which twin wins a pooling / grouping tie is free)."""
+    out = np.zeros_like(grad)
+    for b in range(pts.shape[0]):
+        _, inv = np.unique(pts[b].T, axis=0, return_inverse=True)
+        inv = np.asarray(inv).reshape(-1)
+        acc = np.zeros((3, inv.max() + 1), dtype=np.float64)
+        np.add.at(acc.T, inv, grad[b].T.astype(np.float64))
+        first = np.full(inv.max() + 1, -1)
+        for i, gidx in enumerate(inv):
+            if first[gidx] < 0:
+                first[gidx] = i
+        out[b][:, first] = acc.astype(np.float32)
+    return out
+
+
+def test_pointnetpp_native_path_on_cad_clouds_matches_oracle():
+    """The native SSG classifier (geoa3_pn2ssg_forward / _backward) against the CPU restatement of the reference's
+    classifier (Model/PointNetPP_ssg.py:106-124 over the `_ext` restatement) on CAD clouds: ball queries on thin legs and
+    dense clusters pad / truncate very differently from the ellipsoid's.  Logits at the PointNet bar; the input gradient
+    with coincident twins merged."""
+    from geoa3_amd import pointnet2
+    sd = P2.make_pn2_state_dict(0)
+    net = pointnet2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    pts, _ = _cad(5, 1024, seed=9)
+    xa = pts.cuda().requires_grad_()
+    assert net.native_eligible(xa)
+    la = net(xa)
+    w = torch.randn(la.shape, generator=torch.Generator().manual_seed(1))
+    (la * w.cuda()).sum().backward()
+    xo = pts.clone().requires_grad_()
+    lo = P2.pointnet2_ssg_forward(sd, xo)
+    (lo * w).sum().backward()
+    np.testing.assert_allclose(la.detach().cpu().numpy(), lo.detach().numpy(), rtol=1e-4, atol=3e-4)
+    want, got = _merge_twins(xo.grad.numpy(), pts.numpy()), _merge_twins(xa.grad.cpu().numpy(), pts.numpy())
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * np.abs(want).max())

@@ -479,3 +479,94 @@ def test_fixed_point_objective_for_big_clouds(ops, N, Nr, k, kind):
     a0 = ops.geo_loss_grad(advD, oriD, deterministic=True, dkappa=dk, scratch=False, **vjp)
     np.testing.assert_allclose(a1["grad"].cpu()[:, :, keep].numpy(), a0["grad"].cpu()[:, :, keep].numpy(), rtol=2e-4,
                                atol=2e-6 * max(a0["grad"].abs().max().item(), 1.0))
+
+
+@pytest.mark.parametrize("N,k,case", [(2048, 16, "dkappa1e4"), (4096, 32, "dkappa1e4"), (2048, 16, "near1e-6"),
+                                      (4096, 32, "near1e-6"), (2048, 16, "weights"), (2048, 16, "all")])
+def test_fixed_point_objective_outside_the_attack_loops_magnitudes(ops, N, k, case):
+    """geo_big_kernel's 64-bit fixed-point sums take their scales from the instance (GeoFix: fine + coarse, no silent
+    clamp): a caller-supplied dkappa ~ N(0, 1e4) (the operator-level VJP of _get_kappa_adv, Lib/loss_utils.py:64-82),
+    pairs 1e-6 apart (NOT coincident: pair terms ~ 2 dk / r), w_dis = 1e-3 with w_curv = 1e3.  Against the one-workgroup
+    kernel (fp32 ordered sums) at rtol 2e-4, against the oracle at N = 2048; bit-reproducible."""
+    B = 2
+    ori, nrm = O.make_synthetic_clouds(B, N, seed=N + 3)
+    g = torch.Generator().manual_seed(N + len(case))
+    adv = ori + 0.02 * torch.randn(B, 3, N, generator=g)
+    if case in ("near1e-6", "all"):
+        for j in range(40, 60):                                  # twenty pairs at ~1e-6
+            adv[:, :, 200 + j] = adv[:, :, j] + 1e-6 * torch.randn(B, 3, generator=g)
+    w_dis, w_curv = (1e-3, 1e3) if case in ("weights", "all") else (1.0, 1.0)
+    kw, advD, oriD = _objective_inputs(ops, adv, ori, nrm, k)
+    kw.update(w_dis=w_dis, w_curv=w_curv, w_hd=0.1)
+    new = ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)
+    old = ops.geo_loss_grad(advD, oriD, deterministic=True, scratch=False, **kw)
+    gn, go = new["grad"].cpu().numpy(), old["grad"].cpu().numpy()
+    assert np.isfinite(gn).all()
+    np.testing.assert_allclose(gn, go, rtol=2e-4, atol=2e-7 * np.abs(go).max())
+    if N <= 2048:
+        a = adv.clone().requires_grad_()
+        ka, _ = O.get_kappa_adv(a, ori, nrm, k)
+        con = w_dis * O.chamfer_loss(a, ori) + 0.1 * O.hausdorff_loss(a, ori) + w_curv * O.curvature_loss(a, ori, ka, O.get_kappa_ori(ori, nrm, k))
+        (gw,) = torch.autograd.grad(con.sum(), a)
+        np.testing.assert_allclose(gn, gw.numpy(), rtol=2e-4, atol=2e-6 * float(gw.abs().max()))
+    assert torch.equal(ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)["grad"], new["grad"])
+    if case in ("dkappa1e4", "all"):
+        dk = (1e2 * torch.randn(B, N, generator=g)).cuda() * 1e2     # ~ N(0, 1e4)
+        vjp = dict(kw)
+        vjp.update(w_dis=0.0, w_hd=0.0, w_curv=0.0, dis_type=0)
+        a1 = ops.geo_loss_grad(advD, oriD, deterministic=True, dkappa=dk, **vjp)["grad"]
+        a0 = ops.geo_loss_grad(advD, oriD, deterministic=True, dkappa=dk, scratch=False, **vjp)["grad"]
+        assert torch.isfinite(a1).all()
+        np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=2e-4, atol=2e-7 * float(a0.abs().max()))
+        assert torch.equal(ops.geo_loss_grad(advD, oriD, deterministic=True, dkappa=dk, **vjp)["grad"], a1)
+
+
+def test_fixed_point_objective_is_loud_about_nan_and_huge_terms(ops):
+    """A NaN coordinate, or a pair term beyond the coarse range (dkappa = 1e30 on a pair 1e-7 apart), poisons the gradient of
+    the points it reaches with NaN instead of clamping silently (round 4: every term clamped to +-2^18, a NaN became
+    -262144)."""
+    B, N, k = 2, 2048, 16
+    ori, nrm = O.make_synthetic_clouds(B, N, seed=5)
+    g = torch.Generator().manual_seed(1)
+    adv = ori + 0.02 * torch.randn(B, 3, N, generator=g)
+    kw, advD, oriD = _objective_inputs(ops, adv, ori, nrm, k)
+    bad = advD.clone()
+    bad[0, 1, 77] = float("nan")
+    got = ops.geo_loss_grad(bad, oriD, deterministic=True, **kw)["grad"]
+    assert torch.isnan(got[0, :, 77]).all() and torch.isfinite(got[1]).all()
+    adv2 = adv.clone()
+    adv2[:, :, 301] = adv2[:, :, 300] + 1e-7
+    kw2, adv2D, _ = _objective_inputs(ops, adv2, ori, nrm, k)
+    dk = torch.ones(B, N).cuda()
+    dk[0, 300] = 1e30
+    vjp = dict(kw2)
+    vjp.update(w_dis=0.0, w_hd=0.0, w_curv=0.0, dis_type=0)
+    got = ops.geo_loss_grad(adv2D, oriD, deterministic=True, dkappa=dk, **vjp)["grad"]
+    assert not torch.isfinite(got[0, :, 301]).all()        # (NaN, or the one-workgroup kernel's inf: never a finite clamp)
+    assert torch.isfinite(got[1]).all()
+
+
+@pytest.mark.parametrize("N,k,nblob", [(1024, 16, 700), (1024, 16, 120), (512, 8, 300), (700, 16, 60)])
+def test_pair_parallel_objective_with_overflowing_reverse_lists(ops, N, k, nblob):
+    """geo_fused_kernel's rows hold ~50 sources; a destination with more -- here `nblob` clean points of a tiny dense blob
+    whose common nearest adversarial point is ONE point (what a CAD cloud with a small dense part looks like once the
+    offsets exceed the blob's size), plus hubs of the K-NN graph -- goes through the fixed-point pool.  Values and gradients
+    against the oracle's autograd (Lib/loss_utils.py:28-97), reproducible, batch-independent."""
+    B = 3
+    ori, nrm = O.make_synthetic_clouds(B, N, seed=N + nblob)
+    g = torch.Generator().manual_seed(nblob)
+    ori[:, :, :nblob] = ori[:, :, :1] * 1.5 + 1e-3 * torch.randn(B, 3, nblob, generator=g)     # the blob, off the surface
+    adv = ori + 0.02 * torch.randn(B, 3, N, generator=g)
+    adv[:, :, 1:nblob] += 0.5 * torch.randn(B, 3, nblob - 1, generator=g)                        # its points have left; point 0 stays
+    kw, advD, oriD = _objective_inputs(ops, adv, ori, nrm, k)
+    assert int(torch.bincount(kw["i_oa"][0].long().cpu(), minlength=N).max()) > 56             # a row beyond the capacity
+    out = ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)
+    want_con, want_g = _oracle_objective(adv, ori, nrm, k)
+    np.testing.assert_allclose(out["constrain"].cpu().numpy(), want_con.numpy(), rtol=5e-5, atol=1e-7)
+    np.testing.assert_allclose(out["grad"].cpu().numpy(), want_g.numpy(), rtol=2e-4, atol=2e-6 * float(want_g.abs().max()))
+    grad = out["grad"].clone()
+    for _ in range(3):
+        assert torch.equal(ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)["grad"], grad)
+    one = {n: (v[1:2].contiguous() if torch.is_tensor(v) else v) for n, v in kw.items()}
+    alone = ops.geo_loss_grad(advD[1:2].contiguous(), oriD[1:2].contiguous(), deterministic=True, **one)
+    assert torch.equal(alone["grad"][0], grad[1])
