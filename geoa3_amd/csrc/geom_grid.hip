@@ -155,6 +155,7 @@ __device__ __forceinline__ void grid_ball(const int* __restrict__ s_start, float
 }
 
 constexpr int NN1_WIDE = 16;   // a query whose ball touches more grid columns is walked by the whole wavefront
+constexpr float GRID_BRUTE = 0.12f;   // fraction of the searched cloud inside the queries' boxes beyond which a batch is searched by brute force
 
 template <int PPT, int MODE = 0>   // MODE (tools/ub/nn1_ub.hip): 1 = build only, 2 = seeds only (no ball walk)
 __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ A, const float* __restrict__ R, int Na,
@@ -180,6 +181,100 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
   const GridGeom g = grid_build<GT, PPT>(P, M, s_start, s_fill, s_px, s_py, s_pz, s_pi, s_red);
 
   if (MODE == 1) return;
+  // Points per cell as a 3-D summed-area table (in s_fill, free after the build): the number of points in the cells of a
+  // query's box is eight reads.  A batch of queries whose boxes hold more than GRID_BRUTE of the searched cloud
+  // on average is searched by brute force instead (below): clouds with a dense cluster, thin rods, or iterates far from the
+  // surface put hundreds of points into the few cells a ball touches, and a candidate of the grid walk (a lane's serial
+  // scan of its own column run, four scattered LDS reads each) costs ~10 candidates of the brute-force loop (broadcast
+  // reads, no divergence).  Measured at N = 1024, offsets 0.3 (tools/nn1_cad_probe.py): clusters 1810 us and rods 765 us
+  // per launch through the grid against 167 us all-pairs.  Same candidates order-independently: same bits either way.
+  int* s_sat = s_fill;                                      // [16][16][16] inclusive prefix sums of the cell counts
+  if (MODE == 4) {
+    for (int c = threadIdx.x; c < GC; c += GT) s_sat[c] = s_start[c + 1] - s_start[c];
+    __syncthreads();
+    if (threadIdx.x < GG * GG) {                            // along z
+      int run = 0;
+      for (int z = 0; z < GG; ++z) {
+        run += s_sat[threadIdx.x * GG + z];
+        s_sat[threadIdx.x * GG + z] = run;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < GG * GG) {                            // along y: lines (x, z)
+      const int x = threadIdx.x / GG, z = threadIdx.x % GG;
+      int run = 0;
+      for (int y = 0; y < GG; ++y) {
+        run += s_sat[(x * GG + y) * GG + z];
+        s_sat[(x * GG + y) * GG + z] = run;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < GG * GG) {                            // along x: lines (y, z)
+      int run = 0;
+      for (int x = 0; x < GG; ++x) {
+        run += s_sat[x * GG * GG + threadIdx.x];
+        s_sat[x * GG * GG + threadIdx.x] = run;
+      }
+    }
+    __syncthreads();
+  }
+  auto sat = [&](int x, int y, int z) { return (x < 0 || y < 0 || z < 0) ? 0 : s_sat[(x * GG + y) * GG + z]; };
+  auto in_box = [&](float fx, float fy, float fz, float rho) {   // points in the cells of the ball's bounding box
+    const int x0 = grid_coord(fx - rho), x1 = grid_coord(fx + rho), y0 = grid_coord(fy - rho), y1 = grid_coord(fy + rho);
+    const int z0 = grid_coord(fz - rho), z1 = grid_coord(fz + rho);
+    return sat(x1, y1, z1) - sat(x0 - 1, y1, z1) - sat(x1, y0 - 1, z1) - sat(x1, y1, z0 - 1) + sat(x0 - 1, y0 - 1, z1) +
+           sat(x0 - 1, y1, z0 - 1) + sat(x1, y0 - 1, z0 - 1) - sat(x0 - 1, y0 - 1, z0 - 1);
+  };
+  if (MODE == 4 && PPT > 1) {
+    // Several batches of queries per thread: ONE decision for all of them, and the brute-force sweep keeps a thread's PPT
+    // queries in registers -- every candidate is read from LDS once for all of them
+    float qx[PPT], qy[PPT], qz[PPT], best[PPT];
+    int bi[PPT], qi[PPT];
+    float est = 0.f;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int t = p * GT + threadIdx.x;
+      const bool valid = t < Nq;
+      qi[p] = valid ? (Nq == M ? s_pi[t] : t) : -1;
+      const int q = valid ? qi[p] : 0;
+      qx[p] = Q[q];
+      qy[p] = Q[Nq + q];
+      qz[p] = Q[2 * Nq + q];
+      int si = prior ? prior[(size_t)b * Nq + q] : q;
+      si = si < 0 ? 0 : (si >= M ? M - 1 : si);
+      best[p] = geoa3_sqdist(qx[p], qy[p], qz[p], P[si], P[M + si], P[2 * M + si]);
+      bi[p] = si;
+      const float rho = sqrtf(best[p]) * g.inv_h * 1.00001f + 1e-4f;
+      if (valid) est += (float)in_box((qx[p] - g.ox) * g.inv_h, (qy[p] - g.oy) * g.inv_h, (qz[p] - g.oz) * g.inv_h, rho);
+    }
+    est = wave_sum(est);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = est;
+    __syncthreads();
+    float all = 0.f;
+#pragma unroll
+    for (int w = 0; w < GW; ++w) all += s_red[w];
+    __syncthreads();
+    if (all > GRID_BRUTE * (float)Nq * (float)M) {
+      for (int j = 0; j < M; ++j) {
+        const float cx = s_px[j], cy = s_py[j], cz = s_pz[j];
+        const int i = s_pi[j];
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+          const float d = geoa3_sqdist(qx[p], qy[p], qz[p], cx, cy, cz);
+          const bool take = d < best[p] || (d == best[p] && i < bi[p]);
+          best[p] = take ? d : best[p];
+          bi[p] = take ? i : bi[p];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PPT; ++p)
+        if (qi[p] >= 0) {
+          dout[qi[p]] = best[p];
+          iout[qi[p]] = bi[p];
+        }
+      return;
+    }
+  }
   for (int t0 = 0; t0 < Nq; t0 += GT) {     // (uniform trips: the wave-wide walk below needs every lane)
     const int t = t0 + threadIdx.x;
     const bool valid = t < Nq;
@@ -209,7 +304,42 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
     const float rho = rad * g.inv_h * 1.00001f + 1e-4f;   // (grid_ball's radius in cells)
     const int bx0 = grid_coord(fx - rho), bx1 = grid_coord(fx + rho), by0 = grid_coord(fy - rho), by1 = grid_coord(fy + rho);
     const int bny = by1 - by0 + 1, bcols = (bx1 - bx0 + 1) * bny;
+    bool brute = false;
     if (MODE == 4) {
+      const int inbox = valid ? in_box(fx, fy, fz, rho) : 0;
+      const float tot = wave_sum((float)inbox);
+      float* s_est = s_red;                                 // [GW] (the build's scratch is free)
+      __syncthreads();                                      // (every wave is done with the previous batch's use of it)
+      if ((threadIdx.x & 63) == 0) s_est[threadIdx.x >> 6] = tot;
+      __syncthreads();
+      float all = 0.f;
+#pragma unroll
+      for (int w = 0; w < GW; ++w) all += s_est[w];
+      const int nq = Nq - t0 < GT ? Nq - t0 : GT;
+      brute = PPT == 1 && all > GRID_BRUTE * (float)nq * (float)M;    // (PPT > 1: decided for all batches above)
+    }
+    if (brute) {
+      if (valid) {
+        int j = 0;
+        for (; j + 4 <= M; j += 4) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float d = geoa3_sqdist(qx, qy, qz, s_px[j + u], s_py[j + u], s_pz[j + u]);
+            const int i = s_pi[j + u];
+            const bool take = d < best || (d == best && i < bi);
+            best = take ? d : best;
+            bi = take ? i : bi;
+          }
+        }
+        for (; j < M; ++j) {
+          const float d = geoa3_sqdist(qx, qy, qz, s_px[j], s_py[j], s_pz[j]);
+          const int i = s_pi[j];
+          const bool take = d < best || (d == best && i < bi);
+          best = take ? d : best;
+          bi = take ? i : bi;
+        }
+      }
+    } else if (MODE == 4) {
       // BALANCED walk: the (query, column) pairs of the wavefront's 64 queries are dealt evenly over its lanes -- a query's
       // ball touches 4.9 columns on average but up to 64, and with a query per lane the wavefront walks as long as its
       // widest lane.  Prefix sums of the column counts (LDS, one row per wave) map pair t to (query lane, column); the

@@ -646,106 +646,60 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4,
   }
 }
 
-// dxyz[b][n] = sum over the (centroid m, sample s) with idx[b][m][s] == n of dp[b][m][s], in ascending (m, s): the
-// scatter-add of the grouping gradient (group_points_gpu.cu:60 behind pointnet2_utils.py:318) as an OWNER-side sum over
-// reverse lists built per launch in LDS (histogram, scan, unordered fill, per-owner sort), chunked over the centroids so
-// that a chunk's lists fit.  Padded entries (repeats of a ball's first index) were merged into sample 0 by the producer
-// and are skipped.  One workgroup per instance.  Deterministic, no atomics on floats.
-constexpr int SCAT_BLOCK = 512;
+// dxyz[b][n] = sum over the (centroid m, sample s) with idx[b][m][s] == n of dp[b][m][s]: the scatter-add of the grouping
+// gradient (group_points_gpu.cu:60 behind pointnet2_utils.py:318), one workgroup per instance, as ORDER-FREE sums: every
+// contribution is converted to 64-bit fixed point at the instance's own scale (2^40 / its largest |contribution|: a first
+// pass over the instance's entries) and added by LDS integer atomics -- integer addition is associative, so the result
+// does not depend on the order: deterministic and batch-independent without reverse lists.  Round 4 built per-owner
+// reverse lists in LDS (histogram, scan, fill, per-owner sort) and summed in ascending (m, s): 104 us per launch on the
+// ellipsoid clouds, 530 us on clouds with a dense cluster (one point referenced by hundreds of balls: a single thread
+// heap-sorting its list).  Padded entries (repeats of a ball's first index) were merged into sample 0 by the producer and
+// are skipped.  A NaN / infinite contribution makes the destination (the whole instance, if the scale itself is not
+// finite) NaN: never a silent clamp.
+constexpr int SCAT_BLOCK = 1024;
 __global__ __launch_bounds__(SCAT_BLOCK) void sa1_scatter_kernel(const float* __restrict__ dp, const int32_t* __restrict__ idx,
-                                                                float* __restrict__ dxyz, int N, int M, int rcap) {
-  extern __shared__ __attribute__((aligned(16))) int sc_sm[];
-  int* s_cnt = sc_sm;                                         // [N + 1]
-  float* s_g = reinterpret_cast<float*>(sc_sm + N + 1);       // [3 N]
-  int* rlist = reinterpret_cast<int*>(s_g + 3 * N);           // [rcap]
-  const int b = blockIdx.x, tid = threadIdx.x;
+                                                                float* __restrict__ dxyz, int N, int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sc_acc[];   // [3][N]
+  float* s_red = reinterpret_cast<float*>(sc_acc + 3 * (size_t)N);              // [16]
+  unsigned* s_bad = reinterpret_cast<unsigned*>(s_red + 16);                    // [ceil(N / 32)]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* I = idx + (size_t)b * M * SA_S;
   const float* D = dp + (size_t)b * M * SA_S * 3;
-  for (int i = tid; i < 3 * N; i += SCAT_BLOCK) s_g[i] = 0.f;
-  const int cm = max(1, rcap / SA_S);                         // centroids per chunk
-  for (int m0 = 0; m0 < M; m0 += cm) {
-    const int nent = (min(M, m0 + cm) - m0) * SA_S, e0 = m0 * SA_S;
-    for (int i = tid; i <= N; i += SCAT_BLOCK) s_cnt[i] = 0;
-    __syncthreads();
-    for (int e = tid; e < nent; e += SCAT_BLOCK) {
-      const int ge = e0 + e, q = I[ge];
-      if ((ge & (SA_S - 1)) == 0 || q != I[ge & ~(SA_S - 1)]) atomicAdd(&s_cnt[q], 1);
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const int per = (N + 1 + 63) / 64, a0 = tid * per, a1 = min(a0 + per, N + 1);
-      int sum = 0;
-      for (int i = a0; i < a1; ++i) sum += s_cnt[i];
-      int incl = sum;
+  const int nent = M * SA_S;
+  for (int i = tid; i < 3 * N; i += SCAT_BLOCK) sc_acc[i] = 0ull;
+  for (int i = tid; i < (N + 31) / 32; i += SCAT_BLOCK) s_bad[i] = 0u;
+  float m = 0.f;
+  for (int e = tid; e < 3 * nent; e += SCAT_BLOCK) m = fmaxf(m, __builtin_fabsf(D[e]));
+  m = wave_max(m);
+  if (lane == 0) s_red[wave] = m;
+  __syncthreads();
+  m = 0.f;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (tid >= o) incl += v;
-      }
-      int run = incl - sum;
-      for (int i = a0; i < a1; ++i) {
-        const int c = s_cnt[i];
-        s_cnt[i] = run;
-        run += c;
-      }
+  for (int w = 0; w < SCAT_BLOCK / 64; ++w) m = fmaxf(m, s_red[w]);
+  const bool finite = m <= 3.0e38f;
+  int Ex = (int)((__float_as_uint(m) >> 23) & 0xffu) - 126;        // m < 2^Ex
+  Ex = Ex < -80 ? -80 : (Ex > 80 ? 80 : Ex);
+  const float to = __uint_as_float((unsigned)(40 - Ex + 127) << 23), from = __uint_as_float((unsigned)(Ex - 40 + 127) << 23);
+  for (int e = tid; e < nent; e += SCAT_BLOCK) {
+    const int q = I[e];
+    if ((e & (SA_S - 1)) != 0 && q == I[e & ~(SA_S - 1)]) continue;              // padding: merged into sample 0
+    const float x = D[3 * e], y = D[3 * e + 1], z = D[3 * e + 2];
+    if (!(__builtin_fabsf(x) <= m && __builtin_fabsf(y) <= m && __builtin_fabsf(z) <= m)) {   // NaN
+      atomicOr(&s_bad[q >> 5], 1u << (q & 31));
+      continue;
     }
-    __syncthreads();
-    for (int e = tid; e < nent; e += SCAT_BLOCK) {
-      const int ge = e0 + e, q = I[ge];
-      if ((ge & (SA_S - 1)) == 0 || q != I[ge & ~(SA_S - 1)]) rlist[atomicAdd(&s_cnt[q], 1)] = ge;
-    }
-    __syncthreads();
-    for (int i = tid; i < N; i += SCAT_BLOCK) {
-      const int st = i ? s_cnt[i - 1] : 0, n = s_cnt[i] - st;
-      if (n == 0) continue;
-      int* L = rlist + st;
-      if (n <= 24) {
-        for (int a = 1; a < n; ++a) {
-          const int v = L[a];
-          int c = a - 1;
-          while (c >= 0 && L[c] > v) {
-            L[c + 1] = L[c];
-            --c;
-          }
-          L[c + 1] = v;
-        }
-      } else {
-        auto sift = [&](int start, int end) {
-          int root = start;
-          for (;;) {
-            int child = 2 * root + 1;
-            if (child > end) break;
-            if (child + 1 <= end && L[child] < L[child + 1]) ++child;
-            if (L[root] >= L[child]) break;
-            const int tmp = L[root];
-            L[root] = L[child];
-            L[child] = tmp;
-            root = child;
-          }
-        };
-        for (int h0 = (n - 2) / 2; h0 >= 0; --h0) sift(h0, n - 1);
-        for (int end = n - 1; end > 0; --end) {
-          const int tmp = L[0];
-          L[0] = L[end];
-          L[end] = tmp;
-          sift(0, end - 1);
-        }
-      }
-      float gx = s_g[3 * i], gy = s_g[3 * i + 1], gz = s_g[3 * i + 2];
-      for (int e = 0; e < n; ++e) {
-        const float* d = D + (size_t)L[e] * 3;
-        gx += d[0];
-        gy += d[1];
-        gz += d[2];
-      }
-      s_g[3 * i] = gx;
-      s_g[3 * i + 1] = gy;
-      s_g[3 * i + 2] = gz;
-    }
-    __syncthreads();
+    atomicAdd(&sc_acc[q], (unsigned long long)__float2ll_rn(x * to));
+    atomicAdd(&sc_acc[N + q], (unsigned long long)__float2ll_rn(y * to));
+    atomicAdd(&sc_acc[2 * N + q], (unsigned long long)__float2ll_rn(z * to));
   }
+  __syncthreads();
   float* G = dxyz + (size_t)b * N * 3;
-  for (int i = tid; i < 3 * N; i += SCAT_BLOCK) G[i] = s_g[i];
+  for (int i = tid; i < N; i += SCAT_BLOCK) {
+    const bool bad = !finite || ((s_bad[i >> 5] >> (i & 31)) & 1u);
+    G[3 * i + 0] = bad ? __builtin_nanf("") : __ll2float_rn((long long)sc_acc[i]) * from;
+    G[3 * i + 1] = bad ? __builtin_nanf("") : __ll2float_rn((long long)sc_acc[N + i]) * from;
+    G[3 * i + 2] = bad ? __builtin_nanf("") : __ll2float_rn((long long)sc_acc[2 * N + i]) * from;
+  }
 }
 
 int sa1_grid(int B, int M, int waves, int per_cu) {   // persistent workgroups
@@ -786,8 +740,8 @@ extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, co
   if ((long)B * M > (1L << 24)) return GEOA3_ENOSUPPORT;
   hipStream_t s = geoa3_stream(stream);
   // deterministic scatter (scratch given and the owner's accumulators + at least one centroid's lists fit LDS)
-  const size_t fixed = ((size_t)N + 1) * sizeof(int) + (size_t)3 * N * sizeof(float), cap = 160 * 1024 - 512;
-  const bool det = scratch && fixed + SA_S * sizeof(int) <= cap;
+  const size_t l2 = (size_t)3 * N * sizeof(unsigned long long) + 16 * sizeof(float) + ((size_t)(N + 31) / 32) * sizeof(unsigned);
+  const bool det = scratch && l2 <= 160 * 1024 - 512;     // (N <= ~6800 points: the sums of one instance in LDS)
   if (!det && hipMemsetAsync(grad_xyz, 0, (size_t)B * N * 3 * sizeof(float), s) != hipSuccess) return GEOA3_ELAUNCH;
   const size_t lds = (size_t)sa1_lds_bytes(SA_WB, true);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_bwd_kernel<SA_WB * 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -797,12 +751,9 @@ extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, co
                      grad_out, grad_xyz, grad_new_xyz, det ? scratch : nullptr);
   geoa3_prof_end(GEOA3_PROF_SA1_BWD, s);
   if (det) {
-    size_t rcap = (cap - fixed) / sizeof(int);
-    if (rcap > (size_t)M * SA_S) rcap = (size_t)M * SA_S;
-    const size_t l2 = fixed + rcap * sizeof(int);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)l2);
-    hipLaunchKernelGGL(sa1_scatter_kernel, dim3(B), dim3(SCAT_BLOCK), l2, s, scratch, idx, grad_xyz, N, M, (int)rcap);
+    hipLaunchKernelGGL(sa1_scatter_kernel, dim3(B), dim3(SCAT_BLOCK), l2, s, scratch, idx, grad_xyz, N, M);
   }
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
