@@ -57,17 +57,17 @@ def cfg_full_geoa3(steps, npoint=NPOINT, knn=KNN):
                               npoint=npoint, classes=CLASSES)
 
 
-def cpu_baseline(arch, npoint, knn, budget_s=20.0, threads=0):
+def cpu_baseline(arch, npoint, knn, budget_s=60.0, threads=0):
     """The CPU port (oracle: reference semantics incl. the b batch-1 success-check forwards and the six dense K-NN
     queries per iteration, Attacker/geoA3_attack.py:238-352) timed on the host cores of this box on a BOUNDED sample of
-    the same workload: a 4-instance warm-up iteration sizes the sample (instances x iterations) to ~budget_s."""
+    the same workload: the thread count is swept once (32 / 64 / 128, a 4-instance iteration each) and the
+    best kept; that iteration sizes the sample (b instances x iterations) to ~budget_s of CPU work in THREE
+    (T(b, 1), T(b, 1 + iters)) pairs; the figure is the median pair, the spread is reported beside it."""
+    import statistics
+
     import torch
     from oracle import geoa3_oracle as O
     host_cores = os.cpu_count() or 1
-    # torch's intra-op pool stops scaling on this path well below the core count of the GPU box (measured there: the same
-    # 4-instance iteration takes 73 s on 256 threads and ~4 s on 32): 32 threads unless --cpu-threads says otherwise
-    threads = threads or min(host_cores, 32)
-    torch.set_num_threads(threads)
     if arch == "PointNet":
         sd = O.make_pointnet_state_dict(CLASSES, seed=0)
         net = lambda x: O.pointnet_forward(sd, x)
@@ -86,29 +86,42 @@ def cpu_baseline(arch, npoint, knn, budget_s=20.0, threads=0):
         O.attack(net, ori, nrm, gt, None, cfg_full_geoa3(iters, npoint, knn), init, faithful_success_check=True)
         return time.perf_counter() - t0
 
-    run(2, 1)                                   # first-touch costs (thread pool, allocator) stay out of the sizing run
-    per_inst_it = run(4, 1) / 4.0
-    # sample: b instances x (1 untimed + `iters` timed) iterations, ~budget_s of CPU work in all.  The untimed first
-    # iteration (step 0: nothing to rank, cold caches at this size) is measured on its own by a run of exactly one
-    # iteration and subtracted: timed = T(b, 1 + iters) - T(b, 1), so every timed iteration is a non-step-0 iterate.
-    iters = 2
-    b = int(max(4, min(BATCH, budget_s / max(per_inst_it * 2 * (2 + iters), 1e-6))))
+    # torch's intra-op pool stops scaling on this path well below the core count of the GPU box (measured there: the same
+    # 4-instance iteration takes 73 s on 256 threads and ~4 s on 32): sweep 32 / 64 / 128 once unless --cpu-threads is given
+    cands = [threads] if threads else sorted({min(host_cores, t) for t in (32, 64, 128)})
+    sweep = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        run(2, 1)                               # first-touch costs (thread pool, allocator) stay out of the sizing run
+        sweep[t] = run(4, 1) / 4.0
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    per_inst_it = sweep[threads]
+    # sample: b instances x (1 untimed + `iters` timed) iterations.  The untimed first iteration (step 0: nothing to rank,
+    # cold caches at this size) is measured on its own by a run of exactly one iteration and subtracted:
+    # timed = T(b, 1 + iters) - T(b, 1), so every timed iteration is a non-step-0 iterate.
+    npairs, iters = 3, 2
+    b = int(max(4, min(BATCH, budget_s / max(per_inst_it * npairs * (2 + iters), 1e-6))))
     if b == BATCH:
-        iters = int(max(2, min(20, budget_s / max(per_inst_it * b * 2, 1e-6) - 2)))
-    # min over two pairs; a difference far below the proportional share of the long run is noise (thread-pool warm-up,
-    # another load on the box), not a fast CPU: fall back to the share
-    pairs = [(run(b, 1), run(b, 1 + iters)) for _ in range(2)]
-    t_all = min(p[1] for p in pairs)
-    dt = min(max(p[1] - p[0], 0.0) for p in pairs)
-    share = t_all * iters / (1.0 + iters)
-    if dt < 0.5 * share:
-        dt = share
+        iters = int(max(2, min(20, budget_s / max(per_inst_it * b * npairs, 1e-6) - 2)))
+    pairs = [(run(b, 1), run(b, 1 + iters)) for _ in range(npairs)]
+    # a difference far below the proportional share of the long run is noise (thread-pool warm-up, another load on the
+    # box), not a fast CPU: such a pair counts with the share
+    dts = []
+    for t1, tn in pairs:
+        share = tn * iters / (1.0 + iters)
+        d = tn - t1
+        dts.append(d if d >= 0.5 * share else share)
+    dt = statistics.median(dts)
+    vals = sorted(b * iters / d / BATCH for d in dts)
     return {"value": b * iters / dt / BATCH, "unit": "attack-iterations/sec (250-instance batch)",
             "cores": threads, "host_cores": host_cores, "kind": "port",
+            "spread": {"min": vals[0], "max": vals[-1], "pairs": npairs, "rel": (vals[-1] - vals[0]) / max(vals[1], 1e-12)},
+            "thread_sweep_s_per_instance_iteration": {str(t): round(v, 3) for t, v in sweep.items()},
             "sample": "oracle attack() (%s victim, N=%d, CE + CD + HD + curvature k=%d, reference success check = b "
-                      "batch-1 forwards): %d instances x %d iterations (steps 1..%d, after one untimed step-0 iteration "
-                      "at this size) in %.1f s on %d threads; instance-iterations/s / 250"
-                      % (arch, npoint, knn, b, iters, iters, dt, threads)}
+                      "batch-1 forwards): b = %d instances x %d iterations (steps 1..%d, after one untimed step-0 iteration "
+                      "at this size), median of %d pairs: %.1f s on %d threads (best of %s); instance-iterations/s / 250"
+                      % (arch, npoint, knn, b, iters, iters, npairs, dt, threads, sorted(sweep))}
 
 
 def pmc_traffic(kernel_substr, cfg_tag):
@@ -163,7 +176,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proxy-full", action="store_true",
                     help="shard proxy (--instances): skip the full 250-instance comparison run (profiling)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(host cores, 32), see cpu_baseline)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: the best of 32 / 64 / 128, swept once; see cpu_baseline)")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU work of the baseline sample (three pairs)")
     ap.add_argument("--single-mode", action="store_true",
                     help="skip the second, shorter measurement in the strict fp32-MFMA mode of the convolutions")
     ap.add_argument("--npoint", type=int, default=NPOINT, help="points per cloud (configs[4]: 4096)")
@@ -480,7 +494,7 @@ def main():
                                      "run on a second stream beside the victim's forward)" % extra}
         if not a.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(a.arch, npoint, knn, threads=a.cpu_threads)
+                out["cpu_baseline"] = cpu_baseline(a.arch, npoint, knn, budget_s=a.cpu_budget, threads=a.cpu_threads)
             except Exception as e:  # the baseline never blocks the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))

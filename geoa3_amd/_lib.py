@@ -141,6 +141,7 @@ _lib = None
 
 
 ENOSUPPORT = -3   # GEOA3_ENOSUPPORT
+ABI_VERSION = 500  # GEOA3_ABI_VERSION of include/geoa3_hip.h this file mirrors (tests/test_abi.py holds the two together)
 
 
 class Geoa3Error(RuntimeError):
@@ -160,6 +161,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    have = lib.geoa3_version()
+    if have != ABI_VERSION:
+        raise Geoa3Error("%s was built for ABI version %d, this binding mirrors version %d of include/geoa3_hip.h: rebuild "
+                         "it (`python -m geoa3_amd.build --force`)" % (LIB_PATH, have, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -541,7 +541,7 @@ class AttackRunner:
 RUNNER_CFG_FIELDS = ("attack_label", "iter_max_steps", "curv_loss_knn", "curv_loss_weight", "dis_loss_type",
                      "hd_loss_weight", "cls_loss_type", "optim", "uniform_loss_weight", "npoint", "is_partial_var",
                      "knn_range", "is_subsample_opt", "eval_num", "is_pre_jitter_input", "is_pro_grad",
-                     "brute_force_nn1", "classes", "deterministic")
+                     "brute_force_nn1", "classes", "deterministic", "late_join", "knn_method")
 
 
 def unpack_input(input_data, targeted: bool):

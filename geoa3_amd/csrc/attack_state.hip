@@ -449,7 +449,7 @@ extern "C" int geoa3_attack_begin_search_step(const geoa3_attack_state* st, cons
   return GEOA3_OK;
 }
 
-extern "C" int geoa3_version(void) { return 100; }
+extern "C" int geoa3_version(void) { return GEOA3_ABI_VERSION; }
 
 extern "C" const char* geoa3_strerror(int code) {
   switch (code) {

@@ -287,6 +287,14 @@ class PointNet(nn.Module):
         from . import library
         self._handle = library.register_net(self)  # the scalar the custom op geoa3::pointnet_forward takes for this module
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle: the packed device weights (a ctypes structure of raw pointers: not picklable), the GPU
+        workspace and the handle belong to THIS module and are not copied -- the copy rebuilds its own on first use."""
+        state = dict(self.__dict__)
+        for k in ("_packed", "_packed_key", "_ws_cache", "_handle"):
+            state.pop(k, None)
+        return state
+
     def __setstate__(self, state):
         """copy.deepcopy / pickle: the copy is a module of its own -- its own handle, packed weights and workspace."""
         super().__setstate__(state)

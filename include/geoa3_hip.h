@@ -36,6 +36,10 @@ extern "C" {
 #define GEOA3_ELAUNCH (-2)  /* hipLaunchKernel / hipGetLastError reported a failure */
 #define GEOA3_ENOSUPPORT (-3)
 
+/* The ABI version of this header: bumped on EVERY change of a struct layout or a signature.  geoa3_version() returns the
+ * value the library was built with; a binding must refuse a library whose version differs (geoa3_amd/_lib.py does: a
+ * stale or variant .so would misread the argument structs silently). */
+#define GEOA3_ABI_VERSION 500
 int geoa3_version(void);
 const char* geoa3_strerror(int code);
 
@@ -131,13 +135,18 @@ typedef struct geoa3_geo_args {
    * receives sorted by source) instead of with LDS float atomics: bit-for-bit reproducible and independent of the rest
    * of the batch (what the reference's scatter-adds -- knn_gather / index backward -- do not promise either).
    * Clouds of at most 1024 points take the pair-parallel kernel (a lane per (centre, neighbour) pair, reverse lists as
-   * fixed-capacity rows in LDS, rows sorted in registers); 1025..4096 points with `scratch`: the pair-parallel kernel with
-   * fixed-point sums; otherwise up to ~4800 points the one-workgroup kernel with LDS reverse lists; beyond (up to ~5800)
+   * fixed-capacity rows in LDS, rows sorted in registers; a row beyond its ~50 slots -- a dense cluster, a hub of the
+   * K-NN graph -- through 64-bit fixed-point sums in a small pool, order-free); 1025..4096 points with `scratch`: the
+   * pair-parallel kernel with fixed-point sums; otherwise up to ~4800 points the one-workgroup kernel with LDS reverse lists; beyond (up to ~5800)
    * the sums fall back to LDS float atomics (free order) whatever this flag says. */
   int32_t deterministic;
   /* optional workspace of 16 * B * N bytes (one float4 record per point).  Given, clouds of 1025..4096 points (and smaller
    * ones with k > 32) with the curvature term take the pair-parallel kernel with 64-bit fixed-point gradient sums (geo_big_kernel: order-free and
-   * therefore reproducible; the neighbour table is read once); NULL = the one-workgroup kernel.  Same values to rounding. */
+   * therefore reproducible; the neighbour table is read once); NULL = the one-workgroup kernel.  Same values to rounding.
+   * The fixed-point sums take two power-of-two scales per instance from its largest coefficient X (2 w_curv / (N k) or
+   * max |dkappa| / k, and the Chamfer coefficients): terms up to 2^10 X at 2^-40 X per unit, terms up to 2^34 X (pairs down
+   * to ~1e-10 apart) at 2^-16 X through a pool of 256 destinations.  A term beyond that, a NaN, or a full pool writes NaN
+   * into the gradient of the destination point -- there is no silent saturation. */
   void* scratch;
 } geoa3_geo_args;
 int geoa3_geo_loss_grad(const geoa3_geo_args* args, void* stream);
@@ -404,8 +413,9 @@ int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, const int32_t*
                           int N, int M, float* out, uint8_t* arg, void* stream);
 /* grad_xyz [B,N,3] (the scatter-add over idx) and grad_new_xyz [B,M,3] (= minus the per-centroid sum) from
  * grad_out [B,M,128] (same layout as out); the hidden activations are recomputed, not stored.
- * scratch: geoa3_pn2_sa1_scratch_bytes(B, M) bytes -> the scatter-add is an owner-side sum in ascending (centroid,
- * sample) order (deterministic); NULL -> global float atomics as the reference (group_points_gpu.cu:60). */
+ * scratch: geoa3_pn2_sa1_scratch_bytes(B, M) bytes -> the scatter-add as order-free 64-bit fixed-point sums at the
+ * instance's own scale (deterministic, batch-independent; a NaN / infinite contribution gives NaN, not a clamp);
+ * NULL -> global float atomics as the reference (group_points_gpu.cu:60). */
 int64_t geoa3_pn2_sa1_scratch_bytes(int B, int M);
 int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B,
                            int N, int M, const float* out, const uint8_t* arg, const float* grad_out, float* grad_xyz,

@@ -3,6 +3,8 @@ include/geoa3_hip_debug.h (diagnostics) declare; the product header holds no dia
 mutable global."""
 import os
 import re
+
+import pytest
 import shutil
 import subprocess
 
@@ -65,6 +67,17 @@ def test_struct_layouts_match_header():
     assert members("geoa3_attack_state") == [f[0] for f in _lib.AttackState._fields_]
     assert members("geoa3_pn2ssg_weights") == [f[0] for f in _lib.Pn2SsgWeights._fields_]
     assert members("geoa3_sa1_weights") == [f[0] for f in _lib.Sa1Weights._fields_]
+
+
+def test_abi_version_is_checked():
+    """include/geoa3_hip.h, the built library and the ctypes mirror agree on GEOA3_ABI_VERSION; load() refuses any other."""
+    hdr = open(os.path.join(REPO, "include", "geoa3_hip.h")).read()
+    ver = int(re.search(r"#define GEOA3_ABI_VERSION (\d+)", hdr).group(1))
+    assert ver == _lib.ABI_VERSION == _lib.load().geoa3_version()
+    import unittest.mock as mock
+    with mock.patch.object(_lib, "_lib", None), mock.patch.object(_lib, "ABI_VERSION", ver + 1):
+        with pytest.raises(_lib.Geoa3Error, match="ABI version"):
+            _lib.load()
 
 
 def test_backward_chain_kernel_holds_no_packed_fp32():

@@ -46,6 +46,10 @@ BARS = {   # best: best constrain loss per instance; window: 50-step means of lo
     "n1024_b8_hard": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
     "n1024_b4_margin": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
     "pn2_n1024_b4_tgt": dict(best=0.25, window=0.18, adv=0.15, last_margin=1.0, first=5e-3, first_steps=3),
+    # round 5: instances the reference never breaks (their success flag, the all-ones placeholder and the constants are held
+    # exactly: they are "robust" by construction), and PointNet++ at b = 8 (twice the instances to average over)
+    "n256_b8_fail": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
+    "pn2_n1024_b8_untgt": dict(best=0.25, window=0.18, adv=0.15, last_margin=1.0, first=5e-3, first_steps=3),
 }
 ROBUST_STEPS = 3         # an instance counts as robustly (un)successful in a binary step with >= 3 / 0 adversarial steps
 
@@ -161,6 +165,9 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     robust = (ref_n.sum(0) >= ROBUST_STEPS) | (ref_n.sum(0) == 0)
     chk((out["succ"] == ref_succ)[robust].all(), "success", out["succ"], ref_succ)
     report["success"] = [out["succ"].tolist(), ref_succ.tolist()]
+    # ... and an instance that was never attacked keeps the all-ones placeholder (geoA3_attack.py:225-227)
+    never = ~out["succ"]
+    chk((out["best"][never] == 1.0).all(), "placeholder of the instances never attacked", never)
 
     # (2) fraction of adversarial steps per binary step (batch level)
     fa_ref, fa_got = ref_adv.mean((1, 2)), got_adv.mean((1, 2))
@@ -217,7 +224,9 @@ def test_long_run_statistics_match_reference(long_golden, tag, mode, determinist
     # (per instance; the median over the instances: one sign flip of Adam's first step on a near-zero gradient moves a
     # coordinate by 2 lr, which a PointNet++ victim turns into another farthest-point sample for THAT instance)
     nfirst = bars.get("first_steps", 6)      # (PointNet++: the median instance leaves the shared trajectory at step 4-6; with float atomics at step 3)
-    chk(np.median(dev[:nfirst], axis=1).max() <= bars["first"], "first steps", dev.max(1), np.median(dev, axis=1))
+    # PointNet (no discontinuous sampling in the victim): EVERY instance holds the bar; PointNet++: the median instance
+    first_dev = np.median(dev[:nfirst], axis=1) if case["arch"] == "PointNetPP" else dev[:nfirst].max(1)
+    chk(first_dev.max() <= bars["first"], "first steps", dev.max(1), np.median(dev, axis=1))
     report["fails"] = fails
     outdir = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(outdir):

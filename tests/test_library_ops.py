@@ -71,3 +71,20 @@ def test_net_handles_are_per_module_and_survive_deepcopy():
     assert ha not in library._NETS and library.net_handle(b) == hb and PointNet(40)._handle not in (ha, hb)
     b._handle = 10 ** 9                       # a stale integer (e.g. restored by hand): net_handle() repairs it
     assert library.net_handle(b) != 10 ** 9 and library._NETS[b._handle] is b
+    # a module that HAS run (packed device weights = a ctypes structure of raw pointers, a workspace cache) copies and pickles
+    # too: those belong to the original and are left behind (__getstate__)
+    import ctypes
+    import pickle
+
+    class _Ptrs(ctypes.Structure):
+        _fields_ = [("p", ctypes.c_void_p)]
+
+    class _FakePacked:
+        struct = _Ptrs()
+
+    b._packed, b._packed_key, b._ws_cache = _FakePacked(), ("k",), {"ws": object()}
+    c = copy.deepcopy(b)
+    d = pickle.loads(pickle.dumps(b))
+    for m in (c, d):
+        assert m._packed is None and m._ws_cache == {} and m._handle not in (b._handle,) and library._NETS[m._handle] is m
+        assert all(torch.equal(x, y) for x, y in zip(m.state_dict().values(), b.state_dict().values()))

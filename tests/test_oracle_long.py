@@ -15,7 +15,8 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 @pytest.mark.parametrize("tag,steps", [("n256_b8_hard", 24), ("n256_b8_tgt", 24), ("n1024_b8_hard", 4),
-                                       ("n1024_b4_margin", 6), ("pn2_n1024_b4_tgt", 3)])
+                                       ("n1024_b4_margin", 6), ("pn2_n1024_b4_tgt", 3), ("n256_b8_fail", 10),
+                                       ("pn2_n1024_b8_untgt", 2)])
 def test_oracle_follows_reference_prefix(tag, steps):
     g = np.load(os.path.join(REPO, "tests", "golden", "geoa3_golden_long.npz"), allow_pickle=False)
     case = LONG_CASES[tag]
@@ -66,3 +67,20 @@ def test_long_fixture_bookkeeping_is_consistent():
         assert (step == g[pre + "best_step"]).mean() >= 0.75   # (batch-1 vs batched forward may differ on a near-tie)
         found = g[pre + "best_step"][g[pre + "success"]]
         assert found.size and np.median(found) > 10, (tag, g[pre + "best_step"])
+
+
+def test_failing_case_holds_instances_the_reference_never_breaks():
+    """`n256_b8_fail`: the reference leaves at least two of the eight instances un-attacked after 3 x 100 steps (never
+    adversarial at any step: best_step -1, the all-ones placeholder of geoA3_attack.py:225-227 as best_attack), breaks at
+    least two others, and the binary search lowers every constant on each step (:374-386 through the `output_label` quirk)."""
+    g = np.load(os.path.join(REPO, "tests", "golden", "geoa3_golden_long.npz"), allow_pickle=False)
+    pre = "long/n256_b8_fail/"
+    succ = g[pre + "success"]
+    assert (~succ).sum() >= 2 and succ.sum() >= 2
+    pred, gt, tgt = g[pre + "tr_pred"], g[pre + "gt"], g[pre + "tgt"]
+    never = ~adversarial(pred[:, 1:], gt, tgt, True).any((0, 1))
+    assert (never == ~succ).all()
+    assert (g[pre + "best_step"][~succ] == -1).all()
+    assert (g[pre + "best_attack"][~succ] == 1.0).all() and not (g[pre + "best_attack"][succ] == 1.0).all()
+    scale = g[pre + "tr_scale"][:, 0, :]
+    assert (scale[1:] < scale[:-1]).all()
