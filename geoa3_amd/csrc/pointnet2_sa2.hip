@@ -74,44 +74,50 @@ __device__ __forceinline__ float s2_rlf(float v, int l) { return __int_as_float(
 
 // One wavefront per centre: entries (g, channel) sorted by the channel's arg-max sample, ascending channel inside a
 // sample.  ent_c = channel | sample << 16 | (last entry of its sample) << 31.
+// A stable counting sort in four rounds of 64 channels (round 5; round 4 swept the 64 sample values with four ballots each:
+// 256 ballots per centre, 85 us per launch): a histogram of the samples in LDS, its exclusive prefix (lane = sample), and per
+// round the lanes holding the same sample found by six ballots (one per bit of the sample): the rank inside the group is a
+// population count, the group's first lane advances the sample's running offset for the next round.
 __global__ __launch_bounds__(256) void sa2_sort_kernel(const float* __restrict__ gz, const int32_t* __restrict__ argt,
                                                        float* __restrict__ ent_g, int32_t* __restrict__ ent_c, long centres) {
-  const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= centres) return;
-  int a[4], rank[4];
+  __shared__ int s_hist[4][64], s_run[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long c = (long)blockIdx.x * 4 + wave;
+  if (c >= centres) return;                       // (whole waves leave: no barrier below)
+  int a[4];
   float g[4];
-  bool last[4];
+  s_hist[wave][lane] = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     a[q] = argt[c * S2_C + q * 64 + lane] & 63;
     g[q] = gz[c * S2_C + q * 64 + lane];
-    rank[q] = q * 64 + lane;
-    last[q] = true;
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) atomicAdd(&s_hist[wave][a[q]], 1);
+  const int tot = s_hist[wave][lane];             // entries of sample `lane` (LDS operations of a wave complete in order)
+  int incl = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  s_run[wave][lane] = incl - tot;                 // where the sample's entries start
   const unsigned long long below = (1ull << lane) - 1ull;
-  int base = 0;
-  for (int s = 0; s < 64; ++s) {
-    unsigned long long m[4];
-    int pre[4], n = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      m[q] = __ballot(a[q] == s);
-      pre[q] = n;
-      n += (int)__builtin_popcountll(m[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (a[q] == s) {
-        rank[q] = base + pre[q] + (int)__builtin_popcountll(m[q] & below);
-        last[q] = rank[q] == base + n - 1;
-      }
-    base += n;
-  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    ent_c[c * S2_C + rank[q]] = (q * 64 + lane) | (a[q] << 16) | (last[q] ? (int)0x80000000 : 0);
-    ent_g[c * S2_C + rank[q]] = g[q];
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+      const unsigned long long bal = __ballot((a[q] >> bit) & 1);
+      m &= ((a[q] >> bit) & 1) ? bal : ~bal;
+    }
+    const int r = (int)__builtin_popcountll(m & below), n = (int)__builtin_popcountll(m);
+    const int start = s_run[wave][a[q]];
+    const int pos = start + r;
+    if (r == 0) s_run[wave][a[q]] = start + n;    // one lane per sample: the next round's entries follow
+    const int end = __shfl(incl, a[q], 64);       // one past the sample's last entry
+    ent_c[c * S2_C + pos] = (q * 64 + lane) | (a[q] << 16) | (pos == end - 1 ? (int)0x80000000 : 0);
+    ent_g[c * S2_C + pos] = g[q];
   }
 }
 
