@@ -673,14 +673,17 @@ __global__ __launch_bounds__(SCAT_BLOCK) void sa1_scatter_kernel(const float* __
   for (int i = tid; i < 3 * N; i += SCAT_BLOCK) sc_acc[i] = 0ull;
   for (int i = tid; i < (N + 31) / 32; i += SCAT_BLOCK) s_bad[i] = 0u;
   float m = 0.f;
-  for (int e = tid; e < 3 * nent; e += SCAT_BLOCK) m = fmaxf(m, __builtin_fabsf(D[e]));
+  for (int e = tid; e < 3 * nent; e += SCAT_BLOCK) {   // largest magnitude: as an unsigned maximum of the bit patterns, NaNs skipped
+    const unsigned u = __float_as_uint(D[e]) & 0x7fffffffu;
+    m = __uint_as_float(u > 0x7f800000u ? __float_as_uint(m) : (u > __float_as_uint(m) ? u : __float_as_uint(m)));
+  }
   m = wave_max(m);
   if (lane == 0) s_red[wave] = m;
   __syncthreads();
   m = 0.f;
 #pragma unroll
   for (int w = 0; w < SCAT_BLOCK / 64; ++w) m = fmaxf(m, s_red[w]);
-  const bool finite = m <= 3.0e38f;
+  const bool finite = (__float_as_uint(m) & 0x7fffffffu) < 0x7f800000u;   // (an infinite contribution; NaNs do not reach m: fmaxf)
   int Ex = (int)((__float_as_uint(m) >> 23) & 0xffu) - 126;        // m < 2^Ex
   Ex = Ex < -80 ? -80 : (Ex > 80 ? 80 : Ex);
   const float to = __uint_as_float((unsigned)(40 - Ex + 127) << 23), from = __uint_as_float((unsigned)(Ex - 40 + 127) << 23);
@@ -688,7 +691,9 @@ __global__ __launch_bounds__(SCAT_BLOCK) void sa1_scatter_kernel(const float* __
     const int q = I[e];
     if ((e & (SA_S - 1)) != 0 && q == I[e & ~(SA_S - 1)]) continue;              // padding: merged into sample 0
     const float x = D[3 * e], y = D[3 * e + 1], z = D[3 * e + 2];
-    if (!(__builtin_fabsf(x) <= m && __builtin_fabsf(y) <= m && __builtin_fabsf(z) <= m)) {   // NaN
+    // NaN / infinity by their BIT patterns: this file is compiled with -fno-honor-nans, a floating-point test may be folded
+    const unsigned bx = __float_as_uint(x) & 0x7fffffffu, by = __float_as_uint(y) & 0x7fffffffu, bz = __float_as_uint(z) & 0x7fffffffu;
+    if (bx >= 0x7f800000u || by >= 0x7f800000u || bz >= 0x7f800000u) {
       atomicOr(&s_bad[q >> 5], 1u << (q & 31));
       continue;
     }

@@ -49,7 +49,9 @@ BARS = {   # best: best constrain loss per instance; window: 50-step means of lo
     # round 5: instances the reference never breaks (their success flag, the all-ones placeholder and the constants are held
     # exactly: they are "robust" by construction), and PointNet++ at b = 8 (twice the instances to average over)
     "n256_b8_fail": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
-    "pn2_n1024_b8_tgt10": dict(best=0.25, window=0.18, adv=0.15, last_margin=1.0, first=5e-3, first_steps=3),
+    # (eight instances average the PointNet++ case's chaos down: windows seen at 5.7-8.6 % / adversarial fractions within 0.04
+    #  in both summation modes, against 5-9 % / 0.06 at b = 4: two thirds of that case's bars)
+    "pn2_n1024_b8_tgt": dict(best=0.25, window=0.12, adv=0.10, last_margin=1.0, first=5e-3, first_steps=4),
 }
 ROBUST_STEPS = 3         # an instance counts as robustly (un)successful in a binary step with >= 3 / 0 adversarial steps
 

@@ -340,3 +340,28 @@ def test_native_ssg_batch_independence_and_no_grad(pn2):
         assert torch.equal(lg2.detach(), full) and torch.equal(xr.grad, x.grad)
     finally:
         packed.struct.images = saved
+
+
+def test_first_level_scatter_is_loud_about_nan(pn2):
+    """geoa3_pn2_sa1_backward's order-free fixed-point scatter: a NaN in the upstream gradient of ONE centroid of one instance
+    comes out as NaN in the gradient of the points that centroid gathers (and nowhere in the other instance) -- not as a
+    silently converted zero (the file is compiled with -fno-honor-nans: the check is on bit patterns)."""
+    g = torch.Generator().manual_seed(3)
+    B, N, M = 2, 256, 32
+    xyz = _cloud(B, N, 77).cuda()
+    idx1 = pn2.ext.furthest_point_sampling(xyz, M)
+    new_xyz = torch.gather(xyz, 1, idx1.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    gidx = pn2.ext.ball_query(new_xyz, xyz, 0.4, 64)
+    w = [torch.randn(64, 3, generator=g) * 0.8, torch.randn(64, generator=g) * 0.1, torch.randn(64, 64, generator=g) * 0.18,
+         torch.randn(64, generator=g) * 0.1, torch.randn(128, 64, generator=g) * 0.18, torch.randn(128, generator=g) * 0.1]
+    w = [t.cuda().contiguous() for t in w]
+    x = xyz.clone().requires_grad_()
+    out = pn2._SA1Fused.apply(x, new_xyz, gidx, *w)             # [B,128,M]
+    go = torch.randn(out.shape, generator=g).cuda()
+    go[0, :, 5] = float("nan")
+    out.backward(go)
+    gx = x.grad
+    hit = torch.zeros(N, dtype=torch.bool)
+    hit[gidx[0, 5].long().cpu().unique()] = True
+    assert torch.isnan(gx[0].cpu()[hit]).all()
+    assert torch.isfinite(gx[1]).all()

@@ -16,7 +16,7 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 @pytest.mark.parametrize("tag,steps", [("n256_b8_hard", 24), ("n256_b8_tgt", 24), ("n1024_b8_hard", 4),
                                        ("n1024_b4_margin", 6), ("pn2_n1024_b4_tgt", 3), ("n256_b8_fail", 10),
-                                       ("pn2_n1024_b8_tgt10", 2)])
+                                       ("pn2_n1024_b8_tgt", 2)])
 def test_oracle_follows_reference_prefix(tag, steps):
     g = np.load(os.path.join(REPO, "tests", "golden", "geoa3_golden_long.npz"), allow_pickle=False)
     case = LONG_CASES[tag]
