@@ -125,6 +125,43 @@ __device__ __forceinline__ void sa1_stage(const geoa3_sa1_weights& w, const Sa1L
     L.kw[1] = k2;
     L.kw[2] = k3;
   }
+  // Row (and, for the backward, column) l1 norms of the weights: |W x|_inf <= |W|_l1rows |x|_inf bounds every hidden
+  // activation from the points' largest coordinate, and every back-propagated gradient from the pooled gradient's largest
+  // entry -- RIGOROUSLY, so the power-of-two scales of the operand splits come from scalar integer arithmetic per centroid
+  // instead of a measured maximum per block (16 v_max3 + a 12-step wave reduction per split, a tenth of the kernels'
+  // vector instructions).  An l1 bound over 64 terms is loose by ~2^3 per layer; fp16's exponent range takes 2^10 of slack
+  // before a lo piece turns subnormal.  kw[3..7] = E(.) with x < 2^E(x): W1 rows, b1, W2 rows, b2, then W3 columns /
+  // W2 columns (backward).
+  {
+    float r1 = 0.f, rb1 = 0.f, r2 = 0.f, rb2 = 0.f, c3 = 0.f, c2 = 0.f;
+    if (tid < 64) {
+      r1 = __builtin_fabsf(w.w1[3 * tid]) + __builtin_fabsf(w.w1[3 * tid + 1]) + __builtin_fabsf(w.w1[3 * tid + 2]);
+      rb1 = __builtin_fabsf(w.b1[tid]);
+      rb2 = __builtin_fabsf(w.b2[tid]);
+      for (int kk = 0; kk < 64; ++kk) r2 += __builtin_fabsf(w.w2[tid * 64 + kk]);
+      if (BWD) {
+        for (int ch = 0; ch < 128; ++ch) c3 += __builtin_fabsf(w.w3[ch * 64 + tid]);
+        for (int o = 0; o < 64; ++o) c2 += __builtin_fabsf(w.w2[o * 64 + tid]);
+      }
+    }
+    if (tid < 64) {     // (the first wavefront holds all 64 rows)
+      r1 = wave_max(r1);
+      rb1 = wave_max(rb1);
+      r2 = wave_max(r2);
+      rb2 = wave_max(rb2);
+      c3 = wave_max(c3);
+      c2 = wave_max(c2);
+      auto E = [](float x) { int e = (int)((__float_as_uint(x) >> 23) & 0xffu) - 126; return e < -100 ? -100 : e; };
+      if (tid == 0) {
+        L.kw[3] = E(r1);
+        L.kw[4] = E(rb1);
+        L.kw[5] = E(r2);
+        L.kw[6] = E(rb2);
+        L.kw[7] = E(c3);
+        L.kw[8] = E(c2);
+      }
+    }
+  }
   for (int e = tid; e < 64; e += SA_T) {
     // layer 1 as one k-step of the matrix core (K = 16): against the operand (ph.xyz, one | pl.xyz, one) of the lanes of k
     // half 0 and (ph.xyz, 0 | pl.xyz, 0) of k half 1 -- wh.ph + bh.one + wh.pl + bl.one + wl.ph + wl.pl, fp32 accumulation
@@ -232,7 +269,27 @@ __device__ __forceinline__ void sa1_layer1(const Sa1Lds& L, half8 bop, int lane,
   z[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bop, SA_ZERO16, 0, 0, 0);
   z[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bop, SA_ZERO16, 0, 0, 0);
 }
-// relu in place, k of the block's maximum
+// scales from bounds (sa1_stage): with |p| 2^kp < 2^14,  h1 < 2^e1, e1 = max(EW1 + 14 - kp, EB1) + 1, and the layer-1
+// accumulators (2^(k1 + kp) h1) times 2^kx stay below 2^14 for kx = 14 - e1 - k1 - kp; h2 < 2^e2, e2 = max(EW2 + e1, EB2) + 1
+struct Sa1Scales {
+  int kx, ka, ky;   // operand scale of h1; scale of the layer-2 accumulators (k1 + kp + kx + k2); operand scale of h2
+};
+__device__ __forceinline__ Sa1Scales sa1_scales(int k1, int k2, int kp, int EW1, int EB1, int EW2, int EB2) {
+  const int a = EW1 + 14 - kp, e1 = (a > EB1 ? a : EB1) + 1;
+  Sa1Scales S;
+  S.kx = 14 - e1 - k1 - kp;
+  S.ka = k1 + kp + S.kx + k2;
+  const int b = EW2 + e1, e2 = (b > EB2 ? b : EB2) + 1;
+  S.ky = 14 - e2 - S.ka;
+  return S;
+}
+__device__ __forceinline__ void sa_relu(f32x16 (&z)[2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[t][r] = sa_relu(z[t][r]);
+}
+// relu in place, k of the block's maximum (measured: the pooled gradient's scale still is)
 __device__ __forceinline__ int sa_relu_k(f32x16 (&z)[2]) {
   float m = 0.f;
 #pragma unroll
@@ -318,6 +375,8 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, l31 = lane & 31;
   const int k1 = __builtin_amdgcn_readfirstlane(L.kw[0]), k2 = __builtin_amdgcn_readfirstlane(L.kw[1]),
             k3 = __builtin_amdgcn_readfirstlane(L.kw[2]);
+  const int EW1 = __builtin_amdgcn_readfirstlane(L.kw[3]), EB1 = __builtin_amdgcn_readfirstlane(L.kw[4]),
+            EW2 = __builtin_amdgcn_readfirstlane(L.kw[5]), EB2 = __builtin_amdgcn_readfirstlane(L.kw[6]);
   const int total = B * M, stride = (int)gridDim.x * (SA_T / 64);   // B * M < 2^31 / 128 (checked by the launcher)
   int c = (int)blockIdx.x * (SA_T / 64) + wave;
   Sa1Pts P;
@@ -329,6 +388,7 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
     const int kp = sa1_kp(Q);
     const float sp = sa_pow2(kp);
     const _Float16 one = h ? (_Float16)0.f : (_Float16)sp;
+    const Sa1Scales SC = sa1_scales(k1, k2, kp, EW1, EB1, EW2, EB2);   // the same for both column blocks
     float bv[4];   // best (value, sample) of channel 32 t3 + l31 over this lane's samples
     int bs[4];
     // The two 32-sample column blocks A and B go through the layers SKEWED by one stage, so that every matrix phase of one
@@ -341,19 +401,17 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
     sa1_layer1(L, sa1_bop(Q.ax, Q.ay, Q.az, sp, one), lane, zA);
     sa1_layer1(L, sa1_bop(Q.bx, Q.by, Q.bz, sp, one), lane, zB);
     SA_SB();
-    const int kxA = sa_relu_k(zA);
-    sa_split_tiles(zA, sa_pow2(kxA), xhA, xlA);
+    sa_relu(zA);
+    sa_split_tiles(zA, sa_pow2(SC.kx), xhA, xlA);
     SA_SB();
-    const int kaA = k1 + kp + kxA + k2;
-    sa1_layer2(L, xhA, xlA, sa_pow2(kaA), lane, zA);            // (zA: layer-2 accumulators of A from here)
-    const int kxB = sa_relu_k(zB);
-    sa_split_tiles(zB, sa_pow2(kxB), xhB, xlB);
-    SA_MIX(24, 5)
+    sa1_layer2(L, xhA, xlA, sa_pow2(SC.ka), lane, zA);          // (zA: layer-2 accumulators of A from here)
+    sa_relu(zB);
+    sa_split_tiles(zB, sa_pow2(SC.kx), xhB, xlB);
+    SA_MIX(24, 4)
     SA_SB();
-    const int kaB = k1 + kp + kxB + k2;
-    sa1_layer2(L, xhB, xlB, sa_pow2(kaB), lane, zB);
-    const int kyA = sa_relu_k(zA);
-    sa_split_tiles(zA, sa_pow2(kyA), xhA, xlA);                // the A fragments of the transposed layer 3
+    sa1_layer2(L, xhB, xlB, sa_pow2(SC.ka), lane, zB);
+    sa_relu(zA);
+    sa_split_tiles(zA, sa_pow2(SC.ky), xhA, xlA);              // the A fragments of the transposed layer 3
     SA_MIX(24, 5)
     SA_SB();
     auto tile = [&](const half8 (&xh)[4], const half8 (&xl)[4], int t3, f32x16& a3) {
@@ -384,10 +442,10 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
     };
     f32x16 t0, t1;
     {
-      const float un3 = sa_pow2(-(kaA + kyA + k3));
+      const float un3 = sa_pow2(-(SC.ka + SC.ky + k3));
       tile(xhA, xlA, 0, t0);
-      const int kyB = sa_relu_k(zB);
-      sa_split_tiles(zB, sa_pow2(kyB), xhB, xlB);
+      sa_relu(zB);
+      sa_split_tiles(zB, sa_pow2(SC.ky), xhB, xlB);
       tile(xhA, xlA, 1, t1);
       argmax(t0, un3, 0, 0);
       tile(xhA, xlA, 2, t0);
@@ -396,7 +454,7 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
       argmax(t0, un3, 0, 2);
       SA_MIX(48, 5)
       SA_SB();
-      const float un3b = sa_pow2(-(kaB + kyB + k3));
+      const float un3b = un3;
       tile(xhB, xlB, 0, t0);
       argmax(t1, un3, 0, 3);
       tile(xhB, xlB, 1, t1);
@@ -440,6 +498,12 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4,
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, l31 = lane & 31;
   const int k1 = __builtin_amdgcn_readfirstlane(L.kw[0]), k2 = __builtin_amdgcn_readfirstlane(L.kw[1]),
             k3 = __builtin_amdgcn_readfirstlane(L.kw[2]);
+  const int EW1 = __builtin_amdgcn_readfirstlane(L.kw[3]), EB1 = __builtin_amdgcn_readfirstlane(L.kw[4]),
+            EW2 = __builtin_amdgcn_readfirstlane(L.kw[5]), EB2 = __builtin_amdgcn_readfirstlane(L.kw[6]),
+            EW3T = __builtin_amdgcn_readfirstlane(L.kw[7]);
+  // d h2 = W3^T dz3 with |dz3| 2^kg < 2^14: the accumulators (2^(k3 + kg) d h2) stay below 2^(k3 + EW3T + 14), so the
+  // operand scale of the next product is the same for every centroid
+  const int kd = -k3 - EW3T;
   // one-hot records of the wave's centroid: channel PAIRS (2 q, 2 q + 1) as packed fp16 images of the scaled pooled gradient
   // (hi pieces | lo pieces), and per channel the arg-max sample as a one-hot bit over samples 0-31 | 32-63
   unsigned* s_hp = L.pa + wave * 384;   // [64]
@@ -478,6 +542,7 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4,
     const int kp = sa1_kp(Q);
     const float sp = sa_pow2(kp);
     const _Float16 one = h ? (_Float16)0.f : (_Float16)sp;
+    const Sa1Scales SC = sa1_scales(k1, k2, kp, EW1, EB1, EW2, EB2);
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;   // of sample `lane`
     // The two column blocks (samples 0-31, 32-63) go through the forward recomputation and the three backward products ONE
     // AFTER THE OTHER, each with its own power-of-two scales: half the live accumulators, three waves per SIMD.
@@ -536,7 +601,6 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4,
       }
       // the forward of the block: layers 1 and 2; the sign of the layer-2 accumulators (bias included) is the relu gate
       const half8 bop = sa1_bop(cb ? Q.bx : Q.ax, cb ? Q.by : Q.ay, cb ? Q.bz : Q.az, sp, one);
-      int kd;
       half8 bh[4], bl[4];
       {
         f32x16 a2[2];
@@ -544,21 +608,16 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4,
           f32x16 z[2];
           sa1_layer1(L, bop, lane, z);
           half8 xh[4], xl[4];
-          const int kx = sa_relu_k(z);
-          sa_split_tiles(z, sa_pow2(kx), xh, xl);
-          sa1_layer2(L, xh, xl, sa_pow2(k1 + kp + kx + k2), lane, a2);
+          sa_relu(z);
+          sa_split_tiles(z, sa_pow2(SC.kx), xh, xl);
+          sa1_layer2(L, xh, xl, sa_pow2(SC.ka), lane, a2);
         }
         // through relu 2; the gated accumulator registers are the B operands of d h1 = W2^T dz2 (the W2^T image follows
         // their row order)
-        float m = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            d2[t][r] = a2[t][r] > 0.f ? d2[t][r] : 0.f;
-            m = fmaxf(m, __builtin_fabsf(d2[t][r]));
-          }
-        kd = sa_k(wave_max(m));
+          for (int r = 0; r < 16; ++r) d2[t][r] = a2[t][r] > 0.f ? d2[t][r] : 0.f;
         sa_split_tiles(d2, sa_pow2(kd), bh, bl);
       }
       f32x16 d1[2];
@@ -705,9 +764,11 @@ __global__ __launch_bounds__(SCAT_BLOCK) void sa1_scatter_kernel(const float* __
   float* G = dxyz + (size_t)b * N * 3;
   for (int i = tid; i < N; i += SCAT_BLOCK) {
     const bool bad = !finite || ((s_bad[i >> 5] >> (i & 31)) & 1u);
-    G[3 * i + 0] = bad ? __builtin_nanf("") : __ll2float_rn((long long)sc_acc[i]) * from;
-    G[3 * i + 1] = bad ? __builtin_nanf("") : __ll2float_rn((long long)sc_acc[N + i]) * from;
-    G[3 * i + 2] = bad ? __builtin_nanf("") : __ll2float_rn((long long)sc_acc[2 * N + i]) * from;
+    // (the NaN as a BIT pattern through an integer store: a floating-point NaN constant is undefined under -fno-honor-nans)
+    unsigned* Gu = reinterpret_cast<unsigned*>(G);
+    Gu[3 * i + 0] = bad ? 0x7fc00000u : __float_as_uint(__ll2float_rn((long long)sc_acc[i]) * from);
+    Gu[3 * i + 1] = bad ? 0x7fc00000u : __float_as_uint(__ll2float_rn((long long)sc_acc[N + i]) * from);
+    Gu[3 * i + 2] = bad ? 0x7fc00000u : __float_as_uint(__ll2float_rn((long long)sc_acc[2 * N + i]) * from);
   }
 }
 
