@@ -301,20 +301,24 @@ __device__ __forceinline__ int sa_relu_k(f32x16 (&z)[2]) {
     }
   return sa_k(wave_max(m));
 }
-// layer 2 of one column block: acc[t][r] = 2^kacc (W2 h1 + b2), rows 32 t + mfma_row(r, lane); the bias enters as the
-// accumulators' initial value (b2 * 2^kacc: exact), so the relu gate of the backward is the accumulator's sign
-__device__ __forceinline__ void sa1_layer2(const Sa1Lds& L, const half8 (&xh)[4], const half8 (&xl)[4], float bscale, int lane,
-                                           f32x16 (&acc)[2]) {
+// the bias of layer 2 in the accumulators' layout, times the accumulators' scale (exact: a power of two): once per centroid,
+// the C operand of the first matrix instruction of BOTH column blocks' chains (the blocks share their scales)
+__device__ __forceinline__ void sa1_bias2(const Sa1Lds& L, float bscale, int lane, f32x16 (&bias)[2]) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 b = *reinterpret_cast<const float4*>(L.b2 + 32 * t + 8 * g + 4 * (lane >> 5));
-      acc[t][4 * g + 0] = b.x * bscale;
-      acc[t][4 * g + 1] = b.y * bscale;
-      acc[t][4 * g + 2] = b.z * bscale;
-      acc[t][4 * g + 3] = b.w * bscale;
+      bias[t][4 * g + 0] = b.x * bscale;
+      bias[t][4 * g + 1] = b.y * bscale;
+      bias[t][4 * g + 2] = b.z * bscale;
+      bias[t][4 * g + 3] = b.w * bscale;
     }
+}
+// layer 2 of one column block: acc[t][r] = 2^kacc (W2 h1 + b2), rows 32 t + mfma_row(r, lane); the bias enters as the
+// accumulators' initial value, so the relu gate of the backward is the accumulator's sign
+__device__ __forceinline__ void sa1_layer2(const Sa1Lds& L, const half8 (&xh)[4], const half8 (&xl)[4], const f32x16 (&bias)[2],
+                                           int lane, f32x16 (&acc)[2]) {
   const unsigned char* wr = L.w2h + (lane & 31) * SA_PH + (lane >> 5) * 16;
   half8 fr[2][4];
   auto fetch = [&](int ks, half8 (&f)[4]) {
@@ -330,7 +334,7 @@ __device__ __forceinline__ void sa1_layer2(const Sa1Lds& L, const half8 (&xh)[4]
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const half8 wh = fr[ks & 1][2 * t], wl = fr[ks & 1][2 * t + 1];
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], ks == 0 ? bias[t] : acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acc[t], 0, 0, 0);
     }
@@ -389,6 +393,8 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
     const float sp = sa_pow2(kp);
     const _Float16 one = h ? (_Float16)0.f : (_Float16)sp;
     const Sa1Scales SC = sa1_scales(k1, k2, kp, EW1, EB1, EW2, EB2);   // the same for both column blocks
+    f32x16 bias2[2];
+    sa1_bias2(L, sa_pow2(SC.ka), lane, bias2);
     float bv[4];   // best (value, sample) of channel 32 t3 + l31 over this lane's samples
     int bs[4];
     // The two 32-sample column blocks A and B go through the layers SKEWED by one stage, so that every matrix phase of one
@@ -404,12 +410,12 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
     sa_relu(zA);
     sa_split_tiles(zA, sa_pow2(SC.kx), xhA, xlA);
     SA_SB();
-    sa1_layer2(L, xhA, xlA, sa_pow2(SC.ka), lane, zA);          // (zA: layer-2 accumulators of A from here)
+    sa1_layer2(L, xhA, xlA, bias2, lane, zA);                   // (zA: layer-2 accumulators of A from here)
     sa_relu(zB);
     sa_split_tiles(zB, sa_pow2(SC.kx), xhB, xlB);
     SA_MIX(24, 4)
     SA_SB();
-    sa1_layer2(L, xhB, xlB, sa_pow2(SC.ka), lane, zB);
+    sa1_layer2(L, xhB, xlB, bias2, lane, zB);
     sa_relu(zA);
     sa_split_tiles(zA, sa_pow2(SC.ky), xhA, xlA);              // the A fragments of the transposed layer 3
     SA_MIX(24, 5)
@@ -543,6 +549,8 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4,
     const float sp = sa_pow2(kp);
     const _Float16 one = h ? (_Float16)0.f : (_Float16)sp;
     const Sa1Scales SC = sa1_scales(k1, k2, kp, EW1, EB1, EW2, EB2);
+    f32x16 bias2[2];
+    sa1_bias2(L, sa_pow2(SC.ka), lane, bias2);
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;   // of sample `lane`
     // The two column blocks (samples 0-31, 32-63) go through the forward recomputation and the three backward products ONE
     // AFTER THE OTHER, each with its own power-of-two scales: half the live accumulators, three waves per SIMD.
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(SA_T) __attribute__((amdgpu_waves_per_eu(SA_WB / 4,
           half8 xh[4], xl[4];
           sa_relu(z);
           sa_split_tiles(z, sa_pow2(SC.kx), xh, xl);
-          sa1_layer2(L, xh, xl, sa_pow2(SC.ka), lane, a2);
+          sa1_layer2(L, xh, xl, bias2, lane, a2);
         }
         // through relu 2; the gated accumulator registers are the B operands of d h1 = W2^T dz2 (the W2^T image follows
         // their row order)
