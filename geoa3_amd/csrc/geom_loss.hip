@@ -29,24 +29,34 @@ __device__ __forceinline__ float kappa_point(float px, float py, float pz, float
   return acc / (float)k;
 }
 
-__global__ __launch_bounds__(256) void kappa_kernel(const float* __restrict__ pc, const float* __restrict__ normal,
-                                                    const int32_t* __restrict__ knn_idx,
-                                                    const int32_t* __restrict__ nn_idx, int N, int Nn, int k,
-                                                    float* __restrict__ kappa) {
+// LDS = true (3 N floats fit): the instance's cloud is staged in LDS once per workgroup of 1024 points and the k
+// neighbours of a point are gathered from there -- at N = 4096, k = 32 the gather from global memory fetched 6.3 GB for
+// 0.16 GB of algorithmic traffic (profiles/round4_v5_c5_summary.md; once per batch).
+template <bool LDS>
+__global__ __launch_bounds__(LDS ? 1024 : 256) void kappa_kernel(const float* __restrict__ pc, const float* __restrict__ normal,
+                                                                 const int32_t* __restrict__ knn_idx,
+                                                                 const int32_t* __restrict__ nn_idx, int N, int Nn, int k,
+                                                                 float* __restrict__ kappa) {
+  extern __shared__ __attribute__((aligned(16))) float s_kp[];
   const int b = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
+  const int i = blockIdx.x * (LDS ? 1024 : 256) + threadIdx.x;
   const float* P = pc + (size_t)b * 3 * N;
+  if (LDS) {
+    for (int e = threadIdx.x; e < 3 * N; e += 1024) s_kp[e] = P[e];
+    __syncthreads();
+  }
+  if (i >= N) return;
   const float* Nm = normal + (size_t)b * 3 * Nn;
   const int ni = nn_idx ? nn_idx[(size_t)b * N + i] : i;
   const float nx = Nm[ni], ny = Nm[Nn + ni], nz = Nm[2 * Nn + ni];
   const int32_t* nb = knn_idx + ((size_t)b * N + i) * (k + 1);
+  const float* Q = LDS ? s_kp : P;
   auto fetch = [&](int j, float& x, float& y, float& z) {
-    x = P[j];
-    y = P[N + j];
-    z = P[2 * N + j];
+    x = Q[j];
+    y = Q[N + j];
+    z = Q[2 * N + j];
   };
-  kappa[(size_t)b * N + i] = kappa_point(P[i], P[N + i], P[2 * N + i], nx, ny, nz, nb, k, fetch);
+  kappa[(size_t)b * N + i] = kappa_point(Q[i], Q[N + i], Q[2 * N + i], nx, ny, nz, nb, k, fetch);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1356,9 +1366,15 @@ extern "C" int geoa3_kappa(const float* pc, const float* normal, const int32_t* 
   if (!pc || !normal || !knn_idx || !kappa || B <= 0 || N <= 0 || k <= 0 || Nn < 0) return GEOA3_EINVAL;
   if (Nn == 0) Nn = N;
   if (!nn_idx && Nn != N) return GEOA3_EINVAL;
-  dim3 grid((N + 255) / 256, B);
-  hipLaunchKernelGGL(kappa_kernel, grid, dim3(256), 0, geoa3_stream(stream), pc, normal, knn_idx, nn_idx, N, Nn,
-                     k, kappa);
+  const size_t lds = (size_t)3 * N * sizeof(float);
+  if (N >= 2048 && lds <= 150 * 1024) {   // (below 2048 points the cloud is L2-resident anyway and four waves fill faster)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kappa_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kappa_kernel<true>, dim3((N + 1023) / 1024, B), dim3(1024), lds, geoa3_stream(stream), pc, normal, knn_idx,
+                       nn_idx, N, Nn, k, kappa);
+  } else {
+    hipLaunchKernelGGL(kappa_kernel<false>, dim3((N + 255) / 256, B), dim3(256), 0, geoa3_stream(stream), pc, normal, knn_idx,
+                       nn_idx, N, Nn, k, kappa);
+  }
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -92,6 +92,25 @@ def test_kappa_ori_golden(ops, golden, tag):
     np.testing.assert_allclose(kap.cpu().numpy(), golden[pre + "kappa_ori"], rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("N,k", [(2048, 16), (4096, 32), (3001, 20), (1024, 16)])
+def test_kappa_ori_staged_in_lds_matches_the_gather_and_the_oracle(ops, N, k):
+    """Clouds of 2048 points and more take kappa_kernel<true> (the instance's cloud staged in LDS, 1024 points per
+    workgroup); the arithmetic is the one-point routine of the small-cloud kernel: the same bits as the oracle's
+    expression evaluated per point (Lib/loss_utils.py:52-62), at the golden test's tolerance.  With a clean-to-cloud
+    index (`nn_idx`: the normal of the nearest clean point) as _get_kappa_adv's callers pass it."""
+    from geoa3_amd.data import synthetic_cad_clouds
+    B = 3
+    ori, nrm = synthetic_cad_clouds(B, N, seed=N + k)
+    _, idx = ops.knn_planar(dev(ori), dev(ori), k + 1)
+    kap = ops.kappa(dev(ori), dev(nrm), idx)
+    want = O.get_kappa_ori(ori, nrm, k)
+    np.testing.assert_allclose(kap.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+    perm = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b)) for b in range(B)]).int()
+    nrm_p = torch.gather(nrm, 2, torch.argsort(perm.long(), 1).unsqueeze(1).expand(-1, 3, -1))   # nrm_p[:, :, perm[i]] = nrm[:, :, i]
+    kap2 = ops.kappa(dev(ori), dev(nrm_p), idx, nn_idx=dev(perm))
+    assert torch.equal(kap2, kap)
+
+
 def _geo(ops, golden, tag, **kw):
     pre = "ops/%s/" % tag
     adv, ori, nrm = (dev(T(golden[pre + n])) for n in ("adv", "ori", "nrm"))

@@ -23,6 +23,7 @@ python3 tools/trace_timeline.py $O/p32/trace > $O/p32_timeline.txt
 GEOA3_GEO_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4/trace -o t -- $B --arch PointNetPP --steps 20 --warmup 5 --presteps 20 > $O/c4_trace.log 2>&1
 GEOA3_GEO_STREAM=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4/fetch -o t -- $B --arch PointNetPP --steps 10 --warmup 3 --presteps 10 > $O/c4_fetch.log 2>&1
 GEOA3_GEO_STREAM=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4/write -o t -- $B --arch PointNetPP --steps 10 --warmup 3 --presteps 10 > $O/c4_write.log 2>&1
+GEOA3_GEO_STREAM=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/c4/mfma -o t -- $B --arch PointNetPP --steps 10 --warmup 3 --presteps 10 > $O/c4_mfma.log 2>&1
 python3 tools/trace_timeline.py $O/c4/trace > $O/c4_timeline.txt
 # configs[4]
 GEOA3_GEO_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5/trace -o t -- $B --npoint 4096 --knn 32 --steps 20 --warmup 5 --presteps 60 > $O/c5_trace.log 2>&1
