@@ -55,7 +55,7 @@ class Pn2SsgWeights(C.Structure):
     _fields_ = [("classes", C.c_int32), ("sa1", Sa1Weights)] + [(n, vp) for n in (
         "sa2_wx", "sa2_wf", "sa2_b0", "sa2_wft", "sa2_w1", "sa2_b1", "sa2_w1t", "sa2_w2", "sa2_b2", "sa2_w2t",
         "sa3_wx", "sa3_wf", "sa3_b0", "sa3_wft", "sa3_w1", "sa3_b1", "sa3_w1t", "sa3_w2", "sa3_b2", "sa3_w2t",
-        "f1", "fb1", "f1t", "f2", "fb2", "f2t", "f3", "fb3", "f3t", "images")]
+        "f1", "fb1", "f1t", "f2", "fb2", "f2t", "f3", "fb3", "f3t", "images", "side")]
 
 
 class AttackState(C.Structure):
@@ -110,6 +110,8 @@ SIGNATURES = {
     "geoa3_pn2ssg_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "geoa3_pn2ssg_images_bytes": (C.c_int64, []),
     "geoa3_pn2ssg_pack_images": (C.c_int, [C.POINTER(Pn2SsgWeights), vp, vp]),
+    "geoa3_side_queue_create": (vp, []),
+    "geoa3_side_queue_destroy": (None, [vp]),
     "geoa3_pn2ssg_forward": (C.c_int, [C.POINTER(Pn2SsgWeights), vp, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_pn2ssg_backward": (C.c_int, [C.POINTER(Pn2SsgWeights), vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "geoa3_fps_sample": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
@@ -141,7 +143,7 @@ _lib = None
 
 
 ENOSUPPORT = -3   # GEOA3_ENOSUPPORT
-ABI_VERSION = 500  # GEOA3_ABI_VERSION of include/geoa3_hip.h this file mirrors (tests/test_abi.py holds the two together)
+ABI_VERSION = 501  # GEOA3_ABI_VERSION of include/geoa3_hip.h this file mirrors (tests/test_abi.py holds the two together)
 
 
 class Geoa3Error(RuntimeError):

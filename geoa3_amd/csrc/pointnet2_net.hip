@@ -15,6 +15,7 @@
 //     is applied to the UN-grouped points and the result is gathered (level 2); GroupAll (level 3) has no centre:
 //     layer 1 = relu(W_f f + W_x xyz + b);
 //   * level 3's 512 -> 1024 layer runs as two K = 256 products accumulated before the bias / relu / max tail.
+#include <new>
 #include "pointnet_kernels.h"
 
 namespace {
@@ -343,6 +344,44 @@ extern "C" int geoa3_pn2ssg_pack_images(const geoa3_pn2ssg_weights* pw, void* im
   return pack_images(*pw, images, geoa3_stream(stream));
 }
 
+namespace {
+struct SideQueue {
+  hipStream_t stream;
+  hipEvent_t fork, join;
+};
+}  // namespace
+
+extern "C" void* geoa3_side_queue_create(void) {
+  SideQueue* q = new (std::nothrow) SideQueue{};
+  if (!q) return nullptr;
+  if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete q;
+    return nullptr;
+  }
+  if (hipEventCreateWithFlags(&q->fork, hipEventDisableTiming) != hipSuccess) {
+    (void)hipStreamDestroy(q->stream);
+    delete q;
+    return nullptr;
+  }
+  if (hipEventCreateWithFlags(&q->join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipEventDestroy(q->fork);
+    (void)hipStreamDestroy(q->stream);
+    delete q;
+    return nullptr;
+  }
+  return q;
+}
+
+extern "C" void geoa3_side_queue_destroy(void* side) {
+  SideQueue* q = static_cast<SideQueue*>(side);
+  if (!q) return;
+  (void)hipStreamSynchronize(q->stream);
+  (void)hipEventDestroy(q->join);
+  (void)hipEventDestroy(q->fork);
+  (void)hipStreamDestroy(q->stream);
+  delete q;
+}
+
 extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float* x, int B, int N, float* logits,
                                     void* workspace, void* stream) {
   if (!pw || !x || !logits || !workspace || B <= 0 || N < M1 || pw->classes <= 0) return GEOA3_EINVAL;
@@ -359,18 +398,33 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   hipLaunchKernelGGL(planar_to_points_kernel, g1d((long)B * N), dim3(256), 0, s, x, w.xyz, N, (long)B * N);
   TRY(geoa3_pn2_furthest_point_sampling(w.xyz, B, N, M1, nullptr, w.idx1, stream));
   hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M1), dim3(256), 0, s, w.xyz, w.idx1, w.nx1, N, M1, (long)B * M1);
+  // Level 2's sampling, ball query and shift need only the level-1 centroids: with a side queue in the weights they run
+  // on its stream BESIDE level 1's ball query + MLP (four one-workgroup-per-cloud kernels, 0.14 ms of dependent latency that
+  // the 8 waves per CU of sa1_fwd_kernel leave room for): fork after the centroid gather, join in front of sa2_fwd.  The
+  // call is still ordered on `stream` as a whole (the side stream starts behind an event of it and is waited for).
+  SideQueue* sq = static_cast<SideQueue*>(p.side);
+  const bool use_side = sq != nullptr;
+  hipStream_t s2 = use_side ? sq->stream : s;
+  void* stream2 = use_side ? (void*)sq->stream : stream;
+  if (use_side) {
+    if (hipEventRecord(sq->fork, s) != hipSuccess || hipStreamWaitEvent(sq->stream, sq->fork, 0) != hipSuccess)
+      return GEOA3_ELAUNCH;
+  }
+  // ---- level 2's geometry (:68-76): FPS 128, ball 0.4 x 64, b0 - W_x c
+  TRY(geoa3_pn2_furthest_point_sampling(w.nx1, B, M1, M2, nullptr, w.idx2, stream2));
+  hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M2), dim3(256), 0, s2, w.nx1, w.idx2, w.nx2, M1, M2, (long)B * M2);
+  TRY(geoa3_pn2_ball_query(w.nx2, w.nx1, B, M1, M2, R2, S, w.gidx2, stream2));
+  hipLaunchKernelGGL(affine3_kernel, g1d((long)B * 128 * M2), dim3(256), 0, s2, p.sa2_wx, p.sa2_b0, w.nx2, -1.f, w.shift,
+                     128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
+  if (use_side && hipEventRecord(sq->join, sq->stream) != hipSuccess) return GEOA3_ELAUNCH;
   TRY(geoa3_pn2_ball_query(w.nx1, w.xyz, B, N, M1, R1, S, w.gidx1, stream));
   TRY(geoa3_pn2_sa1_forward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, stream));
   TRY((transpose<float, false>(w.out1, nullptr, w.f1, B, M1, C1, s)));            // [B,512,128] -> [B,128,512]
-  // ---- level 2 (:68-76): FPS 128, ball 0.4 x 64, MLP (128 + 3) -> 128 -> 128 -> 256, max
-  TRY(geoa3_pn2_furthest_point_sampling(w.nx1, B, M1, M2, nullptr, w.idx2, stream));
-  hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M2), dim3(256), 0, s, w.nx1, w.idx2, w.nx2, M1, M2, (long)B * M2);
-  TRY(geoa3_pn2_ball_query(w.nx2, w.nx1, B, M1, M2, R2, S, w.gidx2, stream));
+  // ---- level 2 (:68-76): MLP (128 + 3) -> 128 -> 128 -> 256, max
   TRY(conv_slice(w.f1, 128, 0, 128, img_of(im, IM_SA2_WF), nullptr, nullptr, w.r, 128, B, M1, false, false, s));   // W_f f
   hipLaunchKernelGGL(affine3_add_kernel, g1d((long)B * 128 * M1), dim3(256), 0, s, w.r, p.sa2_wx, (const float*)nullptr,
                      w.nx1, 128, M1, 0, (long)B * 128 * M1);                                               // + W_x xyz
-  hipLaunchKernelGGL(affine3_kernel, g1d((long)B * 128 * M2), dim3(256), 0, s, p.sa2_wx, p.sa2_b0, w.nx2, -1.f, w.shift,
-                     128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
+  if (use_side && hipStreamWaitEvent(s, sq->join, 0) != hipSuccess) return GEOA3_ELAUNCH;
   float* rt = w.df1;   // [B,512,128]: r point-major (a backward buffer, free in forward)
   TRY((transpose<float, false>(w.r, nullptr, rt, B, 128, M1, s)));
   // gather + shift + relu, W1, W2 + max in one kernel; the activations a0 / a1 exist only as gate bits (m0 / m1)

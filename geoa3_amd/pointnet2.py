@@ -21,6 +21,7 @@ GPU tensors only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -602,6 +603,23 @@ class PackedSSG:
         check(lib.geoa3_pn2ssg_pack_images(C.byref(self.struct), images.data_ptr(), _s()), "geoa3_pn2ssg_pack_images")
         self._keep.append(images)
         self.struct.images = images.data_ptr()
+        # a side queue (one stream + two events, owned by this object): level 2's sampling / ball query run beside level 1's MLP
+        # (csrc/pointnet2_net.hip; GEOA3_PN2_SIDE=0: one stream, e.g. for per-kernel traces)
+        self._side = None
+        if os.environ.get("GEOA3_PN2_SIDE", "1") != "0":
+            with torch.cuda.device(device):
+                self._side = lib.geoa3_side_queue_create()
+            if not self._side:
+                raise _lib.Geoa3Error("geoa3_side_queue_create failed")
+            self.struct.side = self._side
+
+    def __del__(self):
+        side, self._side = getattr(self, "_side", None), None
+        if side:
+            try:
+                _lib.load().geoa3_side_queue_destroy(side)
+            except Exception:   # interpreter shutdown: the library or the runtime may be gone
+                pass
 
 
 class _SSGFn(torch.autograd.Function):
@@ -658,6 +676,14 @@ class PointNet2ClassificationSSG(nn.Module):
             nn.Dropout(0.5), nn.Linear(256, 40))
 
     native = True    # class-wide switch (tests compare the native path with the module path)
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: the packed weights (ctypes struct, device images, the side queue's stream) and the
+        workspace belong to THIS object and are rebuilt by the copy's first forward."""
+        state = dict(self.__dict__)
+        for name in ("_packed", "_packed_key", "_ws_cache"):
+            state.pop(name, None)
+        return state
 
     def _weights_key(self, device):
         return (str(device),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))

@@ -39,7 +39,7 @@ extern "C" {
 /* The ABI version of this header: bumped on EVERY change of a struct layout or a signature.  geoa3_version() returns the
  * value the library was built with; a binding must refuse a library whose version differs (geoa3_amd/_lib.py does: a
  * stale or variant .so would misread the argument structs silently). */
-#define GEOA3_ABI_VERSION 500
+#define GEOA3_ABI_VERSION 501
 int geoa3_version(void);
 const char* geoa3_strerror(int code);
 
@@ -447,7 +447,15 @@ typedef struct geoa3_pn2ssg_weights {
   const float *f2, *fb2, *f2t;                       /* [256,512], [256], [512,256] */
   const float *f3, *fb3, *f3t;                       /* [classes,256], [classes], [256,classes] */
   const void* images;   /* geoa3_pn2ssg_pack_images of THESE weights, or NULL (the forward then rebuilds them per call) */
+  void* side;           /* geoa3_side_queue_create(), or NULL: one stream.  With it the forward runs level 2's sampling, ball
+                           query and shift (functions of the level-1 centroids only) on the queue's stream beside level 1's MLP
+                           and joins in front of level 2's MLP: same results, the call is still ordered on `stream` as a whole.
+                           One queue per concurrent caller (the events are re-recorded by every call). */
 } geoa3_pn2ssg_weights;
+/* A HIP stream + two events owned by the caller's module object (the library keeps no global state).  Destroy after the
+ * last call that used it has been enqueued (destroy synchronises the side stream). */
+void* geoa3_side_queue_create(void);
+void geoa3_side_queue_destroy(void* side);
 /* The level-2 / level-3 matrices as split-fp16 fragment images (the order the matrix-core loops read them; one
  * power-of-two scale per matrix): built once per set of weights into `images` (geoa3_pn2ssg_images_bytes() bytes,
  * 256-byte aligned; the `images` member of *w is not read). */

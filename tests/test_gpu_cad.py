@@ -164,4 +164,13 @@ def test_pointnetpp_native_path_on_cad_clouds_matches_oracle():
     (lo * w).sum().backward()
     np.testing.assert_allclose(la.detach().cpu().numpy(), lo.detach().numpy(), rtol=1e-4, atol=3e-4)
     want, got = _merge_twins(xo.grad.numpy(), pts.numpy()), _merge_twins(xa.grad.cpu().numpy(), pts.numpy())
-    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * np.abs(want).max())
+    # Dense clusters and rods hold points a few 1e-4 apart whose pooled activations tie to the last bits: which of two such
+    # neighbours wins a max-pool differs between any two fp32 evaluations (here: 18 points of 5120 with logits equal to
+    # 3e-6, tools/pn2_cad_flips.py), and the winner's gradient lands on it instead of its neighbour.  So: the element-wise
+    # bar on 99 % of the elements, the difference small in norm, and its SUM over each cloud ~0 (mass moved, not changed).
+    bad = ~np.isclose(got, want, rtol=2e-3, atol=2e-4 * np.abs(want).max())
+    assert bad.mean() <= 0.01, int(bad.sum())
+    d = got - want
+    assert np.linalg.norm(d) <= 1e-2 * np.linalg.norm(want)
+    moved = np.abs(d.sum(axis=2)).sum(axis=1) / np.maximum(np.abs(d).sum(axis=(1, 2)), 1e-30)
+    assert (moved <= 0.05).all(), moved

@@ -299,6 +299,55 @@ def test_native_ssg_matches_reference_and_module_path(pn2, golden, tag):
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=5e-3, atol=5e-4 * np.abs(ref).max())
 
 
+def test_native_ssg_side_queue_same_bits_and_module_copies(pn2, monkeypatch):
+    """Level 2's sampling / ball query on the side queue's stream (default) against one stream (GEOA3_PN2_SIDE=0): logits
+    and input gradient bit for bit, over repeated calls on one workspace (the fork / join events are re-recorded by
+    every call), at a batch that fills the chip and at batch 1; and a module that has run deep-copies and pickles (the
+    copy packs its own weights and owns its own queue)."""
+    import copy
+    import pickle
+    sd = P2.make_pn2_state_dict(0)
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+
+    def run(module, pc, w):
+        x = pc.clone().requires_grad_()
+        logits = module(x)
+        (logits * w).sum().backward()
+        return logits.detach().clone(), x.grad.clone()
+
+    got = {}
+    for B in (64, 1):
+        pc, _ = O.make_synthetic_clouds(B, 1024, seed=20 + B)
+        pc = pc.cuda()
+        w = torch.randn(B, 40, generator=torch.Generator().manual_seed(B)).cuda()
+        for side in ("1", "0"):
+            monkeypatch.setenv("GEOA3_PN2_SIDE", side)
+            net._packed = None                      # repack: the queue is created (or not) with the packed weights
+            assert (net.packed(pc.device).struct.side is not None) == (side == "1")
+            for rep in range(6):
+                out = run(net, pc, w)
+                if rep == 0:
+                    got[(B, side)] = out
+                else:
+                    assert torch.equal(out[0], got[(B, side)][0]) and torch.equal(out[1], got[(B, side)][1]), (B, side, rep)
+        assert torch.equal(got[(B, "1")][0], got[(B, "0")][0]) and torch.equal(got[(B, "1")][1], got[(B, "0")][1]), B
+    monkeypatch.setenv("GEOA3_PN2_SIDE", "1")
+    net._packed = None
+    pc, _ = O.make_synthetic_clouds(4, 1024, seed=3)
+    pc = pc.cuda()
+    w = torch.randn(4, 40, generator=torch.Generator().manual_seed(4)).cuda()
+    want = run(net, pc, w)
+    for twin in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
+        assert getattr(twin, "_packed", None) is None
+        out = run(twin.cuda().eval(), pc, w)
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+        assert twin._packed.struct.side != net._packed.struct.side
+
+
 def test_native_ssg_batch_independence_and_no_grad(pn2):
     """Rows of a batched native forward / backward are bit-identical to batch-1 runs (what lets one batched forward
     stand for the reference's b batch-1 success-check forwards, geoA3_attack.py:297), and evaluation under

@@ -6,7 +6,7 @@ python3 bench.py --no-cpu-baseline --arch PointNetPP --steps 40 --warmup 5 --pre
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('c4', d['value'], d['ms_per_step'], d['kernels_ms'].get('sa1_bwd'), d['kernels_ms'].get('sa1_fwd'))"
-GEOA3_GEO_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 bench.py --no-cpu-baseline --single-mode --arch PointNetPP --steps 20 --warmup 5 --presteps 20 > $O/trace.log 2>&1
+GEOA3_PN2_SIDE=0 GEOA3_GEO_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 bench.py --no-cpu-baseline --single-mode --arch PointNetPP --steps 20 --warmup 5 --presteps 20 > $O/trace.log 2>&1
 find $O -name '*kernel_trace.csv' -delete
 python3 - $O <<'P'
 import csv,sys,glob
