@@ -40,7 +40,8 @@ def _hipcc() -> str:
 # -fno-slp-vectorize there: the operand split stays at two instructions per element (sa_split2).
 FILE_FLAGS = {"pointnet_conv_chain.hip": ["-fno-slp-vectorize"], "pointnet_conv_split.hip": ["-fno-slp-vectorize"],
               "pointnet2_sa.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
-              "pointnet2_sa2.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+              "pointnet2_sa2.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+              "pointnet2_ops.hip": ["-fno-slp-vectorize"], "pointnet2_net.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -85,7 +86,10 @@ def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
 # kernels that must not hold packed-FP32 instructions: checked on the ISA the build's own flags produce, so that a
 # lost per-file flag -- or a compiler that forms v_pk_*_f32 in another pass -- fails the BUILD instead of shipping a kernel
 # that is silently wrong in ~1e-4 of its workgroups
-ISA_GUARDS = {"pointnet_conv_chain.hip": ("conv_bwd_chain_kernel", r"v_pk_(mul|fma|add)_f32")}
+# (round 5: and the farthest-point sampler, whose SLP-packed distance update is exact alone and wrong in 1.4e-3 of its rounds
+# beside sa1_fwd_kernel / sa1_bwd_kernel on the same CUs -- tools/ub/pk_fp32_coresidency.hip; EVERY instance of the template)
+ISA_GUARDS = {"pointnet_conv_chain.hip": ("conv_bwd_chain_kernel", r"v_pk_(mul|fma|add)_f32"),
+              "pointnet2_ops.hip": ("fps_kernel", r"v_pk_(mul|fma|add)_f32")}
 
 
 def _isa_guard(src: str, flags) -> None:
@@ -99,15 +103,17 @@ def _isa_guard(src: str, flags) -> None:
         if r.returncode != 0:
             raise RuntimeError("ISA guard: hipcc -S failed for %s:\n%s" % (src, r.stderr))
         asm = open(out).read()
-    m = re.search(r"^(_Z\w*%s\w*):" % kernel, asm, re.M)
-    if not m:
+    found = list(re.finditer(r"^(_Z\w*%s\w*):" % kernel, asm, re.M))
+    if not found:
         raise RuntimeError("ISA guard: kernel %s not found in %s" % (kernel, src))
-    body = asm[m.end():]
-    body = body[:body.index("s_endpgm")]
-    hit = re.search(pattern, body)
-    if hit:
-        raise RuntimeError("ISA guard: %s holds %s (DESIGN 5a: wrong values in lanes 48-63 with two waves per SIMD); compile "
-                           "%s with %s" % (kernel, hit.group(0), os.path.basename(src), FILE_FLAGS.get(os.path.basename(src))))
+    for m in found:   # every instance of a kernel template
+        body = asm[m.end():]
+        body = body[:body.index("s_endpgm")]
+        hit = re.search(pattern, body)
+        if hit:
+            raise RuntimeError("ISA guard: %s holds %s (DESIGN 5a: wrong values beside other wavefronts on its SIMDs); compile "
+                               "%s with %s" % (m.group(1), hit.group(0), os.path.basename(src),
+                                               FILE_FLAGS.get(os.path.basename(src))))
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=(), libdir: str = LIBDIR) -> str:

@@ -81,6 +81,32 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// The same maximum as TWO 32-bit reductions -- the high words, then the low words of the lanes that hold the largest high
+// word -- each step one `v_max_u32` with a DPP operand where the 64-bit form takes two moves, a 64-bit compare and two
+// selects (the sampler's round is this reduction's dependent chain: 42 -> 14 instructions).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+  // (old = 0, the maximum's identity: lanes a row mask leaves out, or without a source lane, see 0 -- and the compiler
+  // folds the move into `v_max_u32_dpp`)
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, true);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = dpp_max_u32<0xB1, 0xF>(v);
+  v = dpp_max_u32<0x4E, 0xF>(v);
+  v = dpp_max_u32<0x141, 0xF>(v);
+  v = dpp_max_u32<0x140, 0xF>(v);
+  v = dpp_max_u32<0x142, 0xA>(v);
+  v = dpp_max_u32<0x143, 0xC>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64_split(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned hmax = wave_max_u32(hi);
+  const unsigned lmax = wave_max_u32(hi == hmax ? lo : 0u);
+  return ((unsigned long long)hmax << 32) | lmax;
+}
+
 // ascending in-place sort of a short int list owned by ONE thread (reverse lists of the deterministic scatter-adds):
 // insertion sort, heap sort beyond 24 entries (bounded work for degenerate inputs whose lists are long)
 __device__ __forceinline__ void geoa3_sort_ints(int* L, int n) {

@@ -17,6 +17,7 @@
 //   * level 3's 512 -> 1024 layer runs as two K = 256 products accumulated before the bias / relu / max tail.
 #include <new>
 #include "pointnet_kernels.h"
+#include "profile.h"
 
 namespace {
 
@@ -164,14 +165,14 @@ __global__ __launch_bounds__(256) void points_to_planar_kernel(const float* __re
   p[2 * (size_t)N] = q[2];
 }
 
-// out[b][m][:] = in[b][idx[b][m]][:]   (rows of 3 floats)
+// out[b][m][:] = in[b][idx[b][m]][:]   (rows of 3 floats), m in [m0, m0 + Mc) of the M; total = B * Mc
 __global__ __launch_bounds__(256) void gather_rows3_kernel(const float* __restrict__ in, const int32_t* __restrict__ idx,
-                                                           float* __restrict__ out, int N, int M, long total) {
+                                                           float* __restrict__ out, int N, int M, int m0, int Mc, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
-  const long b = e / M;
-  const float* p = in + (b * N + idx[e]) * 3;
-  float* q = out + e * 3;
+  const long b = e / Mc, r = b * M + m0 + (e - b * Mc);
+  const float* p = in + (b * N + idx[r]) * 3;
+  float* q = out + r * 3;
   q[0] = p[0];
   q[1] = p[1];
   q[2] = p[2];
@@ -347,39 +348,32 @@ extern "C" int geoa3_pn2ssg_pack_images(const geoa3_pn2ssg_weights* pw, void* im
 namespace {
 struct SideQueue {
   hipStream_t stream;
-  hipEvent_t fork, join;
+  hipEvent_t ev[4], join;   // ev[c]: centroid chunk c of level 1 is chosen and gathered; join: level 2's geometry is done
 };
 }  // namespace
-
-extern "C" void* geoa3_side_queue_create(void) {
-  SideQueue* q = new (std::nothrow) SideQueue{};
-  if (!q) return nullptr;
-  if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete q;
-    return nullptr;
-  }
-  if (hipEventCreateWithFlags(&q->fork, hipEventDisableTiming) != hipSuccess) {
-    (void)hipStreamDestroy(q->stream);
-    delete q;
-    return nullptr;
-  }
-  if (hipEventCreateWithFlags(&q->join, hipEventDisableTiming) != hipSuccess) {
-    (void)hipEventDestroy(q->fork);
-    (void)hipStreamDestroy(q->stream);
-    delete q;
-    return nullptr;
-  }
-  return q;
-}
 
 extern "C" void geoa3_side_queue_destroy(void* side) {
   SideQueue* q = static_cast<SideQueue*>(side);
   if (!q) return;
-  (void)hipStreamSynchronize(q->stream);
-  (void)hipEventDestroy(q->join);
-  (void)hipEventDestroy(q->fork);
-  (void)hipStreamDestroy(q->stream);
+  if (q->stream) (void)hipStreamSynchronize(q->stream);
+  for (hipEvent_t e : q->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (q->join) (void)hipEventDestroy(q->join);
+  if (q->stream) (void)hipStreamDestroy(q->stream);
   delete q;
+}
+
+extern "C" void* geoa3_side_queue_create(void) {
+  SideQueue* q = new (std::nothrow) SideQueue{};
+  if (!q) return nullptr;
+  bool ok = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t& e : q->ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&q->join, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    geoa3_side_queue_destroy(q);
+    return nullptr;
+  }
+  return q;
 }
 
 extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float* x, int B, int N, float* logits,
@@ -396,29 +390,52 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   }
   // ---- level 1 (PointNetPP_ssg.py:58-66): FPS 512, ball 0.2 x 64, MLP 3 -> 64 -> 64 -> 128, max
   hipLaunchKernelGGL(planar_to_points_kernel, g1d((long)B * N), dim3(256), 0, s, x, w.xyz, N, (long)B * N);
-  TRY(geoa3_pn2_furthest_point_sampling(w.xyz, B, N, M1, nullptr, w.idx1, stream));
-  hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M1), dim3(256), 0, s, w.xyz, w.idx1, w.nx1, N, M1, (long)B * M1);
-  // Level 2's sampling, ball query and shift need only the level-1 centroids: with a side queue in the weights they run
-  // on its stream BESIDE level 1's ball query + MLP (four one-workgroup-per-cloud kernels, 0.14 ms of dependent latency that
-  // the 8 waves per CU of sa1_fwd_kernel leave room for): fork after the centroid gather, join in front of sa2_fwd.  The
-  // call is still ordered on `stream` as a whole (the side stream starts behind an event of it and is waited for).
+  // With a side queue in the weights the level is PIPELINED.  The sampler is a chain of 511 dependent rounds in one workgroup
+  // per cloud (0.33 ms whatever the batch), and nothing of the level can start before its first centroid: so the rounds run
+  // in four launches of 128 (the running distances pass through memory: same bits), each followed by the gather and the
+  // ball query of its 128 centroids, on the queue's stream, and the MLP of a chunk runs on `stream` beside the next chunk's.  Behind the last sampler
+  // launch the side stream continues with level 2's sampling, ball query and shift (functions of the level-1 centroids
+  // only) and is joined in front of level 2's MLP.  The call is still ordered on `stream` as a whole (the side stream
+  // starts behind an event of it and is waited for); five kernels more per forward.
   SideQueue* sq = static_cast<SideQueue*>(p.side);
-  const bool use_side = sq != nullptr;
+  // (while bench.py samples sa1_fwd_kernel's time the level runs as one launch per kernel)
+  const bool use_side = sq != nullptr && !geoa3_prof_tag_on(GEOA3_PROF_SA1_FWD) && (size_t)N * 3 * sizeof(float) + 1024 <= 128 * 1024;
   hipStream_t s2 = use_side ? sq->stream : s;
-  void* stream2 = use_side ? (void*)sq->stream : stream;
+  constexpr int CH = 4, MC = M1 / CH;
+  float* fps_td = w.d1;   // [B,N] running distances between the sampler's launches (a backward buffer, free in forward)
+  auto rows = [&](int m0, int m1, hipStream_t st) {   // the centroid rows nx1[:, m0 .. m1 - 1]
+    hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * (m1 - m0)), dim3(256), 0, st, w.xyz, w.idx1, w.nx1, N, M1, m0, m1 - m0,
+                       (long)B * (m1 - m0));
+  };
   if (use_side) {
-    if (hipEventRecord(sq->fork, s) != hipSuccess || hipStreamWaitEvent(sq->stream, sq->fork, 0) != hipSuccess)
-      return GEOA3_ELAUNCH;
+    TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, MC, fps_td, w.idx1, s));
+    rows(0, MC, s);
+    if (hipEventRecord(sq->ev[0], s) != hipSuccess || hipStreamWaitEvent(s2, sq->ev[0], 0) != hipSuccess) return GEOA3_ELAUNCH;
+    TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, 0, MC, R1, S, w.gidx1, s));
+    for (int c = 1; c < CH; ++c) {   // sampler, centroid rows and ball query of chunk c: all on the side stream
+      TRY(launch_pn2_fps_range(w.xyz, B, N, M1, c * MC, (c + 1) * MC, fps_td, w.idx1, s2));
+      rows(c * MC, (c + 1) * MC, s2);
+      TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, c * MC, (c + 1) * MC, R1, S, w.gidx1, s2));
+      if (hipEventRecord(sq->ev[c], s2) != hipSuccess) return GEOA3_ELAUNCH;
+    }
+    for (int c = 0; c < CH; ++c) {
+      if (c > 0 && hipStreamWaitEvent(s, sq->ev[c], 0) != hipSuccess) return GEOA3_ELAUNCH;
+      TRY(launch_sa1_forward_range(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, c * MC, (c + 1) * MC, w.out1, w.arg1, s));
+    }
+  } else {
+    TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, M1, nullptr, w.idx1, s));
+    rows(0, M1, s);
+    TRY(geoa3_pn2_ball_query(w.nx1, w.xyz, B, N, M1, R1, S, w.gidx1, stream));
+    TRY(launch_sa1_forward_range(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, 0, M1, w.out1, w.arg1, s));
   }
-  // ---- level 2's geometry (:68-76): FPS 128, ball 0.4 x 64, b0 - W_x c
-  TRY(geoa3_pn2_furthest_point_sampling(w.nx1, B, M1, M2, nullptr, w.idx2, stream2));
-  hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M2), dim3(256), 0, s2, w.nx1, w.idx2, w.nx2, M1, M2, (long)B * M2);
-  TRY(geoa3_pn2_ball_query(w.nx2, w.nx1, B, M1, M2, R2, S, w.gidx2, stream2));
+  // ---- level 2's geometry (:68-76): FPS 128, ball 0.4 x 64, b0 - W_x c -- on the side stream behind the sampler (every
+  // centroid row is written by then: the first 128 on `stream` before the fork, the others on the side stream itself)
+  TRY(launch_pn2_fps_range(w.nx1, B, M1, M2, 0, M2, nullptr, w.idx2, s2));
+  hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M2), dim3(256), 0, s2, w.nx1, w.idx2, w.nx2, M1, M2, 0, M2, (long)B * M2);
+  TRY(launch_pn2_ball_query_range(w.nx2, w.nx1, B, M1, M2, 0, M2, R2, S, w.gidx2, s2));
   hipLaunchKernelGGL(affine3_kernel, g1d((long)B * 128 * M2), dim3(256), 0, s2, p.sa2_wx, p.sa2_b0, w.nx2, -1.f, w.shift,
                      128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
-  if (use_side && hipEventRecord(sq->join, sq->stream) != hipSuccess) return GEOA3_ELAUNCH;
-  TRY(geoa3_pn2_ball_query(w.nx1, w.xyz, B, N, M1, R1, S, w.gidx1, stream));
-  TRY(geoa3_pn2_sa1_forward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, stream));
+  if (use_side && hipEventRecord(sq->join, s2) != hipSuccess) return GEOA3_ELAUNCH;
   TRY((transpose<float, false>(w.out1, nullptr, w.f1, B, M1, C1, s)));            // [B,512,128] -> [B,128,512]
   // ---- level 2 (:68-76): MLP (128 + 3) -> 128 -> 128 -> 256, max
   TRY(conv_slice(w.f1, 128, 0, 128, img_of(im, IM_SA2_WF), nullptr, nullptr, w.r, 128, B, M1, false, false, s));   // W_f f
@@ -497,6 +514,8 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
     TRY(launch_sa2_bwd(ent_g, ent_c, p.sa2_w2, i1t.p, i1t.un, w.m1, w.m0, da0, B, M2, s));
   }
   float *dr = w.r, *dshift = w.shift;
+  // (the grouping gradient of a range of instances on the side queue beside the next range's sa2_bwd_kernel was measured:
+  // two ranges 4.256 ms against 4.259, four 4.33, three 4.40 -- both kernels are bound by memory traffic: DESIGN 8)
   TRY(geoa3_pn2_group_points_grad_sums(da0, w.gidx2, B, 128, M1, M2, S, dr, dshift, stream));
   TRY(conv_slice(dr, 128, 0, 128, img_of(im, IM_SA2_WFT), nullptr, nullptr, w.df1, C1, B, M1, false, false, s));   // d f1 = W_f^T dr
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M1), dim3(256), 3 * 128 * sizeof(float), s, dr, p.sa2_wx, 1.f, w.dnx1,

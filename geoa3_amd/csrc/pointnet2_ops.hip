@@ -13,7 +13,7 @@
 //   * gradients of gather / group are scatter-adds (atomicAdd, sampling_gpu.cu:42, group_points_gpu.cu:60).
 // Distances are evaluated un-fused, fl(fl(dx*dx + dy*dy) + dz*dz) with each product rounded (the CPU oracle's
 // order); nvcc's contraction choice for the reference is not specified by its sources.
-#include "common.h"
+#include "pointnet_kernels.h"
 
 namespace {
 
@@ -38,14 +38,17 @@ __device__ __forceinline__ float sq3(float dx, float dy, float dz) {
 
 template <int FPS_BLOCK, int FPS_PPT>
 __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict__ xyz, int N, int m, int T,
-                                                        float* __restrict__ temp, int32_t* __restrict__ idxs) {
+                                                        float* __restrict__ temp, int32_t* __restrict__ idxs, int j0, int j1) {
   extern __shared__ __attribute__((aligned(16))) float s_p[];   // [N][3]
   __shared__ unsigned long long s_key[2][FPS_BLOCK / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* P = xyz + (size_t)b * N * 3;
   for (int e = tid; e < N * 3; e += FPS_BLOCK) s_p[e] = P[e];
+  // Straight-line rounds: every register slot is live (the launcher picks FPS_PPT = ceil(N / FPS_BLOCK) rounded up to a power
+  // of two), a slot without a point or with a skipped one carries an all-zero select mask (bit-field insert, key 0) instead
+  // of a branch around its update -- the branchy form spent most of a round in exec-mask bookkeeping (0.73 -> 0.5 us per round)
   float px[FPS_PPT], py[FPS_PPT], pz[FPS_PPT], td[FPS_PPT];
-  unsigned use = 0u;   // bit i: point tid + i*FPS_BLOCK exists and is not skipped
+  unsigned um[FPS_PPT], klo[FPS_PPT];   // ~0 where the slot's point takes part; low key word: ~((k mod T) << 16 | k)
 #pragma unroll
   for (int i = 0; i < FPS_PPT; ++i) {
     const int k = tid + i * FPS_BLOCK;
@@ -53,30 +56,30 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict_
     px[i] = in ? P[k * 3] : 0.f;
     py[i] = in ? P[k * 3 + 1] : 0.f;
     pz[i] = in ? P[k * 3 + 2] : 0.f;
-    td[i] = 1e10f;  // sampling.cpp:74-76
+    // sampling.cpp:74-76; rounds j0 .. j1 - 1 of the m: a launch that does not start at round 0 resumes from the running
+    // distances the launch before it left in `temp` (the same fp32 values: the chunks select the same points bit for bit)
+    td[i] = (j0 > 0 && in) ? temp[(size_t)b * N + k] : 1e10f;
     const float mag = sq3(px[i], py[i], pz[i]);
-    if (in && !(mag <= 1e-3f)) use |= 1u << i;
+    um[i] = (in && !(mag <= 1e-3f)) ? 0xFFFFFFFFu : 0u;
+    klo[i] = 0xFFFFFFFFu - (((unsigned)(k & (T - 1)) << 16) | (unsigned)k);   // k < 8192, T <= 512
   }
-  int old = 0;
-  if (tid == 0) idxs[(size_t)b * m] = 0;
+  int old = j0 > 0 ? idxs[(size_t)b * m + j0 - 1] : 0;
+  if (j0 == 0 && tid == 0) idxs[(size_t)b * m] = 0;
   __syncthreads();
-  for (int j = 1; j < m; ++j) {
+  for (int j = j0 > 1 ? j0 : 1; j < j1; ++j) {
     const float x1 = s_p[old * 3], y1 = s_p[old * 3 + 1], z1 = s_p[old * 3 + 2];
     unsigned long long key = 0ull;
 #pragma unroll
     for (int i = 0; i < FPS_PPT; ++i) {
-      if (i * FPS_BLOCK < N) {   // uniform: skips the register slots this cloud does not use
-        const int k = tid + i * FPS_BLOCK;
-        const bool u = (use >> i) & 1u;
-        const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
-        const float d2 = u ? fminf(d, td[i]) : td[i];
-        td[i] = d2;
-        const unsigned tie = ((unsigned)(k & (T - 1)) << 16) | (unsigned)k;   // k < 8192, T <= 512
-        const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (0xFFFFFFFFu - tie);
-        key = (u && kk > key) ? kk : key;
-      }
+      const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
+      const float dm = d < td[i] ? d : td[i];     // min(d, temp) (sampling_gpu.cu:118); a NaN distance leaves temp as it is
+      // d2 = use ? min(d, td) : td, as a bit select
+      const unsigned d2 = (__float_as_uint(dm) & um[i]) | (__float_as_uint(td[i]) & ~um[i]);
+      td[i] = __uint_as_float(d2);
+      const unsigned long long kk = ((unsigned long long)(d2 & um[i]) << 32) | (klo[i] & um[i]);   // 0 for a slot out of play
+      key = kk > key ? kk : key;
     }
-    key = wave_max_u64(key);
+    key = wave_max_u64_split(key);
     const int buf = j & 1;   // double buffered: the next round's writes cannot race this round's reads
     if (lane == 0) s_key[buf][wave] = key;
     __syncthreads();
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 constexpr int BQW_CPW = 8;   // centres per wavefront
 __global__ __launch_bounds__(256) void ball_query_wave_kernel(const float* __restrict__ new_xyz,
                                                               const float* __restrict__ xyz, int N, int M, float radius2,
-                                                              int nsample, int32_t* __restrict__ idx) {
+                                                              int nsample, int32_t* __restrict__ idx, int m0, int m1, int cpw) {
   extern __shared__ __attribute__((aligned(16))) float s_bq[];   // x[N], y[N], z[N], rows [4][64]
   float *s_x = s_bq, *s_y = s_bq + N, *s_z = s_bq + 2 * N;
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,10 +171,10 @@ __global__ __launch_bounds__(256) void ball_query_wave_kernel(const float* __res
     s_z[e] = p[2];
   }
   __syncthreads();
-  const int j0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * BQW_CPW);
-  for (int c = 0; c < BQW_CPW; ++c) {
+  const int j0 = m0 + __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * cpw);   // centres m0 .. m1 - 1 of the M
+  for (int c = 0; c < cpw; ++c) {
     const int j = j0 + c;
-    if (j >= M) break;
+    if (j >= m1) break;
     const float* C = new_xyz + ((size_t)b * M + j) * 3;
     const float cx = C[0], cy = C[1], cz = C[2];
     int cnt = 0;
@@ -352,23 +355,33 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
 
 }  // namespace
 
-extern "C" int geoa3_pn2_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int32_t* idx,
-                                                 void* stream) {
-  if (!xyz || !idx || B <= 0 || N <= 0 || m <= 0) return GEOA3_EINVAL;
+// rounds j0 .. j1 - 1 of the m (0 <= j0 < j1 <= m); j0 > 0 resumes from `temp` [B,N] (required then), which every launch
+// with temp != null leaves behind
+int launch_pn2_fps_range(const float* xyz, int B, int N, int m, int j0, int j1, float* temp, int32_t* idx, hipStream_t s) {
+  if (!xyz || !idx || B <= 0 || N <= 0 || m <= 0 || j0 < 0 || j1 <= j0 || j1 > m || (j0 > 0 && !temp)) return GEOA3_EINVAL;
   if (N > 512 * 16) return GEOA3_ENOSUPPORT;
   int T = 1;
   while (T * 2 <= N && T * 2 <= 512) T *= 2;  // opt_n_threads(N), cuda_utils.h:13-19
   const size_t lds = (size_t)N * 3 * sizeof(float);
-  if (N <= 2048) {
-    hipLaunchKernelGGL((fps_kernel<256, 8>), dim3(B), dim3(256), lds, geoa3_stream(stream), xyz, N, m, T, temp, idx);
+  if (N <= 512) {
+    hipLaunchKernelGGL((fps_kernel<256, 2>), dim3(B), dim3(256), lds, s, xyz, N, m, T, temp, idx, j0, j1);
+  } else if (N <= 1024) {
+    hipLaunchKernelGGL((fps_kernel<256, 4>), dim3(B), dim3(256), lds, s, xyz, N, m, T, temp, idx, j0, j1);
+  } else if (N <= 2048) {
+    hipLaunchKernelGGL((fps_kernel<256, 8>), dim3(B), dim3(256), lds, s, xyz, N, m, T, temp, idx, j0, j1);
   } else {
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<512, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
-    hipLaunchKernelGGL((fps_kernel<512, 16>), dim3(B), dim3(512), lds, geoa3_stream(stream), xyz, N, m, T, temp, idx);
+    hipLaunchKernelGGL((fps_kernel<512, 16>), dim3(B), dim3(512), lds, s, xyz, N, m, T, temp, idx, j0, j1);
   }
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int32_t* idx,
+                                                 void* stream) {
+  return launch_pn2_fps_range(xyz, B, N, m, 0, m, temp, idx, geoa3_stream(stream));
 }
 
 extern "C" int geoa3_pn2_gather_points(const float* points, const int32_t* idx, int B, int C, int N, int M, float* out,
@@ -391,19 +404,29 @@ extern "C" int geoa3_pn2_gather_points_grad(const float* grad_out, const int32_t
   return GEOA3_OK;
 }
 
+// centres m0 .. m1 - 1 of the M (the wave-per-centre kernel; GEOA3_ENOSUPPORT where the public entry point falls back)
+int launch_pn2_ball_query_range(const float* new_xyz, const float* xyz, int B, int N, int M, int m0, int m1, float radius,
+                                int nsample, int32_t* idx, hipStream_t s) {
+  if (!new_xyz || !xyz || !idx || B <= 0 || N <= 0 || M <= 0 || nsample <= 0 || m0 < 0 || m1 <= m0 || m1 > M) return GEOA3_EINVAL;
+  const size_t lds = (size_t)N * 3 * sizeof(float) + 4 * 64 * sizeof(int);
+  if (nsample > 64 || lds > 128 * 1024) return GEOA3_ENOSUPPORT;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_wave_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // centres per wavefront: 8 for a whole level (the cloud is staged once per 32 centres); a partial range is a short launch
+  // beside other kernels (pointnet2_net.hip), where 8 centres in sequence per wave are its whole duration: 2
+  const int cpw = (m1 - m0 == M) ? BQW_CPW : 2;
+  hipLaunchKernelGGL(ball_query_wave_kernel, dim3((m1 - m0 + 4 * cpw - 1) / (4 * cpw), B), dim3(256), lds, s, new_xyz, xyz,
+                     N, M, radius * radius, nsample, idx, m0, m1, cpw);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
 extern "C" int geoa3_pn2_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
                                     int nsample, int32_t* idx, void* stream) {
   if (!new_xyz || !xyz || !idx || B <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
-  const size_t lds = (size_t)N * 3 * sizeof(float) + 4 * 64 * sizeof(int);
-  if (nsample <= 64 && lds <= 128 * 1024) {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_wave_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(ball_query_wave_kernel, dim3((M + 4 * BQW_CPW - 1) / (4 * BQW_CPW), B), dim3(256), lds,
-                       geoa3_stream(stream), new_xyz, xyz, N, M, radius * radius, nsample, idx);
-    GEOA3_CHECK_LAUNCH();
-    return GEOA3_OK;
-  }
+  const int rc = launch_pn2_ball_query_range(new_xyz, xyz, B, N, M, 0, M, radius, nsample, idx, geoa3_stream(stream));
+  if (rc != GEOA3_ENOSUPPORT) return rc;
   if (hipMemsetAsync(idx, 0, (size_t)B * M * nsample * sizeof(int32_t), geoa3_stream(stream)) != hipSuccess)
     return GEOA3_ELAUNCH;
   hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, geoa3_stream(stream), new_xyz, xyz, N, M,

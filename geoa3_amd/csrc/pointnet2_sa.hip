@@ -372,7 +372,7 @@ __device__ __forceinline__ int sa1_kp(const Sa1Pts& P) {   // 2^kp |p| < 2^14 fo
 template <int SA_T>
 __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                       const int32_t* __restrict__ idx, geoa3_sa1_weights w, int B, int N,
-                                                      int M, float* __restrict__ out, uint8_t* __restrict__ arg) {
+                                                      int M, float* __restrict__ out, uint8_t* __restrict__ arg, int m0, int Mc) {
   extern __shared__ __attribute__((aligned(16))) float sa_sm[];
   const Sa1Lds L = sa1_carve(sa_sm, false);
   sa1_stage<SA_T, false>(w, L);
@@ -381,14 +381,17 @@ __global__ __launch_bounds__(SA_T) void sa1_fwd_kernel(const float* __restrict__
             k3 = __builtin_amdgcn_readfirstlane(L.kw[2]);
   const int EW1 = __builtin_amdgcn_readfirstlane(L.kw[3]), EB1 = __builtin_amdgcn_readfirstlane(L.kw[4]),
             EW2 = __builtin_amdgcn_readfirstlane(L.kw[5]), EB2 = __builtin_amdgcn_readfirstlane(L.kw[6]);
-  const int total = B * M, stride = (int)gridDim.x * (SA_T / 64);   // B * M < 2^31 / 128 (checked by the launcher)
-  int c = (int)blockIdx.x * (SA_T / 64) + wave;
+  // centroids m0 .. m0 + Mc - 1 of every cloud: the walk runs over j in [0, B * Mc), centroid c = (j / Mc) * M + m0 + j % Mc
+  const int total = B * Mc, stride = (int)gridDim.x * (SA_T / 64);   // B * M < 2^31 / 128 (checked by the launcher)
+  auto cof = [&](int j) { return (j / Mc) * M + m0 + j % Mc; };       // (wave-uniform: scalar arithmetic)
+  int jc = (int)blockIdx.x * (SA_T / 64) + wave;
   Sa1Pts P;
-  if (c < total) sa1_load(xyz, new_xyz, idx, c, M, N, lane, P);
-  for (; c < total; c += stride) {
+  if (jc < total) sa1_load(xyz, new_xyz, idx, cof(jc), M, N, lane, P);
+  for (; jc < total; jc += stride) {
     asm volatile("" ::: "memory");   // the weights stay in LDS: no hoisting of their loads out of the centroid loop
+    const int c = cof(jc);
     const Sa1Pts Q = P;
-    if (c + stride < total) sa1_load(xyz, new_xyz, idx, c + stride, M, N, lane, P);
+    if (jc + stride < total) sa1_load(xyz, new_xyz, idx, cof(jc + stride), M, N, lane, P);
     const int kp = sa1_kp(Q);
     const float sp = sa_pow2(kp);
     const _Float16 one = h ? (_Float16)0.f : (_Float16)sp;
@@ -787,20 +790,25 @@ int sa1_grid(int B, int M, int waves, int per_cu) {   // persistent workgroups
 
 }  // namespace
 
-extern "C" int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, const int32_t* idx,
-                                     const geoa3_sa1_weights* w, int B, int N, int M, float* out, uint8_t* arg,
-                                     void* stream) {
-  if (!xyz || !new_xyz || !idx || !w || !out || !arg || B <= 0 || N <= 0 || M <= 0) return GEOA3_EINVAL;
+int launch_sa1_forward_range(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B, int N,
+                             int M, int m0, int m1, float* out, uint8_t* arg, hipStream_t s) {
+  if (!xyz || !new_xyz || !idx || !w || !out || !arg || B <= 0 || N <= 0 || M <= 0 || m0 < 0 || m1 <= m0 || m1 > M) return GEOA3_EINVAL;
   if ((long)B * M > (1L << 24)) return GEOA3_ENOSUPPORT;
   const size_t lds = (size_t)sa1_lds_bytes(SA_WF, false);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_fwd_kernel<SA_WF * 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  geoa3_prof_begin(GEOA3_PROF_SA1_FWD, geoa3_stream(stream));
-  hipLaunchKernelGGL(sa1_fwd_kernel<SA_WF * 64>, dim3(sa1_grid(B, M, SA_WF, 1)), dim3(SA_WF * 64), lds, geoa3_stream(stream), xyz, new_xyz, idx, *w,
-                     B, N, M, out, arg);
-  geoa3_prof_end(GEOA3_PROF_SA1_FWD, geoa3_stream(stream));
+  geoa3_prof_begin(GEOA3_PROF_SA1_FWD, s);
+  hipLaunchKernelGGL(sa1_fwd_kernel<SA_WF * 64>, dim3(sa1_grid(B, m1 - m0, SA_WF, 1)), dim3(SA_WF * 64), lds, s, xyz, new_xyz, idx, *w,
+                     B, N, M, out, arg, m0, m1 - m0);
+  geoa3_prof_end(GEOA3_PROF_SA1_FWD, s);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
+}
+
+extern "C" int geoa3_pn2_sa1_forward(const float* xyz, const float* new_xyz, const int32_t* idx,
+                                     const geoa3_sa1_weights* w, int B, int N, int M, float* out, uint8_t* arg,
+                                     void* stream) {
+  return launch_sa1_forward_range(xyz, new_xyz, idx, w, B, N, M, 0, M, out, arg, geoa3_stream(stream));
 }
 
 extern "C" int64_t geoa3_pn2_sa1_scratch_bytes(int B, int M) {

@@ -197,3 +197,12 @@ int launch_sa2_bwd(const float* ent_g, const int32_t* ent_c, const float* W2, co
 int launch_sa2_fwd(const float* rT, const int32_t* gidx, const float* shift, const void* w1_img, const float* w1_un,
                    const float* b1, const void* w2_img, const float* w2_un, const float* b2, float* out, int32_t* arg,
                    unsigned long long* m0, unsigned long long* m1, int B, int N1, int M, hipStream_t s);
+
+// PointNet++ level 1 in centroid ranges (pointnet2_net.hip pipelines the sampler's rounds against the MLP of the centroids
+// it has already chosen): the sampler's rounds j0 .. j1 - 1 (resuming from `temp`), ball query and forward MLP of centroids
+// m0 .. m1 - 1 of every cloud
+int launch_pn2_fps_range(const float* xyz, int B, int N, int m, int j0, int j1, float* temp, int32_t* idx, hipStream_t s);
+int launch_pn2_ball_query_range(const float* new_xyz, const float* xyz, int B, int N, int M, int m0, int m1, float radius,
+                                int nsample, int32_t* idx, hipStream_t s);
+int launch_sa1_forward_range(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B, int N,
+                             int M, int m0, int m1, float* out, uint8_t* arg, hipStream_t s);

@@ -10,5 +10,6 @@
 #define GEOA3_PROF_FC 6       // fully connected chains (all launches of one forward or backward chain)
 #define GEOA3_PROF_GEO 7      // geo_loss_grad_kernel
 bool geoa3_prof_on();
+bool geoa3_prof_tag_on(int tag);   // this tag is being sampled (bench.py's per-kernel figures)
 void geoa3_prof_begin(int tag, hipStream_t s);
 void geoa3_prof_end(int tag, hipStream_t s);

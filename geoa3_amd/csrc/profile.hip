@@ -16,6 +16,7 @@ struct Prof {
 }  // namespace
 
 bool geoa3_prof_on() { return g_prof.cap > 0; }
+bool geoa3_prof_tag_on(int tag) { return g_prof.cap > 0 && tag >= 0 && tag < GEOA3_PROF_TAGS && ((g_prof.mask >> tag) & 1u); }
 
 void geoa3_prof_begin(int tag, hipStream_t s) {
   if (g_prof.cap <= 0 || tag < 0 || tag >= GEOA3_PROF_TAGS || g_prof.n[tag] >= g_prof.cap) return;

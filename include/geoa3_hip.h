@@ -447,12 +447,14 @@ typedef struct geoa3_pn2ssg_weights {
   const float *f2, *fb2, *f2t;                       /* [256,512], [256], [512,256] */
   const float *f3, *fb3, *f3t;                       /* [classes,256], [classes], [256,classes] */
   const void* images;   /* geoa3_pn2ssg_pack_images of THESE weights, or NULL (the forward then rebuilds them per call) */
-  void* side;           /* geoa3_side_queue_create(), or NULL: one stream.  With it the forward runs level 2's sampling, ball
-                           query and shift (functions of the level-1 centroids only) on the queue's stream beside level 1's MLP
-                           and joins in front of level 2's MLP: same results, the call is still ordered on `stream` as a whole.
-                           One queue per concurrent caller (the events are re-recorded by every call). */
+  void* side;           /* geoa3_side_queue_create(), or NULL: one stream.  With it the forward is pipelined: the sampler's rounds
+                           of level 1 in four launches, each followed by the gather + ball query of its 128 centroids, and then
+                           level 2's sampling, ball query and shift (functions of the level-1 centroids only) on the queue's
+                           stream, beside level 1's MLP on `stream`; joined in front of level 2's MLP.  Same bits; the call is
+                           still ordered on `stream` as a whole.  One queue per concurrent caller (the events are re-recorded by
+                           every call). */
 } geoa3_pn2ssg_weights;
-/* A HIP stream + two events owned by the caller's module object (the library keeps no global state).  Destroy after the
+/* A HIP stream + five events owned by the caller's module object (the library keeps no global state).  Destroy after the
  * last call that used it has been enqueued (destroy synchronises the side stream). */
 void* geoa3_side_queue_create(void);
 void geoa3_side_queue_destroy(void* side);
