@@ -11,6 +11,7 @@
 #include "../../geoa3_amd/csrc/pointnet2_ops.hip"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 // FILL 0: fp32 fma chains; 1: + one v_mfma_f32_32x32x16_f16 per 16 fmas; 2: LDS traffic instead; 5: PACKED fp32 fma chains
@@ -135,5 +136,54 @@ int main() {
   trial(7, 100, "beside the library's sa1_bwd_kernel");
   trial(4, 200, "beside the library's ball query");
   trial(-1, 40, "alone again");
+
+  // ---- the library's OWN geometry kernels (compiled with the SLP vectoriser, they hold packed FP32) run beside the sa1
+  // kernels in every PointNet++ iteration (second stream of the attack loop): the same comparison for them
+  {
+    std::vector<float> pa((size_t)B * 3 * N), pr((size_t)B * 3 * N);
+    for (size_t e = 0; e < pa.size(); ++e) {
+      pr[e] = (rand() % 20001 - 10000) * 1e-4f;
+      pa[e] = pr[e] + (rand() % 2001 - 1000) * 1e-5f;
+    }
+    float *da, *dr, *d1, *d2, *kd, *r1, *r2, *rkd;
+    int32_t *i1, *i2, *ki, *ri1, *ri2, *rki, *prior;
+    void* scr;
+    const int K = 17;
+    const size_t nb = (size_t)B * N;
+    hipMalloc(&da, pa.size() * 4); hipMalloc(&dr, pr.size() * 4);
+    hipMalloc(&d1, nb * 4); hipMalloc(&d2, nb * 4); hipMalloc(&i1, nb * 4); hipMalloc(&i2, nb * 4);
+    hipMalloc(&r1, nb * 4); hipMalloc(&r2, nb * 4); hipMalloc(&ri1, nb * 4); hipMalloc(&ri2, nb * 4);
+    hipMalloc(&kd, nb * K * 4); hipMalloc(&ki, nb * K * 4); hipMalloc(&rkd, nb * K * 4); hipMalloc(&rki, nb * K * 4);
+    hipMalloc(&prior, nb * K * 4);
+    hipMalloc(&scr, (size_t)geoa3_knn_self_scratch_bytes(B, N));
+    hipMemcpy(da, pa.data(), pa.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dr, pr.data(), pr.size() * 4, hipMemcpyHostToDevice);
+    geoa3_grid_nn1_pair(da, dr, B, N, N, nullptr, nullptr, r1, ri1, r2, ri2, sa);
+    geoa3_knn(dr, dr, B, N, N, K, nullptr, rkd, prior, sa);            // the clean cloud's table as the prior
+    geoa3_knn_self(da, B, N, K, prior, rkd, rki, scr, 0, sa);
+    hipStreamSynchronize(sa);
+    std::vector<int32_t> h0(nb * K), h1(nb * K);
+    auto same = [&](const void* x, const void* y, size_t bytes) {
+      hipMemcpy(h0.data(), x, bytes, hipMemcpyDeviceToHost);
+      hipMemcpy(h1.data(), y, bytes, hipMemcpyDeviceToHost);
+      return memcmp(h0.data(), h1.data(), bytes) == 0;
+    };
+    for (int nbk = 0; nbk < 2; ++nbk) {
+      long wrong_nn1 = 0, wrong_knn = 0;
+      const int reps = 150;
+      for (int r = 0; r < reps; ++r) {
+        if (nbk == 0) geoa3_pn2_sa1_forward(dx, dnx, dgi, &sw, B, N, M, dsa, darg, sb);
+        else geoa3_pn2_sa1_backward(dx, dnx, dgi, &sw, B, N, M, dsa, darg, dgo, dgx, dgn, dscr, sb);
+        geoa3_grid_nn1_pair(da, dr, B, N, N, nullptr, nullptr, d1, i1, d2, i2, sa);
+        geoa3_knn_self(da, B, N, K, prior, kd, ki, scr, 0, sa);
+        hipStreamSynchronize(sa);
+        hipStreamSynchronize(sb);
+        wrong_nn1 += !(same(d1, r1, nb * 4) && same(i1, ri1, nb * 4) && same(d2, r2, nb * 4) && same(i2, ri2, nb * 4));
+        wrong_knn += !(same(kd, rkd, nb * K * 4) && same(ki, rki, nb * K * 4));
+      }
+      printf("library grid 1-NN + self K-NN beside %s: %d launches, %ld / %ld with a wrong table\n",
+             nbk == 0 ? "sa1_fwd_kernel" : "sa1_bwd_kernel", reps, wrong_nn1, wrong_knn);
+    }
+  }
   return 0;
 }
