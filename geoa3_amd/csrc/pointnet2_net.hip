@@ -401,7 +401,7 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   // (while bench.py samples sa1_fwd_kernel's time the level runs as one launch per kernel)
   const bool use_side = sq != nullptr && !geoa3_prof_tag_on(GEOA3_PROF_SA1_FWD) && (size_t)N * 3 * sizeof(float) + 1024 <= 128 * 1024;
   hipStream_t s2 = use_side ? sq->stream : s;
-  constexpr int CH = 4, MC = M1 / CH;
+  constexpr int CH = 4, MC = M1 / CH;   // (1 / 2 / 4 / 8 launches measured: 4.228 / 4.221 / 4.196 / 4.205 ms per iteration)
   float* fps_td = w.d1;   // [B,N] running distances between the sampler's launches (a backward buffer, free in forward)
   auto rows = [&](int m0, int m1, hipStream_t st) {   // the centroid rows nx1[:, m0 .. m1 - 1]
     hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * (m1 - m0)), dim3(256), 0, st, w.xyz, w.idx1, w.nx1, N, M1, m0, m1 - m0,
