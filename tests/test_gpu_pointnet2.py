@@ -348,6 +348,38 @@ def test_native_ssg_side_queue_same_bits_and_module_copies(pn2, monkeypatch):
         assert twin._packed.struct.side != net._packed.struct.side
 
 
+def test_native_ssg_forward_replays_as_a_graph_with_its_side_queue(pn2):
+    """The pipelined forward (two streams inside one call, forked and joined by events) is capturable: a HIP graph of it,
+    replayed on new inputs, gives the eager call's bits."""
+    sd = P2.make_pn2_state_dict(0)
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    a, _ = O.make_synthetic_clouds(8, 1024, seed=31)
+    b, _ = O.make_synthetic_clouds(8, 1024, seed=32)
+    a, b = a.cuda(), b.cuda()
+    with torch.no_grad():
+        want_a, want_b = net(a).clone(), net(b).clone()
+        assert net.packed(a.device).struct.side is not None
+        x = a.clone()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=s, capture_error_mode="relaxed"):
+            out = net(x)
+        torch.cuda.current_stream().wait_stream(s)
+        for _ in range(3):
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want_a)
+        x.copy_(b)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want_b)
+
+
 def test_native_ssg_batch_independence_and_no_grad(pn2):
     """Rows of a batched native forward / backward are bit-identical to batch-1 runs (what lets one batched forward
     stand for the reference's b batch-1 success-check forwards, geoA3_attack.py:297), and evaluation under
