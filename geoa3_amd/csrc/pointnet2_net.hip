@@ -396,7 +396,8 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   // ball query of its 128 centroids, on the queue's stream, and the MLP of a chunk runs on `stream` beside the next chunk's.  Behind the last sampler
   // launch the side stream continues with level 2's sampling, ball query and shift (functions of the level-1 centroids
   // only) and is joined in front of level 2's MLP.  The call is still ordered on `stream` as a whole (the side stream
-  // starts behind an event of it and is waited for); five kernels more per forward.
+  // starts behind an event of it and is waited for); twelve launches more per forward.  (A launch failure between the fork
+  // and the join returns with the side stream un-joined: harmless for eager streams, it invalidates a stream capture.)
   SideQueue* sq = static_cast<SideQueue*>(p.side);
   // (while bench.py samples sa1_fwd_kernel's time the level runs as one launch per kernel)
   const bool use_side = sq != nullptr && !geoa3_prof_tag_on(GEOA3_PROF_SA1_FWD) && (size_t)N * 3 * sizeof(float) + 1024 <= 128 * 1024;
@@ -436,14 +437,14 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   hipLaunchKernelGGL(affine3_kernel, g1d((long)B * 128 * M2), dim3(256), 0, s2, p.sa2_wx, p.sa2_b0, w.nx2, -1.f, w.shift,
                      128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
   if (use_side && hipEventRecord(sq->join, s2) != hipSuccess) return GEOA3_ELAUNCH;
-  TRY((transpose<float, false>(w.out1, nullptr, w.f1, B, M1, C1, s)));            // [B,512,128] -> [B,128,512]
-  // ---- level 2 (:68-76): MLP (128 + 3) -> 128 -> 128 -> 256, max
-  TRY(conv_slice(w.f1, 128, 0, 128, img_of(im, IM_SA2_WF), nullptr, nullptr, w.r, 128, B, M1, false, false, s));   // W_f f
-  hipLaunchKernelGGL(affine3_add_kernel, g1d((long)B * 128 * M1), dim3(256), 0, s, w.r, p.sa2_wx, (const float*)nullptr,
-                     w.nx1, 128, M1, 0, (long)B * 128 * M1);                                               // + W_x xyz
+  // ---- level 2 (:68-76): MLP (128 + 3) -> 128 -> 128 -> 256, max.  r = W_f f + W_x xyz per POINT, point-major in and out
+  // (one kernel: the features leave level 1 point-major and the gather below wants r point-major)
+  float* rt = w.df1;   // [B,512,128] (a backward buffer, free in forward)
+  {
+    const Img wfi = img_of(im, IM_SA2_WF);
+    TRY(launch_sa2_pre(w.out1, w.nx1, wfi.p, wfi.un, p.sa2_wx, rt, (long)B * M1, s));
+  }
   if (use_side && hipStreamWaitEvent(s, sq->join, 0) != hipSuccess) return GEOA3_ELAUNCH;
-  float* rt = w.df1;   // [B,512,128]: r point-major (a backward buffer, free in forward)
-  TRY((transpose<float, false>(w.r, nullptr, rt, B, 128, M1, s)));
   // gather + shift + relu, W1, W2 + max in one kernel; the activations a0 / a1 exist only as gate bits (m0 / m1)
   {
     const Img i1 = img_of(im, IM_SA2_W1), i2 = img_of(im, IM_SA2_W2);

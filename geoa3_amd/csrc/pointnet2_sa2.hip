@@ -862,7 +862,122 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Level 2's pre-transformed first layer per POINT, in one kernel (round 5):
+//   rT[p][co] = sum_k f[p][k] Wf[co][k] + sum_d Wx[co][d] xyz[p][d]        f = level 1's pooled features, point-major
+// (pointnet2_modules.py:57-70 behind the rearrangement of pointnet2_net.hip).  It was four launches -- transpose to
+// channel-major, the generic split convolution, + W_x xyz, transpose back: 0.13 ms for 0.13 GB that a single pass moves
+// in 0.03.  Level 1 writes its features point-major and level 2's gather wants r point-major: with the POINTS as the
+// matrix core's rows neither transpose exists.  A wave owns 32 points: their 128 features are 64 registers, the tile's
+// own power-of-two scale comes from their maximum, the three coordinates ride in a ninth k-step whose B fragments are
+// W_x at the image's scale; four 32-channel column tiles of 27 matrix instructions each.
+struct Sa2PreArgs {
+  const float* X;        // [P][128]
+  const float* xyz;      // [P][3]
+  const _Float16* img;   // fragment image of Wf (launch_frag_image: rows = output channels)
+  const float* un;       // [1]: 1 / the image's scale
+  const float* Wx;       // [128][3]
+  float* Y;              // [P][128]
+  long P;                // points (a multiple of 32)
+};
+
+constexpr int sa2_pre_lds() { return S2_K * S2_K * 4 + 4 * 2 * 64 * 16; }
+
+__global__ __launch_bounds__(256) void sa2_pre_kernel(Sa2PreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s2_sm[];
+  half8* s_w = reinterpret_cast<half8*>(s2_sm);                     // [(tile * 8 + c) * 2 + piece][lane]
+  half8* s_wx = s_w + S2_K * S2_K * 4 / 16;                         // [tile * 2 + piece][lane]: the coordinates' k-step
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const half8* src = reinterpret_cast<const half8*>(a.img);
+    for (int e = tid; e < S2_K * S2_K * 4 / 16; e += 256) s_w[e] = src[e];
+  }
+  const float unW = a.un[0];
+  {   // B fragments of the ninth k-step: lane (column co = 32 t + l31, k = 8 h + j): W_x[co][k] for k < 3, at the image's scale
+    const float sw = 1.0f / unW;   // (a power of two)
+    const int t = wave;            // four waves, four column tiles
+    const int co = 32 * t + l31;
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (h == 0) {
+      x[0] = a.Wx[3 * co];
+      x[1] = a.Wx[3 * co + 1];
+      x[2] = a.Wx[3 * co + 2];
+    }
+    half8 wh, wl;
+    s2_split8(x, sw, wh, wl);
+    s_wx[(t * 2 + 0) * 64 + lane] = wh;
+    s_wx[(t * 2 + 1) * 64 + lane] = wl;
+  }
+  __syncthreads();
+  const long tiles = a.P / 32;
+  for (long tl = (long)blockIdx.x * 4 + wave; tl < tiles; tl += (long)gridDim.x * 4) {
+    const long p0 = tl * 32;
+    // ---- the tile's operands: row = point p0 + l31, k = 16 c + 8 h + j
+    const float* row = a.X + (p0 + l31) * S2_K + 8 * h;
+    float raw[8][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 b0 = *reinterpret_cast<const float4*>(row + 16 * c);
+      const float4 b1 = *reinterpret_cast<const float4*>(row + 16 * c + 4);
+      raw[c][0] = b0.x; raw[c][1] = b0.y; raw[c][2] = b0.z; raw[c][3] = b0.w;
+      raw[c][4] = b1.x; raw[c][5] = b1.y; raw[c][6] = b1.z; raw[c][7] = b1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, __builtin_fabsf(raw[c][j]));
+    }
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (h == 0) {
+      const float* pz = a.xyz + (p0 + l31) * 3;
+      q[0] = pz[0];
+      q[1] = pz[1];
+      q[2] = pz[2];
+    }
+    mx = fmaxf(mx, fmaxf(__builtin_fabsf(q[0]), fmaxf(__builtin_fabsf(q[1]), __builtin_fabsf(q[2]))));
+    const unsigned Ex = s2_exp(wave_max(mx));
+    const float sx = s2_scale(Ex);
+    half8 ah[9], al[9];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s2_split8(raw[c], sx, ah[c], al[c]);
+    s2_split8(q, sx, ah[8], al[8]);
+    const float unscale = s2_unscale(Ex) * unW;
+    float* Y = a.Y + p0 * S2_K + l31;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const half8* wf = s_w + (size_t)t * 8 * 2 * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const half8 bh = c < 8 ? wf[(c * 2 + 0) * 64] : s_wx[(t * 2 + 0) * 64 + lane];
+        const half8 bl = c < 8 ? wf[(c * 2 + 1) * 64] : s_wx[(t * 2 + 1) * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c], bh, acc, 0, 0, 0);
+      }
+      // acc[r]: point p0 + (r & 3) + 8 (r >> 2) + 4 h, channel 32 t + l31: 128 contiguous bytes per point and half-wave
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[(size_t)mfma_row(r, lane) * S2_K + 32 * t] = acc[r] * unscale;
+    }
+  }
+}
+
 }  // namespace
+
+int launch_sa2_pre(const float* X, const float* xyz, const void* wf_img, const float* wf_un, const float* Wx, float* Y, long P,
+                   hipStream_t s) {
+  if (P <= 0 || P % 32 != 0) return GEOA3_ENOSUPPORT;
+  Sa2PreArgs a{X, xyz, static_cast<const _Float16*>(wf_img), wf_un, Wx, Y, P};
+  const int lds = sa2_pre_lds();
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const long tiles = P / 32;
+  const unsigned grid = (unsigned)((tiles + 3) / 4 < 512 ? (tiles + 3) / 4 : 512);   // two workgroups per CU (72 KB of LDS each)
+  hipLaunchKernelGGL(sa2_pre_kernel, dim3(grid), dim3(256), lds, s, a);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
 
 int launch_sa2_sort(const float* gz, const int32_t* argt, float* ent_g, int32_t* ent_c, long centres, hipStream_t s) {
   hipLaunchKernelGGL(sa2_sort_kernel, dim3((unsigned)((centres + 3) / 4)), dim3(256), 0, s, gz, argt, ent_g, ent_c, centres);

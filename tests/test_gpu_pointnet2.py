@@ -29,7 +29,8 @@ def _cloud(B, N, seed, skip=True, dup=True):
     return xyz
 
 
-@pytest.mark.parametrize("B,N,m", [(3, 1024, 512), (2, 512, 128), (2, 700, 300), (1, 2048, 512), (2, 64, 64), (1, 5, 3)])
+@pytest.mark.parametrize("B,N,m", [(3, 1024, 512), (2, 512, 128), (2, 700, 300), (1, 2048, 512), (2, 64, 64), (1, 5, 3),
+                                   (2, 1500, 200), (1, 3000, 300), (1, 8192, 64), (2, 513, 40), (2, 1025, 40)])
 def test_fps_exact(pn2, B, N, m):
     xyz = _cloud(B, N, 100 + N)
     got = pn2.ext.furthest_point_sampling(xyz.cuda(), m).cpu()
