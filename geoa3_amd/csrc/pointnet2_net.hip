@@ -442,7 +442,7 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   float* rt = w.df1;   // [B,512,128] (a backward buffer, free in forward)
   {
     const Img wfi = img_of(im, IM_SA2_WF);
-    TRY(launch_sa2_pre(w.out1, w.nx1, wfi.p, wfi.un, p.sa2_wx, rt, (long)B * M1, s));
+    TRY(launch_sa2_pre(w.out1, false, 0, w.nx1, wfi.p, wfi.un, p.sa2_wx, rt, (long)B * M1, s));
   }
   if (use_side && hipStreamWaitEvent(s, sq->join, 0) != hipSuccess) return GEOA3_ELAUNCH;
   // gather + shift + relu, W1, W2 + max in one kernel; the activations a0 / a1 exist only as gate bits (m0 / m1)
@@ -518,7 +518,10 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   // (the grouping gradient of a range of instances on the side queue beside the next range's sa2_bwd_kernel was measured:
   // two ranges 4.256 ms against 4.259, four 4.33, three 4.40 -- both kernels are bound by memory traffic: DESIGN 8)
   TRY(geoa3_pn2_group_points_grad_sums(da0, w.gidx2, B, 128, M1, M2, S, dr, dshift, stream));
-  TRY(conv_slice(dr, 128, 0, 128, img_of(im, IM_SA2_WFT), nullptr, nullptr, w.df1, C1, B, M1, false, false, s));   // d f1 = W_f^T dr
+  {   // d f1 = W_f^T dr, written centroid-major for level 1's backward (no [B,128,512] tensor, no transpose)
+    const Img wti = img_of(im, IM_SA2_WFT);
+    TRY(launch_sa2_pre(dr, true, M1, nullptr, wti.p, wti.un, nullptr, w.g1, (long)B * M1, s));
+  }
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M1), dim3(256), 3 * 128 * sizeof(float), s, dr, p.sa2_wx, 1.f, w.dnx1,
                      128, M1, 0, (long)B * M1);                                                        // d xyz1 = W_x^T dr
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 128 * sizeof(float), s, dshift, p.sa2_wx, -1.f,
@@ -526,7 +529,6 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   hipLaunchKernelGGL(scatter_rows3_kernel, dim3((M1 + 255) / 256, B), dim3(256), M2 * sizeof(int32_t), s, w.dnx2, w.idx2,
                      w.dnx1, M1, M2, 1);                                                               // gather(new_xyz1, idx2)
   // ---- level 1
-  TRY((transpose<float, false>(w.df1, nullptr, w.g1, B, C1, M1, s)));              // [B,128,512] -> centroid-major
   // (the [B,512,64,3] contributions go through the level-2 buffer d1, free by now)
   TRY(geoa3_pn2_sa1_backward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, w.g1, w.gxyz, w.gnx1, w.d1, stream));
   hipLaunchKernelGGL(add_inplace_kernel, g1d((long)B * M1 * 3), dim3(256), 0, s, w.dnx1, w.gnx1, (long)B * M1 * 3);

@@ -873,17 +873,21 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
 // own power-of-two scale comes from their maximum, the three coordinates ride in a ninth k-step whose B fragments are
 // W_x at the image's scale; four 32-channel column tiles of 27 matrix instructions each.
 struct Sa2PreArgs {
-  const float* X;        // [P][128]
-  const float* xyz;      // [P][3]
+  const float* X;        // [P][128]; XT: channel-major [P / Np][128][Np]
+  const float* xyz;      // [P][3], or null: no coordinate term
   const _Float16* img;   // fragment image of Wf (launch_frag_image: rows = output channels)
   const float* un;       // [1]: 1 / the image's scale
   const float* Wx;       // [128][3]
   float* Y;              // [P][128]
   long P;                // points (a multiple of 32)
+  int Np;                // XT: points per instance (a multiple of 32)
 };
 
 constexpr int sa2_pre_lds() { return S2_K * S2_K * 4 + 4 * 2 * 64 * 16; }
 
+// XT: the same product with X channel-major (the backward's d f = W_f^T d r from the grouping gradient's layout, written
+// centroid-major for level 1's backward: again no transpose)
+template <bool XT, bool XYZ>   // XYZ: with the coordinate term (a.xyz, a.Wx)
 __global__ __launch_bounds__(256) void sa2_pre_kernel(Sa2PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s2_sm[];
   half8* s_w = reinterpret_cast<half8*>(s2_sm);                     // [(tile * 8 + c) * 2 + piece][lane]
@@ -895,7 +899,7 @@ __global__ __launch_bounds__(256) void sa2_pre_kernel(Sa2PreArgs a) {
     for (int e = tid; e < S2_K * S2_K * 4 / 16; e += 256) s_w[e] = src[e];
   }
   const float unW = a.un[0];
-  {   // B fragments of the ninth k-step: lane (column co = 32 t + l31, k = 8 h + j): W_x[co][k] for k < 3, at the image's scale
+  if (XYZ) {   // B fragments of the ninth k-step: lane (column co = 32 t + l31, k = 8 h + j): W_x[co][k] for k < 3, at the image's scale
     const float sw = 1.0f / unW;   // (a power of two)
     const int t = wave;            // four waves, four column tiles
     const int co = 32 * t + l31;
@@ -915,20 +919,31 @@ __global__ __launch_bounds__(256) void sa2_pre_kernel(Sa2PreArgs a) {
   for (long tl = (long)blockIdx.x * 4 + wave; tl < tiles; tl += (long)gridDim.x * 4) {
     const long p0 = tl * 32;
     // ---- the tile's operands: row = point p0 + l31, k = 16 c + 8 h + j
-    const float* row = a.X + (p0 + l31) * S2_K + 8 * h;
     float raw[8][8];
     float mx = 0.f;
+    if (!XT) {
+      const float* row = a.X + (p0 + l31) * S2_K + 8 * h;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float4 b0 = *reinterpret_cast<const float4*>(row + 16 * c);
-      const float4 b1 = *reinterpret_cast<const float4*>(row + 16 * c + 4);
-      raw[c][0] = b0.x; raw[c][1] = b0.y; raw[c][2] = b0.z; raw[c][3] = b0.w;
-      raw[c][4] = b1.x; raw[c][5] = b1.y; raw[c][6] = b1.z; raw[c][7] = b1.w;
+      for (int c = 0; c < 8; ++c) {
+        const float4 b0 = *reinterpret_cast<const float4*>(row + 16 * c);
+        const float4 b1 = *reinterpret_cast<const float4*>(row + 16 * c + 4);
+        raw[c][0] = b0.x; raw[c][1] = b0.y; raw[c][2] = b0.z; raw[c][3] = b0.w;
+        raw[c][4] = b1.x; raw[c][5] = b1.y; raw[c][6] = b1.z; raw[c][7] = b1.w;
+      }
+    } else {   // X[b][k][n]: a lane's eight k are Np floats apart, the 32 points of a half-wave contiguous
+      const long b = p0 / a.Np;
+      const float* col = a.X + (b * S2_K + 8 * h) * a.Np + (p0 - b * a.Np) + l31;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[c][j] = col[(size_t)(16 * c + j) * a.Np];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
       for (int j = 0; j < 8; ++j) mx = fmaxf(mx, __builtin_fabsf(raw[c][j]));
-    }
     float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (h == 0) {
+    if (XYZ && h == 0) {
       const float* pz = a.xyz + (p0 + l31) * 3;
       q[0] = pz[0];
       q[1] = pz[1];
@@ -950,7 +965,7 @@ __global__ __launch_bounds__(256) void sa2_pre_kernel(Sa2PreArgs a) {
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const half8* wf = s_w + (size_t)t * 8 * 2 * 64 + lane;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
+      for (int c = 0; c < (XYZ ? 9 : 8); ++c) {
         const half8 bh = c < 8 ? wf[(c * 2 + 0) * 64] : s_wx[(t * 2 + 0) * 64 + lane];
         const half8 bl = c < 8 ? wf[(c * 2 + 1) * 64] : s_wx[(t * 2 + 1) * 64 + lane];
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bh, acc, 0, 0, 0);
@@ -966,15 +981,24 @@ __global__ __launch_bounds__(256) void sa2_pre_kernel(Sa2PreArgs a) {
 
 }  // namespace
 
-int launch_sa2_pre(const float* X, const float* xyz, const void* wf_img, const float* wf_un, const float* Wx, float* Y, long P,
-                   hipStream_t s) {
-  if (P <= 0 || P % 32 != 0) return GEOA3_ENOSUPPORT;
-  Sa2PreArgs a{X, xyz, static_cast<const _Float16*>(wf_img), wf_un, Wx, Y, P};
+int launch_sa2_pre(const float* X, bool x_channel_major, int Np, const float* xyz, const void* wf_img, const float* wf_un,
+                   const float* Wx, float* Y, long P, hipStream_t s) {
+  if (P <= 0 || P % 32 != 0 || (x_channel_major && (Np <= 0 || Np % 32 != 0 || P % Np != 0)) || (xyz && !Wx)) return GEOA3_ENOSUPPORT;
+  Sa2PreArgs a{X, xyz, static_cast<const _Float16*>(wf_img), wf_un, Wx, Y, P, Np};
   const int lds = sa2_pre_lds();
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const long tiles = P / 32;
   const unsigned grid = (unsigned)((tiles + 3) / 4 < 512 ? (tiles + 3) / 4 : 512);   // two workgroups per CU (72 KB of LDS each)
-  hipLaunchKernelGGL(sa2_pre_kernel, dim3(grid), dim3(256), lds, s, a);
+#define GEOA3_PRE(XT_, XYZ_)                                                                                             \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_pre_kernel<XT_, XYZ_>),                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                          \
+    hipLaunchKernelGGL((sa2_pre_kernel<XT_, XYZ_>), dim3(grid), dim3(256), lds, s, a);                                    \
+  } while (0)
+  if (x_channel_major && xyz) GEOA3_PRE(true, true);
+  else if (x_channel_major) GEOA3_PRE(true, false);
+  else if (xyz) GEOA3_PRE(false, true);
+  else GEOA3_PRE(false, false);
+#undef GEOA3_PRE
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -206,6 +206,7 @@ int launch_pn2_ball_query_range(const float* new_xyz, const float* xyz, int B, i
                                 int nsample, int32_t* idx, hipStream_t s);
 int launch_sa1_forward_range(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B, int N,
                              int M, int m0, int m1, float* out, uint8_t* arg, hipStream_t s);
-// level 2's pre-transformed first layer per point: Y[p][co] = sum_k X[p][k] Wf[co][k] + sum_d Wx[co][d] xyz[p][d], all point-major
-int launch_sa2_pre(const float* X, const float* xyz, const void* wf_img, const float* wf_un, const float* Wx, float* Y, long P,
-                   hipStream_t s);
+// level 2's pre-transformed first layer per point: Y[p][co] = sum_k X[p][k] W[co][k] (+ sum_d Wx[co][d] xyz[p][d]), Y point-major;
+// X point-major [P][128], or channel-major [P / Np][128][Np] (the backward's d f = W_f^T d r with W = the image of W_f^T)
+int launch_sa2_pre(const float* X, bool x_channel_major, int Np, const float* xyz, const void* wf_img, const float* wf_un,
+                   const float* Wx, float* Y, long P, hipStream_t s);
