@@ -504,11 +504,9 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 256 * sizeof(float), s, w.dh1, p.sa3_wx, 1.f,
                      w.dnx2, 256, M2, 0, (long)B * M2);
   // ---- level 2: pooled layer's sparse gradient (centre-major, relu-gated) -> W2^T -> W1^T -> scatter of the gather
-  TRY((transpose<float, true>(w.dout2, w.out2, w.gz, B, C2, M2, s)));              // [B,256,128] -> [B,128,256], gated
-  TRY((transpose<int32_t, false>(w.arg2, nullptr, w.argt, B, C2, M2, s)));
   float* ent_g = w.d1;   // the level-1 scratch, free until sa1_backward
   int32_t* ent_c = reinterpret_cast<int32_t*>(w.d1 + (size_t)B * M2 * C2);
-  TRY(launch_sa2_sort(w.gz, w.argt, ent_g, ent_c, (long)B * M2, s));
+  TRY(launch_sa2_sort_cm(w.dout2, w.out2, w.arg2, ent_g, ent_c, B, M2, s));   // gate, both transposes and the per-centre sort
   float* da0 = w.da0;
   {
     const Img i1t = img_of(im, IM_SA2_W1T);

@@ -78,30 +78,20 @@ __device__ __forceinline__ float s2_rlf(float v, int l) { return __int_as_float(
 // 256 ballots per centre, 85 us per launch): a histogram of the samples in LDS, its exclusive prefix (lane = sample), and per
 // round the lanes holding the same sample found by six ballots (one per bit of the sample): the rank inside the group is a
 // population count, the group's first lane advances the sample's running offset for the next round.
-__global__ __launch_bounds__(256) void sa2_sort_kernel(const float* __restrict__ gz, const int32_t* __restrict__ argt,
-                                                       float* __restrict__ ent_g, int32_t* __restrict__ ent_c, long centres) {
-  __shared__ int s_hist[4][64], s_run[4][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long c = (long)blockIdx.x * 4 + wave;
-  if (c >= centres) return;                       // (whole waves leave: no barrier below)
-  int a[4];
-  float g[4];
-  s_hist[wave][lane] = 0;
+// the sort of ONE centre's 256 (value, sample) pairs by a wavefront: lane holds channels q * 64 + lane
+__device__ __forceinline__ void sa2_sort_centre(const int (&a)[4], const float (&g)[4], int* hist, int* run, int lane,
+                                                float* __restrict__ eg, int32_t* __restrict__ ec) {
+  hist[lane] = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    a[q] = argt[c * S2_C + q * 64 + lane] & 63;
-    g[q] = gz[c * S2_C + q * 64 + lane];
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) atomicAdd(&s_hist[wave][a[q]], 1);
-  const int tot = s_hist[wave][lane];             // entries of sample `lane` (LDS operations of a wave complete in order)
+  for (int q = 0; q < 4; ++q) atomicAdd(&hist[a[q]], 1);
+  const int tot = hist[lane];             // entries of sample `lane` (LDS operations of a wave complete in order)
   int incl = tot;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int v = __shfl_up(incl, o, 64);
     if (lane >= o) incl += v;
   }
-  s_run[wave][lane] = incl - tot;                 // where the sample's entries start
+  run[lane] = incl - tot;                 // where the sample's entries start
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -112,12 +102,68 @@ __global__ __launch_bounds__(256) void sa2_sort_kernel(const float* __restrict__
       m &= ((a[q] >> bit) & 1) ? bal : ~bal;
     }
     const int r = (int)__builtin_popcountll(m & below), n = (int)__builtin_popcountll(m);
-    const int start = s_run[wave][a[q]];
+    const int start = run[a[q]];
     const int pos = start + r;
-    if (r == 0) s_run[wave][a[q]] = start + n;    // one lane per sample: the next round's entries follow
+    if (r == 0) run[a[q]] = start + n;    // one lane per sample: the next round's entries follow
     const int end = __shfl(incl, a[q], 64);       // one past the sample's last entry
-    ent_c[c * S2_C + pos] = (q * 64 + lane) | (a[q] << 16) | (pos == end - 1 ? (int)0x80000000 : 0);
-    ent_g[c * S2_C + pos] = g[q];
+    ec[pos] = (q * 64 + lane) | (a[q] << 16) | (pos == end - 1 ? (int)0x80000000 : 0);
+    eg[pos] = g[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void sa2_sort_kernel(const float* __restrict__ gz, const int32_t* __restrict__ argt,
+                                                       float* __restrict__ ent_g, int32_t* __restrict__ ent_c, long centres) {
+  __shared__ int s_hist[4][64], s_run[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long c = (long)blockIdx.x * 4 + wave;
+  if (c >= centres) return;                       // (whole waves leave: no barrier below)
+  int a[4];
+  float g[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a[q] = argt[c * S2_C + q * 64 + lane] & 63;
+    g[q] = gz[c * S2_C + q * 64 + lane];
+  }
+  sa2_sort_centre(a, g, s_hist[wave], s_run[wave], lane, ent_g + c * S2_C, ent_c + c * S2_C);
+}
+
+// The same lists straight from the channel-major tensors the level-3 backward leaves (round 5): d out2, out2 (the relu gate)
+// and arg2, all [B][256][M] -- the gated transpose of the gradient, the transpose of the arg-max table and the sort were three
+// launches (20 + 18 + 30 us) around two [B,128,256] tensors.  A workgroup takes 32 centres of one instance: the [256][32]
+// tiles arrive as 128-byte rows, cross through LDS (value rows of 257 floats, samples as bytes), and each of 16 wavefronts
+// sorts two centres.
+constexpr int S2_SORT_M = 32, S2_SORT_W = 16;   // 16 wavefronts: two centres each
+__global__ __launch_bounds__(64 * S2_SORT_W) void sa2_sort_cm_kernel(const float* __restrict__ dout, const float* __restrict__ outp,
+                                                                     const int32_t* __restrict__ arg, float* __restrict__ ent_g,
+                                                                     int32_t* __restrict__ ent_c, int M) {
+  __shared__ float s_g[S2_SORT_M][S2_C + 1];
+  __shared__ unsigned char s_a[S2_SORT_M][S2_C + 4];
+  __shared__ int s_hist[S2_SORT_W][64], s_run[S2_SORT_W][64];
+  const int b = blockIdx.y, m0 = blockIdx.x * S2_SORT_M, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = tid & 31, ty = tid >> 5;   // 32 channel rows per pass
+  const size_t base = (size_t)b * S2_C * M;
+#pragma unroll
+  for (int i = 0; i < S2_C / (2 * S2_SORT_W); ++i) {
+    const int ch = ty + 2 * S2_SORT_W * i, m = m0 + tx;
+    if (m < M) {
+      const size_t e = base + (size_t)ch * M + m;
+      s_g[tx][ch] = outp[e] > 0.f ? dout[e] : 0.f;
+      s_a[tx][ch] = (unsigned char)(arg[e] & 63);
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < S2_SORT_M / S2_SORT_W; ++i) {
+    const int ml = wave * (S2_SORT_M / S2_SORT_W) + i;
+    if (m0 + ml >= M) break;                       // (wave-uniform)
+    int a[4];
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = s_a[ml][q * 64 + lane];
+      g[q] = s_g[ml][q * 64 + lane];
+    }
+    const size_t c = (size_t)b * M + m0 + ml;
+    sa2_sort_centre(a, g, s_hist[wave], s_run[wave], lane, ent_g + c * S2_C, ent_c + c * S2_C);
   }
 }
 
@@ -1005,6 +1051,13 @@ int launch_sa2_pre(const float* X, bool x_channel_major, int Np, const float* xy
 
 int launch_sa2_sort(const float* gz, const int32_t* argt, float* ent_g, int32_t* ent_c, long centres, hipStream_t s) {
   hipLaunchKernelGGL(sa2_sort_kernel, dim3((unsigned)((centres + 3) / 4)), dim3(256), 0, s, gz, argt, ent_g, ent_c, centres);
+  GEOA3_CHECK_LAUNCH();
+  return GEOA3_OK;
+}
+
+int launch_sa2_sort_cm(const float* dout, const float* outp, const int32_t* arg, float* ent_g, int32_t* ent_c, int B, int M,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(sa2_sort_cm_kernel, dim3((M + S2_SORT_M - 1) / S2_SORT_M, B), dim3(64 * S2_SORT_W), 0, s, dout, outp, arg, ent_g, ent_c, M);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

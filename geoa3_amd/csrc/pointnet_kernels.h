@@ -210,3 +210,6 @@ int launch_sa1_forward_range(const float* xyz, const float* new_xyz, const int32
 // X point-major [P][128], or channel-major [P / Np][128][Np] (the backward's d f = W_f^T d r with W = the image of W_f^T)
 int launch_sa2_pre(const float* X, bool x_channel_major, int Np, const float* xyz, const void* wf_img, const float* wf_un,
                    const float* Wx, float* Y, long P, hipStream_t s);
+// sa2_bwd_kernel's sorted (value, channel) lists straight from d out2 / out2 (relu gate) / arg2, all channel-major [B][256][M]
+int launch_sa2_sort_cm(const float* dout, const float* outp, const int32_t* arg, float* ent_g, int32_t* ent_c, int B, int M,
+                       hipStream_t s);
