@@ -402,26 +402,28 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   // (while bench.py samples sa1_fwd_kernel's time the level runs as one launch per kernel)
   const bool use_side = sq != nullptr && !geoa3_prof_tag_on(GEOA3_PROF_SA1_FWD) && (size_t)N * 3 * sizeof(float) + 1024 <= 128 * 1024;
   hipStream_t s2 = use_side ? sq->stream : s;
-  constexpr int CH = 4, MC = M1 / CH;   // (1 / 2 / 4 / 8 launches measured: 4.228 / 4.221 / 4.196 / 4.205 ms per iteration)
+  constexpr int CH = 4;   // (1 / 2 / 4 / 8 equal launches measured: 4.228 / 4.221 / 4.196 / 4.205 ms per iteration)
+  // (a smaller first launch -- 32 / 64 / 96 centroids -- to start the MLP earlier: 4.01-4.02 / 4.00-4.01 / 3.99 ms against 3.97)
+  constexpr int cut[CH + 1] = {0, M1 / 4, M1 / 2, 3 * M1 / 4, M1};
   float* fps_td = w.d1;   // [B,N] running distances between the sampler's launches (a backward buffer, free in forward)
   auto rows = [&](int m0, int m1, hipStream_t st) {   // the centroid rows nx1[:, m0 .. m1 - 1]
     hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * (m1 - m0)), dim3(256), 0, st, w.xyz, w.idx1, w.nx1, N, M1, m0, m1 - m0,
                        (long)B * (m1 - m0));
   };
   if (use_side) {
-    TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, MC, fps_td, w.idx1, s));
-    rows(0, MC, s);
+    TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, cut[1], fps_td, w.idx1, s));
+    rows(0, cut[1], s);
     if (hipEventRecord(sq->ev[0], s) != hipSuccess || hipStreamWaitEvent(s2, sq->ev[0], 0) != hipSuccess) return GEOA3_ELAUNCH;
-    TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, 0, MC, R1, S, w.gidx1, s));
+    TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, 0, cut[1], R1, S, w.gidx1, s));
     for (int c = 1; c < CH; ++c) {   // sampler, centroid rows and ball query of chunk c: all on the side stream
-      TRY(launch_pn2_fps_range(w.xyz, B, N, M1, c * MC, (c + 1) * MC, fps_td, w.idx1, s2));
-      rows(c * MC, (c + 1) * MC, s2);
-      TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, c * MC, (c + 1) * MC, R1, S, w.gidx1, s2));
+      TRY(launch_pn2_fps_range(w.xyz, B, N, M1, cut[c], cut[c + 1], fps_td, w.idx1, s2));
+      rows(cut[c], cut[c + 1], s2);
+      TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, cut[c], cut[c + 1], R1, S, w.gidx1, s2));
       if (hipEventRecord(sq->ev[c], s2) != hipSuccess) return GEOA3_ELAUNCH;
     }
     for (int c = 0; c < CH; ++c) {
       if (c > 0 && hipStreamWaitEvent(s, sq->ev[c], 0) != hipSuccess) return GEOA3_ELAUNCH;
-      TRY(launch_sa1_forward_range(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, c * MC, (c + 1) * MC, w.out1, w.arg1, s));
+      TRY(launch_sa1_forward_range(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, cut[c], cut[c + 1], w.out1, w.arg1, s));
     }
   } else {
     TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, M1, nullptr, w.idx1, s));
