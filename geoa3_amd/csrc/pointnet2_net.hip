@@ -491,6 +491,7 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   TRY(fc(w.g512, 512, p.f1t, nullptr, w.g1024, C3, B, false, w.p3, s));   // gated by the pooled layer's relu
   // ---- level 3: the pooled gradient reaches one point per channel: d h2 = relu'(h2) . sum_{ch : arg = point} g W2[ch]
   // (the sparse walk of the PointNet 1024-wide layers, in four 128-row slices of h2), then W1^T (two), Wf^T / Wx^T
+  SideQueue* sq = static_cast<SideQueue*>(p.side);
   for (int k0 = 0; k0 < 512; k0 += 128) {
     WideBwdArgs a{};
     a.g = w.g1024; a.arg = w.arg3;
@@ -498,7 +499,7 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
     a.Z = w.h2 + (size_t)k0 * M2; a.sZb = (long)512 * M2; a.ldZ = M2;
     a.dX = w.dh2 + (size_t)k0 * M2; a.sXb = (long)512 * M2; a.ldX = M2;
     a.Co = C3; a.N = M2; a.B = B; a.taps = 1;
-    TRY(launch_wide_max_bwd(a, s));
+    TRY(launch_wide_max_bwd(a, s));   // (two of the four independent slices on the side queue: 3.966 ms against 3.965)
   }
   for (int k0 = 0; k0 < 512; k0 += 256)
     TRY(conv_slice(w.dh2, 512, k0, 256, img_of(im, IM_SA3_W1T), nullptr, w.h1, w.dh1, 256, B, M2, false, k0 > 0, s));
@@ -522,15 +523,23 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
     const Img wti = img_of(im, IM_SA2_WFT);
     TRY(launch_sa2_pre(dr, true, M1, nullptr, wti.p, wti.un, nullptr, w.g1, (long)B * M1, s));
   }
-  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M1), dim3(256), 3 * 128 * sizeof(float), s, dr, p.sa2_wx, 1.f, w.dnx1,
+  // the coordinate gradients of the level (three small kernels, needed only behind level 1's backward) on the side queue
+  // beside sa1_bwd_kernel
+  const bool side_tail = sq != nullptr;   // (3.934 ms against 3.965)
+  hipStream_t st = side_tail ? sq->stream : s;
+  if (side_tail && (hipEventRecord(sq->ev[1], s) != hipSuccess || hipStreamWaitEvent(st, sq->ev[1], 0) != hipSuccess))
+    return GEOA3_ELAUNCH;
+  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M1), dim3(256), 3 * 128 * sizeof(float), st, dr, p.sa2_wx, 1.f, w.dnx1,
                      128, M1, 0, (long)B * M1);                                                        // d xyz1 = W_x^T dr
-  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 128 * sizeof(float), s, dshift, p.sa2_wx, -1.f,
+  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 128 * sizeof(float), st, dshift, p.sa2_wx, -1.f,
                      w.dnx2, 128, M2, 1, (long)B * M2);                                                // d c -= W_x^T dshift
-  hipLaunchKernelGGL(scatter_rows3_kernel, dim3((M1 + 255) / 256, B), dim3(256), M2 * sizeof(int32_t), s, w.dnx2, w.idx2,
+  hipLaunchKernelGGL(scatter_rows3_kernel, dim3((M1 + 255) / 256, B), dim3(256), M2 * sizeof(int32_t), st, w.dnx2, w.idx2,
                      w.dnx1, M1, M2, 1);                                                               // gather(new_xyz1, idx2)
+  if (side_tail && hipEventRecord(sq->join, st) != hipSuccess) return GEOA3_ELAUNCH;
   // ---- level 1
   // (the [B,512,64,3] contributions go through the level-2 buffer d1, free by now)
   TRY(geoa3_pn2_sa1_backward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, w.g1, w.gxyz, w.gnx1, w.d1, stream));
+  if (side_tail && hipStreamWaitEvent(s, sq->join, 0) != hipSuccess) return GEOA3_ELAUNCH;
   hipLaunchKernelGGL(add_inplace_kernel, g1d((long)B * M1 * 3), dim3(256), 0, s, w.dnx1, w.gnx1, (long)B * M1 * 3);
   hipLaunchKernelGGL(scatter_rows3_kernel, dim3((N + 255) / 256, B), dim3(256), M1 * sizeof(int32_t), s, w.dnx1, w.idx1,
                      w.gxyz, N, M1, 1);                                                                // gather(xyz, idx1)
