@@ -152,17 +152,25 @@ __global__ __launch_bounds__(256) void planar_to_points_kernel(const float* __re
   q[1] = p[N];
   q[2] = p[2 * (size_t)N];
 }
-__global__ __launch_bounds__(256) void points_to_planar_kernel(const float* __restrict__ xyz, float* __restrict__ x, int N,
-                                                               long total) {
+// (xyz2: a second point-major tensor added on the way, or null)
+__global__ __launch_bounds__(256) void points_to_planar_kernel(const float* __restrict__ xyz, const float* __restrict__ xyz2,
+                                                               float* __restrict__ x, int N, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const long b = e / N;
   const int n = (int)(e - b * N);
   const float* q = xyz + e * 3;
+  float v0 = q[0], v1 = q[1], v2 = q[2];
+  if (xyz2) {
+    const float* r = xyz2 + e * 3;
+    v0 += r[0];
+    v1 += r[1];
+    v2 += r[2];
+  }
   float* p = x + b * 3 * N + n;
-  p[0] = q[0];
-  p[N] = q[1];
-  p[2 * (size_t)N] = q[2];
+  p[0] = v0;
+  p[N] = v1;
+  p[2 * (size_t)N] = v2;
 }
 
 // out[b][m][:] = in[b][idx[b][m]][:]   (rows of 3 floats), m in [m0, m0 + Mc) of the M; total = B * Mc
@@ -535,15 +543,21 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
                      w.dnx2, 128, M2, 1, (long)B * M2);                                                // d c -= W_x^T dshift
   hipLaunchKernelGGL(scatter_rows3_kernel, dim3((M1 + 255) / 256, B), dim3(256), M2 * sizeof(int32_t), st, w.dnx2, w.idx2,
                      w.dnx1, M1, M2, 1);                                                               // gather(new_xyz1, idx2)
-  if (side_tail && hipEventRecord(sq->join, st) != hipSuccess) return GEOA3_ELAUNCH;
   // ---- level 1
   // (the [B,512,64,3] contributions go through the level-2 buffer d1, free by now)
-  TRY(geoa3_pn2_sa1_backward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, w.g1, w.gxyz, w.gnx1, w.d1, stream));
-  if (side_tail && hipStreamWaitEvent(s, sq->join, 0) != hipSuccess) return GEOA3_ELAUNCH;
-  hipLaunchKernelGGL(add_inplace_kernel, g1d((long)B * M1 * 3), dim3(256), 0, s, w.dnx1, w.gnx1, (long)B * M1 * 3);
-  hipLaunchKernelGGL(scatter_rows3_kernel, dim3((N + 255) / 256, B), dim3(256), M1 * sizeof(int32_t), s, w.dnx1, w.idx1,
-                     w.gxyz, N, M1, 1);                                                                // gather(xyz, idx1)
-  hipLaunchKernelGGL(points_to_planar_kernel, g1d((long)B * N), dim3(256), 0, s, w.gxyz, dx, N, (long)B * N);
+  TRY(launch_sa1_backward(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, w.out1, w.arg1, w.g1, w.gxyz, w.gnx1, w.d1,
+                          side_tail ? sq->ev[2] : nullptr, stream));
+  // the centroids' own gradient rows (d nx1 += level 1's share; scattered to their points) beside level 1's scatter kernel,
+  // into a buffer of their own; the two are added on the way to the planar output
+  float* gx2 = side_tail ? w.f1 : w.gxyz;   // (w.f1: [B,128,512] floats of the forward, free here)
+  if (side_tail && hipStreamWaitEvent(st, sq->ev[2], 0) != hipSuccess) return GEOA3_ELAUNCH;
+  hipLaunchKernelGGL(add_inplace_kernel, g1d((long)B * M1 * 3), dim3(256), 0, st, w.dnx1, w.gnx1, (long)B * M1 * 3);
+  hipLaunchKernelGGL(scatter_rows3_kernel, dim3((N + 255) / 256, B), dim3(256), M1 * sizeof(int32_t), st, w.dnx1, w.idx1,
+                     gx2, N, M1, side_tail ? 0 : 1);                                                   // gather(xyz, idx1)
+  if (side_tail && (hipEventRecord(sq->join, st) != hipSuccess || hipStreamWaitEvent(s, sq->join, 0) != hipSuccess))
+    return GEOA3_ELAUNCH;
+  hipLaunchKernelGGL(points_to_planar_kernel, g1d((long)B * N), dim3(256), 0, s, w.gxyz, side_tail ? gx2 : (const float*)nullptr, dx,
+                     N, (long)B * N);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -816,10 +816,21 @@ extern "C" int64_t geoa3_pn2_sa1_scratch_bytes(int B, int M) {
   return (int64_t)B * M * SA_S * 3 * (int64_t)sizeof(float);
 }
 
+// (after_bwd: recorded behind sa1_bwd_kernel, in front of the scatter -- grad_new_xyz is complete there)
+int launch_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B, int N, int M,
+                        const float* out, const uint8_t* arg, const float* grad_out, float* grad_xyz, float* grad_new_xyz,
+                        float* scratch, hipEvent_t after_bwd, void* stream);
+
 extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx,
                                       const geoa3_sa1_weights* w, int B, int N, int M, const float* out,
                                       const uint8_t* arg, const float* grad_out, float* grad_xyz, float* grad_new_xyz,
                                       float* scratch, void* stream) {
+  return launch_sa1_backward(xyz, new_xyz, idx, w, B, N, M, out, arg, grad_out, grad_xyz, grad_new_xyz, scratch, nullptr, stream);
+}
+
+int launch_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B, int N, int M,
+                        const float* out, const uint8_t* arg, const float* grad_out, float* grad_xyz, float* grad_new_xyz,
+                        float* scratch, hipEvent_t after_bwd, void* stream) {
   if (!xyz || !new_xyz || !idx || !w || !out || !arg || !grad_out || !grad_xyz || !grad_new_xyz || B <= 0 || N <= 0 ||
       M <= 0)
     return GEOA3_EINVAL;
@@ -836,6 +847,7 @@ extern "C" int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, co
   hipLaunchKernelGGL(sa1_bwd_kernel<SA_WB * 64>, dim3(sa1_grid(B, M, SA_WB, 1)), dim3(SA_WB * 64), lds, s, xyz, new_xyz, idx, *w, B, N, M, out, arg,
                      grad_out, grad_xyz, grad_new_xyz, det ? scratch : nullptr);
   geoa3_prof_end(GEOA3_PROF_SA1_BWD, s);
+  if (after_bwd && hipEventRecord(after_bwd, s) != hipSuccess) return GEOA3_ELAUNCH;
   if (det) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa1_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)l2);

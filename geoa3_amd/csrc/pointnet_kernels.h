@@ -213,3 +213,7 @@ int launch_sa2_pre(const float* X, bool x_channel_major, int Np, const float* xy
 // sa2_bwd_kernel's sorted (value, channel) lists straight from d out2 / out2 (relu gate) / arg2, all channel-major [B][256][M]
 int launch_sa2_sort_cm(const float* dout, const float* outp, const int32_t* arg, float* ent_g, int32_t* ent_c, int B, int M,
                        hipStream_t s);
+// geoa3_pn2_sa1_backward with an event recorded between its two kernels (grad_new_xyz complete, grad_xyz not yet)
+int launch_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B, int N, int M,
+                        const float* out, const uint8_t* arg, const float* grad_out, float* grad_xyz, float* grad_new_xyz,
+                        float* scratch, hipEvent_t after_bwd, void* stream);
