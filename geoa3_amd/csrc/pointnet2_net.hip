@@ -512,8 +512,12 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   for (int k0 = 0; k0 < 512; k0 += 256)
     TRY(conv_slice(w.dh2, 512, k0, 256, img_of(im, IM_SA3_W1T), nullptr, w.h1, w.dh1, 256, B, M2, false, k0 > 0, s));
   TRY(conv_slice(w.dh1, 256, 0, 256, img_of(im, IM_SA3_WFT), nullptr, nullptr, w.dout2, C2, B, M2, false, false, s));
-  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 256 * sizeof(float), s, w.dh1, p.sa3_wx, 1.f,
-                     w.dnx2, 256, M2, 0, (long)B * M2);
+  {   // level 3's coordinate gradient: first read by the side queue's kernels below, so it runs there too (in order)
+    hipStream_t s3 = sq ? sq->stream : s;
+    if (sq && (hipEventRecord(sq->ev[3], s) != hipSuccess || hipStreamWaitEvent(s3, sq->ev[3], 0) != hipSuccess)) return GEOA3_ELAUNCH;
+    hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 256 * sizeof(float), s3, w.dh1, p.sa3_wx, 1.f,
+                       w.dnx2, 256, M2, 0, (long)B * M2);
+  }
   // ---- level 2: pooled layer's sparse gradient (centre-major, relu-gated) -> W2^T -> W1^T -> scatter of the gather
   float* ent_g = w.d1;   // the level-1 scratch, free until sa1_backward
   int32_t* ent_c = reinterpret_cast<int32_t*>(w.d1 + (size_t)B * M2 * C2);
