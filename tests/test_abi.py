@@ -100,3 +100,31 @@ def test_backward_chain_kernel_holds_no_packed_fp32():
     assert start >= 0 and "v_mfma_f32_32x32x16_f16" in body
     assert not re.search(r"v_pk_(mul|fma|add)_f32", body)
     assert re.search(r"\.amdhsa_next_free_vgpr\s+2\d\d", asm)       # (two waves per SIMD: more than 128 registers is fine)
+
+
+def test_sampler_and_side_queue_kernels_hold_no_packed_fp32():
+    """DESIGN 5a, second sighting: the farthest-point sampler with an SLP-packed distance update is exact alone and wrong in
+    1.4e-3 of its rounds beside sa1_fwd_kernel (tools/ub/pk_fp32_coresidency.hip).  The kernels that run on the PointNet++
+    side queue live in pointnet2_ops.hip / pointnet2_net.hip: with the build's flags none of them may hold a
+    compiler-formed packed-FP32 instruction."""
+    import tempfile
+    from geoa3_amd import build as B
+    side = {"pointnet2_ops.hip": ["fps_kernel", "ball_query_wave_kernel"],
+            "pointnet2_net.hip": ["gather_rows3_kernel", "affine3_kernel", "affine3_grad_kernel", "scatter_rows3_kernel",
+                                  "add_inplace_kernel"]}
+    for name, kernels in side.items():
+        src = os.path.join(REPO, "geoa3_amd", "csrc", name)
+        flags = [f for f in B.FLAGS if f != "-fPIC"] + B.FILE_FLAGS[name]
+        assert "-fno-slp-vectorize" in flags
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            subprocess.run([B._hipcc()] + flags + ["-S", "--cuda-device-only", "-o", out, src], check=True, capture_output=True)
+            asm = open(out).read()
+        for k in kernels:
+            found = list(re.finditer(r"^(_Z\w*%s\w*):" % k, asm, re.M))
+            assert found, (name, k)
+            for m in found:      # every instance of a template
+                body = asm[m.end():]
+                body = body[:body.index("s_endpgm")]
+                assert not re.search(r"v_pk_(?:mul|fma|add)_f32", body), (name, m.group(1))
+    assert "fps_kernel" in B.ISA_GUARDS["pointnet2_ops.hip"][0]
