@@ -77,8 +77,7 @@ struct Ws {
   int32_t *idx1, *gidx1, *idx2, *gidx2, *arg2, *arg3;
   uint8_t* arg1;
   // backward
-  float *g256, *g512, *g1024, *dh2, *dh1, *dout2, *dnx2, *gz, *d1, *df1, *dnx1, *g1, *gxyz, *gnx1;
-  int32_t* argt;
+  float *g256, *g512, *g1024, *dh2, *dh1, *dout2, *dnx2, *d1, *df1, *dnx1, *g1, *gxyz, *gnx1;
   unsigned long long *m0, *m1;   // relu gates of the level-2 activations a0, a1 as bits [B * M2][128]
   void* images;   // fragment images, when the caller passes none (geoa3_pn2ssg_weights::images == NULL)
   size_t total;
@@ -123,8 +122,6 @@ Ws carve(void* base, int B, int N) {
   w.dh1 = (float*)take(b * 256 * M2 * f);
   w.dout2 = (float*)take(b * C2 * M2 * f);
   w.dnx2 = (float*)take(b * M2 * 3 * f);
-  w.gz = (float*)take(b * M2 * C2 * f);
-  w.argt = (int32_t*)take(b * M2 * C2 * 4);
   w.d1 = (float*)take(b * 128 * M2 * S * f);
   w.df1 = (float*)take(b * C1 * M1 * f);
   w.dnx1 = (float*)take(b * M1 * 3 * f);
