@@ -38,10 +38,19 @@ def _hipcc() -> str:
 # pointnet2_sa.hip, pointnet2_sa2.hip: relu / max of matrix-core results without the canonicalising v_max x, x the IEEE maxnum semantics put in front
 # of every one of them (a sixth of the level-1 kernels' vector instructions); NaNs still propagate through the products.
 # -fno-slp-vectorize there: the operand split stays at two instructions per element (sa_split2).
-FILE_FLAGS = {"pointnet_conv_chain.hip": ["-fno-slp-vectorize"], "pointnet_conv_split.hip": ["-fno-slp-vectorize"],
-              "pointnet2_sa.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
-              "pointnet2_sa2.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
-              "pointnet2_ops.hip": ["-fno-slp-vectorize"], "pointnet2_net.hip": ["-fno-slp-vectorize"]}
+# -fno-slp-vectorize: the SLP vectoriser's packed-FP32 instructions (v_pk_add / mul / fma_f32) are behind three sightings of
+# wrong values on gfx950 (conv_bwd_chain_kernel at two waves per SIMD; the sampler beside sa1_fwd_kernel;
+# geo_fused_kernel's long-row path at four waves per SIMD) -- every file compiles without them except the four where the
+# packing pays (pointnet.hip, pointnet_gemm.hip, pointnet_gram.hip, pointnet2_mlp.hip: +5.5 % on configs[1] without it;
+# tools/gpu_ab_noslp.sh), whose kernels stay under the replay soak's five shapes.
+_NOSLP = ["-fno-slp-vectorize"]
+FILE_FLAGS = {"pointnet_conv_chain.hip": _NOSLP, "pointnet_conv_split.hip": _NOSLP,
+              "pointnet2_sa.hip": ["-fno-honor-nans"] + _NOSLP, "pointnet2_sa2.hip": ["-fno-honor-nans"] + _NOSLP,
+              "pointnet2_ops.hip": _NOSLP, "pointnet2_net.hip": _NOSLP,
+              "geom_loss.hip": _NOSLP, "geom_aux.hip": _NOSLP, "geom_grid.hip": _NOSLP, "geom_nn.hip": _NOSLP,
+              "geom_slab.hip": _NOSLP,
+              "pointnet_wide.hip": _NOSLP, "pointnet_wide16.hip": _NOSLP, "pointnet_wide_bwdconv.hip": _NOSLP,
+              "pointnet_wide_split.hip": _NOSLP}
 
 
 def sources():
@@ -63,8 +72,17 @@ def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
     flags = list(flags or FLAGS)
     if "--no-file-flags" in flags:     # (tools: the build WITHOUT the per-file flags, e.g. the faulty one of DESIGN 5a)
         flags.remove("--no-file-flags")
+    elif os.path.basename(src) in os.environ.get("GEOA3_NO_FILE_FLAGS_FOR", "").split(",") and objdir != OBJDIR:
+        pass                           # (tools: a variant build without SOME files' flags)
     else:
         flags += FILE_FLAGS.get(os.path.basename(src), [])
+    # (tools: GEOA3_EXTRA_FILE_FLAGS="a.hip,b.hip:-fflag" adds a flag to some files of a VARIANT build, e.g. to price
+    # -fno-slp-vectorize file by file: tools/gpu_ab_noslp.sh)
+    extra = os.environ.get("GEOA3_EXTRA_FILE_FLAGS", "")
+    if extra and objdir != OBJDIR:
+        names, _, fl = extra.partition(":")
+        if os.path.basename(src) in names.split(",") and fl not in flags:
+            flags.append(fl)
     obj = os.path.join(objdir, os.path.basename(src) + ".o")
     stamp = obj + ".sha1"
     dig = _digest(src, flags)
@@ -76,7 +94,8 @@ def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
-    if os.path.basename(src) in ISA_GUARDS and "--no-file-flags" not in (flags_in or ()):
+    if (os.path.basename(src) in ISA_GUARDS and "--no-file-flags" not in (flags_in or ()) and
+            not (objdir != OBJDIR and os.environ.get("GEOA3_NO_FILE_FLAGS_FOR"))):   # (a tools variant may build the faulty form)
         _isa_guard(src, flags)
     with open(stamp, "w") as f:
         f.write(dig)
@@ -89,7 +108,8 @@ def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
 # (round 5: and the farthest-point sampler, whose SLP-packed distance update is exact alone and wrong in 1.4e-3 of its rounds
 # beside sa1_fwd_kernel / sa1_bwd_kernel on the same CUs -- tools/ub/pk_fp32_coresidency.hip; EVERY instance of the template)
 ISA_GUARDS = {"pointnet_conv_chain.hip": ("conv_bwd_chain_kernel", r"v_pk_(mul|fma|add)_f32"),
-              "pointnet2_ops.hip": ("fps_kernel", r"v_pk_(mul|fma|add)_f32")}
+              "pointnet2_ops.hip": ("fps_kernel", r"v_pk_(mul|fma|add)_f32"),
+              "geom_loss.hip": ("geo_fused_kernel", r"v_pk_(mul|fma|add)_f32")}
 
 
 def _isa_guard(src: str, flags) -> None:

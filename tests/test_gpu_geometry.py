@@ -394,6 +394,25 @@ def _oracle_objective(adv, ori, nrm, k):
     return con.detach(), g
 
 
+@pytest.mark.parametrize("N,k,ncoin", [(512, 8, 40), (700, 16, 40), (1024, 16, 120)])
+def test_pair_parallel_objective_long_rows_are_bit_stable_on_a_full_chip(ops, N, k, ncoin):
+    """DESIGN 5a, third sighting: with the packed-FP32 instructions the SLP vectoriser formed in geo_fused_kernel, the
+    gradient of the points that own 40-source rows differed from launch to launch -- in half of the launches at 40
+    instances (one workgroup per CU on 40 CUs, four wavefronts per SIMD), almost never at the 3 instances the test above
+    uses.  geom_loss.hip is compiled without them (geoa3_amd/build.py FILE_FLAGS / ISA_GUARDS); 200 launches, every bit."""
+    B = 40
+    ori, nrm = O.make_synthetic_clouds(B, N, seed=N + k)
+    g = torch.Generator().manual_seed(N)
+    adv = ori + 0.02 * torch.randn(B, 3, N, generator=g)
+    adv[:, :, 100:100 + ncoin] = adv[:, :, 100:101]
+    kw, advD, oriD = _objective_inputs(ops, adv, ori, nrm, k)
+    out = ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)
+    grad, con = out["grad"].clone(), out["constrain"].clone()
+    for rep in range(200):
+        out = ops.geo_loss_grad(advD, oriD, deterministic=True, out=out, **kw)
+        assert torch.equal(out["grad"], grad) and torch.equal(out["constrain"], con), rep
+
+
 @pytest.mark.parametrize("N,k,kind", [(1024, 16, "coincident120"), (700, 16, "coincident40"), (512, 8, "coincident40"),
                                       (1024, 16, "plain"), (2048, 16, "plain")])
 def test_pair_parallel_objective_special_paths(ops, N, k, kind):
