@@ -27,11 +27,17 @@ FREE = {"knn_scratch"}
     (64, 1024, 16, "PointNet", "f32", 1000),       # the fp32-MFMA kernels
     (16, 4096, 32, "PointNet", None, 300),         # configs[4]: cell-grid K-NN, fixed-point objective
     (32, 1024, 16, "PointNetPP", None, 500),       # configs[3]
+    (60, 1024, 16, "PointNet", "cad", 1500),       # CAD-like clouds: long reverse-list rows (the fixed-point pool, the owner-side
+                                                   # merges), brute-force 1-NN batches; 80 presteps so that the clusters have formed
+    (40, 1024, 16, "PointNetPP", "cad", 300),
 ])
 def test_one_iteration_replayed_is_bit_stable(b, n, k, arch, mode, iters):
     import iteration_replay_soak as S
     iters = max(50, int(iters * float(os.environ.get("GEOA3_SOAK_SCALE", "1"))))
-    r = S.make_runner(b, n, k, arch, mode, presteps=20)
+    if mode == "cad":
+        r = S.make_runner(b, n, k, arch, None, presteps=80, data="cad")
+    else:
+        r = S.make_runner(b, n, k, arch, mode, presteps=20)
     differing, by = S.replay(r, iters, 20)
     by = {name: cnt for name, cnt in by.items() if name not in FREE}
     assert not by, "%d of %d replays differ: %s" % (differing, iters, by)
