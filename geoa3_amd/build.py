@@ -40,17 +40,14 @@ def _hipcc() -> str:
 # -fno-slp-vectorize there: the operand split stays at two instructions per element (sa_split2).
 # -fno-slp-vectorize: the SLP vectoriser's packed-FP32 instructions (v_pk_add / mul / fma_f32) are behind three sightings of
 # wrong values on gfx950 (conv_bwd_chain_kernel at two waves per SIMD; the sampler beside sa1_fwd_kernel;
-# geo_fused_kernel's long-row path at four waves per SIMD) -- every file compiles without them except the four where the
-# packing pays (pointnet.hip, pointnet_gemm.hip, pointnet_gram.hip, pointnet2_mlp.hip: +5.5 % on configs[1] without it;
-# tools/gpu_ab_noslp.sh), whose kernels stay under the replay soak's five shapes.
+# geo_fused_kernel's long-row path at four waves per SIMD) -- every file compiles without them except the ONE where the
+# packing pays (pointnet_gemm.hip: conv_cm64_kernel and the FC kernels, +4.6 % on configs[1] without it; every other file 0:
+# tools/gpu_ab_noslp.sh), whose kernels stay under the replay soak's seven shapes.
 _NOSLP = ["-fno-slp-vectorize"]
-FILE_FLAGS = {"pointnet_conv_chain.hip": _NOSLP, "pointnet_conv_split.hip": _NOSLP,
-              "pointnet2_sa.hip": ["-fno-honor-nans"] + _NOSLP, "pointnet2_sa2.hip": ["-fno-honor-nans"] + _NOSLP,
-              "pointnet2_ops.hip": _NOSLP, "pointnet2_net.hip": _NOSLP,
-              "geom_loss.hip": _NOSLP, "geom_aux.hip": _NOSLP, "geom_grid.hip": _NOSLP, "geom_nn.hip": _NOSLP,
-              "geom_slab.hip": _NOSLP,
-              "pointnet_wide.hip": _NOSLP, "pointnet_wide16.hip": _NOSLP, "pointnet_wide_bwdconv.hip": _NOSLP,
-              "pointnet_wide_split.hip": _NOSLP}
+SLP_FILES = ("pointnet_gemm.hip",)
+FILE_FLAGS = {f: list(_NOSLP) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and f not in SLP_FILES}
+for _f in ("pointnet2_sa.hip", "pointnet2_sa2.hip"):
+    FILE_FLAGS[_f] = ["-fno-honor-nans"] + _NOSLP
 
 
 def sources():
