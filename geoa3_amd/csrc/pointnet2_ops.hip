@@ -68,10 +68,22 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict_
   __syncthreads();
   for (int j = j0 > 1 ? j0 : 1; j < j1; ++j) {
     const float x1 = s_p[old * 3], y1 = s_p[old * 3 + 1], z1 = s_p[old * 3 + 2];
+#ifdef GEOA3_FPS_PRENEG
+    float nx1 = -x1, ny1 = -y1, nz1 = -z1;
+    asm volatile("" : "+v"(nx1), "+v"(ny1), "+v"(nz1));   // (opaque: not folded back into a modifier)
+    float nx1b = nx1, ny1b = ny1, nz1b = nz1;
+    asm volatile("" : "+v"(nx1b), "+v"(ny1b), "+v"(nz1b));
+#endif
     unsigned long long key = 0ull;
 #pragma unroll
     for (int i = 0; i < FPS_PPT; ++i) {
+#if defined(GEOA3_FPS_PRENEG) && GEOA3_FPS_PRENEG == 2   // (... and without op_sel: odd slots take a second copy of the negated point)
+      const float d = (i & 1) ? sq3(px[i] + nx1b, py[i] + ny1b, pz[i] + nz1b) : sq3(px[i] + nx1, py[i] + ny1, pz[i] + nz1);
+#elif defined(GEOA3_FPS_PRENEG)   // (tools/ub/pk_fp32_coresidency.hip: the packed subtraction without `neg` modifiers)
+      const float d = sq3(px[i] + nx1, py[i] + ny1, pz[i] + nz1);
+#else
       const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
+#endif
       const float dm = d < td[i] ? d : td[i];     // min(d, temp) (sampling_gpu.cu:118); a NaN distance leaves temp as it is
       // d2 = use ? min(d, td) : td, as a bit select
       const unsigned d2 = (__float_as_uint(dm) & um[i]) | (__float_as_uint(td[i]) & ~um[i]);

@@ -16,7 +16,7 @@
 
 // FILL 0: fp32 fma chains; 1: + one v_mfma_f32_32x32x16_f16 per 16 fmas; 2: LDS traffic instead; 5: PACKED fp32 fma chains
 // (v_pk_fma_f32 on explicit two-element vectors); 6: packed multiplies + v_cvt_pk_f16_f32 + v_fma_mix (the operand split
-// of the library's matrix-core kernels)
+// of the library's matrix-core kernels); 8: packed fma / add WITH neg source modifiers
 template <int FILL>
 __global__ __launch_bounds__(512) void filler_kernel(float* out, int iters) {
   __shared__ float s_f[512];
@@ -38,6 +38,17 @@ __global__ __launch_bounds__(512) void filler_kernel(float* out, int iters) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) p = __builtin_elementwise_fma(p, q, q);
       a = p[0] + p[1];
+    }
+    if (FILL == 8) {   // PACKED fp32 with NEG source modifiers: v_pk_fma_f32 p, q, -r  and  v_pk_add_f32 p, -q
+      typedef float float2v __attribute__((ext_vector_type(2)));
+      float2v p = {a, c}, q = {b, b}, r = {c, a};
+      asm volatile("" : "+v"(p), "+v"(q), "+v"(r));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p = __builtin_elementwise_fma(p, q, -r);
+        r = p - q;
+      }
+      a = p[0] + p[1] + r[0];
     }
     if (FILL == 6) {
       typedef float float2v __attribute__((ext_vector_type(2)));
@@ -107,6 +118,7 @@ int main() {
       if (fill == 2) hipLaunchKernelGGL(filler_kernel<2>, dim3(256), dim3(512), 0, sb, dout, 4000);
       if (fill == 5) hipLaunchKernelGGL(filler_kernel<5>, dim3(256), dim3(512), 0, sb, dout, 4000);
       if (fill == 6) hipLaunchKernelGGL(filler_kernel<6>, dim3(256), dim3(512), 0, sb, dout, 2500);
+      if (fill == 8) hipLaunchKernelGGL(filler_kernel<8>, dim3(256), dim3(512), 0, sb, dout, 4000);
       if (fill == 3) geoa3_pn2_sa1_forward(dx, dnx, dgi, &sw, B, N, M, dsa, darg, sb);
       if (fill == 7) geoa3_pn2_sa1_backward(dx, dnx, dgi, &sw, B, N, M, dsa, darg, dgo, dgx, dgn, dscr, sb);
       if (fill == 4) geoa3_pn2_ball_query(dnx, dx, B, N, M, 0.2f, 64, dgi, sb);
@@ -132,6 +144,7 @@ int main() {
   trial(2, 40, "beside fma chains + LDS reads");
   trial(5, 40, "beside PACKED fp32 fma chains");
   trial(6, 40, "beside packed mul + cvt_pk + fma_mix");
+  trial(8, 100, "beside PACKED fp32 with NEG modifiers");
   trial(3, 200, "beside the library's sa1_fwd_kernel");
   trial(7, 100, "beside the library's sa1_bwd_kernel");
   trial(4, 200, "beside the library's ball query");
