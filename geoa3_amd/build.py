@@ -43,7 +43,7 @@ def _hipcc() -> str:
 # geo_fused_kernel's long-row path at four waves per SIMD) -- every file compiles without them except the ONE where the
 # packing pays (pointnet_gemm.hip: conv_cm64_kernel and the FC kernels, +4.6 % on configs[1] without it; every other file 0:
 # tools/gpu_ab_noslp.sh), whose kernels stay under the replay soak's seven shapes.
-_NOSLP = ["-fno-slp-vectorize"]
+_NOSLP = ["-fno-slp-vectorize", "-fno-vectorize"]   # (the loop vectoriser pairs fp32 work the same way: sa1_stage, attack_state)
 SLP_FILES = ("pointnet_gemm.hip",)
 FILE_FLAGS = {f: list(_NOSLP) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and f not in SLP_FILES}
 for _f in ("pointnet2_sa.hip", "pointnet2_sa2.hip"):
@@ -91,7 +91,7 @@ def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
-    if (os.path.basename(src) in ISA_GUARDS and "--no-file-flags" not in (flags_in or ()) and
+    if ("--no-file-flags" not in (flags_in or ()) and
             not (objdir != OBJDIR and os.environ.get("GEOA3_NO_FILE_FLAGS_FOR"))):   # (a tools variant may build the faulty form)
         _isa_guard(src, flags)
     with open(stamp, "w") as f:
@@ -109,10 +109,15 @@ ISA_GUARDS = {"pointnet_conv_chain.hip": ("conv_bwd_chain_kernel", r"v_pk_(mul|f
               "geom_loss.hip": ("geo_fused_kernel", r"v_pk_(mul|fma|add)_f32")}
 
 
+# ... and NO file, whatever its flags, may hold a packed-FP32 instruction with a neg_lo / neg_hi source modifier: the form the
+# reproducer narrows the fault to (the same kernel on a pre-negated operand is clean: DESIGN 5a)
+ISA_GUARD_ALL = r"v_pk_(mul|fma|add)_f32[^\n]*neg_(lo|hi)"
+
+
 def _isa_guard(src: str, flags) -> None:
     import re
     import tempfile
-    kernel, pattern = ISA_GUARDS[os.path.basename(src)]
+    kernel, pattern = ISA_GUARDS.get(os.path.basename(src), (None, None))
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "guard.s")
         cmd = [_hipcc()] + [f for f in flags if f != "-fPIC"] + ["-S", "--cuda-device-only", "-o", out, src]
@@ -120,6 +125,13 @@ def _isa_guard(src: str, flags) -> None:
         if r.returncode != 0:
             raise RuntimeError("ISA guard: hipcc -S failed for %s:\n%s" % (src, r.stderr))
         asm = open(out).read()
+    hit = re.search(ISA_GUARD_ALL, asm)
+    if hit:
+        raise RuntimeError("ISA guard: %s holds '%s' (DESIGN 5a: packed FP32 with a neg modifier goes wrong beside other "
+                           "wavefronts on its SIMDs); negate the operand beforehand or compile the file with %s"
+                           % (os.path.basename(src), hit.group(0).strip(), " ".join(_NOSLP)))
+    if kernel is None:
+        return
     found = list(re.finditer(r"^(_Z\w*%s\w*):" % kernel, asm, re.M))
     if not found:
         raise RuntimeError("ISA guard: kernel %s not found in %s" % (kernel, src))

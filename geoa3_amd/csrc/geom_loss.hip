@@ -1434,7 +1434,7 @@ extern "C" int geoa3_geo_loss_grad(const geoa3_geo_args* a, void* stream) {
   }
   if ((a->deterministic || !a->grad) && a->scratch && do_curv && (a->N > GEO_T || a->k > 32) && a->N <= 4096 && a->k <= 64) {
     // the pair-parallel kernel with fixed-point sums (see geo_big_kernel)
-    const int N = a->N, Nr = a->Nr > 0 ? a->Nr : a->N;
+    const int N = a->N;
     const bool two_side = a->dis_type == 1 && !a->single_side && a->d_oa != nullptr;
     if (two_side && !a->i_oa) return GEOA3_EINVAL;
     {

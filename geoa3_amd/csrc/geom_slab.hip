@@ -128,17 +128,26 @@ __global__ __launch_bounds__(SB_T) void slab_bin_kernel(const float* __restrict_
 }
 
 typedef float slab_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void slab_sqdist2(float qx, float qy, float qz, float x0, float x1, float y0, float y1,
+// Two candidates' squared distances to the query per packed instruction.  The query arrives NEGATED (slab_negq, once per
+// query): the differences are x + (-q) -- plain v_pk_add_f32, no `neg` source modifier; the packed subtraction q - x is the
+// instruction form behind the wrong values of DESIGN 5a.  (x - q)^2 and (q - x)^2 are the same bits.
+__device__ __forceinline__ void slab_sqdist2(float nqx, float nqy, float nqz, float x0, float x1, float y0, float y1,
                                              float z0, float z1, float& d0, float& d1) {
 #pragma clang fp contract(off)
-  const slab_f2 dx = slab_f2{qx, qx} - slab_f2{x0, x1};
-  const slab_f2 dy = slab_f2{qy, qy} - slab_f2{y0, y1};
-  const slab_f2 dz = slab_f2{qz, qz} - slab_f2{z0, z1};
+  const slab_f2 dx = slab_f2{x0, x1} + slab_f2{nqx, nqx};
+  const slab_f2 dy = slab_f2{y0, y1} + slab_f2{nqy, nqy};
+  const slab_f2 dz = slab_f2{z0, z1} + slab_f2{nqz, nqz};
   const slab_f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
   const slab_f2 s = xx + yy;
   const slab_f2 d = s + zz;
   d0 = d.x;
   d1 = d.y;
+}
+__device__ __forceinline__ void slab_negq(float qx, float qy, float qz, float& nqx, float& nqy, float& nqz) {
+  nqx = -qx;
+  nqy = -qy;
+  nqz = -qz;
+  asm volatile("" : "+v"(nqx), "+v"(nqy), "+v"(nqz));   // (opaque: not folded back into a modifier of the packed add)
 }
 
 __device__ __forceinline__ bool slab_lex_less(float da, int ia, float db, int ib) {
@@ -235,6 +244,8 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
   const SlabGeo g = geo[b];
   const int pc = live ? pos : N - 1;
   const float qx = Sb[pc], qy = Sb[N + pc], qz = Sb[2 * N + pc];
+  float nqx, nqy, nqz;
+  slab_negq(qx, qy, qz, nqx, nqy, nqz);
   const int qo = Ib[pc];                                     // the query's original index
   if (tid == 0) {
     s_lo = SB_NB;
@@ -319,8 +330,8 @@ __global__ __launch_bounds__(SK_BLOCK) void knn_slab_kernel(const float* __restr
         // two candidates per instruction: v_pk_add_f32 / v_pk_mul_f32 are IEEE per component, so with contraction off
         // the distances are the bits of geoa3_sqdist (3 sub + 3 mul + 2 add = 4 packed instructions per point)
         float da[4];
-        slab_sqdist2(qx, qy, qz, rx.x, rx.y, ry.x, ry.y, rz.x, rz.y, da[0], da[1]);
-        slab_sqdist2(qx, qy, qz, rx.z, rx.w, ry.z, ry.w, rz.z, rz.w, da[2], da[3]);
+        slab_sqdist2(nqx, nqy, nqz, rx.x, rx.y, ry.x, ry.y, rz.x, rz.y, da[0], da[1]);
+        slab_sqdist2(nqx, nqy, nqz, rx.z, rx.w, ry.z, ry.w, rz.z, rz.w, da[2], da[3]);
         // branch-free append: the candidate is written to the list's next slot whether it qualifies or not and the
         // slot is kept only if it does (a passed-over `if` per candidate is a taken branch per candidate: with two
         // waves per SIMD the scan ran at ~140 cycles per candidate).  cnt <= CAP - 4 here (the check below)
@@ -421,6 +432,8 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
   const SlabGeo g = geo[b];
   const int pc = live ? pos : N - 1;
   const float qx = Sb[pc], qy = Sb[N + pc], qz = Sb[2 * N + pc];
+  float nqx, nqy, nqz;
+  slab_negq(qx, qy, qz, nqx, nqy, nqz);
   const int qo = Ib[pc];                                     // the query's original index
   if (tid == 0) {
     s_lo = SB_NB;
@@ -563,8 +576,8 @@ __global__ __launch_bounds__(SK_BLOCK) __attribute__((amdgpu_waves_per_eu(MULTI 
       ny = *reinterpret_cast<const float4*>(&s_ref[SK_CHUNK + jn]);
       nz = *reinterpret_cast<const float4*>(&s_ref[2 * SK_CHUNK + jn]);
       float da[4];
-      slab_sqdist2(qx, qy, qz, rx.x, rx.y, ry.x, ry.y, rz.x, rz.y, da[0], da[1]);
-      slab_sqdist2(qx, qy, qz, rx.z, rx.w, ry.z, ry.w, rz.z, rz.w, da[2], da[3]);
+      slab_sqdist2(nqx, nqy, nqz, rx.x, rx.y, ry.x, ry.y, rz.x, rz.y, da[0], da[1]);
+      slab_sqdist2(nqx, nqy, nqz, rx.z, rx.w, ry.z, ry.w, rz.z, rz.w, da[2], da[3]);
       // branch-free append: the position goes to the list's next slot whether the candidate qualifies or not, and the
       // slot is kept only if it does.  cnt <= SP_CAP - 4 here (the check below)
 #pragma unroll

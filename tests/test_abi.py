@@ -128,3 +128,25 @@ def test_sampler_and_side_queue_kernels_hold_no_packed_fp32():
                 body = body[:body.index("s_endpgm")]
                 assert not re.search(r"v_pk_(?:mul|fma|add)_f32", body), (name, m.group(1))
     assert "fps_kernel" in B.ISA_GUARDS["pointnet2_ops.hip"][0]
+
+
+def test_build_refuses_neg_modified_packed_fp32_in_every_file():
+    """the reproducer narrows the fault to packed FP32 carrying neg_lo / neg_hi source modifiers (the same kernel on
+    a pre-negated operand is clean).  The build disassembles EVERY file after compiling it and refuses that form; here: the
+    pattern itself, and that the two files which used to hold it (the slab K-NN's explicit packed subtraction, the level-1
+    kernels' loop-vectorised stage) are free of it with the build's flags."""
+    import tempfile
+    from geoa3_amd import build as B
+    pat = re.compile(B.ISA_GUARD_ALL)
+    assert pat.search("\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] neg_lo:[0,1] neg_hi:[0,1]\n")
+    assert pat.search("\tv_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel_hi:[1,1,0] neg_lo:[0,0,1]\n")
+    assert not pat.search("\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0]\n\tv_sub_f32 v1, v2, v3 neg_lo\n")
+    for name in ("geom_slab.hip", "pointnet2_sa.hip"):
+        src = os.path.join(REPO, "geoa3_amd", "csrc", name)
+        flags = [f for f in B.FLAGS if f != "-fPIC"] + B.FILE_FLAGS[name]
+        assert "-fno-vectorize" in flags and "-fno-slp-vectorize" in flags
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            subprocess.run([B._hipcc()] + flags + ["-S", "--cuda-device-only", "-o", out, src], check=True, capture_output=True)
+            asm = open(out).read()
+        assert "v_pk_" in asm and not pat.search(asm), name     # (their explicit packed multiplies / adds stay)
