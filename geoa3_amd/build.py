@@ -109,9 +109,12 @@ ISA_GUARDS = {"pointnet_conv_chain.hip": ("conv_bwd_chain_kernel", r"v_pk_(mul|f
               "geom_loss.hip": ("geo_fused_kernel", r"v_pk_(mul|fma|add)_f32")}
 
 
-# ... and NO file, whatever its flags, may hold a packed-FP32 instruction with a neg_lo / neg_hi source modifier: the form the
-# reproducer narrows the fault to (the same kernel on a pre-negated operand is clean: DESIGN 5a)
-ISA_GUARD_ALL = r"v_pk_(mul|fma|add)_f32[^\n]*neg_(lo|hi)"
+# ... and NO file, whatever its flags, may hold a packed-FP32 arithmetic instruction with an op_sel bit -- a LOW result that
+# reads the HIGH half of a source register pair.  That is the form the stand-alone reproducer pins the fault on
+# (tools/ub/pk_neg_mfma_min.hip: v_pk_add / mul / fma_f32 with op_sel on src1 return src1 = 0 in lanes 48-63, ~1e-8 .. 5e-7 of
+# the executions, when the neighbouring wavefronts mix vector and f16 matrix instructions; op_sel_hi, neg and v_pk_mov_b32 are
+# clean: DESIGN 5a).  Only the SLP vectoriser forms it; every kernel that ever failed held one to eight of them.
+ISA_GUARD_ALL = r"v_pk_(mul|fma|add)_f32[^\n]*op_sel:\[[^\]]*1"
 
 
 def _isa_guard(src: str, flags) -> None:
@@ -127,9 +130,9 @@ def _isa_guard(src: str, flags) -> None:
         asm = open(out).read()
     hit = re.search(ISA_GUARD_ALL, asm)
     if hit:
-        raise RuntimeError("ISA guard: %s holds '%s' (DESIGN 5a: packed FP32 with a neg modifier goes wrong beside other "
-                           "wavefronts on its SIMDs); negate the operand beforehand or compile the file with %s"
-                           % (os.path.basename(src), hit.group(0).strip(), " ".join(_NOSLP)))
+        raise RuntimeError("ISA guard: %s holds '%s' (DESIGN 5a: packed FP32 with op_sel reads a zero operand in lanes 48-63 "
+                           "beside matrix-core wavefronts); keep the two values apart (an opaque asm barrier) or compile the "
+                           "file with %s" % (os.path.basename(src), hit.group(0).strip(), " ".join(_NOSLP)))
     if kernel is None:
         return
     found = list(re.finditer(r"^(_Z\w*%s\w*):" % kernel, asm, re.M))

@@ -130,23 +130,26 @@ def test_sampler_and_side_queue_kernels_hold_no_packed_fp32():
     assert "fps_kernel" in B.ISA_GUARDS["pointnet2_ops.hip"][0]
 
 
-def test_build_refuses_neg_modified_packed_fp32_in_every_file():
-    """the reproducer narrows the fault to packed FP32 carrying neg_lo / neg_hi source modifiers (the same kernel on
-    a pre-negated operand is clean).  The build disassembles EVERY file after compiling it and refuses that form; here: the
-    pattern itself, and that the two files which used to hold it (the slab K-NN's explicit packed subtraction, the level-1
-    kernels' loop-vectorised stage) are free of it with the build's flags."""
+def test_build_refuses_packed_fp32_with_op_sel_in_every_file():
+    """the stand-alone reproducer (tools/ub/pk_neg_mfma_min.hip) pins the fault on packed FP32 arithmetic with an
+    op_sel bit -- a low result reading the HIGH half of a source pair returns that operand as zero in lanes 48-63 beside
+    wavefronts that mix vector and matrix instructions.  The build disassembles EVERY file after compiling it and refuses
+    that form; here: the pattern itself, and that the file which keeps the SLP vectoriser (whose T-Net transform used to be
+    packed that way) and the sampler's file are free of it with the build's flags."""
     import tempfile
     from geoa3_amd import build as B
     pat = re.compile(B.ISA_GUARD_ALL)
-    assert pat.search("\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] neg_lo:[0,1] neg_hi:[0,1]\n")
-    assert pat.search("\tv_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel_hi:[1,1,0] neg_lo:[0,0,1]\n")
-    assert not pat.search("\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0]\n\tv_sub_f32 v1, v2, v3 neg_lo\n")
-    for name in ("geom_slab.hip", "pointnet2_sa.hip"):
+    assert pat.search("\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n")
+    assert pat.search("\tv_pk_fma_f32 v[2:3], v[4:5], s[6:7], v[8:9] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n")
+    assert pat.search("\tv_pk_mul_f32 v[4:5], v[2:3], v[4:5] op_sel:[1,0] op_sel_hi:[0,1]\n")
+    assert not pat.search("\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0] neg_lo:[0,1]\n\tv_pk_mov_b32 v[6:7], v[4:5], v[4:5] op_sel:[1,0]\n")
+    for name in ("pointnet_gemm.hip", "pointnet2_ops.hip", "geom_slab.hip"):
         src = os.path.join(REPO, "geoa3_amd", "csrc", name)
-        flags = [f for f in B.FLAGS if f != "-fPIC"] + B.FILE_FLAGS[name]
-        assert "-fno-vectorize" in flags and "-fno-slp-vectorize" in flags
+        flags = [f for f in B.FLAGS if f != "-fPIC"] + B.FILE_FLAGS.get(name, [])
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "k.s")
             subprocess.run([B._hipcc()] + flags + ["-S", "--cuda-device-only", "-o", out, src], check=True, capture_output=True)
             asm = open(out).read()
-        assert "v_pk_" in asm and not pat.search(asm), name     # (their explicit packed multiplies / adds stay)
+        assert not pat.search(asm), name
+        if name != "pointnet2_ops.hip":
+            assert "v_pk_" in asm, name     # (their packed multiplies / adds without op_sel stay)

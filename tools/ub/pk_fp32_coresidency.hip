@@ -69,6 +69,63 @@ __global__ __launch_bounds__(512) void filler_kernel(float* out, int iters) {
   if (a == 12345.f || acc[0] == 1.f) out[blockIdx.x] = a;
 }
 
+// WHERE the sampler's wavefronts sit in the SIMD's register file: a neighbour with NR live registers per lane at two waves per
+// SIMD pushes every later wave behind 2 * NR registers (the sa1 kernels: 188 / 232).  MODE 0: fma chains over all NR
+// registers; 1: the registers held, the waves ASLEEP (s_sleep: no vector instruction issues beside the sampler); 2: fma
+// chains + dense v_mfma_f32_32x32x16_f16 on non-zero data; 3: the same on ZERO data; 4: ONE matrix instruction per pass of
+// the chains instead of four; 5: matrix instructions only (no chains); 6: v_mfma_f32_32x32x2_f32 (the fp32 matrix instruction);
+// 7: v_mfma_f32_16x16x32_f16
+template <int NR, int MODE>
+__global__ __launch_bounds__(512) void bloat_kernel(float* out, int iters) {
+  float r[NR];
+  const float b = 1.0001f, c = 0.5f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    r[i] = threadIdx.x * 1e-3f + i;
+    asm volatile("" : "+v"(r[i]));
+  }
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  f32x16 acc = {};
+  half8 h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = MODE == 3 ? (_Float16)0.f : (_Float16)(0.01f * (threadIdx.x & 7) + 0.1f * i);
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc4 = {};
+  float hf = 0.01f * (threadIdx.x & 7) + 0.1f;
+  asm volatile("" : "+v"(hf));
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 1) {
+      __builtin_amdgcn_s_sleep(64);
+    } else {
+      if (MODE != 5) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) r[i] = __builtin_fmaf(r[i], b, c);
+      }
+      if (MODE == 2 || MODE == 3 || MODE == 5) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, acc, 0, 0, 0);
+      }
+      if (MODE == 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, acc, 0, 0, 0);
+      if (MODE == 6) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hf, hf, acc, 0, 0, 0);
+      }
+      if (MODE == 7) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, h, acc4, 0, 0, 0);
+      }
+    }
+  }
+  float a = acc[0] + acc[7] + acc4[1];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    asm volatile("" : "+v"(r[i]));
+    a += r[i];
+  }
+  if (a == 12345.f) out[blockIdx.x] = a;
+}
+
 int main() {
   const int B = 250, N = 1024, m = 512;
   std::vector<float> xyz((size_t)B * N * 3);
@@ -119,6 +176,17 @@ int main() {
       if (fill == 5) hipLaunchKernelGGL(filler_kernel<5>, dim3(256), dim3(512), 0, sb, dout, 4000);
       if (fill == 6) hipLaunchKernelGGL(filler_kernel<6>, dim3(256), dim3(512), 0, sb, dout, 2500);
       if (fill == 8) hipLaunchKernelGGL(filler_kernel<8>, dim3(256), dim3(512), 0, sb, dout, 4000);
+      if (fill == 10) hipLaunchKernelGGL((bloat_kernel<200, 0>), dim3(256), dim3(512), 0, sb, dout, 500);
+      if (fill == 11) hipLaunchKernelGGL((bloat_kernel<48, 0>), dim3(256), dim3(512), 0, sb, dout, 2000);
+      if (fill == 12) hipLaunchKernelGGL((bloat_kernel<200, 1>), dim3(256), dim3(512), 0, sb, dout, 60000);
+      if (fill == 13) hipLaunchKernelGGL((bloat_kernel<200, 2>), dim3(256), dim3(512), 0, sb, dout, 400);
+      if (fill == 14) hipLaunchKernelGGL((bloat_kernel<48, 2>), dim3(256), dim3(512), 0, sb, dout, 1500);
+      if (fill == 15) hipLaunchKernelGGL((bloat_kernel<120, 0>), dim3(256), dim3(512), 0, sb, dout, 800);
+      if (fill == 16) hipLaunchKernelGGL((bloat_kernel<48, 3>), dim3(256), dim3(512), 0, sb, dout, 1500);
+      if (fill == 17) hipLaunchKernelGGL((bloat_kernel<48, 4>), dim3(256), dim3(512), 0, sb, dout, 1800);
+      if (fill == 18) hipLaunchKernelGGL((bloat_kernel<48, 5>), dim3(256), dim3(512), 0, sb, dout, 4000);
+      if (fill == 19) hipLaunchKernelGGL((bloat_kernel<48, 6>), dim3(256), dim3(512), 0, sb, dout, 1000);
+      if (fill == 20) hipLaunchKernelGGL((bloat_kernel<48, 7>), dim3(256), dim3(512), 0, sb, dout, 1800);
       if (fill == 3) geoa3_pn2_sa1_forward(dx, dnx, dgi, &sw, B, N, M, dsa, darg, sb);
       if (fill == 7) geoa3_pn2_sa1_backward(dx, dnx, dgi, &sw, B, N, M, dsa, darg, dgo, dgx, dgn, dscr, sb);
       if (fill == 4) geoa3_pn2_ball_query(dnx, dx, B, N, M, 0.2f, 64, dgi, sb);
@@ -145,6 +213,19 @@ int main() {
   trial(5, 40, "beside PACKED fp32 fma chains");
   trial(6, 40, "beside packed mul + cvt_pk + fma_mix");
   trial(8, 100, "beside PACKED fp32 with NEG modifiers");
+  if (getenv("PK_BLOAT")) {
+    trial(11, 40, "beside 48-register fma waves");
+    trial(15, 40, "beside 120-register fma waves");
+    trial(10, 100, "beside 200-register fma waves");
+    trial(12, 100, "beside 200-register SLEEPING waves");
+    trial(14, 40, "beside 48-register fma + MFMA");
+    trial(13, 100, "beside 200-register fma + MFMA");
+    trial(16, 40, "beside fma + 4 MFMA on ZERO data");
+    trial(17, 40, "beside fma + 1 MFMA per pass");
+    trial(18, 40, "beside MFMA only, back to back");
+    trial(19, 40, "beside fma + 4 fp32 MFMA (32x32x2)");
+    trial(20, 40, "beside fma + 4 MFMA 16x16x32 f16");
+  }
   trial(3, 200, "beside the library's sa1_fwd_kernel");
   trial(7, 100, "beside the library's sa1_bwd_kernel");
   trial(4, 200, "beside the library's ball query");
