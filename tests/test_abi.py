@@ -153,3 +153,18 @@ def test_build_refuses_packed_fp32_with_op_sel_in_every_file():
         assert not pat.search(asm), name
         if name != "pointnet2_ops.hip":
             assert "v_pk_" in asm, name     # (their packed multiplies / adds without op_sel stay)
+
+
+def test_one_instruction_reproducer_builds():
+    """tools/ub/pk_neg_mfma_min.hip (the stand-alone reproducer of the op_sel fault) needs nothing but hipcc: it
+    must keep compiling for gfx950, and its victim must hold the instruction it is about."""
+    import tempfile
+    from geoa3_amd import build as B
+    src = os.path.join(REPO, "tools", "ub", "pk_neg_mfma_min.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r.s")
+        subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-O3", "-w", "-S", "--cuda-device-only", "-o", out, src],
+                       check=True, capture_output=True)
+        asm = open(out).read()
+    assert re.search(r"v_pk_add_f32 v\[\d+:\d+\], v\[\d+:\d+\], v\[100:101\] op_sel:\[0,1\]", asm)
+    assert "v_mfma_f32_32x32x16_f16" in asm
