@@ -15,6 +15,7 @@
 //   14: as 13, all LDS data landed first     15: as 13 without neg     16: op_sel_hi:[1,0] on all three (no op_sel)
 //   17: v_pk_mov_b32 op_sel:[1,0] (swap)     18: v_pk_mul_f32 op_sel:[0,1]     19: v_pk_fma_f32 op_sel:[0,1,0]
 //   20: v_pk_add_f32 A, p2 op_sel:[1,0] (the pair as src0)     21 / 22: v_pk_mul_f32 A, p2 op_sel:[1,0] (/ + op_sel_hi:[0,1])
+//   23: v_fma_mixhi_f16 ... op_sel:[0,0,1] op_sel_hi:[0,0,1] (an f16 operand from the HIGH 16 bits of one register)
 // VICTIM 0-12: one packed instruction per iteration, earlier hypotheses (none ever failed):
 // VICTIM 0: the packed subtraction with neg modifiers; 1: the packed ADD of a pre-negated q (no modifier); 2: v_pk_mul_f32
 // with neg; 3: v_pk_fma_f32 with neg on the addend; 4: as 0 with q read from LDS (ds_read2_b32, every lane the same address)
@@ -83,6 +84,20 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* in, unsigned* 
         asm volatile("v_sub_f32 %0, %1, %2" : "=v"(e0) : "v"(p[0]), "v"(q[0]));
         asm volatile("v_sub_f32 %0, %1, %2" : "=v"(e1) : "v"(p[1]), "v"(q[1]));
       }
+    } else if (VICTIM == 23) {   // v_fma_mixhi_f16 with op_sel on an f16 source (the HIGH 16 bits of ONE register: the operand split of
+      unsigned gu, wu;           // the library's matrix-core kernels), against v_fma_mixlo_f16 on the shifted register
+      unsigned va = (unsigned)((i * 12) & 8180);
+      asm volatile("" : "+v"(va));
+      __syncthreads();
+      asm volatile("ds_read2_b32 v[100:101], %2 offset1:1\n\tds_read_b32 v102, %2 offset:8\n\ts_waitcnt lgkmcnt(0)\n\t"
+                   "v_mov_b32 v104, 0\n\t"
+                   "v_fma_mixhi_f16 v104, v102, v100, -v101 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                   "v_lshrrev_b32 v105, 16, v101\n\tv_mov_b32 v106, 0\n\t"
+                   "v_fma_mixlo_f16 v106, v102, v100, -v105 op_sel_hi:[0,0,1]\n\t"
+                   "v_lshrrev_b32 %0, 16, v104\n\tv_and_b32 %1, 0xffff, v106"
+                   : "=&v"(gu), "=&v"(wu) : "v"(va) : "v100", "v101", "v102", "v104", "v105", "v106", "memory");
+      d[0] = __uint_as_float(gu); d[1] = 0.f;
+      e0 = __uint_as_float(wu); e1 = 0.f;
     } else if (VICTIM >= 13 && VICTIM <= 22) {
       f2 d1, d2, p2 = {p[1], p[0]}, p3 = {q[0], q[1]};
       float a0, a1, b0;
@@ -307,6 +322,7 @@ int main() {
       if (victim == 18) hipLaunchKernelGGL(victim_kernel<18>, dim3(WG), dim3(256), 0, sa, din, dcount, dsamp, iters);
       if (victim == 19) hipLaunchKernelGGL(victim_kernel<19>, dim3(WG), dim3(256), 0, sa, din, dcount, dsamp, iters);
       if (victim == 20) hipLaunchKernelGGL(victim_kernel<20>, dim3(WG), dim3(256), 0, sa, din, dcount, dsamp, iters);
+      if (victim == 23) hipLaunchKernelGGL(victim_kernel<23>, dim3(WG), dim3(256), 0, sa, din, dcount, dsamp, iters);
       if (victim == 21) hipLaunchKernelGGL(victim_kernel<21>, dim3(WG), dim3(256), 0, sa, din, dcount, dsamp, iters);
       if (victim == 22) hipLaunchKernelGGL(victim_kernel<22>, dim3(WG), dim3(256), 0, sa, din, dcount, dsamp, iters);
       if (victim == 8) hipLaunchKernelGGL(victim_kernel<8>, dim3(WG), dim3(256), 0, sa, din, dcount, dsamp, iters);
@@ -327,7 +343,7 @@ int main() {
     printf("%-58s %2d launches: %llu with a wrong value, %llu wrong lane-results of %.1e (%.1e)\n", name, reps, launches_wrong,
            wrong, total, (double)wrong / total);
     fflush(stdout);
-    if (victim >= 13) {
+    if (victim >= 13 && victim <= 22) {
       static Sample3 h3[16];
       unsigned n3 = 0;
       CK(hipMemcpyFromSymbol(&n3, HIP_SYMBOL(g_n3), 4));
@@ -370,6 +386,8 @@ int main() {
     trial(20, 4, "middle = v_pk_add_f32 op_sel:[1,0] (pair as src0): beside chains + 1 MFMA");
     trial(17, 4, "middle = v_pk_mov_b32 op_sel:[1,0] (swap): beside chains + 1 MFMA");
     trial(16, 4, "neg, op_sel_hi:[1,0] on all three: beside chains + 1 MFMA");
+    trial(23, 1, "v_fma_mixhi_f16 op_sel:[0,0,1] (f16 from the high 16 bits): beside chains + 4 MFMA");
+    trial(23, 4, "v_fma_mixhi_f16 op_sel:[0,0,1]: beside chains + 1 MFMA");
     trial(13, 3, "sampler's sequence: beside matrix instructions only");
     trial(13, 4, "sampler's sequence: beside chains + 1 MFMA");
     return 0;
