@@ -129,8 +129,9 @@ __global__ __launch_bounds__(SB_T) void slab_bin_kernel(const float* __restrict_
 
 typedef float slab_f2 __attribute__((ext_vector_type(2)));
 // Two candidates' squared distances to the query per packed instruction.  The query arrives NEGATED (slab_negq, once per
-// query): the differences are x + (-q) -- plain v_pk_add_f32, no `neg` source modifier; the packed subtraction q - x is the
-// instruction form behind the wrong values of DESIGN 5a.  (x - q)^2 and (q - x)^2 are the same bits.
+// query): the differences are x + (-q) -- plain v_pk_add_f32 without a source modifier.  (x - q)^2 and (q - x)^2 are the same
+// bits.  (Written while `neg` modifiers were suspected of the wrong values of DESIGN 5a; the form that matters turned out to be
+// op_sel, which these hand-built pairs never carried.  Kept: it costs nothing and the build refuses op_sel either way.)
 __device__ __forceinline__ void slab_sqdist2(float nqx, float nqy, float nqz, float x0, float x1, float y0, float y1,
                                              float z0, float z1, float& d0, float& d1) {
 #pragma clang fp contract(off)
