@@ -469,7 +469,8 @@ int launch_fc(const FcArgs& a, hipStream_t s) {
   // 16 x 16 tiles while a 32 x 32 tiling would leave most CUs without a workgroup
   const long tiles32 = (long)((a.Nout + 31) / 32) * ((a.M + 31) / 32) * (a.batch > 1 ? a.batch : 1);
   if (a.kscratch && waves == 16 && a.K >= 2048 && a.batch <= 1 && (a.tile == 16 || (a.tile == 0 && tiles32 < 256))) {
-    // K spread over four workgroups per tile (same partial sums, same order: see fc_kernel)
+    // K spread over four workgroups per tile (same partial sums, same order: see fc_kernel) -- at every batch size: at 32
+    // instances one 16-wave workgroup per tile instead makes the iteration 0.4805 against 0.4727 ms
     dim3 grid((a.Nout + 15) / 16, (a.M + 15) / 16, 4);
     hipLaunchKernelGGL((fc_kernel<16, 4, 4>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL((fc_ksplit_reduce_kernel<16, 16>), dim3(grid.x, grid.y), dim3(64), 0, s, a);
