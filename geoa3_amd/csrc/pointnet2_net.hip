@@ -455,8 +455,10 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   // gather + shift + relu, W1, W2 + max in one kernel; the activations a0 / a1 exist only as gate bits (m0 / m1)
   {
     const Img i1 = img_of(im, IM_SA2_W1), i2 = img_of(im, IM_SA2_W2);
+    geoa3_prof_begin(GEOA3_PROF_SA2_FWD, s);
     TRY(launch_sa2_fwd(rt, w.gidx2, w.shift, i1.p, i1.un, p.sa2_b1, i2.p, i2.un, p.sa2_b2, w.out2, w.arg2, w.m0, w.m1, B, M1,
                        M2, s));
+    geoa3_prof_end(GEOA3_PROF_SA2_FWD, s);
   }
   // ---- level 3 (:78-82, GroupAll): MLP (256 + 3) -> 256 -> 512 -> 1024 on the 128 points, max over them
   TRY(conv_slice(w.out2, 256, 0, 256, img_of(im, IM_SA3_WF), nullptr, nullptr, w.h1, 256, B, M2, false, false, s));
@@ -522,12 +524,16 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   float* da0 = w.da0;
   {
     const Img i1t = img_of(im, IM_SA2_W1T);
+    geoa3_prof_begin(GEOA3_PROF_SA2_BWD, s);
     TRY(launch_sa2_bwd(ent_g, ent_c, p.sa2_w2, i1t.p, i1t.un, w.m1, w.m0, da0, B, M2, s));
+    geoa3_prof_end(GEOA3_PROF_SA2_BWD, s);
   }
   float *dr = w.r, *dshift = w.shift;
   // (the grouping gradient of a range of instances on the side queue beside the next range's sa2_bwd_kernel was measured:
   // two ranges 4.256 ms against 4.259, four 4.33, three 4.40 -- both kernels are bound by memory traffic: DESIGN 8)
+  geoa3_prof_begin(GEOA3_PROF_SA2_GRAD, s);
   TRY(geoa3_pn2_group_points_grad_sums(da0, w.gidx2, B, 128, M1, M2, S, dr, dshift, stream));
+  geoa3_prof_end(GEOA3_PROF_SA2_GRAD, s);
   {   // d f1 = W_f^T dr, written centroid-major for level 1's backward (no [B,128,512] tensor, no transpose)
     const Img wti = img_of(im, IM_SA2_WFT);
     TRY(launch_sa2_pre(dr, true, M1, nullptr, wti.p, wti.un, nullptr, w.g1, (long)B * M1, s));

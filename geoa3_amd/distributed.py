@@ -97,3 +97,45 @@ def sharded_attack(run_shard: Callable, pc: torch.Tensor, normal: torch.Tensor, 
     loss_t = torch.as_tensor(np.asarray(loss, dtype=np.float32), device=dev).t().contiguous()   # [bl, iters]
     loss_all = _gather_rows(loss_t, counts, group).t()
     return (best_all, tgt_all, succ_all.cpu().numpy().astype(bool), step_all.cpu().tolist(), loss_all.cpu().tolist())
+
+
+def gather_results_timed(best: torch.Tensor, succ: torch.Tensor, step: torch.Tensor, loss: torch.Tensor,
+                         counts: Sequence[int], repeats: int = 5, sync: Callable[[], None] = None, group=None) -> dict:
+    """The per-batch result gather of `sharded_attack` on tensors of the caller's shapes (best_attack [bl,3,n], success
+    [bl] uint8, best step [bl] int64, loss history [bl,iters]), timed: one untimed pass, then `repeats` passes between two
+    barriers.  -> {"ms": average per gather (max over ranks), "bytes": payload of the whole batch, "ranks": world}.
+    bench.py prints it in the rank-0 line of an N-rank run (the one collective of the path besides the 4-byte label
+    broadcast per binary step)."""
+    import time
+    world = dist.get_world_size(group)
+    sync = sync or (lambda: None)
+
+    def once():
+        return [_gather_rows(x.contiguous(), counts, group) for x in (best, succ, step, loss)]
+
+    outs = once()
+    sync()
+    dist.barrier(group)
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        once()
+    sync()
+    dist.barrier(group)
+    dt = (time.perf_counter() - t0) / repeats
+    t = torch.tensor([dt], dtype=torch.float64, device=best.device if not _host_staged(group) else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    nbytes = sum(int(o.numel()) * o.element_size() for o in outs)
+    return {"ms": float(t.item()) * 1e3, "bytes": nbytes, "ranks": world, "rows": [int(o.shape[0]) for o in outs][0],
+            "GBps": nbytes / max(float(t.item()), 1e-12) / 1e9}
+
+
+def rank_roll_call(device, group=None) -> dict:
+    """All-gather of one int32 per rank holding the rank id (a DEVICE tensor under RCCL): what came back is the proof
+    that the backend connected `world` distinct ranks.  -> {"world", "ranks": [...], "ok", "backend"}."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = torch.tensor([rank], dtype=torch.int32, device=device)
+    got = [torch.full_like(mine, -1) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
+    ranks = [int(g.item()) for g in got]
+    return {"world": world, "ranks": ranks, "ok": ranks == list(range(world)), "backend": dist.get_backend(group),
+            "device": str(mine.device)}

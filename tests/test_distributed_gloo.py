@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from geoa3_amd.distributed import owner_of_last_instance, shard_bounds, sharded_attack
+from geoa3_amd.distributed import (gather_results_timed, owner_of_last_instance, rank_roll_call, shard_bounds,
+                                   sharded_attack)
 from oracle import geoa3_oracle as O
 
 
@@ -63,8 +64,14 @@ def _worker(rank, world, port, q):
         return O.attack(net, pc, normal, g, None, cfg, init, loss_divisor=global_batch, last_label_hook=hook)
 
     out = sharded_attack(run_shard, ori, nrm, gt, gt, inits)
+    # the evidence bench.py prints in an N-rank run: the timed result gather of a batch and the roll call of the rank ids
+    counts = [h - l for l, h in shard_bounds(250, world)]
+    bl = counts[rank]
+    gather = gather_results_timed(torch.full((bl, 3, 64), float(rank)), torch.ones(bl, dtype=torch.uint8),
+                                  torch.zeros(bl, dtype=torch.int64), torch.zeros(bl, 50), counts, repeats=2)
+    roll = rank_roll_call(torch.device("cpu"))
     if rank == 0:
-        q.put((out[0].numpy(), out[1].numpy(), out[2], out[3], np.asarray(out[4], dtype=np.float32)))
+        q.put((out[0].numpy(), out[1].numpy(), out[2], out[3], np.asarray(out[4], dtype=np.float32), gather, roll))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,7 +89,10 @@ def test_two_rank_sharded_attack_equals_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    best, tgt, succ, step, loss = q.get(timeout=500)
+    best, tgt, succ, step, loss, gather, roll = q.get(timeout=500)
+    assert roll == {"world": 2, "ranks": [0, 1], "ok": True, "backend": "gloo", "device": "cpu"}
+    assert gather["ranks"] == 2 and gather["rows"] == 250 and gather["ms"] > 0
+    assert gather["bytes"] == 250 * (3 * 64 * 4 + 1 + 8 + 50 * 4)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -47,6 +47,17 @@ def test_bench_two_ranks_strong_scaling_on_one_gpu():
     # value = iterations/s of the WHOLE 250-instance batch = steps / seconds in strong mode
     assert abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]
     assert out["roofline"]["frac"] > 0 and out["roofline"]["executed_frac"] == pytest.approx(3 * out["roofline"]["frac"], rel=1e-2)
+    # the N-rank evidence: both scaling modes, per-rank step times, the timed result gather, the roll call of rank ids
+    mg = out["multi_gpu"]
+    assert mg["headline_scaling"] == "strong" and mg["other_scaling"]["scaling"] == "weak"
+    assert mg["other_scaling"]["instances_per_gpu"] == 250 and mg["other_scaling"]["global_batch"] == 500
+    assert mg["other_scaling"]["value"] > 0 and mg["other_scaling"]["ms_per_step"] > out["ms_per_step"]
+    pr = mg["ms_per_step_per_rank"]
+    assert len(pr["all"]) == 2 and 0 < pr["min"] <= pr["max"] <= out["ms_per_step"] * 1.001
+    assert mg["rank_roll_call"]["ranks"] == [0, 1] and mg["rank_roll_call"]["ok"]
+    assert mg["result_gather"]["rows"] == 250 and mg["result_gather"]["ranks"] == 2 and mg["result_gather"]["ms"] > 0
+    assert mg["result_gather"]["bytes"] == 250 * (3 * 1024 * 4 + 1 + 8 + 500 * 4)
+    assert "other_configs" not in out              # only the plain 1-GPU default command appends them
 
 
 @pytest.mark.timeout(900)
