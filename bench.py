@@ -13,7 +13,7 @@ Workloads (BASELINE.json `configs`):
                                   headline keys of the JSON line describe THIS workload and nothing else.
                                   With no workload flag the same run then appends `other_configs`: configs[3], configs[4],
                                   the 32-instance shard of configs[2] (with its full-batch comparison) and configs[1] /
-                                  configs[4] on CAD-like clouds -- GPU legs only, `--other-steps` timed steps each
+                                  configs[4] / configs[3] on CAD-like clouds -- GPU legs only, `--other-steps` timed steps each
                                   (`--no-other-configs` skips them)
   --gpus N (N > 1)                configs[2]: the SAME 250-instance batch sharded over N GPUs (`--scaling strong`, the
                                   default: rank r holds shard_bounds(250, N)[r] instances, loss divisor 1/250, no
@@ -601,7 +601,9 @@ def main():
                    dict(name="configs[1] on CAD-like clouds", arch="PointNet", npoint=1024, knn=16, data="cad",
                         instances=BATCH, cfg_idx=1),
                    dict(name="configs[4] on CAD-like clouds", arch="PointNet", npoint=4096, knn=32, data="cad",
-                        instances=BATCH, cfg_idx=4)):
+                        instances=BATCH, cfg_idx=4),
+                   dict(name="configs[3] on CAD-like clouds", arch="PointNetPP", npoint=1024, knn=16, data="cad",
+                        instances=BATCH, cfg_idx=3)):
             try:
                 others.append(gpu_leg(bench, steps=st, warmup=ws, presteps=ps, **kw))
             except Exception as e:   # a failing extra leg never takes the headline down; it is reported as failed

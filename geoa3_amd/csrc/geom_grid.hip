@@ -30,10 +30,10 @@ __device__ __forceinline__ int grid_coord(float f) {
 }
 
 // Bins the M points of P (planar, stride M) into the grid.  On return (after the trailing barrier) s_start[c] ..
-// s_start[c+1] delimit the points of cell c = (cx*GG + cy)*GG + cz in s_px/s_py/s_pz/s_pi.
+// s_start[c+1] delimit the points of cell c = (cx*GG + cy)*GG + cz in s_p4 (x, y, z, index bits).
 template <int T, int PPT>
 __device__ __forceinline__ GridGeom grid_build(const float* __restrict__ P, int M, int* s_start, int* s_fill,
-                                               float* s_px, float* s_py, float* s_pz, int* s_pi, float* s_red) {
+                                               float4* s_p4, float* s_red) {
   constexpr int GT = T, GW = T / GEOA3_WAVE, CPT = GC / T;   // CPT: cell counters scanned per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float px[PPT], py[PPT], pz[PPT];
@@ -120,10 +120,7 @@ __device__ __forceinline__ GridGeom grid_build(const float* __restrict__ P, int 
     const int i = tid + p * GT;
     if (i < M) {
       const int pos = s_start[cell[p]] + atomicAdd(&s_fill[cell[p]], 1);
-      s_px[pos] = px[p];
-      s_py[pos] = py[p];
-      s_pz[pos] = pz[p];
-      s_pi[pos] = i;
+      s_p4[pos] = make_float4(px[p], py[p], pz[p], __int_as_float(i));   // one 16-byte record per point: (x, y, z, index bits)
     }
   }
   __syncthreads();
@@ -154,11 +151,49 @@ __device__ __forceinline__ void grid_ball(const int* __restrict__ s_start, float
   }
 }
 
+// One candidate against a query's running (distance, index) minimum -- lexicographic, the un-fused distance of every search.
+__device__ __forceinline__ void nn1_take(float& best, int& bi, float qx, float qy, float qz, const float4 c) {
+  const float d = geoa3_sqdist(qx, qy, qz, c.x, c.y, c.z);
+  const int i = __float_as_int(c.w);
+  const bool take = (d < best) | ((d == best) & (i < bi));   // (no short circuit: the scans stay branch-free)
+  best = take ? d : best;
+  bi = take ? i : bi;
+}
+// The candidates [a0, a1) of the sorted cloud, four 16-byte LDS reads in flight.
+__device__ __forceinline__ void nn1_scan(const float4* __restrict__ p4, int a0, int a1, float qx, float qy, float qz, float& best,
+                                         int& bi) {
+  int j = a0;
+  for (; j + 4 <= a1; j += 4) {
+    const float4 c0 = p4[j], c1 = p4[j + 1], c2 = p4[j + 2], c3 = p4[j + 3];
+    nn1_take(best, bi, qx, qy, qz, c0);
+    nn1_take(best, bi, qx, qy, qz, c1);
+    nn1_take(best, bi, qx, qy, qz, c2);
+    nn1_take(best, bi, qx, qy, qz, c3);
+  }
+  for (; j < a1; ++j) nn1_take(best, bi, qx, qy, qz, p4[j]);
+}
+
 constexpr int NN1_WIDE = 16;   // a query whose ball touches more grid columns is walked by the whole wavefront
-constexpr float GRID_BRUTE = 0.12f;   // fraction of the searched cloud inside the queries' boxes beyond which a batch is searched by brute force
+#ifndef GEOA3_GRID_BRUTE
+#define GEOA3_GRID_BRUTE 0.12f
+#endif
+#ifndef GEOA3_NN1_DIRECT
+#define GEOA3_NN1_DIRECT 8
+#endif
+#ifndef GEOA3_NN1_CHUNK
+#define GEOA3_NN1_CHUNK 16
+#endif
+constexpr float GRID_BRUTE = GEOA3_GRID_BRUTE;   // fraction of the searched cloud inside the queries' boxes beyond which a batch is searched by brute force
+constexpr int NN1_DIRECT = GEOA3_NN1_DIRECT;     // candidates of a column run scanned by the (query, column) pair's own lane
+#ifndef GEOA3_NN1_LONG
+#define GEOA3_NN1_LONG 24
+#endif
+constexpr int NN1_LONG = GEOA3_NN1_LONG;         // a trip with a run longer than this is dealt a second time (below)
+constexpr int NN1_CHUNK = GEOA3_NN1_CHUNK;       // the rest of a run is dealt over the wavefront's lanes in chunks of this size
 
 template <int PPT, int MODE = 0>   // MODE (tools/ub/nn1_ub.hip): 1 = build only, 2 = seeds only (no ball walk)
-__global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ A, const float* __restrict__ R, int Na,
+// (two workgroups per CU while the cloud's LDS allows it -- up to 1024 points: at most 64 registers there)
+__global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const float* __restrict__ A, const float* __restrict__ R, int Na,
                                                       int Nr, const int32_t* prior_ar, const int32_t* prior_ra,
                                                       float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, int wide_thr) {
   // prior_* (optional, may alias i_*): a searched-cloud index per query -- last iteration's answer -- used as the seed
@@ -174,11 +209,8 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
   int* s_start = reinterpret_cast<int*>(g_smem);            // [GC + 1]
   int* s_fill = s_start + GC + 4;                            // [GC]
   float* s_red = reinterpret_cast<float*>(s_fill + GC);      // [GW*6 + GW]
-  float* s_px = s_red + GW * 8;
-  float* s_py = s_px + M;
-  float* s_pz = s_py + M;
-  int* s_pi = reinterpret_cast<int*>(s_pz + M);
-  const GridGeom g = grid_build<GT, PPT>(P, M, s_start, s_fill, s_px, s_py, s_pz, s_pi, s_red);
+  float4* s_p4 = reinterpret_cast<float4*>(s_red + GW * 8);   // [M] (x, y, z, index bits) in cell order
+  const GridGeom g = grid_build<GT, PPT>(P, M, s_start, s_fill, s_p4, s_red);
 
   if (MODE == 1) return;
   // Points per cell as a 3-D summed-area table (in s_fill, free after the build): the number of points in the cells of a
@@ -235,7 +267,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
     for (int p = 0; p < PPT; ++p) {
       const int t = p * GT + threadIdx.x;
       const bool valid = t < Nq;
-      qi[p] = valid ? (Nq == M ? s_pi[t] : t) : -1;
+      qi[p] = valid ? (Nq == M ? __float_as_int(s_p4[t].w) : t) : -1;
       const int q = valid ? qi[p] : 0;
       qx[p] = Q[q];
       qy[p] = Q[Nq + q];
@@ -255,15 +287,25 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
     for (int w = 0; w < GW; ++w) all += s_red[w];
     __syncthreads();
     if (all > GRID_BRUTE * (float)Nq * (float)M) {
+      // every point against every query: the searched cloud is staged again in INDEX order, so that the running minimum
+      // needs the strict comparison only (ascending indices: the first of equal distances wins, as in nn1_pair_kernel) --
+      // 11 instead of 14 instructions per pair, and the seeds are not needed
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        const int i = p * GT + threadIdx.x;
+        if (i < M) s_p4[i] = make_float4(P[i], P[M + i], P[2 * M + i], 0.f);
+        best[p] = G_INF;
+        bi[p] = 0;
+      }
+      __syncthreads();
       for (int j = 0; j < M; ++j) {
-        const float cx = s_px[j], cy = s_py[j], cz = s_pz[j];
-        const int i = s_pi[j];
+        const float4 c = s_p4[j];
 #pragma unroll
         for (int p = 0; p < PPT; ++p) {
-          const float d = geoa3_sqdist(qx[p], qy[p], qz[p], cx, cy, cz);
-          const bool take = d < best[p] || (d == best[p] && i < bi[p]);
-          best[p] = take ? d : best[p];
-          bi[p] = take ? i : bi[p];
+          const float d = geoa3_sqdist(qx[p], qy[p], qz[p], c.x, c.y, c.z);
+          const bool lt = d < best[p];
+          best[p] = lt ? d : best[p];
+          bi[p] = lt ? j : bi[p];
         }
       }
 #pragma unroll
@@ -280,7 +322,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
     const bool valid = t < Nq;
     // equal-sized clouds: walk the queries in the searched cloud's cell order (query i is a perturbation of point i
     // in the attack loop), so that the lanes of a wavefront look at the same few cells
-    const int q = valid ? (Nq == M ? s_pi[t] : t) : 0;
+    const int q = valid ? (Nq == M ? __float_as_int(s_p4[t].w) : t) : 0;
     const float qx = Q[q], qy = Q[Nq + q], qz = Q[2 * Nq + q];
     const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
     // seed: any real point gives a valid radius.  Last iteration's nearest neighbour when the caller has it,
@@ -319,24 +361,21 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
       brute = PPT == 1 && all > GRID_BRUTE * (float)nq * (float)M;    // (PPT > 1: decided for all batches above)
     }
     if (brute) {
-      if (valid) {
-        int j = 0;
-        for (; j + 4 <= M; j += 4) {
+      // (workgroup-uniform: the cloud once more in INDEX order, strict comparison, no seed -- as above)
+      __syncthreads();
+      if (threadIdx.x < M) s_p4[threadIdx.x] = make_float4(P[threadIdx.x], P[M + threadIdx.x], P[2 * M + threadIdx.x], 0.f);
+      __syncthreads();
+      best = G_INF;
+      bi = 0;
+      for (int j = 0; j < M; j += 4) {      // (M <= 1024 here; the tail reads stay inside the workgroup's LDS and are masked)
+        const float4 c0 = s_p4[j], c1 = s_p4[j + 1], c2 = s_p4[j + 2], c3 = s_p4[j + 3];
+        const float4 cc[4] = {c0, c1, c2, c3};
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float d = geoa3_sqdist(qx, qy, qz, s_px[j + u], s_py[j + u], s_pz[j + u]);
-            const int i = s_pi[j + u];
-            const bool take = d < best || (d == best && i < bi);
-            best = take ? d : best;
-            bi = take ? i : bi;
-          }
-        }
-        for (; j < M; ++j) {
-          const float d = geoa3_sqdist(qx, qy, qz, s_px[j], s_py[j], s_pz[j]);
-          const int i = s_pi[j];
-          const bool take = d < best || (d == best && i < bi);
-          best = take ? d : best;
-          bi = take ? i : bi;
+        for (int u = 0; u < 4; ++u) {
+          const float d = geoa3_sqdist(qx, qy, qz, cc[u].x, cc[u].y, cc[u].z);
+          const bool lt = (d < best) & (j + u < M);
+          best = lt ? d : best;
+          bi = lt ? j + u : bi;
         }
       }
     } else if (MODE == 4) {
@@ -346,7 +385,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
       // query's box comes over by lane permutes; a pair's best candidate goes into the query's 64-bit key (distance
       // bits : index -- the lexicographic (distance, index) order) with an LDS atomic minimum.  Same candidates, same
       // result.
-      unsigned long long* s_key = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(s_pi + M) + 7) & ~(uintptr_t)7);   // [GT]
+      unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_p4 + M);   // [GT]
       int* s_pre = reinterpret_cast<int*>(s_key + GT);                                    // [GW][64]
       const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
       const int nc = valid ? bcols : 0;
@@ -360,6 +399,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
       s_pre[wv * 64 + lane] = incl - nc;
       s_key[threadIdx.x] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi;
       const int* pre = s_pre + wv * 64;
+      int* cpre = s_pre + GW * 64 + wv * 64;           // [GW][64]: chunk prefix of the trip in flight
       for (int t0p = 0; t0p < total; t0p += 64) {      // (uniform trips: the lane permutes below need every source lane)
         const int t = t0p + lane;
         const bool act = t < total;
@@ -374,20 +414,57 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
         const float ex = fmaxf(fmaxf((float)xx - wfx, wfx - (float)(xx + 1)), 0.f);
         const float ey = fmaxf(fmaxf((float)yy - wfy, wfy - (float)(yy + 1)), 0.f);
         const float rem = wrho * wrho - ex * ex - ey * ey;
+        int js = 0, len = 0;
         if (act && rem >= 0.f) {
           const float zr = __builtin_amdgcn_sqrtf(rem) + 1e-4f;
           const int col = (xx * GG + yy) * GG;
-          const int js = s_start[col + grid_coord(wfz - zr)], je = s_start[col + grid_coord(wfz + zr) + 1];
+          js = s_start[col + grid_coord(wfz - zr)];
+          len = s_start[col + grid_coord(wfz + zr) + 1] - js;
+        }
+        // A pair's lane scans the first NN1_DIRECT candidates of its column run itself.  What a run holds beyond them is
+        // cut into chunks of NN1_CHUNK candidates and the chunks of the trip's 64 runs are dealt evenly over the lanes
+        // again: a trip lasts as long as its longest lane, and the runs of one trip differ by an order of magnitude (a
+        // thin rod, a table leg or a dense cluster puts hundreds of points into one column of cells beside empty ones; at
+        // 4096 points a run holds 30-120 points even on a uniform surface).  Same candidates, same keys, same result.
+        {
+          // (a trip whose longest run is short is scanned as it is: the second dealing costs ~100 instructions)
+          const bool deal = __ballot(len > NN1_LONG) != 0ull;      // (wave-uniform)
+          const int nd = (!deal || len < NN1_DIRECT) ? len : NN1_DIRECT;
           float cbest = G_INF;
           int cbi = 0x7fffffff;
-          for (int j = js; j < je; ++j) {
-            const float d = geoa3_sqdist(wqx, wqy, wqz, s_px[j], s_py[j], s_pz[j]);
-            const int i = s_pi[j];
-            const bool take = d < cbest || (d == cbest && i < cbi);
-            cbest = take ? d : cbest;
-            cbi = take ? i : cbi;
+          nn1_scan(s_p4, js, js + nd, wqx, wqy, wqz, cbest, cbi);
+          if (nd > 0) atomicMin(&s_key[wv * 64 + l], ((unsigned long long)__float_as_uint(cbest) << 32) | (unsigned)cbi);
+          const int rest = len - nd;
+          const int nch = (rest + NN1_CHUNK - 1) / NN1_CHUNK;
+          if (deal) {
+            int cin = nch;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const int v = __shfl_up(cin, o, 64);
+              if (lane >= o) cin += v;
+            }
+            const int ktot = __builtin_amdgcn_readlane(cin, 63);
+            cpre[lane] = cin - nch;
+            const int rs = js + nd;                     // the rest of this lane's run: [rs, rs + rest)
+            for (int k0 = 0; k0 < ktot; k0 += 64) {     // (uniform trips again)
+              const int k = k0 + lane;
+              const bool act2 = k < ktot;
+              int p = 0;
+#pragma unroll
+              for (int st = 32; st > 0; st >>= 1) p += (cpre[p + st] <= k) ? st : 0;
+              const int ch = act2 ? k - cpre[p] : 0;
+              const float pqx = __shfl(wqx, p, 64), pqy = __shfl(wqy, p, 64), pqz = __shfl(wqz, p, 64);
+              const int prs = __shfl(rs, p, 64), prest = __shfl(rest, p, 64), pl = __shfl(l, p, 64);
+              if (act2) {
+                const int a0 = prs + ch * NN1_CHUNK;
+                const int a1 = (ch + 1) * NN1_CHUNK < prest ? a0 + NN1_CHUNK : prs + prest;
+                float kbest = G_INF;
+                int kbi = 0x7fffffff;
+                nn1_scan(s_p4, a0, a1, pqx, pqy, pqz, kbest, kbi);
+                atomicMin(&s_key[wv * 64 + pl], ((unsigned long long)__float_as_uint(kbest) << 32) | (unsigned)kbi);
+              }
+            }
           }
-          if (je > js) atomicMin(&s_key[wv * 64 + l], ((unsigned long long)__float_as_uint(cbest) << 32) | (unsigned)cbi);
         }
       }
       const unsigned long long k = s_key[threadIdx.x];
@@ -400,13 +477,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
         atomicAdd(reinterpret_cast<unsigned long long*>(d_ar), 1ull);
         atomicAdd(reinterpret_cast<unsigned long long*>(d_ar) + 1, (unsigned long long)(e - s));
       }
-      for (int j = s; j < e; ++j) {
-        const float d = geoa3_sqdist(qx, qy, qz, s_px[j], s_py[j], s_pz[j]);
-        const int i = s_pi[j];
-        const bool take = d < best || (d == best && i < bi);
-        best = take ? d : best;
-        bi = take ? i : bi;
-      }
+      nn1_scan(s_p4, s, e, qx, qy, qz, best, bi);
     });
     if (MODE == 0) {
       constexpr int nact = 64;
@@ -431,13 +502,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
           const float zr = __builtin_amdgcn_sqrtf(rem) + 1e-4f;
           const int col = (xx * GG + yy) * GG;
           const int js = s_start[col + grid_coord(wfz - zr)], je = s_start[col + grid_coord(wfz + zr) + 1];
-          for (int j = js; j < je; ++j) {
-            const float d = geoa3_sqdist(wqx, wqy, wqz, s_px[j], s_py[j], s_pz[j]);
-            const int i = s_pi[j];
-            const bool take = d < cbest || (d == cbest && i < cbi);
-            cbest = take ? d : cbest;
-            cbi = take ? i : cbi;
-          }
+          nn1_scan(s_p4, js, je, wqx, wqy, wqz, cbest, cbi);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {      // lexicographic minimum over the wave
@@ -460,7 +525,7 @@ __global__ __launch_bounds__(GT) void grid_nn1_kernel(const float* __restrict__ 
   }
 }
 
-size_t grid_nn1_lds(int M) { return ((size_t)(GC + 4) + GC + GW * 8 + 4 * (size_t)M + 2 + 2 * GT + GW * 64) * 4; }
+size_t grid_nn1_lds(int M) { return ((size_t)(GC + 4) + GC + GW * 8 + 4 * (size_t)M + 2 + 2 * GT + 2 * GW * 64) * 4; }
 
 }  // namespace
 
