@@ -55,7 +55,7 @@ class Pn2SsgWeights(C.Structure):
     _fields_ = [("classes", C.c_int32), ("sa1", Sa1Weights)] + [(n, vp) for n in (
         "sa2_wx", "sa2_wf", "sa2_b0", "sa2_wft", "sa2_w1", "sa2_b1", "sa2_w1t", "sa2_w2", "sa2_b2", "sa2_w2t",
         "sa3_wx", "sa3_wf", "sa3_b0", "sa3_wft", "sa3_w1", "sa3_b1", "sa3_w1t", "sa3_w2", "sa3_b2", "sa3_w2t",
-        "f1", "fb1", "f1t", "f2", "fb2", "f2t", "f3", "fb3", "f3t", "images", "side")]
+        "f1", "fb1", "f1t", "f2", "fb2", "f2t", "f3", "fb3", "f3t", "images", "side")] + [("flags", C.c_int32)]
 
 
 class AttackState(C.Structure):
@@ -97,6 +97,8 @@ SIGNATURES = {
     "geoa3_pn2_gather_points": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_pn2_gather_points_grad": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_pn2_ball_query": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp]),
+    "geoa3_pn2_ball_query_ex": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, C.c_int, vp]),
+    "geoa3_pn2_furthest_point_sampling_ex": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "geoa3_pn2_group_points": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_pn2_group_points_grad": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "geoa3_pn2_bias_relu": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_long, vp]),
@@ -143,7 +145,8 @@ _lib = None
 
 
 ENOSUPPORT = -3   # GEOA3_ENOSUPPORT
-ABI_VERSION = 501  # GEOA3_ABI_VERSION of include/geoa3_hip.h this file mirrors (tests/test_abi.py holds the two together)
+PN2_CONTRACT = 1   # GEOA3_PN2_CONTRACT
+ABI_VERSION = 600  # GEOA3_ABI_VERSION of include/geoa3_hip.h this file mirrors (tests/test_abi.py holds the two together)
 
 
 class Geoa3Error(RuntimeError):

@@ -54,8 +54,8 @@ class AttackRunner:
         # ... and the PointNet++ SSG classifier of geoa3_amd/pointnet2.py (eval mode, xyz only) is native too:
         # geoa3_pn2ssg_forward / _backward (csrc/pointnet2_net.hip)
         from .pointnet2 import PointNet2ClassificationSSG
-        self.ssg = (isinstance(net, PointNet2ClassificationSSG) and net.native and not net.training and
-                    not net.use_normal and min(n, int(_cfg(cfg, "npoint", n))) >= 512)
+        self.ssg = (isinstance(net, PointNet2ClassificationSSG) and not net.training and not net.use_normal and
+                    min(n, int(_cfg(cfg, "npoint", n))) >= PointNet2ClassificationSSG.MIN_POINTS)
         self.native = isinstance(net, PointNet) or self.ssg
         if self.native:
             self.packed = net.packed(device)

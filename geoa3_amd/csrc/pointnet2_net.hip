@@ -338,8 +338,11 @@ int fc(const float* X, int K, const float* W, const float* bias, float* Y, int N
 
 }  // namespace
 
+constexpr int MIN_N = 32;      // (the sampler picks 512 centroids of ANY cloud, repeating points of a small one: sampling_gpu.cu:69-173)
+constexpr int MAX_N = 8192;    // the sampler's register tiling (pointnet2_ops.hip); also keeps N * 3 <= C1 * M1 floats (gx2 below)
+
 extern "C" int64_t geoa3_pn2ssg_workspace_bytes(int B, int N) {
-  if (B <= 0 || N < M1) return -1;
+  if (B <= 0 || N < MIN_N || N > MAX_N) return -1;
   return (int64_t)carve(nullptr, B, N).total;
 }
 
@@ -383,7 +386,7 @@ extern "C" void* geoa3_side_queue_create(void) {
 
 extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float* x, int B, int N, float* logits,
                                     void* workspace, void* stream) {
-  if (!pw || !x || !logits || !workspace || B <= 0 || N < M1 || pw->classes <= 0) return GEOA3_EINVAL;
+  if (!pw || !x || !logits || !workspace || B <= 0 || N < MIN_N || N > MAX_N || pw->classes <= 0) return GEOA3_EINVAL;
   if (((uintptr_t)workspace & 255) != 0 || !weights_complete(*pw)) return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
   const geoa3_pn2ssg_weights& p = *pw;
@@ -404,6 +407,7 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   // starts behind an event of it and is waited for); twelve launches more per forward.  (A launch failure between the fork
   // and the join returns with the side stream un-joined: harmless for eager streams, it invalidates a stream capture.)
   SideQueue* sq = static_cast<SideQueue*>(p.side);
+  const bool ct = (p.flags & GEOA3_PN2_CONTRACT) != 0;   // the _ext distances as nvcc's default contraction forms them
   // (while bench.py samples sa1_fwd_kernel's time the level runs as one launch per kernel)
   const bool use_side = sq != nullptr && !geoa3_prof_tag_on(GEOA3_PROF_SA1_FWD) && (size_t)N * 3 * sizeof(float) + 1024 <= 128 * 1024;
   hipStream_t s2 = use_side ? sq->stream : s;
@@ -416,14 +420,14 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
                        (long)B * (m1 - m0));
   };
   if (use_side) {
-    TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, cut[1], fps_td, w.idx1, s));
+    TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, cut[1], fps_td, w.idx1, s, ct));
     rows(0, cut[1], s);
     if (hipEventRecord(sq->ev[0], s) != hipSuccess || hipStreamWaitEvent(s2, sq->ev[0], 0) != hipSuccess) return GEOA3_ELAUNCH;
-    TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, 0, cut[1], R1, S, w.gidx1, s));
+    TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, 0, cut[1], R1, S, w.gidx1, s, ct));
     for (int c = 1; c < CH; ++c) {   // sampler, centroid rows and ball query of chunk c: all on the side stream
-      TRY(launch_pn2_fps_range(w.xyz, B, N, M1, cut[c], cut[c + 1], fps_td, w.idx1, s2));
+      TRY(launch_pn2_fps_range(w.xyz, B, N, M1, cut[c], cut[c + 1], fps_td, w.idx1, s2, ct));
       rows(cut[c], cut[c + 1], s2);
-      TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, cut[c], cut[c + 1], R1, S, w.gidx1, s2));
+      TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, cut[c], cut[c + 1], R1, S, w.gidx1, s2, ct));
       if (hipEventRecord(sq->ev[c], s2) != hipSuccess) return GEOA3_ELAUNCH;
     }
     for (int c = 0; c < CH; ++c) {
@@ -431,16 +435,16 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
       TRY(launch_sa1_forward_range(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, cut[c], cut[c + 1], w.out1, w.arg1, s));
     }
   } else {
-    TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, M1, nullptr, w.idx1, s));
+    TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, M1, nullptr, w.idx1, s, ct));
     rows(0, M1, s);
-    TRY(geoa3_pn2_ball_query(w.nx1, w.xyz, B, N, M1, R1, S, w.gidx1, stream));
+    TRY(geoa3_pn2_ball_query_ex(w.nx1, w.xyz, B, N, M1, R1, S, w.gidx1, ct ? GEOA3_PN2_CONTRACT : 0, stream));
     TRY(launch_sa1_forward_range(w.xyz, w.nx1, w.gidx1, &p.sa1, B, N, M1, 0, M1, w.out1, w.arg1, s));
   }
   // ---- level 2's geometry (:68-76): FPS 128, ball 0.4 x 64, b0 - W_x c -- on the side stream behind the sampler (every
   // centroid row is written by then: the first 128 on `stream` before the fork, the others on the side stream itself)
-  TRY(launch_pn2_fps_range(w.nx1, B, M1, M2, 0, M2, nullptr, w.idx2, s2));
+  TRY(launch_pn2_fps_range(w.nx1, B, M1, M2, 0, M2, nullptr, w.idx2, s2, ct));
   hipLaunchKernelGGL(gather_rows3_kernel, g1d((long)B * M2), dim3(256), 0, s2, w.nx1, w.idx2, w.nx2, M1, M2, 0, M2, (long)B * M2);
-  TRY(launch_pn2_ball_query_range(w.nx2, w.nx1, B, M1, M2, 0, M2, R2, S, w.gidx2, s2));
+  TRY(launch_pn2_ball_query_range(w.nx2, w.nx1, B, M1, M2, 0, M2, R2, S, w.gidx2, s2, ct));
   hipLaunchKernelGGL(affine3_kernel, g1d((long)B * 128 * M2), dim3(256), 0, s2, p.sa2_wx, p.sa2_b0, w.nx2, -1.f, w.shift,
                      128, M2, (long)B * 128 * M2);                                                         // b0 - W_x c
   if (use_side && hipEventRecord(sq->join, s2) != hipSuccess) return GEOA3_ELAUNCH;
@@ -486,7 +490,8 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
 
 extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float* x, const float* dlogits, int B, int N,
                                      float* dx, void* workspace, void* stream) {
-  if (!pw || !x || !dlogits || !dx || !workspace || B <= 0 || N < M1 || pw->classes <= 0) return GEOA3_EINVAL;
+  if (!pw || !x || !dlogits || !dx || !workspace || B <= 0 || N < MIN_N || N > MAX_N || pw->classes <= 0) return GEOA3_EINVAL;
+  static_assert((size_t)MAX_N * 3 <= (size_t)C1 * M1, "gx2 borrows the forward's f1 buffer");
   if (((uintptr_t)workspace & 255) != 0 || !weights_complete(*pw)) return GEOA3_EINVAL;
   hipStream_t s = geoa3_stream(stream);
   const geoa3_pn2ssg_weights& p = *pw;
@@ -517,7 +522,9 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
     hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 256 * sizeof(float), s3, w.dh1, p.sa3_wx, 1.f,
                        w.dnx2, 256, M2, 0, (long)B * M2);
   }
-  // ---- level 2: pooled layer's sparse gradient (centre-major, relu-gated) -> W2^T -> W1^T -> scatter of the gather
+  // ---- level 2: pooled layer's sparse gradient -> W2^T -> W1^T -> the grouping's scatter-add, in ONE pass over the rows
+  // ordered by the point they gather from (pointnet2_sa2b.hip): the [B,128,128,64] grouped gradient never exists
+#ifdef GEOA3_SA2_CENTRE_MAJOR   // (tools: the round-5 pair of kernels around the 1.05 GB tensor, for A/B runs)
   float* ent_g = w.d1;   // the level-1 scratch, free until sa1_backward
   int32_t* ent_c = reinterpret_cast<int32_t*>(w.d1 + (size_t)B * M2 * C2);
   TRY(launch_sa2_sort_cm(w.dout2, w.out2, w.arg2, ent_g, ent_c, B, M2, s));   // gate, both transposes and the per-centre sort
@@ -538,16 +545,38 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
     const Img wti = img_of(im, IM_SA2_WFT);
     TRY(launch_sa2_pre(dr, true, M1, nullptr, wti.p, wti.un, nullptr, w.g1, (long)B * M1, s));
   }
+#else
+  float* dr = w.r;          // [B][512][128] POINT-major
+  void* sb = w.da0;         // the pass's scratch (0.64 MB per cloud of the 4 MB the grouped gradient took)
+  geoa3_prof_begin(GEOA3_PROF_SA2_GRAD, s);
+  TRY(launch_sa2b_prep(w.dout2, w.out2, w.arg2, w.gidx2, w.m1, w.m0, sb, dr, B, s));
+  geoa3_prof_end(GEOA3_PROF_SA2_GRAD, s);
+  {
+    const Img i1t = img_of(im, IM_SA2_W1T);
+    geoa3_prof_begin(GEOA3_PROF_SA2_BWD, s);
+    TRY(launch_sa2b_bwd(sb, p.sa2_w2, i1t.p, i1t.un, p.sa2_wx, dr, B, s));
+    geoa3_prof_end(GEOA3_PROF_SA2_BWD, s);
+  }
+  {   // d f1 = W_f^T dr, written centroid-major for level 1's backward
+    const Img wti = img_of(im, IM_SA2_WFT);
+    TRY(launch_sa2_pre(dr, false, 0, nullptr, wti.p, wti.un, nullptr, w.g1, (long)B * M1, s));
+  }
+#endif
   // the coordinate gradients of the level (three small kernels, needed only behind level 1's backward) on the side queue
   // beside sa1_bwd_kernel
   const bool side_tail = sq != nullptr;   // (3.934 ms against 3.965)
   hipStream_t st = side_tail ? sq->stream : s;
   if (side_tail && (hipEventRecord(sq->ev[1], s) != hipSuccess || hipStreamWaitEvent(st, sq->ev[1], 0) != hipSuccess))
     return GEOA3_ELAUNCH;
+#ifdef GEOA3_SA2_CENTRE_MAJOR
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M1), dim3(256), 3 * 128 * sizeof(float), st, dr, p.sa2_wx, 1.f, w.dnx1,
                      128, M1, 0, (long)B * M1);                                                        // d xyz1 = W_x^T dr
   hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 128 * sizeof(float), st, dshift, p.sa2_wx, -1.f,
                      w.dnx2, 128, M2, 1, (long)B * M2);                                                // d c -= W_x^T dshift
+#else
+  TRY(launch_affine3_grad_pm(dr, p.sa2_wx, w.dnx1, (long)B * M1, st));                                 // d xyz1 = W_x^T dr
+  TRY(launch_sa2b_centre(sb, w.dnx2, B, st));                                                          // d c -= W_x^T d shift
+#endif
   hipLaunchKernelGGL(scatter_rows3_kernel, dim3((M1 + 255) / 256, B), dim3(256), M2 * sizeof(int32_t), st, w.dnx2, w.idx2,
                      w.dnx1, M1, M2, 1);                                                               // gather(new_xyz1, idx2)
   // ---- level 1

@@ -11,14 +11,18 @@
 //   * ball query (ball_query_gpu.cu:9-44): first `nsample` points IN INDEX ORDER with d^2 < r^2; the first hit
 //     pre-fills every slot; no hit leaves zeros.
 //   * gradients of gather / group are scatter-adds (atomicAdd, sampling_gpu.cu:42, group_points_gpu.cu:60).
-// Distances are evaluated un-fused, fl(fl(dx*dx + dy*dy) + dz*dz) with each product rounded (the CPU oracle's
-// order); nvcc's contraction choice for the reference is not specified by its sources.
+// Distances are evaluated un-fused by default, fl(fl(dx*dx + dy*dy) + dz*dz) with each product rounded (the CPU oracle's
+// order).  GEOA3_PN2_CONTRACT (the *_ex entry points, geoa3_pn2ssg_weights::flags) selects the form nvcc -O3 most likely
+// gave the reference's binary (setup.py:32 passes no -fmad flag; the default contracts): fmaf(dz, dz, fmaf(dy, dy, dx*dx))
+// for sampling_gpu.cu:100,103-104 and ball_query_gpu.cu:31-32 -- for users who compare indices with a CUDA run.
 #include "pointnet_kernels.h"
 
 namespace {
 
+template <bool CT = false>
 __device__ __forceinline__ float sq3(float dx, float dy, float dz) {
 #pragma clang fp contract(off)
+  if (CT) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
   const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
   const float s = xx + yy;
   return s + zz;
@@ -36,7 +40,7 @@ __device__ __forceinline__ float sq3(float dx, float dy, float dz) {
 // wave per SIMD: a round is a dependent chain (update, DPP reduction, LDS exchange), two waves on a SIMD only take turns
 // issuing the same ~100 instructions
 
-template <int FPS_BLOCK, int FPS_PPT>
+template <int FPS_BLOCK, int FPS_PPT, bool CT = false>
 __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict__ xyz, int N, int m, int T,
                                                         float* __restrict__ temp, int32_t* __restrict__ idxs, int j0, int j1) {
   extern __shared__ __attribute__((aligned(16))) float s_p[];   // [N][3]
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict_
     // sampling.cpp:74-76; rounds j0 .. j1 - 1 of the m: a launch that does not start at round 0 resumes from the running
     // distances the launch before it left in `temp` (the same fp32 values: the chunks select the same points bit for bit)
     td[i] = (j0 > 0 && in) ? temp[(size_t)b * N + k] : 1e10f;
-    const float mag = sq3(px[i], py[i], pz[i]);
+    const float mag = sq3<CT>(px[i], py[i], pz[i]);
     um[i] = (in && !(mag <= 1e-3f)) ? 0xFFFFFFFFu : 0u;
     klo[i] = 0xFFFFFFFFu - (((unsigned)(k & (T - 1)) << 16) | (unsigned)k);   // k < 8192, T <= 512
   }
@@ -78,11 +82,11 @@ __global__ __launch_bounds__(FPS_BLOCK) void fps_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < FPS_PPT; ++i) {
 #if defined(GEOA3_FPS_PRENEG) && GEOA3_FPS_PRENEG == 2   // (... and without op_sel: odd slots take a second copy of the negated point)
-      const float d = (i & 1) ? sq3(px[i] + nx1b, py[i] + ny1b, pz[i] + nz1b) : sq3(px[i] + nx1, py[i] + ny1, pz[i] + nz1);
+      const float d = (i & 1) ? sq3<CT>(px[i] + nx1b, py[i] + ny1b, pz[i] + nz1b) : sq3<CT>(px[i] + nx1, py[i] + ny1, pz[i] + nz1);
 #elif defined(GEOA3_FPS_PRENEG)   // (tools/ub/pk_fp32_coresidency.hip: the packed subtraction without `neg` modifiers)
-      const float d = sq3(px[i] + nx1, py[i] + ny1, pz[i] + nz1);
+      const float d = sq3<CT>(px[i] + nx1, py[i] + ny1, pz[i] + nz1);
 #else
-      const float d = sq3(px[i] - x1, py[i] - y1, pz[i] - z1);
+      const float d = sq3<CT>(px[i] - x1, py[i] - y1, pz[i] - z1);
 #endif
       const float dm = d < td[i] ? d : td[i];     // min(d, temp) (sampling_gpu.cu:118); a NaN distance leaves temp as it is
       // d2 = use ? min(d, td) : td, as a bit select
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(256) void gather_points_grad_kernel(const float* __
 // ball query: one thread per centre, the cloud of the instance staged in LDS in chunks; all lanes read the
 // same point (broadcast) and stop individually once their ball is full.
 constexpr int BQ_CHUNK = 1024;
+template <bool CT = false>
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ new_xyz,
                                                          const float* __restrict__ xyz, int N, int M, float radius2,
                                                          int nsample, int32_t* __restrict__ idx) {
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
     __syncthreads();
     if (__syncthreads_and(cnt >= nsample)) break;
     for (int k = 0; k < kn && !__all(cnt >= nsample); ++k) {
-      const float d2 = sq3(cx - s_p[k * 3], cy - s_p[k * 3 + 1], cz - s_p[k * 3 + 2]);
+      const float d2 = sq3<CT>(cx - s_p[k * 3], cy - s_p[k * 3 + 1], cz - s_p[k * 3 + 2]);
       if (cnt < nsample && d2 < radius2) {
         if (cnt == 0)
           for (int l = 0; l < nsample; ++l) out[l] = k0 + k;
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 // `nsample` indices is assembled in LDS and leaves as one coalesced store (no memset, no per-hit global writes; the
 // thread-per-centre form above ran 250 us for 512 centres x 1024 points x 250 instances).
 constexpr int BQW_CPW = 8;   // centres per wavefront
+template <bool CT = false>
 __global__ __launch_bounds__(256) void ball_query_wave_kernel(const float* __restrict__ new_xyz,
                                                               const float* __restrict__ xyz, int N, int M, float radius2,
                                                               int nsample, int32_t* __restrict__ idx, int m0, int m1, int cpw) {
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256) void ball_query_wave_kernel(const float* __res
     for (int k0 = 0; k0 < N && cnt < nsample; k0 += 64) {
       const int k = k0 + lane;
       bool hit = false;
-      if (k < N) hit = sq3(cx - s_x[k], cy - s_y[k], cz - s_z[k]) < radius2;
+      if (k < N) hit = sq3<CT>(cx - s_x[k], cy - s_y[k], cz - s_z[k]) < radius2;
       const unsigned long long mask = __ballot(hit);
       if (mask == 0ull) continue;
       if (cnt == 0) row[lane] = k0 + (int)__builtin_ctzll(mask);     // the first hit pre-fills every slot
@@ -369,31 +375,44 @@ __global__ __launch_bounds__(256) void group_points_grad64_kernel(const float* _
 
 // rounds j0 .. j1 - 1 of the m (0 <= j0 < j1 <= m); j0 > 0 resumes from `temp` [B,N] (required then), which every launch
 // with temp != null leaves behind
-int launch_pn2_fps_range(const float* xyz, int B, int N, int m, int j0, int j1, float* temp, int32_t* idx, hipStream_t s) {
+int launch_pn2_fps_range(const float* xyz, int B, int N, int m, int j0, int j1, float* temp, int32_t* idx, hipStream_t s,
+                         bool contract) {
   if (!xyz || !idx || B <= 0 || N <= 0 || m <= 0 || j0 < 0 || j1 <= j0 || j1 > m || (j0 > 0 && !temp)) return GEOA3_EINVAL;
   if (N > 512 * 16) return GEOA3_ENOSUPPORT;
   int T = 1;
   while (T * 2 <= N && T * 2 <= 512) T *= 2;  // opt_n_threads(N), cuda_utils.h:13-19
   const size_t lds = (size_t)N * 3 * sizeof(float);
-  if (N <= 512) {
-    hipLaunchKernelGGL((fps_kernel<256, 2>), dim3(B), dim3(256), lds, s, xyz, N, m, T, temp, idx, j0, j1);
-  } else if (N <= 1024) {
-    hipLaunchKernelGGL((fps_kernel<256, 4>), dim3(B), dim3(256), lds, s, xyz, N, m, T, temp, idx, j0, j1);
-  } else if (N <= 2048) {
-    hipLaunchKernelGGL((fps_kernel<256, 8>), dim3(B), dim3(256), lds, s, xyz, N, m, T, temp, idx, j0, j1);
-  } else {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<512, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-    hipLaunchKernelGGL((fps_kernel<512, 16>), dim3(B), dim3(512), lds, s, xyz, N, m, T, temp, idx, j0, j1);
-  }
+#define GEOA3_FPS(BLK, PPT)                                                                                              \
+  do {                                                                                                                   \
+    if (contract) {                                                                                                      \
+      if (lds > 48 * 1024)                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<BLK, PPT, true>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+      hipLaunchKernelGGL((fps_kernel<BLK, PPT, true>), dim3(B), dim3(BLK), lds, s, xyz, N, m, T, temp, idx, j0, j1);      \
+    } else {                                                                                                             \
+      if (lds > 48 * 1024)                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<BLK, PPT, false>),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+      hipLaunchKernelGGL((fps_kernel<BLK, PPT, false>), dim3(B), dim3(BLK), lds, s, xyz, N, m, T, temp, idx, j0, j1);     \
+    }                                                                                                                    \
+  } while (0)
+  if (N <= 512) GEOA3_FPS(256, 2);
+  else if (N <= 1024) GEOA3_FPS(256, 4);
+  else if (N <= 2048) GEOA3_FPS(256, 8);
+  else GEOA3_FPS(512, 16);
+#undef GEOA3_FPS
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
 
 extern "C" int geoa3_pn2_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int32_t* idx,
                                                  void* stream) {
-  return launch_pn2_fps_range(xyz, B, N, m, 0, m, temp, idx, geoa3_stream(stream));
+  return launch_pn2_fps_range(xyz, B, N, m, 0, m, temp, idx, geoa3_stream(stream), false);
+}
+extern "C" int geoa3_pn2_furthest_point_sampling_ex(const float* xyz, int B, int N, int m, float* temp, int32_t* idx,
+                                                    int flags, void* stream) {
+  if (flags & ~GEOA3_PN2_CONTRACT) return GEOA3_EINVAL;
+  return launch_pn2_fps_range(xyz, B, N, m, 0, m, temp, idx, geoa3_stream(stream), (flags & GEOA3_PN2_CONTRACT) != 0);
 }
 
 extern "C" int geoa3_pn2_gather_points(const float* points, const int32_t* idx, int B, int C, int N, int M, float* out,
@@ -418,33 +437,43 @@ extern "C" int geoa3_pn2_gather_points_grad(const float* grad_out, const int32_t
 
 // centres m0 .. m1 - 1 of the M (the wave-per-centre kernel; GEOA3_ENOSUPPORT where the public entry point falls back)
 int launch_pn2_ball_query_range(const float* new_xyz, const float* xyz, int B, int N, int M, int m0, int m1, float radius,
-                                int nsample, int32_t* idx, hipStream_t s) {
+                                int nsample, int32_t* idx, hipStream_t s, bool contract) {
   if (!new_xyz || !xyz || !idx || B <= 0 || N <= 0 || M <= 0 || nsample <= 0 || m0 < 0 || m1 <= m0 || m1 > M) return GEOA3_EINVAL;
   const size_t lds = (size_t)N * 3 * sizeof(float) + 4 * 64 * sizeof(int);
   if (nsample > 64 || lds > 128 * 1024) return GEOA3_ENOSUPPORT;
+  auto kern = contract ? ball_query_wave_kernel<true> : ball_query_wave_kernel<false>;
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_wave_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   // centres per wavefront: 8 for a whole level (the cloud is staged once per 32 centres); a partial range is a short launch
   // beside other kernels (pointnet2_net.hip), where 8 centres in sequence per wave are its whole duration: 2
   const int cpw = (m1 - m0 == M) ? BQW_CPW : 2;
-  hipLaunchKernelGGL(ball_query_wave_kernel, dim3((m1 - m0 + 4 * cpw - 1) / (4 * cpw), B), dim3(256), lds, s, new_xyz, xyz,
+  hipLaunchKernelGGL(kern, dim3((m1 - m0 + 4 * cpw - 1) / (4 * cpw), B), dim3(256), lds, s, new_xyz, xyz,
                      N, M, radius * radius, nsample, idx, m0, m1, cpw);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
 
-extern "C" int geoa3_pn2_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
-                                    int nsample, int32_t* idx, void* stream) {
+static int ball_query_impl(const float* new_xyz, const float* xyz, int B, int N, int M, float radius, int nsample, int32_t* idx,
+                           bool contract, void* stream) {
   if (!new_xyz || !xyz || !idx || B <= 0 || N <= 0 || M <= 0 || nsample <= 0) return GEOA3_EINVAL;
-  const int rc = launch_pn2_ball_query_range(new_xyz, xyz, B, N, M, 0, M, radius, nsample, idx, geoa3_stream(stream));
+  const int rc = launch_pn2_ball_query_range(new_xyz, xyz, B, N, M, 0, M, radius, nsample, idx, geoa3_stream(stream), contract);
   if (rc != GEOA3_ENOSUPPORT) return rc;
   if (hipMemsetAsync(idx, 0, (size_t)B * M * nsample * sizeof(int32_t), geoa3_stream(stream)) != hipSuccess)
     return GEOA3_ELAUNCH;
-  hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, geoa3_stream(stream), new_xyz, xyz, N, M,
+  auto kern = contract ? ball_query_kernel<true> : ball_query_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3((M + 255) / 256, B), dim3(256), 0, geoa3_stream(stream), new_xyz, xyz, N, M,
                      radius * radius, nsample, idx);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
+}
+extern "C" int geoa3_pn2_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
+                                    int nsample, int32_t* idx, void* stream) {
+  return ball_query_impl(new_xyz, xyz, B, N, M, radius, nsample, idx, false, stream);
+}
+extern "C" int geoa3_pn2_ball_query_ex(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
+                                       int nsample, int32_t* idx, int flags, void* stream) {
+  if (flags & ~GEOA3_PN2_CONTRACT) return GEOA3_EINVAL;
+  return ball_query_impl(new_xyz, xyz, B, N, M, radius, nsample, idx, (flags & GEOA3_PN2_CONTRACT) != 0, stream);
 }
 
 extern "C" int geoa3_pn2_group_points(const float* points, const int32_t* idx, int B, int C, int N, int M, int nsample,

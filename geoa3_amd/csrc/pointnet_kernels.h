@@ -201,9 +201,10 @@ int launch_sa2_fwd(const float* rT, const int32_t* gidx, const float* shift, con
 // PointNet++ level 1 in centroid ranges (pointnet2_net.hip pipelines the sampler's rounds against the MLP of the centroids
 // it has already chosen): the sampler's rounds j0 .. j1 - 1 (resuming from `temp`), ball query and forward MLP of centroids
 // m0 .. m1 - 1 of every cloud
-int launch_pn2_fps_range(const float* xyz, int B, int N, int m, int j0, int j1, float* temp, int32_t* idx, hipStream_t s);
+int launch_pn2_fps_range(const float* xyz, int B, int N, int m, int j0, int j1, float* temp, int32_t* idx, hipStream_t s,
+                         bool contract = false);
 int launch_pn2_ball_query_range(const float* new_xyz, const float* xyz, int B, int N, int M, int m0, int m1, float radius,
-                                int nsample, int32_t* idx, hipStream_t s);
+                                int nsample, int32_t* idx, hipStream_t s, bool contract = false);
 int launch_sa1_forward_range(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B, int N,
                              int M, int m0, int m1, float* out, uint8_t* arg, hipStream_t s);
 // level 2's pre-transformed first layer per point: Y[p][co] = sum_k X[p][k] W[co][k] (+ sum_d Wx[co][d] xyz[p][d]), Y point-major;
@@ -213,6 +214,15 @@ int launch_sa2_pre(const float* X, bool x_channel_major, int Np, const float* xy
 // sa2_bwd_kernel's sorted (value, channel) lists straight from d out2 / out2 (relu gate) / arg2, all channel-major [B][256][M]
 int launch_sa2_sort_cm(const float* dout, const float* outp, const int32_t* arg, float* ent_g, int32_t* ent_c, int B, int M,
                        hipStream_t s);
+// level 2's backward with the rows in destination order (pointnet2_sa2b.hip): prep (rows, entries, gate words per cloud) ->
+// the pass (d r [B][512][128] point-major, the rows' coordinate terms) -> d c of the centres; W_x^T of a point-major tensor
+size_t sa2b_scratch_bytes(int B);
+int launch_sa2b_prep(const float* dout, const float* outp, const int32_t* arg, const int32_t* gidx, const unsigned long long* m1,
+                     const unsigned long long* m0, void* scratch, float* dr, int B, hipStream_t s);
+int launch_sa2b_bwd(const void* scratch, const float* W2, const void* w1t_img, const float* w1t_un, const float* Wx, float* dr,
+                    int B, hipStream_t s);
+int launch_sa2b_centre(const void* scratch, float* dnx2, int B, hipStream_t s);
+int launch_affine3_grad_pm(const float* dY, const float* Wx, float* dp, long points, hipStream_t s);
 // geoa3_pn2_sa1_backward with an event recorded between its two kernels (grad_new_xyz complete, grad_xyz not yet)
 int launch_sa1_backward(const float* xyz, const float* new_xyz, const int32_t* idx, const geoa3_sa1_weights* w, int B, int N, int M,
                         const float* out, const uint8_t* arg, const float* grad_out, float* grad_xyz, float* grad_new_xyz,

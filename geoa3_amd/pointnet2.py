@@ -9,13 +9,14 @@ Mirrors, for the classifier path only, the three layers of the reference's vendo
     (Model/PointNetPP_ssg.py:51-124) with the reference's state_dict keys (SA_modules.{0,1,2}.mlps.0.{0..8}.*,
     fc_layer.{0,1,3,4,7}.*), so `load_state_dict(torch.load(...)['state_dict'])` works (main_attack.py:139-145).
 
-Two execution paths:
-  * NATIVE (eval mode, frozen weights, xyz-only input of >= 512 points -- the attack's victim): the whole classifier,
-    forward and input gradient, is one call each into libgeoa3_hip.so (`geoa3_pn2ssg_forward / _backward`,
-    csrc/pointnet2_net.hip): FPS, ball query, the fused level 1, the split-fp16 1x1 convolutions, the pooled layers
-    and the FC head are hand-written HIP kernels; no torch operator and no library GEMM runs in between;
-  * MODULE (everything else: training-mode statistics, weight gradients, extra feature channels): the layer-by-layer
-    composition below on the same HIP operators, with torch.nn modules for the MLPs.
+ONE execution path: the whole classifier, forward and input gradient, is one call each into libgeoa3_hip.so
+(`geoa3_pn2ssg_forward / _backward`, csrc/pointnet2_net.hip): FPS, ball query, the fused levels, the split-fp16 1x1
+convolutions, the pooled layers and the FC head are hand-written HIP kernels; no torch operator and no library GEMM runs
+in between.  It serves what the attack needs -- an eval-mode victim, xyz-only input, d logits / d input -- and refuses
+everything else loudly (training-mode statistics, weight gradients, extra feature channels: the reference's training is
+outside SURVEY 8).  The operator boundary (`ext`, the autograd Functions, the groupers) is usable on its own.
+`ext_contract` / GEOA3_PN2_CONTRACT=1: the sampler's and the ball queries' squared distances as nvcc's default
+contraction forms them; default: un-fused, as the CPU oracle.
 GPU tensors only.
 """
 from __future__ import annotations
@@ -26,7 +27,6 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check
@@ -55,16 +55,27 @@ def _frozen(mlp) -> bool:
     return not torch.is_grad_enabled() or not any(p.requires_grad for p in mlp.parameters())
 
 
+def ext_contract_default() -> bool:
+    """GEOA3_PN2_CONTRACT=1: the `_ext` distances contracted (fmaf(dz, dz, fmaf(dy, dy, dx * dx))), as nvcc -O3 with its
+    default -fmad=true most likely compiled sampling_gpu.cu:100,103-104 / ball_query_gpu.cu:31-32; default un-fused."""
+    return os.environ.get("GEOA3_PN2_CONTRACT", "0") == "1"
+
+
+def _ext_flags(contract: Optional[bool]) -> int:
+    return _lib.PN2_CONTRACT if (ext_contract_default() if contract is None else contract) else 0
+
+
 class _Ext:
-    """`pointnet2_ops._ext` replacement: same six entry points, backed by the C ABI."""
+    """`pointnet2_ops._ext` replacement: same six entry points, backed by the C ABI (`contract`: see
+    ext_contract_default; None = the environment's choice)."""
 
     @staticmethod
-    def furthest_point_sampling(xyz: Tensor, nsamples: int) -> Tensor:
+    def furthest_point_sampling(xyz: Tensor, nsamples: int, contract: Optional[bool] = None) -> Tensor:
         _chk(xyz, torch.float32)
         B, N, _ = xyz.shape
         out = torch.zeros(B, nsamples, device=xyz.device, dtype=torch.int32)
-        check(_lib.load().geoa3_pn2_furthest_point_sampling(xyz.data_ptr(), B, N, nsamples, None, out.data_ptr(), _s()),
-              "furthest_point_sampling")
+        check(_lib.load().geoa3_pn2_furthest_point_sampling_ex(xyz.data_ptr(), B, N, nsamples, None, out.data_ptr(),
+                                                               _ext_flags(contract), _s()), "furthest_point_sampling")
         return out
 
     @staticmethod
@@ -87,13 +98,13 @@ class _Ext:
         return out
 
     @staticmethod
-    def ball_query(new_xyz: Tensor, xyz: Tensor, radius: float, nsample: int) -> Tensor:
+    def ball_query(new_xyz: Tensor, xyz: Tensor, radius: float, nsample: int, contract: Optional[bool] = None) -> Tensor:
         _chk(new_xyz, torch.float32), _chk(xyz, torch.float32)
         B, M, _ = new_xyz.shape
         N = xyz.shape[1]
         out = torch.empty(B, M, nsample, device=xyz.device, dtype=torch.int32)
-        check(_lib.load().geoa3_pn2_ball_query(new_xyz.data_ptr(), xyz.data_ptr(), B, N, M, float(radius), nsample,
-                                               out.data_ptr(), _s()), "ball_query")
+        check(_lib.load().geoa3_pn2_ball_query_ex(new_xyz.data_ptr(), xyz.data_ptr(), B, N, M, float(radius), nsample,
+                                                  out.data_ptr(), _ext_flags(contract), _s()), "ball_query")
         return out
 
     @staticmethod
@@ -220,211 +231,6 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
-class _BiasRelu(torch.autograd.Function):
-    """y = relu(z + shift[c]) in place on the GEMM output (one pass over the [B,C,M*S] tensor)."""
-
-    @staticmethod
-    def forward(ctx, z, shift):
-        B, C, L = z.shape
-        check(_lib.load().geoa3_pn2_bias_relu(z.data_ptr(), shift.data_ptr(), B, C, L, _s()), "bias_relu")
-        ctx.mark_dirty(z)
-        ctx.save_for_backward(z)
-        return z
-
-    @staticmethod
-    def backward(ctx, g):
-        (y,) = ctx.saved_tensors
-        g = g.contiguous()
-        check(_lib.load().geoa3_pn2_relu_grad(y.data_ptr(), g.data_ptr(), g.data_ptr(), g.numel(), _s()), "relu_grad")
-        return g, None
-
-
-class _BiasReluMax(torch.autograd.Function):
-    """out[b,c,m] = max_s relu(z[b,c,m,s] + shift[c]) without writing the activated tensor."""
-
-    @staticmethod
-    def forward(ctx, z, shift, M, S):
-        B, C, _ = z.shape
-        out = torch.empty(B, C, M, device=z.device, dtype=torch.float32)
-        arg = torch.empty(B, C, M, device=z.device, dtype=torch.int32)
-        check(_lib.load().geoa3_pn2_bias_relu_max(z.data_ptr(), shift.data_ptr(), B, C, M, S, out.data_ptr(),
-                                                  arg.data_ptr(), _s()), "bias_relu_max")
-        ctx.save_for_backward(out, arg)
-        ctx.S = S
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        out, arg = ctx.saved_tensors
-        B, C, M = out.shape
-        dz = torch.empty(B, C, M * ctx.S, device=out.device, dtype=torch.float32)
-        check(_lib.load().geoa3_pn2_bias_relu_max_grad(g.contiguous().data_ptr(), out.data_ptr(), arg.data_ptr(), B, C, M,
-                                                       ctx.S, dz.data_ptr(), _s()), "bias_relu_max_grad")
-        return dz, None, None, None
-
-
-fuse_tail = True   # module-wide switch (tests compare the fused tail with the GEMM + tail-pass path)
-
-
-def _conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor], gate: Optional[Tensor], relu: bool) -> Tensor:
-    """geoa3_conv1x1: [B,K,L] -> [B,Co,L] with the epilogue fused (csrc/pointnet_conv_split.hip)."""
-    B, K, L = x.shape
-    Co = w.shape[0]
-    y = torch.empty(B, Co, L, device=x.device, dtype=torch.float32)
-    check(_lib.load().geoa3_conv1x1(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                    gate.data_ptr() if gate is not None else None, y.data_ptr(), B, L, K, Co,
-                                    1 if relu else 0, _s()), "geoa3_conv1x1")
-    return y
-
-
-class _SharedTail(torch.autograd.Function):
-    """Layers 2.. of a shared MLP with frozen weights, ending in the max over the S samples, on the HIP 1x1-convolution
-    operator: relu(W h + shift) is ONE kernel per layer (no separate bias/relu pass), the last layer's bias + relu +
-    max is the existing tail kernel, and in backward every input-gradient product carries the relu gate of the layer
-    below in its epilogue (no relu_grad pass).  Returns [B,C,M]; gradient w.r.t. the input activation only."""
-
-    @staticmethod
-    def forward(ctx, h, M, S, *wb):
-        ws, bs = wb[0::2], wb[1::2]
-        acts = [h]
-        for w, b in zip(ws[:-1], bs[:-1]):
-            acts.append(_conv1x1(acts[-1], w, b, None, True))
-        z = _conv1x1(acts[-1], ws[-1], None, None, False)
-        B, C, _ = z.shape
-        out = torch.empty(B, C, M, device=z.device, dtype=torch.float32)
-        arg = torch.empty(B, C, M, device=z.device, dtype=torch.int32)
-        check(_lib.load().geoa3_pn2_bias_relu_max(z.data_ptr(), bs[-1].data_ptr(), B, C, M, S, out.data_ptr(),
-                                                  arg.data_ptr(), _s()), "bias_relu_max")
-        ctx.save_for_backward(out, arg, *acts[1:])
-        ctx.wts = [w.t().contiguous() for w in ws]
-        ctx.S = S
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        out, arg, *acts = ctx.saved_tensors          # acts: the relu'd outputs of layers 2 .. last-1
-        B, C, M = out.shape
-        dz = torch.empty(B, C, M * ctx.S, device=out.device, dtype=torch.float32)
-        check(_lib.load().geoa3_pn2_bias_relu_max_grad(g.contiguous().data_ptr(), out.data_ptr(), arg.data_ptr(), B, C, M,
-                                                       ctx.S, dz.data_ptr(), _s()), "bias_relu_max_grad")
-        for i in range(len(ctx.wts) - 1, -1, -1):   # d/d(input of layer i), gated by that input's relu when it is ours
-            dz = _conv1x1(dz, ctx.wts[i], None, acts[i - 1] if i > 0 else None, False)
-        return (dz, None, None) + (None,) * (2 * len(ctx.wts))
-
-
-class _PretransformedSA(torch.autograd.Function):
-    """A whole set-abstraction level with frozen weights after its first layer has been applied to the un-grouped
-    points (PointnetSAModuleMSG._pretransformed_level): gather + shift + relu in one pass, the remaining layers on the
-    fused convolution operator, the max over the samples; in backward the last input-gradient convolution carries the
-    first layer's relu gate, so what is left is the row sums (d shift) and the scatter-add of the gather (d r).
-    forward(r [B,C,N], idx [B,M,S] int32, shift [B,C,M], *(W, shift) of layers 2..) -> [B,C_out,M]."""
-
-    @staticmethod
-    def forward(ctx, r, idx, shift, *wb):
-        lib = _lib.load()
-        B, C, N = r.shape
-        M, S = idx.shape[1], idx.shape[2]
-        h = torch.empty(B, C, M * S, device=r.device, dtype=torch.float32)
-        check(lib.geoa3_pn2_group_shift_relu(r.data_ptr(), idx.data_ptr(), shift.data_ptr(), B, C, N, M, S,
-                                             h.data_ptr(), _s()), "group_shift_relu")
-        ws, bs = wb[0::2], wb[1::2]
-        acts = [h]
-        for w, b in zip(ws[:-1], bs[:-1]):
-            acts.append(_conv1x1(acts[-1], w, b, None, True))
-        Co, Kl = ws[-1].shape
-        out = torch.empty(B, Co, M, device=r.device, dtype=torch.float32)
-        arg = torch.empty(B, Co, M, device=r.device, dtype=torch.int32)
-        ctx.pooled = S == 64 and Kl == 128          # the last layer + max over the samples as ONE kernel
-        if ctx.pooled:
-            check(lib.geoa3_conv1x1_max64(acts[-1].data_ptr(), ws[-1].data_ptr(), bs[-1].data_ptr(), out.data_ptr(),
-                                          arg.data_ptr(), B, M * S, Kl, Co, _s()), "conv1x1_max64")
-        else:
-            z = _conv1x1(acts[-1], ws[-1], None, None, False)
-            check(lib.geoa3_pn2_bias_relu_max(z.data_ptr(), bs[-1].data_ptr(), B, Co, M, S, out.data_ptr(),
-                                              arg.data_ptr(), _s()), "bias_relu_max")
-        ctx.save_for_backward(out, arg, idx, *acts)
-        ctx.wts = [w.t().contiguous() for w in ws]
-        ctx.dims = (N, M, S)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        out, arg, idx, *acts = ctx.saved_tensors      # acts[0]: the gathered first layer, acts[i]: output of layer i + 1
-        N, M, S = ctx.dims
-        B, Co, _ = out.shape
-        last = len(ctx.wts) - 1
-        if ctx.pooled and Co == 256:   # the pooled layer's sparse gradient is formed inside the convolution
-            gz = (g * (out > 0)).transpose(1, 2).contiguous()          # centre-major [B, M, Co]
-            argt = arg.transpose(1, 2).contiguous()
-            ci = ctx.wts[last].shape[0]
-            dz = torch.empty(B, ci, M * S, device=out.device, dtype=torch.float32)
-            check(lib.geoa3_conv1x1_onehot64(gz.data_ptr(), argt.data_ptr(), ctx.wts[last].data_ptr(), acts[last].data_ptr(),
-                                             dz.data_ptr(), B, M * S, Co, ci, _s()), "conv1x1_onehot64")
-            last -= 1
-        else:
-            dz = torch.empty(B, Co, M * S, device=out.device, dtype=torch.float32)
-            check(lib.geoa3_pn2_bias_relu_max_grad(g.contiguous().data_ptr(), out.data_ptr(), arg.data_ptr(), B, Co, M, S,
-                                                   dz.data_ptr(), _s()), "bias_relu_max_grad")
-        for i in range(last, -1, -1):                 # every product gated by the relu of the layer below
-            dz = _conv1x1(dz, ctx.wts[i], None, acts[i], False)
-        C = dz.shape[1]
-        dshift = torch.empty(B, C, M, device=dz.device, dtype=torch.float32)
-        dr = torch.empty(B, C, N, device=dz.device, dtype=torch.float32)
-        rc = lib.geoa3_pn2_group_points_grad_sums(dz.data_ptr(), idx.data_ptr(), B, C, N, M, S, dr.data_ptr(),
-                                                  dshift.data_ptr(), _s())
-        if rc == _lib.ENOSUPPORT:   # other ball sizes: two passes
-            check(lib.geoa3_pn2_shift_relu_grad(None, dz.data_ptr(), None, dshift.data_ptr(), B * C * M, S, _s()),
-                  "shift_relu_grad")
-            rc = lib.geoa3_pn2_group_points_grad(dz.data_ptr(), idx.data_ptr(), B, C, N, M, S, dr.data_ptr(), _s())
-        check(rc, "group_points_grad")
-        return (dr, None, dshift) + (None,) * (2 * len(ctx.wts))
-
-
-def _tail_eligible(folded, first: int) -> bool:
-    """Layers first.. can run on geoa3_conv1x1 in both directions: K and Co in {64,128,256} / multiples of 64."""
-    return all(w.shape[1] in (64, 128, 256) and w.shape[0] in (64, 128, 256) for w, _ in folded[first:])
-
-
-def run_shared_mlp(mlp: nn.Sequential, x: Tensor, fuse_max: bool = False) -> Tensor:
-    """Apply a build_shared_mlp() stack to x [B,C,M,S] (eval mode).  Each Conv2d 1x1 + BatchNorm2d + ReLU triple is
-    ONE channel GEMM (hipBLASLt; BatchNorm's running-statistics scale folded into the weights) followed by ONE
-    in-place HIP pass relu(z + shift); with fuse_max the last triple's tail also takes the max over the S samples
-    (== F.max_pool2d over nsample, pointnet2_modules.py:66-70) and returns [B,C,M] without materialising its
-    activation.  Falls back to the plain module stack in training mode."""
-    layers = list(mlp)
-    triples = []
-    ok = len(layers) % 3 == 0
-    for i in range(0, len(layers) - 2, 3):
-        conv, bn, act = layers[i], layers[i + 1], layers[i + 2]
-        ok = ok and isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.bias is None and \
-            isinstance(bn, nn.BatchNorm2d) and not bn.training and isinstance(act, nn.ReLU)
-        triples.append((conv, bn))
-    if not ok or not x.is_cuda:
-        y = mlp(x)
-        return F.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1) if fuse_max else y
-    B, _, M, S = x.shape
-    h = x.reshape(B, x.shape[1], M * S)
-    # frozen weights (the attack's victim) + the max at the end: the first layer (K = Ci + 3, not a multiple of 64)
-    # stays a GEMM + tail pass, the remaining layers run on the fused HIP operator
-    if (fuse_max and fuse_tail and len(triples) >= 2 and _frozen(mlp)):
-        folded = _fold_triples(mlp)
-        if folded is not None and _tail_eligible(folded, 1):
-            (w0, b0) = folded[0]
-            h = _BiasRelu.apply(torch.matmul(w0, h), b0)
-            flat = [t for wb in folded[1:] for t in wb]
-            return _SharedTail.apply(h.contiguous(), M, S, *flat)
-    for n, (conv, bn) in enumerate(triples):
-        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-        shift = (bn.bias - bn.running_mean * scale).contiguous()
-        w = conv.weight.view(conv.out_channels, conv.in_channels) * scale.view(-1, 1)
-        z = torch.matmul(w, h)                                   # [B,Co,M*S]
-        if fuse_max and n == len(triples) - 1:
-            return _BiasReluMax.apply(z, shift, M, S)
-        h = _BiasRelu.apply(z, shift)
-    return h.view(B, -1, M, S)
-
-
 def _fold_triples(mlp: nn.Sequential):
     """[(W [Co,Ci] with the BatchNorm scale folded in, shift [Co])] of an eval-mode build_shared_mlp stack, or None
     when the stack is not Conv2d 1x1 (no bias) + eval BatchNorm2d + ReLU triples."""
@@ -443,41 +249,12 @@ def _fold_triples(mlp: nn.Sequential):
     return out
 
 
-class _SA1Fused(torch.autograd.Function):
-    """geoa3_pn2_sa1_forward / _backward: grouped xyz -> MLP 3->64->64->128 -> max over 64 samples, one wavefront per
-    centroid, no activation in memory (pointnet2_sa.hip).  Differentiable in xyz and new_xyz (input-gradient only:
-    the attack never needs weight gradients)."""
-
-    @staticmethod
-    def forward(ctx, xyz, new_xyz, idx, w1, b1, w2, b2, w3, b3):
-        B, N, _ = xyz.shape
-        M = new_xyz.shape[1]
-        xyz, new_xyz = _chk(xyz.contiguous(), torch.float32), _chk(new_xyz.contiguous(), torch.float32)
-        out = torch.empty(B, M, 128, device=xyz.device, dtype=torch.float32)    # centroid-major rows
-        arg = torch.empty(B, M, 128, device=xyz.device, dtype=torch.uint8)
-        ws = _lib.Sa1Weights(*[t.data_ptr() for t in (w1, b1, w2, b2, w3, b3)])
-        check(_lib.load().geoa3_pn2_sa1_forward(xyz.data_ptr(), new_xyz.data_ptr(), _chk(idx, torch.int32).data_ptr(),
-                                                ws, B, N, M, out.data_ptr(), arg.data_ptr(), _s()), "sa1_forward")
-        ctx.save_for_backward(xyz, new_xyz, idx, out, arg, w1, b1, w2, b2, w3, b3)
-        return out.transpose(1, 2).contiguous()                                  # [B,128,M] as the reference
-
-    @staticmethod
-    def backward(ctx, g):
-        xyz, new_xyz, idx, out, arg, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
-        B, N, _ = xyz.shape
-        M = new_xyz.shape[1]
-        gx = torch.empty_like(xyz)
-        gn = torch.empty_like(new_xyz)
-        ws = _lib.Sa1Weights(*[t.data_ptr() for t in (w1, b1, w2, b2, w3, b3)])
-        scratch = torch.empty(B, M, 64, 3, device=xyz.device, dtype=torch.float32)   # owner-ordered scatter (deterministic)
-        check(_lib.load().geoa3_pn2_sa1_backward(xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), ws, B, N, M,
-                                                 out.data_ptr(), arg.data_ptr(),
-                                                 g.transpose(1, 2).contiguous().data_ptr(),
-                                                 gx.data_ptr(), gn.data_ptr(), scratch.data_ptr(), _s()), "sa1_backward")
-        return gx, gn, None, None, None, None, None, None, None
-
-
 class PointnetSAModuleMSG(nn.Module):
+    """pointnet2_modules.py:77-126: holds the level's groupers and shared MLPs under the reference's parameter names
+    (`mlps.0.{0,1,3,4,6,7}.*`), so checkpoints load unchanged.  The levels are EXECUTED by the native classifier
+    (geoa3_pn2ssg_forward / _backward through PointNet2ClassificationSSG.forward); the layer-by-layer composition of
+    torch modules is not part of this package (tests/_pn2_module_path.py keeps one as a checker)."""
+
     def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True):
         super().__init__()
         assert len(radii) == len(nsamples) == len(mlps)
@@ -493,57 +270,8 @@ class PointnetSAModuleMSG(nn.Module):
             self.mlps.append(build_shared_mlp(spec, bn))
 
     def forward(self, xyz: Tensor, features: Optional[Tensor]):
-        new_xyz = None
-        if self.npoint is not None:
-            centres = furthest_point_sample(xyz, self.npoint)
-            new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
-        outs = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            fused = self._fused_level1(grouper, mlp, xyz, new_xyz, features)
-            if fused is None:
-                fused = self._pretransformed_level(grouper, mlp, xyz, new_xyz, features)
-            if fused is not None:
-                outs.append(fused)
-                continue
-            outs.append(run_shared_mlp(mlp, grouper(xyz, new_xyz, features), fuse_max=True))   # [B, C, npoint]
-        return new_xyz, torch.cat(outs, dim=1)
-
-    fuse_level1 = True   # class-wide switch (tests compare the fused kernel with the layer-by-layer path)
-    pretransform = True  # class-wide switch: first layer applied before the grouping (see _pretransformed_level)
-
-    def _pretransformed_level(self, grouper, mlp, xyz, new_xyz, features):
-        """A level with features (SA_modules[1] of the SSG classifier), frozen weights: its first layer is linear in
-        the gathered inputs, W [xyz_j - c_m ; f_j] = (W_x xyz + W_f f)_j - (W_x c)_m, so it is applied to the N
-        un-grouped points once (two small GEMMs) and the RESULT is gathered; the grouped [B, C+3, npoint, nsample]
-        tensor, the cat and the K = C + 3 GEMM over npoint * nsample columns never exist.  The remaining layers run on
-        the fused convolution operator (_SharedTail).  None when the level has another shape."""
-        if not (self.pretransform and fuse_tail and features is not None and isinstance(grouper, QueryAndGroup) and
-                grouper.use_xyz and xyz.is_cuda and not mlp.training and
-                _frozen(mlp)):
-            return None
-        folded = _fold_triples(mlp)
-        if folded is None or len(folded) < 2 or not _tail_eligible(folded, 1):
-            return None
-        (w0, b0) = folded[0]                                       # [Co, 3 + C]: xyz columns first (QueryAndGroup's cat)
-        idx = ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
-        wx, wf = w0[:, :3].contiguous(), w0[:, 3:].contiguous()
-        r = torch.matmul(wf, features) + torch.matmul(wx, xyz.transpose(1, 2))          # [B, Co, N]
-        shift = b0.view(1, -1, 1) - torch.matmul(wx, new_xyz.transpose(1, 2))           # [B, Co, npoint]
-        flat = [t for wb in folded[1:] for t in wb]
-        return _PretransformedSA.apply(r.contiguous(), idx, shift.contiguous(), *flat)
-
-    def _fused_level1(self, grouper, mlp, xyz, new_xyz, features):
-        """The xyz-only 3->64->64->128 level with 64 samples per ball (SA_modules[0] of the SSG classifier) as ONE
-        kernel per direction; None when this level has another shape, is training, or keeps weight gradients."""
-        if not (self.fuse_level1 and features is None and isinstance(grouper, QueryAndGroup) and grouper.use_xyz and
-                grouper.nsample == 64 and xyz.is_cuda and _frozen(mlp)):
-            return None
-        folded = _fold_triples(mlp)
-        if folded is None or [tuple(w.shape) for w, _ in folded] != [(64, 3), (64, 64), (128, 64)]:
-            return None
-        idx = ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
-        (w1, b1), (w2, b2), (w3, b3) = folded
-        return _SA1Fused.apply(xyz, new_xyz, idx, w1, b1, w2, b2, w3, b3)
+        raise _lib.Geoa3Error("a set-abstraction level does not run on its own in geoa3_amd: the SSG classifier is one native "
+                              "forward / input-gradient (PointNet2ClassificationSSG.forward, eval mode)")
 
 
 class PointnetSAModule(PointnetSAModuleMSG):
@@ -597,6 +325,7 @@ class PackedSSG:
         self.classes = int(fc[7].out_features)
         sa1 = _lib.Sa1Weights(*[dev(t) for t in (w11, b11, w12, b12, w13, b13)])
         self.struct = _lib.Pn2SsgWeights(classes=self.classes, sa1=sa1, images=None, **{k: dev(v) for k, v in f.items()})
+        self.struct.flags = _ext_flags(getattr(net, "ext_contract", None))
         # the level-2 / level-3 matrices once more, as the split-fp16 fragment images the matrix-core loops read
         lib = _lib.load()
         images = torch.empty(int(lib.geoa3_pn2ssg_images_bytes()), dtype=torch.uint8, device=device)
@@ -632,7 +361,7 @@ class _SSGFn(torch.autograd.Function):
         lib = _lib.load()
         nbytes = lib.geoa3_pn2ssg_workspace_bytes(B, N)
         if nbytes < 0:
-            raise _lib.Geoa3Error("geoa3_pn2ssg: needs at least 512 points per cloud")
+            raise _lib.Geoa3Error("geoa3_pn2ssg: unsupported cloud size (B=%d, N=%d)" % (B, N))
         ws = ws_cache.get("ws")
         if ws is None or ws.numel() < nbytes or ws.device != x.device:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -661,9 +390,10 @@ class _SSGFn(torch.autograd.Function):
 class PointNet2ClassificationSSG(nn.Module):
     """Model/PointNetPP_ssg.py:51-124 (40 output classes hard-coded as in the reference, main_attack.py:140)."""
 
-    def __init__(self, use_xyz: bool = True, use_normal: bool = False):
+    def __init__(self, use_xyz: bool = True, use_normal: bool = False, ext_contract: Optional[bool] = None):
         super().__init__()
         self.use_xyz, self.use_normal = use_xyz, use_normal
+        self.ext_contract = ext_contract   # None: GEOA3_PN2_CONTRACT decides (ext_contract_default)
         c0 = 3 if use_normal else 0
         self.SA_modules = nn.ModuleList([
             PointnetSAModule(npoint=512, radius=0.2, nsample=64, mlp=[c0, 64, 64, 128], use_xyz=use_xyz),
@@ -675,8 +405,6 @@ class PointNet2ClassificationSSG(nn.Module):
             nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.ReLU(True),
             nn.Dropout(0.5), nn.Linear(256, 40))
 
-    native = True    # class-wide switch (tests compare the native path with the module path)
-
     def __getstate__(self):
         """copy.deepcopy / pickle: the packed weights (ctypes struct, device images, the side queue's stream) and the
         workspace belong to THIS object and are rebuilt by the copy's first forward."""
@@ -686,7 +414,8 @@ class PointNet2ClassificationSSG(nn.Module):
         return state
 
     def _weights_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (str(device), _ext_flags(self.ext_contract)) + tuple(
+            (p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def packed(self, device) -> PackedSSG:
         key = self._weights_key(device)
@@ -694,20 +423,23 @@ class PointNet2ClassificationSSG(nn.Module):
             self._packed, self._packed_key = PackedSSG(self, device), key
         return self._packed
 
+    MIN_POINTS = 32   # (a sampler block needs points to choose from; the reference samples 512 centroids of any cloud)
+
     def native_eligible(self, pointcloud: Tensor) -> bool:
-        """The native kernels form the input gradient only and fold eval-mode BatchNorm statistics."""
-        return (self.native and pointcloud.is_cuda and not self.training and pointcloud.size(1) == 3 and
-                pointcloud.size(2) >= 512 and not self.use_normal and _frozen(self))
+        """What the native kernels serve: an eval-mode xyz-only victim whose weights take no gradient (they form the input
+        gradient only and fold the BatchNorm running statistics) on a device tensor [B,3,N]."""
+        return (pointcloud.is_cuda and not self.training and pointcloud.dim() == 3 and pointcloud.size(1) == 3 and
+                pointcloud.size(2) >= self.MIN_POINTS and not self.use_normal and self.use_xyz and _frozen(self))
 
     def forward(self, pointcloud: Tensor) -> Tensor:
-        """pointcloud [B, 3(+C), N] (the attack's layout) -> logits [B, 40]"""
-        if self.native_eligible(pointcloud):
-            if not hasattr(self, "_ws_cache"):
-                self._ws_cache = {}
-            return _SSGFn.apply(pointcloud, self.packed(pointcloud.device), self._ws_cache)
-        pc = pointcloud.transpose(2, 1)
-        xyz = pc[..., 0:3].contiguous()
-        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
-        for module in self.SA_modules:
-            xyz, features = module(xyz, features)
-        return self.fc_layer(features.squeeze(-1))
+        """pointcloud [B, 3, N] (the attack's layout) -> logits [B, 40]"""
+        if not self.native_eligible(pointcloud):
+            raise _lib.Geoa3Error(
+                "PointNet2ClassificationSSG runs as the attack's victim only: eval() mode, a CUDA tensor [B,3,N>=%d] (xyz "
+                "only, use_normal=False), and no weight gradient (torch.no_grad() or requires_grad_(False) on the "
+                "parameters) -- got training=%s, shape=%s, device=%s, use_normal=%s, weights frozen=%s.  Training and "
+                "feature-channel inputs are outside this package (SURVEY 8)."
+                % (self.MIN_POINTS, self.training, tuple(pointcloud.shape), pointcloud.device, self.use_normal, _frozen(self)))
+        if not hasattr(self, "_ws_cache"):
+            self._ws_cache = {}
+        return _SSGFn.apply(pointcloud, self.packed(pointcloud.device), self._ws_cache)

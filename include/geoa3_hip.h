@@ -39,7 +39,7 @@ extern "C" {
 /* The ABI version of this header: bumped on EVERY change of a struct layout or a signature.  geoa3_version() returns the
  * value the library was built with; a binding must refuse a library whose version differs (geoa3_amd/_lib.py does: a
  * stale or variant .so would misread the argument structs silently). */
-#define GEOA3_ABI_VERSION 501
+#define GEOA3_ABI_VERSION 600
 int geoa3_version(void);
 const char* geoa3_strerror(int code);
 
@@ -341,6 +341,15 @@ int geoa3_pn2_gather_points_grad(const float* grad_out, const int32_t* idx, int 
 /* ball_query.cpp:10-32 / ball_query_gpu.cu:9-54: idx [B,M,nsample] (zeroed here) */
 int geoa3_pn2_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius, int nsample,
                          int32_t* idx, void* stream);
+/* The same two with `flags`.  GEOA3_PN2_CONTRACT: the squared distances (and the sampler's |p|^2 <= 1e-3 skip test) as
+ * fmaf(dz, dz, fmaf(dy, dy, dx * dx)) -- what nvcc's default -fmad=true makes of sampling_gpu.cu:100,103-104 and
+ * ball_query_gpu.cu:31-32 (setup.py:32 builds with -O3 and no -fmad flag) -- instead of the un-fused default.  For
+ * comparing indices with a CUDA run of the reference; the two forms differ only at near-ties. */
+#define GEOA3_PN2_CONTRACT 1
+int geoa3_pn2_furthest_point_sampling_ex(const float* xyz, int B, int N, int m, float* temp, int32_t* idx, int flags,
+                                         void* stream);
+int geoa3_pn2_ball_query_ex(const float* new_xyz, const float* xyz, int B, int N, int M, float radius, int nsample,
+                            int32_t* idx, int flags, void* stream);
 /* group_points.cpp:13-34 / group_points_gpu.cu:8-39: out[b,c,j,k] = points[b,c,idx[b,j,k]] */
 int geoa3_pn2_group_points(const float* points, const int32_t* idx, int B, int C, int N, int M, int nsample,
                            float* out, void* stream);
@@ -431,7 +440,8 @@ int geoa3_pn2_sa1_backward(const float* xyz, const float* new_xyz, const int32_t
  * shift = bn.bias - mean * scale.  The first layer of levels 2 and 3 is split into its xyz columns (w?_wx [Co,3], the
  * first three input channels: QueryAndGroup / GroupAll cat xyz first) and its feature columns (w?_wf); *t = the
  * transposed matrix ([K,Co] row-major) used by the input gradient.
- * x, dx: planar [B,3,N] (the attack's layout), N >= 512; workspace: geoa3_pn2ssg_workspace_bytes(B, N) bytes, 256-byte
+ * x, dx: planar [B,3,N] (the attack's layout), 32 <= N <= 8192 (a cloud of fewer than 512 points has its points repeated
+ * by the sampler, as in the reference); workspace: geoa3_pn2ssg_workspace_bytes(B, N) bytes, 256-byte
  * aligned, the SAME buffer for forward and the backward that follows it (backward reads the forward's activations).
  * ------------------------------------------------------------------------------------------ */
 typedef struct geoa3_pn2ssg_weights {
@@ -453,6 +463,7 @@ typedef struct geoa3_pn2ssg_weights {
                            stream, beside level 1's MLP on `stream`; joined in front of level 2's MLP.  Same bits; the call is
                            still ordered on `stream` as a whole.  One queue per concurrent caller (the events are re-recorded by
                            every call). */
+  int32_t flags;        /* GEOA3_PN2_CONTRACT: the sampler's and the ball queries' distances contracted (see above); 0 = default */
 } geoa3_pn2ssg_weights;
 /* A HIP stream + five events owned by the caller's module object (the library keeps no global state).  Destroy after the
  * last call that used it has been enqueued (destroy synchronises the side stream). */

@@ -14,7 +14,10 @@ built in this image (no nvcc, no CUDA runtime): there is no oracle/_ref for it. 
 tests/golden/make_golden.py registers as `pointnet2_ops._ext` BEFORE importing the reference's Python
 (pointnet2_utils.py / pointnet2_modules.py / PointNetPP_ssg.py run unchanged on top of them), so the golden fixtures
 pin the reference's Python composition; the native arithmetic itself is pinned to the .cu semantics only
-("parity unpinned" for the nvcc contraction choice in the distance expressions: evaluated un-fused here).
+("parity unpinned" for the nvcc contraction choice in the distance expressions: evaluated un-fused by default).
+`contract=True` evaluates them as nvcc -O3 most likely compiled them (setup.py:32 passes no -fmad flag, the default is
+-fmad=true): dx*dx + dy*dy + dz*dz -> fmaf(dz, dz, fmaf(dy, dy, dx*dx)) (sampling_gpu.cu:100,103-104,
+ball_query_gpu.cu:31-32), with the fused multiply-add emulated exactly (_fmaf32).
 """
 from __future__ import annotations
 
@@ -29,6 +32,44 @@ def _sq3(dx, dy, dz):
     return f(f(f(dx * dx) + f(dy * dy)) + f(dz * dz))
 
 
+def _fmaf32(a, b, c):
+    """fl32(a * b + c) with ONE rounding, element-wise on float32 arrays.  The product of two float32 values is exact in
+    float64; the sum with c is rounded to float64 first, which could double-round only if that float64 lay within one
+    float64 ulp of a float32 rounding boundary: those elements (none in practice) are redone in exact rational
+    arithmetic."""
+    a, b, c = (np.asarray(v, dtype=np.float32) for v in (a, b, c))
+    a, b, c = np.broadcast_arrays(a, b, c)
+    s = a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)
+    out = s.astype(np.float32)
+    # a float32 boundary is a float64 whose low 29 mantissa bits are 1000...0: flag anything within 2 float64 ulps of one
+    bits = s.view(np.int64) if s.flags.c_contiguous else np.ascontiguousarray(s).view(np.int64)
+    low = bits & ((1 << 29) - 1)
+    risky = np.abs(low - (1 << 28)) <= 2
+    if risky.any():
+        from fractions import Fraction
+        flat_out = out.reshape(-1).copy()
+        fa, fb, fc = a.reshape(-1), b.reshape(-1), c.reshape(-1)
+        for i in np.nonzero(risky.reshape(-1))[0]:
+            if not np.isfinite(s.reshape(-1)[i]):
+                continue
+            exact = Fraction(float(fa[i])) * Fraction(float(fb[i])) + Fraction(float(fc[i]))
+            lo = np.float32(float(exact))                      # float(Fraction) rounds correctly to float64 ...
+            cands = [lo, np.nextafter(lo, np.float32(np.inf)), np.nextafter(lo, np.float32(-np.inf))]
+            best = min(cands, key=lambda v: (abs(Fraction(float(v)) - exact), int(np.float32(v).view(np.int32)) & 1))
+            flat_out[i] = best                                  # ... and the nearest float32 (ties to even) is picked exactly
+        out = flat_out.reshape(out.shape)
+    return out
+
+
+def _sq3_arrays(dx, dy, dz, contract: bool):
+    """the squared distance of float32 arrays: un-fused (default) or as fmaf(dz, dz, fmaf(dy, dy, dx * dx))."""
+    f = np.float32
+    if contract:
+        return _fmaf32(dz, dz, _fmaf32(dy, dy, (dx * dx).astype(f)))
+    s = ((dx * dx).astype(f) + (dy * dy).astype(f)).astype(f)
+    return (s + (dz * dz).astype(f)).astype(f)
+
+
 def opt_n_threads(work_size: int) -> int:
     """cuda_utils.h:13-19: clamp(2^floor(log2(work_size)), 1, 512)."""
     p = 1
@@ -37,7 +78,7 @@ def opt_n_threads(work_size: int) -> int:
     return max(min(p, 512), 1)
 
 
-def furthest_point_sampling(xyz: Tensor, npoint: int) -> Tensor:
+def furthest_point_sampling(xyz: Tensor, npoint: int, contract: bool = False) -> Tensor:
     """xyz [B,N,3] f32 -> idx [B,npoint] int32."""
     P = xyz.detach().cpu().numpy().astype(np.float32)
     B, N, _ = P.shape
@@ -47,15 +88,13 @@ def furthest_point_sampling(xyz: Tensor, npoint: int) -> Tensor:
     tt = kk % T
     for b in range(B):
         p = P[b]
-        mag = ((p[:, 0] * p[:, 0]).astype(np.float32) + (p[:, 1] * p[:, 1]).astype(np.float32)).astype(np.float32)
-        mag = (mag + (p[:, 2] * p[:, 2]).astype(np.float32)).astype(np.float32)
+        mag = _sq3_arrays(p[:, 0], p[:, 1], p[:, 2], contract)
         use = ~(mag <= np.float32(1e-3))
         temp = np.full(N, 1e10, dtype=np.float32)
         old = 0
         for j in range(1, npoint):
             d = p - p[old]
-            dd = ((d[:, 0] * d[:, 0]).astype(np.float32) + (d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
-            dd = (dd + (d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+            dd = _sq3_arrays(d[:, 0], d[:, 1], d[:, 2], contract)
             temp = np.where(use, np.minimum(dd, temp), temp)
             if not use.any():
                 old = 0
@@ -83,7 +122,7 @@ def gather_points_grad(grad_out: Tensor, idx: Tensor, n: int) -> Tensor:
     return g
 
 
-def ball_query(new_xyz: Tensor, xyz: Tensor, radius: float, nsample: int) -> Tensor:
+def ball_query(new_xyz: Tensor, xyz: Tensor, radius: float, nsample: int, contract: bool = False) -> Tensor:
     """new_xyz [B,M,3], xyz [B,N,3] -> idx [B,M,nsample] int32 (note the extension's argument order)."""
     C, P = new_xyz.detach().cpu().numpy().astype(np.float32), xyz.detach().cpu().numpy().astype(np.float32)
     B, M, _ = C.shape
@@ -91,8 +130,7 @@ def ball_query(new_xyz: Tensor, xyz: Tensor, radius: float, nsample: int) -> Ten
     out = np.zeros((B, M, nsample), dtype=np.int32)
     for b in range(B):
         d = C[b][:, None, :] - P[b][None, :, :]                                   # [M,N,3] f32
-        d2 = ((d[..., 0] * d[..., 0]).astype(np.float32) + (d[..., 1] * d[..., 1]).astype(np.float32)).astype(np.float32)
-        d2 = (d2 + (d[..., 2] * d[..., 2]).astype(np.float32)).astype(np.float32)
+        d2 = _sq3_arrays(d[..., 0], d[..., 1], d[..., 2], contract)
         inside = d2 < r2
         for j in range(M):
             hits = np.nonzero(inside[j])[0][:nsample]

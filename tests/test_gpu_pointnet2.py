@@ -8,6 +8,7 @@ from oracle import geoa3_oracle as O
 from oracle import pointnet2_oracle as P2
 
 pytestmark = pytest.mark.gpu
+from tests import _pn2_module_path as MP   # noqa: E402  (the layer-by-layer CHECKER: torch modules + single HIP operators)
 T = torch.from_numpy
 
 
@@ -118,10 +119,12 @@ def test_ssg_classifier_matches_reference_python(pn2, golden, tag):
     assert set(net.state_dict()) == set(sd) and len(sd) == 68
     net.load_state_dict(sd)
     net = net.cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)           # the victim's weights take no gradient (the module refuses anything else)
     pre = "pn2/%s/" % tag
     x = T(golden[pre + "pc"]).cuda().requires_grad_()
     logits = net(x)
-    # fp32 tolerance: MIOpen/hipBLASLt sum in a different order than the CPU convolutions
+    # (the bar this test has held since the layer-by-layer path; the native path's own, tighter bar is further down)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), golden[pre + "logits"], rtol=1e-3, atol=2e-3)
     (logits * T(golden[pre + "w"]).cuda()).sum().backward()
     ref = golden[pre + "g_pc"].copy()
@@ -142,21 +145,16 @@ def test_fused_first_level_matches_layerwise_path_and_reference(pn2, golden, tag
     net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     net.load_state_dict(sd)
     net = net.cuda().eval()
-    net.native = False                    # the layer-by-layer module path (the native path has its own test below)
     for p in net.parameters():
         p.requires_grad_(False)           # as the attack driver does: only d/d input is needed
     pre = "pn2/%s/" % tag
     w = T(golden[pre + "w"]).cuda()
     res = {}
-    for fused in (True, False):
-        pn2.PointnetSAModuleMSG.fuse_level1 = fused
-        try:
-            x = T(golden[pre + "pc"]).cuda().requires_grad_()
-            logits = net(x)
-            (logits * w).sum().backward()
-            res[fused] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
-        finally:
-            pn2.PointnetSAModuleMSG.fuse_level1 = True
+    for fused in (True, False):           # the layer-by-layer checker path (the native path has its own test below)
+        x = T(golden[pre + "pc"]).cuda().requires_grad_()
+        logits = MP.module_forward(net, x, fuse_level1=fused)
+        (logits * w).sum().backward()
+        res[fused] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(res[True][0], golden[pre + "logits"], rtol=1e-3, atol=2e-3)
     ref = golden[pre + "g_pc"].copy()
@@ -182,7 +180,7 @@ def test_fused_first_level_operator(pn2):
           torch.randn(64, 64, device="cuda") * 0.2, torch.randn(64, device="cuda") * 0.1,
           torch.randn(128, 64, device="cuda") * 0.2, torch.randn(128, device="cuda") * 0.1]
     xa, na = xyz.clone().requires_grad_(), new_xyz.clone().requires_grad_()
-    out = pn2._SA1Fused.apply(xa, na, idx, *ws)
+    out = MP._SA1Fused.apply(xa, na, idx, *ws)
     g = torch.randn_like(out)
     out.backward(g)
     xb, nb = xyz.clone().requires_grad_(), new_xyz.clone().requires_grad_()
@@ -207,21 +205,16 @@ def test_fused_shared_mlp_tail_matches_gemm_path_and_reference(pn2, golden, tag)
     net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     net.load_state_dict(sd)
     net = net.cuda().eval()
-    net.native = False
     for p in net.parameters():
         p.requires_grad_(False)
     pre = "pn2/%s/" % tag
     w = T(golden[pre + "w"]).cuda()
     res = {}
     for fused in (True, False):
-        pn2.fuse_tail = fused
-        try:
-            x = T(golden[pre + "pc"]).cuda().requires_grad_()
-            logits = net(x)
-            (logits * w).sum().backward()
-            res[fused] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
-        finally:
-            pn2.fuse_tail = True
+        x = T(golden[pre + "pc"]).cuda().requires_grad_()
+        logits = MP.module_forward(net, x, fuse_tail=fused)
+        (logits * w).sum().backward()
+        res[fused] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(res[True][0], golden[pre + "logits"], rtol=1e-3, atol=2e-3)
     ref = golden[pre + "g_pc"].copy()
@@ -241,21 +234,16 @@ def test_pretransformed_level_matches_grouped_path_and_reference(pn2, golden, ta
     net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
     net.load_state_dict(sd)
     net = net.cuda().eval()
-    net.native = False
     for p in net.parameters():
         p.requires_grad_(False)
     pre = "pn2/%s/" % tag
     w = T(golden[pre + "w"]).cuda()
     res = {}
     for fused in (True, False):
-        pn2.PointnetSAModuleMSG.pretransform = fused
-        try:
-            x = T(golden[pre + "pc"]).cuda().requires_grad_()
-            logits = net(x)
-            (logits * w).sum().backward()
-            res[fused] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
-        finally:
-            pn2.PointnetSAModuleMSG.pretransform = True
+        x = T(golden[pre + "pc"]).cuda().requires_grad_()
+        logits = MP.module_forward(net, x, pretransform=fused)
+        (logits * w).sum().backward()
+        res[fused] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(res[True][0], golden[pre + "logits"], rtol=1e-3, atol=2e-3)
     ref = golden[pre + "g_pc"].copy()
@@ -282,10 +270,9 @@ def test_native_ssg_matches_reference_and_module_path(pn2, golden, tag):
     w = T(golden[pre + "w"]).cuda()
     res = {}
     for native in (True, False):
-        net.native = native
         x = T(golden[pre + "pc"]).cuda().requires_grad_()
-        assert net.native_eligible(x) == native
-        logits = net(x)
+        assert net.native_eligible(x)
+        logits = net(x) if native else MP.module_forward(net, x)
         assert (type(logits.grad_fn).__name__ == "_SSGFnBackward") == native
         (logits * w).sum().backward()
         res[native] = (logits.detach().cpu().numpy(), x.grad.cpu().numpy().copy())
@@ -438,7 +425,7 @@ def test_first_level_scatter_is_loud_about_nan(pn2):
          torch.randn(64, generator=g) * 0.1, torch.randn(128, 64, generator=g) * 0.18, torch.randn(128, generator=g) * 0.1]
     w = [t.cuda().contiguous() for t in w]
     x = xyz.clone().requires_grad_()
-    out = pn2._SA1Fused.apply(x, new_xyz, gidx, *w)             # [B,128,M]
+    out = MP._SA1Fused.apply(x, new_xyz, gidx, *w)             # [B,128,M]
     go = torch.randn(out.shape, generator=g).cuda()
     go[0, :, 5] = float("nan")
     out.backward(go)
@@ -447,3 +434,155 @@ def test_first_level_scatter_is_loud_about_nan(pn2):
     hit[gidx[0, 5].long().cpu().unique()] = True
     assert torch.isnan(gx[0].cpu()[hit]).all()
     assert torch.isfinite(gx[1]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: the opt-in CONTRACTED distances (what nvcc's default -fmad=true most likely made of sampling_gpu.cu:100,103-104
+# and ball_query_gpu.cu:31-32), small clouds on the native classifier, and the one-backend rule
+# ---------------------------------------------------------------------------------------------------------------------
+def _near_tie_cloud(B, N, seed):
+    """Points on a coarse lattice (many exactly / nearly equal distances) plus a little noise: where the two roundings of
+    dx^2 + dy^2 + dz^2 part ways."""
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.randint(-8, 9, (B, N, 3), generator=g).float() * 0.0625
+    xyz = xyz + (torch.rand(B, N, 3, generator=g) - 0.5) * 2e-6
+    xyz[:, 3] = 0.0
+    return xyz.contiguous()
+
+
+@pytest.mark.parametrize("B,N,m", [(2, 1024, 512), (2, 512, 128), (1, 2048, 300), (2, 300, 300), (1, 4096, 64)])
+def test_fps_contracted_mode_exact(pn2, B, N, m):
+    """GEOA3_PN2_CONTRACT: fmaf(dz, dz, fmaf(dy, dy, dx * dx)) -- exact against the oracle's contracted variant on smooth and
+    on near-tie clouds; the default entry point is untouched by the flag."""
+    for xyz in (_cloud(B, N, 300 + N), _near_tie_cloud(B, N, 7 + N)):
+        got_c = pn2.ext.furthest_point_sampling(xyz.cuda(), m, contract=True).cpu()
+        got_u = pn2.ext.furthest_point_sampling(xyz.cuda(), m, contract=False).cpu()
+        assert torch.equal(got_c, P2.furthest_point_sampling(xyz, m, contract=True))
+        assert torch.equal(got_u, P2.furthest_point_sampling(xyz, m))
+
+
+@pytest.mark.parametrize("B,N,M,r,ns", [(2, 1024, 512, 0.2, 64), (2, 512, 128, 0.4, 64), (1, 900, 70, 0.5, 80)])
+def test_ball_query_contracted_mode_exact(pn2, B, N, M, r, ns):
+    for xyz in (_cloud(B, N, 400 + N), _near_tie_cloud(B, N, 11 + N)):
+        centres = xyz[:, :M].clone()
+        got_c = pn2.ext.ball_query(centres.cuda(), xyz.cuda(), r, ns, contract=True).cpu()
+        got_u = pn2.ext.ball_query(centres.cuda(), xyz.cuda(), r, ns, contract=False).cpu()
+        assert torch.equal(got_c, P2.ball_query(centres, xyz, r, ns, contract=True))
+        assert torch.equal(got_u, P2.ball_query(centres, xyz, r, ns))
+
+
+def test_contracted_mode_is_not_a_no_op(pn2):
+    """Offsets on the sphere of radius r whose squared length rounds to the two sides of r^2 under the two evaluations (found
+    by search with the oracle's arithmetic): the default ball holds exactly the points the un-fused form admits, the
+    contracted ball exactly those the fused form admits -- and the two sets differ."""
+    r = np.float32(0.3)
+    r2 = np.float32(r * r)
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal((400000, 3))
+    u = (u / np.linalg.norm(u, axis=1, keepdims=True) * float(r)).astype(np.float32)
+    un = P2._sq3_arrays(u[:, 0], u[:, 1], u[:, 2], False) < r2
+    fu = P2._sq3_arrays(u[:, 0], u[:, 1], u[:, 2], True) < r2
+    pick = np.nonzero(un != fu)[0][:24]
+    assert len(pick) >= 8                                   # (about 1 in 10^3 of the sphere's points)
+    pts = torch.from_numpy(np.concatenate([np.zeros((1, 3), np.float32), u[pick]])).unsqueeze(0).contiguous()   # centre first
+    centre = pts[:, :1].clone()                              # the origin: d = -offset, squares equal
+    for ct in (False, True):
+        got = pn2.ext.ball_query(centre.cuda(), pts.cuda(), float(r), 32, contract=ct).cpu()
+        assert torch.equal(got, P2.ball_query(centre, pts, float(r), 32, contract=ct))
+        inside = (fu if ct else un)[pick]
+        want = sorted([0] + [1 + i for i in np.nonzero(inside)[0]])
+        assert sorted(set(got[0, 0].tolist())) == want
+    assert (un[pick] != fu[pick]).all()
+
+
+def test_native_ssg_contracted_flag_reaches_the_samplers(pn2):
+    """PointNet2ClassificationSSG(ext_contract=True): the native classifier's own FPS / ball queries take the contracted
+    distances -- its logits equal the oracle classifier's evaluated over the contracted operators, and the flag is part
+    of the packed-weights key (a module that has run in one mode repacks for the other)."""
+    sd = P2.make_pn2_state_dict(0)
+    xyz = _near_tie_cloud(2, 1024, 99)
+    pc = xyz.permute(0, 2, 1).contiguous()
+    out = {}
+    for ct in (False, True):
+        net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False, ext_contract=ct)
+        net.load_state_dict(sd)
+        net = net.cuda().eval()
+        with torch.no_grad():
+            out[ct] = net(pc.cuda()).cpu().numpy()
+        # the oracle classifier over the same variant of the two operators
+        orig = (P2.furthest_point_sampling, P2.ball_query)
+        try:
+            P2.furthest_point_sampling = lambda x, m, _f=orig[0], _c=ct: _f(x, m, contract=_c)
+            P2.ball_query = lambda c, x, r, n, _f=orig[1], _c=ct: _f(c, x, r, n, contract=_c)
+            with torch.no_grad():
+                want = P2.pointnet2_ssg_forward(sd, pc).numpy()
+        finally:
+            P2.furthest_point_sampling, P2.ball_query = orig
+        np.testing.assert_allclose(out[ct], want, rtol=1e-4, atol=3e-4)
+        assert int(net.packed(torch.device("cuda", 0)).struct.flags) == (1 if ct else 0)
+    # one module, both modes in turn: the flag is part of the packed-weights key
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        a = net(pc.cuda()).cpu().numpy()
+        net.ext_contract = True
+        b = net(pc.cuda()).cpu().numpy()
+    assert int(net.packed(torch.device("cuda", 0)).struct.flags) == 1
+    np.testing.assert_array_equal(a, out[False])
+    np.testing.assert_array_equal(b, out[True])
+
+
+@pytest.mark.parametrize("N", [256, 100])
+def test_native_ssg_small_cloud_against_the_oracle(pn2, N):
+    """A 256-point (and a 100-point) victim on the NATIVE kernels: the sampler picks 512 / 128 centroids of a cloud that has
+    fewer points (repeats, as the reference's kernel does), balls are padded; logits and input gradient against the CPU
+    restatement of the reference (its autograd through torch.gather = the scatter-adds)."""
+    sd = P2.make_pn2_state_dict(0)
+    pc, _ = O.make_synthetic_clouds(3, N, seed=77)
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    x = pc.clone().cuda().requires_grad_()
+    assert net.native_eligible(x)
+    logits = net(x)
+    assert type(logits.grad_fn).__name__ == "_SSGFnBackward"
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(3, 40, generator=g)
+    (logits * w.cuda()).sum().backward()
+    xo = pc.clone().requires_grad_()
+    lo = P2.pointnet2_ssg_forward(sd, xo)
+    (lo * w).sum().backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lo.detach().numpy(), rtol=1e-4, atol=3e-4)
+    ref, got = xo.grad.numpy(), x.grad.cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
+
+
+def test_one_backend_everything_else_is_refused_loudly(pn2):
+    """No second backend behind a dispatch: what the native classifier does not serve raises, it does not fall back to
+    torch modules (training mode, weight gradients, feature channels, CPU tensors)."""
+    from geoa3_amd._lib import Geoa3Error
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False).cuda()
+    x = torch.randn(2, 3, 600, device="cuda")
+    net.train()
+    with pytest.raises(Geoa3Error, match="eval"):
+        net(x)
+    net.eval()
+    with pytest.raises(Geoa3Error, match="weight gradient"):
+        net(x)                                            # parameters still require grad and autograd is on
+    with torch.no_grad():
+        assert net(x).shape == (2, 40)
+    with pytest.raises(Geoa3Error):
+        with torch.no_grad():
+            net(x.cpu())
+    net6 = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=True).cuda().eval()
+    with pytest.raises(Geoa3Error, match="use_normal"):
+        with torch.no_grad():
+            net6(torch.randn(2, 6, 600, device="cuda"))
+    with pytest.raises(Geoa3Error):
+        net.SA_modules[0](x.transpose(1, 2).contiguous(), None)
+    import inspect
+    import geoa3_amd.pointnet2 as mod
+    assert "matmul" not in inspect.getsource(mod)
