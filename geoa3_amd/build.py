@@ -54,6 +54,19 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+_HIPCC_VERSION = None
+
+
+def hipcc_version() -> str:
+    """`hipcc --version` (first lines): part of every object's stamp -- a compiler update rebuilds the library and so puts
+    every file through the ISA guard again."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        r = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True)
+        _HIPCC_VERSION = (r.stdout + r.stderr).strip()
+    return _HIPCC_VERSION
+
+
 def _digest(path: str, flags=None) -> str:
     h = hashlib.sha1()
     for p in [path] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
@@ -61,6 +74,9 @@ def _digest(path: str, flags=None) -> str:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(flags or FLAGS).encode())
+    # the compiler and the guard itself: a new hipcc, or a changed guard pattern, re-checks every object
+    h.update(hipcc_version().encode())
+    h.update(repr((ISA_GUARD_ALL, sorted(ISA_GUARDS.items()))).encode())
     return h.hexdigest()
 
 
@@ -114,7 +130,45 @@ ISA_GUARDS = {"pointnet_conv_chain.hip": ("conv_bwd_chain_kernel", r"v_pk_(mul|f
 # (tools/ub/pk_neg_mfma_min.hip: v_pk_add / mul / fma_f32 with op_sel on src1 return src1 = 0 in lanes 48-63, ~1e-8 .. 5e-7 of
 # the executions, when the neighbouring wavefronts mix vector and f16 matrix instructions; op_sel_hi, neg and v_pk_mov_b32 are
 # clean: DESIGN 5a).  Only the SLP vectoriser forms it; every kernel that ever failed held one to eight of them.
-ISA_GUARD_ALL = r"v_pk_(mul|fma|add)_f32[^\n]*op_sel:\[[^\]]*1"
+# The pattern is deliberately wider than today's spelling (`op_sel:[0,1,0]`): any packed-FP32 arithmetic mnemonic (mul / fma /
+# add, with or without an encoding suffix) whose operand-select list -- `op_sel`, NOT `op_sel_hi` -- names a high half for
+# any source, whatever the separator a future disassembler prints.  tests/test_abi.py compiles a source that MUST be refused
+# (isa_guard_selftest), so a compiler that forms or prints the instruction differently fails the test suite, not a user.
+ISA_GUARD_ALL = r"(?i)v_pk_(mul|fma|add)_f32\w*[^\n]*\bop_sel\s*[:=]\s*\[[^\]]*1"
+
+
+GUARD_SELFTEST_SOURCE = r"""
+// MUST be refused by the ISA guard: packed FP32 arithmetic whose LOW result reads the HIGH half of a source register pair
+#include <hip/hip_runtime.h>
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ void guard_selftest_kernel(const f2* a, const f2* b, f2* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const f2 x = a[i], y = b[i];
+  const f2 ys = {y.y, y.x};          // swapped halves: v_pk_fma_f32 ... op_sel:[0,1,0] op_sel_hi:[1,0,1]
+  out[i] = x * ys + x;
+}
+"""
+
+
+def isa_guard_selftest() -> str:
+    """Compile a ten-line source that holds the faulty instruction form with the library's own flags and run the guard on
+    it: returns the guard's refusal message, raises AssertionError when the guard lets it through (a compiler that no
+    longer forms the instruction from this source, or prints it in a spelling the pattern misses)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "guard_selftest.hip")
+        with open(src, "w") as f:
+            f.write(GUARD_SELFTEST_SOURCE)
+        try:
+            _isa_guard(src, FLAGS)
+        except RuntimeError as e:
+            if "ISA guard" in str(e) and "op_sel" in str(e):
+                return str(e)
+            raise
+    raise AssertionError("the ISA guard accepted a source that holds packed FP32 arithmetic with op_sel on a source operand: "
+                         "either this hipcc (%s) no longer forms v_pk_*_f32 ... op_sel from the self-test source, or it prints "
+                         "it in a way ISA_GUARD_ALL misses -- look at the disassembly before trusting the build"
+                         % hipcc_version().splitlines()[0])
 
 
 def _isa_guard(src: str, flags) -> None:

@@ -647,19 +647,23 @@ __device__ __forceinline__ void geo_sort_regs(int (&v)[W]) {
 #define GEO_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #define GEO_RCP(x) __builtin_amdgcn_rcpf(x)
 #endif
+// (The multiply-adds are spelled out and contraction is OFF inside: the overflowed-row path forms a row's terms at two
+// call sites -- the pair lane in phase 1, the owner in phase 2 -- whose sums must agree bit for bit whichever of them
+// converts a given term; left to -ffp-contract=fast each inlined copy is fused as its surroundings suggest.)
 __device__ __forceinline__ void geo_pair_grad(float px, float py, float pz, float nx, float ny, float nz, float dk, float qx,
                                               float qy, float qz, float& dvx, float& dvy, float& dvz, float& t_out) {
+#pragma clang fp contract(off)
   const float vx = qx - px, vy = qy - py, vz = qz - pz;
-  const float r = GEO_SQRT(vx * vx + vy * vy + vz * vz);
+  const float r = GEO_SQRT(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
   const float inv = GEO_RCP(fmaxf(r, NORM_EPS));
   const float ux = vx * inv, uy = vy * inv, uz = vz * inv;
-  const float t = ux * nx + uy * ny + uz * nz;
+  const float t = __builtin_fmaf(uz, nz, __builtin_fmaf(uy, ny, ux * nx));
   const float sg = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
   const float c = dk * sg * inv;
   if (r >= NORM_EPS) {  // d(v/|v|)/dv = (I - u u^T)/|v|
-    dvx = c * (nx - t * ux);
-    dvy = c * (ny - t * uy);
-    dvz = c * (nz - t * uz);
+    dvx = c * __builtin_fmaf(-t, ux, nx);
+    dvy = c * __builtin_fmaf(-t, uy, ny);
+    dvz = c * __builtin_fmaf(-t, uz, nz);
   } else {              // clamp active: v/eps, the norm path carries no gradient
     dvx = c * nx;
     dvy = c * ny;
@@ -772,11 +776,13 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
   const GeoFix FX = geo_fix_make(geo_coef_bound(A, N, Nr, xmax));
   auto ovf_add = [&](int q, float x, float y, float z) {   // a term of an overflowed row
     const float mm = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
-    const int sl = (mm <= FX.lim_c) ? geo_pool_find(pool, q, true) : -1;
-    if (sl < 0) {                                          // pool full, out of range or NaN: the owner writes NaN
+    if (!(mm <= FX.lim_c)) {                               // out of the fixed-point range, or NaN: the owner writes NaN
       atomicOr(&s_cnt[q], (int)0x40000000);
       return;
     }
+    const int sl = geo_pool_find(pool, q, true);
+    if (sl < 0) return;   // pool FULL: the workgroup has more overflowed rows than slots -- a count every owner sees below,
+                          // and then every overflowed row is summed by its owner's walk over the tables instead
     const bool fine = mm <= FX.lim_f;
     const float mul = fine ? FX.to_f : FX.to_c;
     const int o = sl * 6 + (fine ? 0 : 3);
@@ -958,6 +964,13 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
   const int ncnt_raw = mine ? s_cnt[me] : 0;
   const int ncnt = ncnt_raw & 0x3fffffff;
   const int n = ncnt <= C ? ncnt : 0;
+  // how many rows of this workgroup overflowed: a function of the tables alone (not of arrival order).  More than the pool
+  // has slots (hubs of the K-NN graph, many clean points sharing few adversarial neighbours): the pool's contents are
+  // incomplete for SOME rows -- which ones is arrival order -- so NO row uses it: every overflowed row's owner walks the
+  // neighbour table and the clean cloud's nearest-point table for its sources, ascending -- the sums the ordered path
+  // forms, slow (N k + Nr reads per row) and exact.  (Round 5 wrote NaN here.)
+  const int n_ovf = __syncthreads_count(mine && ncnt > C);
+  const bool pool_short = n_ovf > GEO_POOL_CAP;
   uint16_t* L = s_rows + (mine ? me - r0 : 0) * stride;
   int nmax = n;
 #pragma unroll
@@ -1059,7 +1072,18 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
         }
     }
   }
-  if (ncnt > C) {
+  if (ncnt > C && pool_short) {
+    if (do_curv)
+      for (int c = 0; c < N; ++c) {                 // sources ascending: point c lists this point among its k neighbours
+        const int32_t* row = tab + (size_t)c * k1 + 1;
+        bool hit = false;
+        for (int mm = 0; mm < k; ++mm) hit = hit || row[mm] == me;
+        if (hit) receive(c);
+      }
+    if (two_side)
+      for (int j = 0; j < Nr; ++j)                  // clean points whose nearest adversarial point this is, ascending
+        if (A.i_oa[bNr + j] == me) receive(N + j);
+  } else if (ncnt > C) {
     // overflowed row: the C sources the row holds (WHICH ones is the appends' arrival order) are converted by the owner and
     // added to what the later arrivals put into the pool in phase 1 -- integer sums, so the split does not matter
     long long fxs = 0, fys = 0, fzs = 0, cxs = 0, cys = 0, czs = 0;
@@ -1099,7 +1123,7 @@ __global__ __launch_bounds__(GEO_T) void geo_fused_kernel(geoa3_geo_args A, int 
       cys += (long long)pool.acc[sl * 6 + 4];
       czs += (long long)pool.acc[sl * 6 + 5];
     } else {
-      bad = true;       // (a row overflows only through appends that reached the pool: it was full)
+      bad = true;       // (cannot happen: a row overflows only through appends that reached the pool, and it was not full)
     }
     gx += __ll2float_rn(fxs) * FX.from_f + __ll2float_rn(cxs) * FX.from_c;
     gy += __ll2float_rn(fys) * FX.from_f + __ll2float_rn(cys) * FX.from_c;

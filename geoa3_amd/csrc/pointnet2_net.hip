@@ -76,6 +76,7 @@ struct Ws {
   float *xyz, *nx1, *out1, *f1, *nx2, *r, *shift, *da0, *out2, *h1, *h2, *z3, *p3, *q1, *q2;
   int32_t *idx1, *gidx1, *idx2, *gidx2, *arg2, *arg3;
   uint8_t* arg1;
+  int32_t* bad;    // [B]: the cloud holds a NaN / Inf coordinate (its logits and its input gradient are NaN)
   // backward
   float *g256, *g512, *g1024, *dh2, *dh1, *dout2, *dnx2, *d1, *df1, *dnx1, *g1, *gxyz, *gnx1;
   unsigned long long *m0, *m1;   // relu gates of the level-2 activations a0, a1 as bits [B * M2][128]
@@ -128,6 +129,7 @@ Ws carve(void* base, int B, int N) {
   w.g1 = (float*)take(b * M1 * C1 * f);
   w.gxyz = (float*)take(b * N * 3 * f);
   w.gnx1 = (float*)take(b * M1 * 3 * f);
+  w.bad = (int32_t*)take(b * 4);
   w.m0 = (unsigned long long*)take(b * M2 * 128 * 8);
   w.m1 = (unsigned long long*)take(b * M2 * 128 * 8);
   w.images = take(img_off(IM_COUNT));
@@ -149,9 +151,24 @@ __global__ __launch_bounds__(256) void planar_to_points_kernel(const float* __re
   q[1] = p[N];
   q[2] = p[2 * (size_t)N];
 }
-// (xyz2: a second point-major tensor added on the way, or null)
+// A NaN / Inf coordinate must not come out as finite logits: the level kernels are compiled with -fno-honor-nans (relu / max
+// without the canonicalising instruction), the sampler skips what it cannot compare, a ball query never admits a NaN
+// distance.  One workgroup per cloud looks at the bits and leaves a flag; the cloud's logits and its input gradient are NaN.
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, int32_t* __restrict__ bad, int n3) {
+  const unsigned* p = reinterpret_cast<const unsigned*>(x) + (size_t)blockIdx.x * n3;
+  bool any = false;
+  for (int e = threadIdx.x; e < n3; e += 256) any = any || (p[e] & 0x7f800000u) == 0x7f800000u;
+  const int r = __syncthreads_or(any);
+  if (threadIdx.x == 0) bad[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void poison_rows_kernel(float* __restrict__ y, const int32_t* __restrict__ bad, int cols, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < total && bad[e / cols]) y[e] = __uint_as_float(0x7fc00000u);
+}
+// (xyz2: a second point-major tensor added on the way, or null; bad: clouds whose gradient is NaN, see above)
 __global__ __launch_bounds__(256) void points_to_planar_kernel(const float* __restrict__ xyz, const float* __restrict__ xyz2,
-                                                               float* __restrict__ x, int N, long total) {
+                                                               float* __restrict__ x, int N, long total,
+                                                               const int32_t* __restrict__ bad) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const long b = e / N;
@@ -164,6 +181,7 @@ __global__ __launch_bounds__(256) void points_to_planar_kernel(const float* __re
     v1 += r[1];
     v2 += r[2];
   }
+  if (bad[b]) v0 = v1 = v2 = __uint_as_float(0x7fc00000u);
   float* p = x + b * 3 * N + n;
   p[0] = v0;
   p[N] = v1;
@@ -358,6 +376,22 @@ struct SideQueue {
   hipStream_t stream;
   hipEvent_t ev[4], join;   // ev[c]: centroid chunk c of level 1 is chosen and gathered; join: level 2's geometry is done
 };
+
+// A failing launch between a fork and its join must not leave the side stream un-joined (an eager caller would reuse the
+// workspace under kernels still running there; a stream capture would be left with an unjoined branch): once armed, leaving the
+// scope on any path records the queue's join event and makes `main` wait for it.
+struct SideJoin {
+  SideQueue* q = nullptr;
+  hipStream_t main = nullptr;
+  void arm(SideQueue* queue, hipStream_t m) { q = queue; main = m; }
+  void disarm() { q = nullptr; }
+  ~SideJoin() {
+    if (q) {
+      (void)hipEventRecord(q->join, q->stream);
+      (void)hipStreamWaitEvent(main, q->join, 0);
+    }
+  }
+};
 }  // namespace
 
 extern "C" void geoa3_side_queue_destroy(void* side) {
@@ -397,6 +431,7 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
     im = w.images;
   }
   // ---- level 1 (PointNetPP_ssg.py:58-66): FPS 512, ball 0.2 x 64, MLP 3 -> 64 -> 64 -> 128, max
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(B), dim3(256), 0, s, x, w.bad, 3 * N);
   hipLaunchKernelGGL(planar_to_points_kernel, g1d((long)B * N), dim3(256), 0, s, x, w.xyz, N, (long)B * N);
   // With a side queue in the weights the level is PIPELINED.  The sampler is a chain of 511 dependent rounds in one workgroup
   // per cloud (0.33 ms whatever the batch), and nothing of the level can start before its first centroid: so the rounds run
@@ -405,12 +440,13 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   // launch the side stream continues with level 2's sampling, ball query and shift (functions of the level-1 centroids
   // only) and is joined in front of level 2's MLP.  The call is still ordered on `stream` as a whole (the side stream
   // starts behind an event of it and is waited for); twelve launches more per forward.  (A launch failure between the fork
-  // and the join returns with the side stream un-joined: harmless for eager streams, it invalidates a stream capture.)
+  // and the join still joins the side stream: SideJoin.)
   SideQueue* sq = static_cast<SideQueue*>(p.side);
   const bool ct = (p.flags & GEOA3_PN2_CONTRACT) != 0;   // the _ext distances as nvcc's default contraction forms them
   // (while bench.py samples sa1_fwd_kernel's time the level runs as one launch per kernel)
   const bool use_side = sq != nullptr && !geoa3_prof_tag_on(GEOA3_PROF_SA1_FWD) && (size_t)N * 3 * sizeof(float) + 1024 <= 128 * 1024;
   hipStream_t s2 = use_side ? sq->stream : s;
+  SideJoin fork;
   constexpr int CH = 4;   // (1 / 2 / 4 / 8 equal launches measured: 4.228 / 4.221 / 4.196 / 4.205 ms per iteration)
   // (a smaller first launch -- 32 / 64 / 96 centroids -- to start the MLP earlier: 4.01-4.02 / 4.00-4.01 / 3.99 ms against 3.97)
   constexpr int cut[CH + 1] = {0, M1 / 4, M1 / 2, 3 * M1 / 4, M1};
@@ -423,6 +459,7 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
     TRY(launch_pn2_fps_range(w.xyz, B, N, M1, 0, cut[1], fps_td, w.idx1, s, ct));
     rows(0, cut[1], s);
     if (hipEventRecord(sq->ev[0], s) != hipSuccess || hipStreamWaitEvent(s2, sq->ev[0], 0) != hipSuccess) return GEOA3_ELAUNCH;
+    fork.arm(sq, s);   // from here to the join below every early return still joins the side stream
     TRY(launch_pn2_ball_query_range(w.nx1, w.xyz, B, N, M1, 0, cut[1], R1, S, w.gidx1, s, ct));
     for (int c = 1; c < CH; ++c) {   // sampler, centroid rows and ball query of chunk c: all on the side stream
       TRY(launch_pn2_fps_range(w.xyz, B, N, M1, cut[c], cut[c + 1], fps_td, w.idx1, s2, ct));
@@ -456,6 +493,7 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
     TRY(launch_sa2_pre(w.out1, false, 0, w.nx1, wfi.p, wfi.un, p.sa2_wx, rt, (long)B * M1, s));
   }
   if (use_side && hipStreamWaitEvent(s, sq->join, 0) != hipSuccess) return GEOA3_ELAUNCH;
+  fork.disarm();
   // gather + shift + relu, W1, W2 + max in one kernel; the activations a0 / a1 exist only as gate bits (m0 / m1)
   {
     const Img i1 = img_of(im, IM_SA2_W1), i2 = img_of(im, IM_SA2_W2);
@@ -484,6 +522,7 @@ extern "C" int geoa3_pn2ssg_forward(const geoa3_pn2ssg_weights* pw, const float*
   TRY(fc(w.p3, C3, p.f1, p.fb1, w.q1, 512, B, true, nullptr, s));
   TRY(fc(w.q1, 512, p.f2, p.fb2, w.q2, 256, B, true, nullptr, s));
   TRY(fc(w.q2, 256, p.f3, p.fb3, logits, p.classes, B, false, nullptr, s));
+  hipLaunchKernelGGL(poison_rows_kernel, g1d((long)B * p.classes), dim3(256), 0, s, logits, w.bad, p.classes, (long)B * p.classes);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }
@@ -504,6 +543,7 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   // ---- level 3: the pooled gradient reaches one point per channel: d h2 = relu'(h2) . sum_{ch : arg = point} g W2[ch]
   // (the sparse walk of the PointNet 1024-wide layers, in four 128-row slices of h2), then W1^T (two), Wf^T / Wx^T
   SideQueue* sq = static_cast<SideQueue*>(p.side);
+  SideJoin fork;
   for (int k0 = 0; k0 < 512; k0 += 128) {
     WideBwdArgs a{};
     a.g = w.g1024; a.arg = w.arg3;
@@ -519,6 +559,7 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   {   // level 3's coordinate gradient: first read by the side queue's kernels below, so it runs there too (in order)
     hipStream_t s3 = sq ? sq->stream : s;
     if (sq && (hipEventRecord(sq->ev[3], s) != hipSuccess || hipStreamWaitEvent(s3, sq->ev[3], 0) != hipSuccess)) return GEOA3_ELAUNCH;
+    if (sq) fork.arm(sq, s);   // the side stream holds work of this call until the join at the end: every early return joins it
     hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 256 * sizeof(float), s3, w.dh1, p.sa3_wx, 1.f,
                        w.dnx2, 256, M2, 0, (long)B * M2);
   }
@@ -592,8 +633,9 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
                      gx2, N, M1, side_tail ? 0 : 1);                                                   // gather(xyz, idx1)
   if (side_tail && (hipEventRecord(sq->join, st) != hipSuccess || hipStreamWaitEvent(s, sq->join, 0) != hipSuccess))
     return GEOA3_ELAUNCH;
+  fork.disarm();
   hipLaunchKernelGGL(points_to_planar_kernel, g1d((long)B * N), dim3(256), 0, s, w.gxyz, side_tail ? gx2 : (const float*)nullptr, dx,
-                     N, (long)B * N);
+                     N, (long)B * N, w.bad);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
 }

@@ -608,3 +608,41 @@ def test_pair_parallel_objective_with_overflowing_reverse_lists(ops, N, k, nblob
     one = {n: (v[1:2].contiguous() if torch.is_tensor(v) else v) for n, v in kw.items()}
     alone = ops.geo_loss_grad(advD[1:2].contiguous(), oriD[1:2].contiguous(), deterministic=True, **one)
     assert torch.equal(alone["grad"][0], grad[1])
+
+
+def test_pair_parallel_objective_more_overflowed_rows_than_pool_slots(ops):
+    """More rows overflow in ONE workgroup than the fixed-point pool has slots (128): a dense clean cloud (16 x the
+    adversarial cloud's points, the dense-cloud path's shape) whose nearest adversarial points are the 140 that stayed
+    near the surface, ~117 clean sources each.  Round 5 wrote NaN into those rows; now every overflowed row of such a
+    workgroup is summed by its owner's walk over the tables: finite, equal to the oracle's autograd
+    (Lib/loss_utils.py:28-50), bit-reproducible and batch-independent."""
+    B, N, Nr, stay = 2, 1024, 16384, 140
+    g = torch.Generator().manual_seed(17)
+    ori = torch.randn(B, 3, Nr, generator=g)
+    ori = ori / ori.norm(dim=1, keepdim=True)
+    adv = torch.randn(B, 3, N, generator=g)
+    adv = adv / adv.norm(dim=1, keepdim=True)
+    i = torch.arange(stay, dtype=torch.float64)                # the stayers on a Fibonacci lattice: equal shares of the clean cloud
+    z = 1.0 - (2.0 * i + 1.0) / stay
+    phi = i * (3.141592653589793 * (3.0 - 5.0 ** 0.5))
+    fib = torch.stack([(1 - z * z).sqrt() * phi.cos(), (1 - z * z).sqrt() * phi.sin(), z]).float()
+    adv[:, :, :stay] = fib.unsqueeze(0) + 1e-3 * torch.randn(B, 3, stay, generator=g)
+    adv[:, 0, stay:] += 10.0                                   # the others have left: no clean point is nearest to them
+    advD, oriD = dev(adv), dev(ori)
+    d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(advD, oriD)
+    rows = torch.bincount(i_oa[0].long().cpu(), minlength=N)
+    assert int((rows > 56).sum()) > 128 and int(rows[stay:].sum()) == 0      # > 128 overflowed rows (capacity 48), all in the first owner range
+    kw = dict(d_ao=d_ao, i_ao=i_ao, d_oa=d_oa, i_oa=i_oa, k=0, dis_type=1, w_dis=1.0, w_hd=0.1, w_curv=0.0)
+    out = ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)
+    a = adv.clone().requires_grad_()
+    con = O.chamfer_loss(a, ori) + 0.1 * O.hausdorff_loss(a, ori)
+    (want_g,) = torch.autograd.grad(con.sum(), a)
+    grad = out["grad"].clone()
+    assert torch.isfinite(grad).all()
+    np.testing.assert_allclose(out["constrain"].cpu().numpy(), con.detach().numpy(), rtol=5e-5, atol=1e-7)
+    np.testing.assert_allclose(grad.cpu().numpy(), want_g.numpy(), rtol=2e-4, atol=2e-6 * float(want_g.abs().max()))
+    for _ in range(3):
+        assert torch.equal(ops.geo_loss_grad(advD, oriD, deterministic=True, **kw)["grad"], grad)
+    one = {n: (v[1:2].contiguous() if torch.is_tensor(v) else v) for n, v in kw.items()}
+    alone = ops.geo_loss_grad(advD[1:2].contiguous(), oriD[1:2].contiguous(), deterministic=True, **one)
+    assert torch.equal(alone["grad"][0], grad[1])

@@ -586,3 +586,32 @@ def test_one_backend_everything_else_is_refused_loudly(pn2):
     import inspect
     import geoa3_amd.pointnet2 as mod
     assert "matmul" not in inspect.getsource(mod)
+
+
+def test_native_ssg_nan_input_is_loud(pn2):
+    """pointnet2_sa*.hip are compiled with -fno-honor-nans (relu / max without the canonicalising instruction): a NaN
+    coordinate must still surface -- non-finite logits for THAT cloud, untouched logits for its neighbours in the batch."""
+    sd = P2.make_pn2_state_dict(0)
+    net = pn2.PointNet2ClassificationSSG(use_xyz=True, use_normal=False)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    pc, _ = O.make_synthetic_clouds(3, 1024, seed=5)
+    with torch.no_grad():
+        clean = net(pc.cuda()).cpu()
+        bad = pc.clone()
+        bad[1, :, 100] = float("nan")
+        got = net(bad.cuda()).cpu()
+    assert torch.isfinite(clean).all()
+    assert torch.isnan(got[1]).all()
+    assert torch.equal(got[0], clean[0]) and torch.equal(got[2], clean[2])
+    # ... and so must its input gradient (the neighbours' stays finite and unchanged)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    w = torch.randn(3, 40, generator=torch.Generator().manual_seed(1)).cuda()
+    grads = []
+    for cloud in (pc, bad):
+        x = cloud.clone().cuda().requires_grad_()
+        (torch.nan_to_num(net(x)) * w).sum().backward()      # (the weights of the NaN rows do not matter: d logits is finite)
+        grads.append(x.grad.cpu())
+    assert torch.isnan(grads[1][1]).all() and torch.isfinite(grads[1][0]).all() and torch.isfinite(grads[1][2]).all()
+    assert torch.equal(grads[1][0], grads[0][0]) and torch.equal(grads[1][2], grads[0][2])
