@@ -56,7 +56,7 @@ TAG_SA2_FWD, TAG_SA2_BWD, TAG_SA2_GRAD = 8, 9, 10
 NTAGS = 12
 TAG_NAMES = {TAG_CONV5: "conv5_wide_max", TAG_TNET: "tnet_wide_max(x2)", TAG_NN1: "nn1_pair", TAG_KNN: "knn",
              TAG_GEO: "geo_loss_grad", TAG_SA1_BWD: "sa1_bwd", TAG_SA1_FWD: "sa1_fwd", TAG_SA2_FWD: "sa2_fwd",
-             TAG_SA2_BWD: "sa2_bwd", TAG_SA2_GRAD: "sa2_group_grad"}
+             TAG_SA2_BWD: "sa2_bwd", TAG_SA2_GRAD: "sa2_bwd_prep"}
 
 
 def cfg_full_geoa3(steps, npoint=NPOINT, knn=KNN):
@@ -230,8 +230,9 @@ def pn2_rooflines(kms, B):
                       2.0 * (128 * 64 + 64 * 64 + 64 * 3) * B * 512 * 64),
         TAG_SA2_FWD: ("sa2_fwd8_kernel (PointNet++ level 2: gather + shift + relu, 128->128, 128->256 + max, split-fp16 "
                       "operands)", 2.0 * (128 * 128 + 128 * 256) * B * 128 * 64),
-        TAG_SA2_BWD: ("sa2_bwd_kernel (PointNet++ level 2 input gradient: sparse pooled gradient through W2 rows, then "
-                      "W1^T on the matrix core)", 2.0 * (128 * 128 * 64 + 256 * 128) * B * 128),
+        TAG_SA2_BWD: ("sa2b_bwd_kernel (PointNet++ level 2 input gradient + the grouping's scatter-add, rows in destination "
+                      "order: sparse pooled gradient through W2 rows, W1^T on the matrix core, per-point sums on chip; "
+                      "algorithmic flops = the dense form's)", 2.0 * (128 * 128 * 64 + 256 * 128) * B * 128),
     }
     out = {}
     for tag, (name, flops) in spec.items():
@@ -462,7 +463,7 @@ def gpu_leg(bench, name, arch, npoint, knn, data, instances, steps, warmup, pres
         roofs = pn2_rooflines(kms, instances)
         big = max(roofs, key=lambda t: roofs[t]["avg_launch_ms"]) if roofs else None
         out["roofline"] = attach_traffic(roofs.get(big), {TAG_SA1_BWD: "sa1_bwd_kernel", TAG_SA2_FWD: "sa2_fwd8_kernel",
-                                                         TAG_SA2_BWD: "sa2_bwd_kernel"}.get(big, ""), "c4",
+                                                         TAG_SA2_BWD: "sa2b_bwd_kernel"}.get(big, ""), "c4",
                                          instances == BATCH and data == "ellipsoid")
         out["other_large_kernels"] = [roofs[t] for t in roofs if t != big]
     out["cd_kernel"] = cd_kernel_line(kms.get(TAG_NN1), instances, npoint)
@@ -662,7 +663,7 @@ def main():
             roofs = pn2_rooflines(kms, B)
             big = max(roofs, key=lambda t: roofs[t]["avg_launch_ms"]) if roofs else None
             out["roofline"] = attach_traffic(roofs.get(big), {TAG_SA1_BWD: "sa1_bwd_kernel", TAG_SA2_FWD: "sa2_fwd8_kernel",
-                                                             TAG_SA2_BWD: "sa2_bwd_kernel"}.get(big, ""), "c4", full_size)
+                                                             TAG_SA2_BWD: "sa2b_bwd_kernel"}.get(big, ""), "c4", full_size)
             out["other_large_kernels"] = [roofs[t] for t in roofs if t != big]
         if other is not None:
             omode, osteps, odt, okms = other

@@ -79,7 +79,7 @@ struct Ws {
   int32_t* bad;    // [B]: the cloud holds a NaN / Inf coordinate (its logits and its input gradient are NaN)
   // backward
   float *g256, *g512, *g1024, *dh2, *dh1, *dout2, *dnx2, *d1, *df1, *dnx1, *g1, *gxyz, *gnx1;
-  unsigned long long *m0, *m1;   // relu gates of the level-2 activations a0, a1 as bits [B * M2][128]
+  unsigned *m0, *m1;   // relu gates of the level-2 activations a0, a1 as bits per row: [B * M2][64][4]
   void* images;   // fragment images, when the caller passes none (geoa3_pn2ssg_weights::images == NULL)
   size_t total;
 };
@@ -106,7 +106,7 @@ Ws carve(void* base, int B, int N) {
   w.gidx2 = (int32_t*)take(b * M2 * S * 4);
   w.r = (float*)take(b * 128 * M1 * f);
   w.shift = (float*)take(b * 128 * M2 * f);
-  w.da0 = (float*)take(b * 128 * M2 * S * f);   // the level-2 activations a0 / a1 exist only as gate bits (m0 / m1)
+  w.da0 = (float*)take(sa2b_scratch_bytes(B));   // level 2's backward: rows, entries, tiles (the [B,128,128,64] grouped gradient this slot held until round 5 no longer exists)
   w.out2 = (float*)take(b * C2 * M2 * f);
   w.arg2 = (int32_t*)take(b * C2 * M2 * 4);
   w.h1 = (float*)take(b * 256 * M2 * f);
@@ -130,8 +130,8 @@ Ws carve(void* base, int B, int N) {
   w.gxyz = (float*)take(b * N * 3 * f);
   w.gnx1 = (float*)take(b * M1 * 3 * f);
   w.bad = (int32_t*)take(b * 4);
-  w.m0 = (unsigned long long*)take(b * M2 * 128 * 8);
-  w.m1 = (unsigned long long*)take(b * M2 * 128 * 8);
+  w.m0 = (unsigned*)take(b * M2 * S * 16);
+  w.m1 = (unsigned*)take(b * M2 * S * 16);
   w.images = take(img_off(IM_COUNT));
   w.total = off;
   return w;
@@ -565,59 +565,29 @@ extern "C" int geoa3_pn2ssg_backward(const geoa3_pn2ssg_weights* pw, const float
   }
   // ---- level 2: pooled layer's sparse gradient -> W2^T -> W1^T -> the grouping's scatter-add, in ONE pass over the rows
   // ordered by the point they gather from (pointnet2_sa2b.hip): the [B,128,128,64] grouped gradient never exists
-#ifdef GEOA3_SA2_CENTRE_MAJOR   // (tools: the round-5 pair of kernels around the 1.05 GB tensor, for A/B runs)
-  float* ent_g = w.d1;   // the level-1 scratch, free until sa1_backward
-  int32_t* ent_c = reinterpret_cast<int32_t*>(w.d1 + (size_t)B * M2 * C2);
-  TRY(launch_sa2_sort_cm(w.dout2, w.out2, w.arg2, ent_g, ent_c, B, M2, s));   // gate, both transposes and the per-centre sort
-  float* da0 = w.da0;
-  {
-    const Img i1t = img_of(im, IM_SA2_W1T);
-    geoa3_prof_begin(GEOA3_PROF_SA2_BWD, s);
-    TRY(launch_sa2_bwd(ent_g, ent_c, p.sa2_w2, i1t.p, i1t.un, w.m1, w.m0, da0, B, M2, s));
-    geoa3_prof_end(GEOA3_PROF_SA2_BWD, s);
-  }
-  float *dr = w.r, *dshift = w.shift;
-  // (the grouping gradient of a range of instances on the side queue beside the next range's sa2_bwd_kernel was measured:
-  // two ranges 4.256 ms against 4.259, four 4.33, three 4.40 -- both kernels are bound by memory traffic: DESIGN 8)
-  geoa3_prof_begin(GEOA3_PROF_SA2_GRAD, s);
-  TRY(geoa3_pn2_group_points_grad_sums(da0, w.gidx2, B, 128, M1, M2, S, dr, dshift, stream));
-  geoa3_prof_end(GEOA3_PROF_SA2_GRAD, s);
-  {   // d f1 = W_f^T dr, written centroid-major for level 1's backward (no [B,128,512] tensor, no transpose)
-    const Img wti = img_of(im, IM_SA2_WFT);
-    TRY(launch_sa2_pre(dr, true, M1, nullptr, wti.p, wti.un, nullptr, w.g1, (long)B * M1, s));
-  }
-#else
   float* dr = w.r;          // [B][512][128] POINT-major
-  void* sb = w.da0;         // the pass's scratch (0.64 MB per cloud of the 4 MB the grouped gradient took)
+  void* sb = w.da0;         // the pass's scratch (0.4 MB per cloud)
   geoa3_prof_begin(GEOA3_PROF_SA2_GRAD, s);
-  TRY(launch_sa2b_prep(w.dout2, w.out2, w.arg2, w.gidx2, w.m1, w.m0, sb, dr, B, s));
+  TRY(launch_sa2b_prep(w.dout2, w.out2, w.arg2, w.gidx2, sb, dr, B, s));
   geoa3_prof_end(GEOA3_PROF_SA2_GRAD, s);
   {
     const Img i1t = img_of(im, IM_SA2_W1T);
     geoa3_prof_begin(GEOA3_PROF_SA2_BWD, s);
-    TRY(launch_sa2b_bwd(sb, p.sa2_w2, i1t.p, i1t.un, p.sa2_wx, dr, B, s));
+    TRY(launch_sa2b_bwd(sb, w.m1, w.m0, p.sa2_w2, i1t.p, i1t.un, p.sa2_wx, dr, B, s));
     geoa3_prof_end(GEOA3_PROF_SA2_BWD, s);
   }
   {   // d f1 = W_f^T dr, written centroid-major for level 1's backward
     const Img wti = img_of(im, IM_SA2_WFT);
     TRY(launch_sa2_pre(dr, false, 0, nullptr, wti.p, wti.un, nullptr, w.g1, (long)B * M1, s));
   }
-#endif
   // the coordinate gradients of the level (three small kernels, needed only behind level 1's backward) on the side queue
   // beside sa1_bwd_kernel
   const bool side_tail = sq != nullptr;   // (3.934 ms against 3.965)
   hipStream_t st = side_tail ? sq->stream : s;
   if (side_tail && (hipEventRecord(sq->ev[1], s) != hipSuccess || hipStreamWaitEvent(st, sq->ev[1], 0) != hipSuccess))
     return GEOA3_ELAUNCH;
-#ifdef GEOA3_SA2_CENTRE_MAJOR
-  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M1), dim3(256), 3 * 128 * sizeof(float), st, dr, p.sa2_wx, 1.f, w.dnx1,
-                     128, M1, 0, (long)B * M1);                                                        // d xyz1 = W_x^T dr
-  hipLaunchKernelGGL(affine3_grad_kernel, g1d((long)B * M2), dim3(256), 3 * 128 * sizeof(float), st, dshift, p.sa2_wx, -1.f,
-                     w.dnx2, 128, M2, 1, (long)B * M2);                                                // d c -= W_x^T dshift
-#else
   TRY(launch_affine3_grad_pm(dr, p.sa2_wx, w.dnx1, (long)B * M1, st));                                 // d xyz1 = W_x^T dr
   TRY(launch_sa2b_centre(sb, w.dnx2, B, st));                                                          // d c -= W_x^T d shift
-#endif
   hipLaunchKernelGGL(scatter_rows3_kernel, dim3((M1 + 255) / 256, B), dim3(256), M2 * sizeof(int32_t), st, w.dnx2, w.idx2,
                      w.dnx1, M1, M2, 1);                                                               // gather(new_xyz1, idx2)
   // ---- level 1

@@ -14,7 +14,7 @@
 //   sa2b_prep_kernel   one workgroup per cloud: the hit rows (centre, sample) counted, ranked by (destination, centre) through
 //                      per-destination centre bit sets (deterministic: no arrival order anywhere), cut into P parts at
 //                      destination boundaries and into tiles of 64 rows; the pooled gradient's live entries (channel, value)
-//                      laid out row by row in that order; both relu gates transposed to 128-bit words per row
+//                      laid out row by row in that order
 //   sa2b_bwd_kernel    one workgroup per (cloud, part), two tiles at a time: phase 1 the sparse W2 product into an fp32 tile
 //                      in LDS (lane = k, W2 rows 32 entries ahead), phase 2 W1^T on the matrix core with split-fp16 operands
 //                      (the tile's own power-of-two scale), gated result back into the tile, phase 3 two wavefronts walk the
@@ -40,10 +40,8 @@ constexpr int SB_TILES = SB_ROWS / 64 + SB_P;   // most tiles
 #endif
 
 // per-cloud scratch (bytes), in this order
-constexpr size_t SB_OFF_KEY = 0;                                   // int32 [8192]  dest | centre << 9 | sample << 16 | last-of-dest << 31
-constexpr size_t SB_OFF_G1 = SB_OFF_KEY + (size_t)SB_ROWS * 4;     // uint4 [8192]  a1 > 0, bit k
-constexpr size_t SB_OFF_G0 = SB_OFF_G1 + (size_t)SB_ROWS * 16;     // uint4 [8192]  a0 > 0, bit i
-constexpr size_t SB_OFF_EC = SB_OFF_G0 + (size_t)SB_ROWS * 16;     // int32 [32768] channel | column << 16 | last-of-row << 31
+constexpr size_t SB_OFF_KEY = 0;                                   // int32 [8192]  dest | sample << 9 | centre << 15 | last-of-dest << 31
+constexpr size_t SB_OFF_EC = SB_OFF_KEY + (size_t)SB_ROWS * 4;     // int32 [32768] channel | column << 16 | last-of-row << 31
 constexpr size_t SB_OFF_EG = SB_OFF_EC + (size_t)SB_ENT * 4;       // float [32768]
 constexpr size_t SB_OFF_TD = SB_OFF_EG + (size_t)SB_ENT * 4;       // int4 [SB_TILES] row0, rows, entry0, entries | (entries of rows 0-31) << 16
 constexpr size_t SB_OFF_PT = SB_OFF_TD + (size_t)SB_TILES * 16;    // int32 [8]: tile prefix of the parts
@@ -56,8 +54,6 @@ struct SbPrepArgs {
   const float* outp;               // [B][256][128] out2 (relu gate of the pooled layer)
   const int32_t* arg;              // [B][256][128] arg-max sample
   const int32_t* gidx;             // [B][128][64] ball query
-  const unsigned long long* m1;    // [B * 128][128] a1 > 0, bit s
-  const unsigned long long* m0;
   unsigned char* scratch;          // [B][SB_BYTES]
   float* dr;                       // [B][512][128]: rows of destinations no hit row gathers from are zeroed here
 };
@@ -83,22 +79,6 @@ __device__ __forceinline__ int sb_part_of(const int* pb, int pos) {
 #pragma unroll
   for (int q = 1; q < SB_P; ++q) p += pos >= pb[q] ? 1 : 0;
   return p;
-}
-
-// 64 x 64 bit matrix across a wavefront: lane i holds row i (bit j = M[i][j]) -> lane j holds column j (bit i = M[i][j]);
-// six exchange rounds with the lane 32 / 16 / .. / 1 away (the recursive block transpose)
-__device__ __forceinline__ unsigned long long sb_transpose64(unsigned long long x, int lane) {
-  constexpr unsigned long long M[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
-                                       0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const int d = 32 >> r;
-    const unsigned long long m = M[r];
-    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)x, d, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), d, 64);
-    const unsigned long long p = ((unsigned long long)hi << 32) | lo;
-    x = (lane & d) ? ((x & ~m) | ((p & ~m) >> d)) : ((x & m) | ((p & m) << d));
-  }
-  return x;
 }
 
 // exclusive scan of n ints in LDS in place by the whole workgroup (n <= 8 * SBP_T); returns the total to every thread
@@ -144,8 +124,6 @@ __global__ __launch_bounds__(SBP_T) void sa2b_prep_kernel(SbPrepArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* sc = A.scratch + (size_t)b * SB_BYTES;
   int32_t* rkey = reinterpret_cast<int32_t*>(sc + SB_OFF_KEY);
-  uint4* rg1 = reinterpret_cast<uint4*>(sc + SB_OFF_G1);
-  uint4* rg0 = reinterpret_cast<uint4*>(sc + SB_OFF_G0);
   int32_t* ec = reinterpret_cast<int32_t*>(sc + SB_OFF_EC);
   float* eg = reinterpret_cast<float*>(sc + SB_OFF_EG);
   int4* tdesc = reinterpret_cast<int4*>(sc + SB_OFF_TD);
@@ -179,6 +157,13 @@ __global__ __launch_bounds__(SBP_T) void sa2b_prep_kernel(SbPrepArgs A) {
   stage_load(0, st);
 
   for (int e = tid; e < SB_N1 * 4; e += SBP_T) (&L.mask[0][0])[e] = 0u;
+  {   // the ball query's destinations: the whole [128][64] table in one round of loads
+    int gv[SB_ROWS / SBP_T];
+#pragma unroll
+    for (int i = 0; i < SB_ROWS / SBP_T; ++i) gv[i] = A.gidx[(size_t)b * SB_ROWS + i * SBP_T + tid];
+#pragma unroll
+    for (int i = 0; i < SB_ROWS / SBP_T; ++i) (&L.dst[0][0])[i * SBP_T + tid] = (unsigned short)gv[i];
+  }
   // ---- pass 1: live entries per (centre, sample); the ball query's destinations
   for (int m0 = 0; m0 < SB_M; m0 += SBP_ROUND) {
     __syncthreads();
@@ -194,7 +179,6 @@ __global__ __launch_bounds__(SBP_T) void sa2b_prep_kernel(SbPrepArgs A) {
         if (L.g[ml][q * 64 + lane] != 0.f) atomicAdd(&L.hist[wave][L.a[ml][q * 64 + lane]], 1);
       const int c = L.hist[wave][lane];          // (LDS operations of a wave complete in order)
       L.cnt[m][lane] = (unsigned short)c;
-      L.dst[m][lane] = (unsigned short)A.gidx[((size_t)b * SB_M + m) * SB_S + lane];
       const unsigned long long hm = __ballot(c > 0);
       if (lane == 0) hit[m] = hm;
     }
@@ -249,7 +233,7 @@ __global__ __launch_bounds__(SBP_T) void sa2b_prep_kernel(SbPrepArgs A) {
       const int pos = L.dstart[j] + rank;
       L.rpos[m][s] = (unsigned short)pos;
       L.rent[pos] = c;
-      rkey[pos] = j | (m << 9) | (s << 16) | (pos == L.dstart[j + 1] - 1 ? (int)0x80000000 : 0);
+      rkey[pos] = j | (s << 9) | (m << 15) | (pos == L.dstart[j + 1] - 1 ? (int)0x80000000 : 0);
     }
   }
   __syncthreads();
@@ -292,8 +276,7 @@ __global__ __launch_bounds__(SBP_T) void sa2b_prep_kernel(SbPrepArgs A) {
     tdesc[t] = make_int4(row0, rows, e0, (e1 - e0) | ((em - e0) << 16));
   }
   if (GEOA3_SB_STOP == 2) return;
-  // ---- pass 2: the entries row by row (ascending channel inside a row: the stable counting sort of sa2_sort_centre),
-  // and the rows' gate words
+  // ---- pass 2: the entries row by row (ascending channel inside a row: a stable counting sort by sample)
   for (int m0 = 0; m0 < SB_M; m0 += SBP_ROUND) {
     __syncthreads();
     stage_store(st);
@@ -302,10 +285,6 @@ __global__ __launch_bounds__(SBP_T) void sa2b_prep_kernel(SbPrepArgs A) {
 #pragma unroll 1
     for (int i = 0; i < SBP_ROUND / SBP_W; ++i) {
       const int ml = wave * (SBP_ROUND / SBP_W) + i, m = m0 + ml;
-      // (the centre's gate words: requested here, used behind the entries)
-      const unsigned long long* w1 = A.m1 + ((size_t)b * SB_M + m) * S2_K;
-      const unsigned long long* w0 = A.m0 + ((size_t)b * SB_M + m) * S2_K;
-      const unsigned long long a1lo = w1[lane], a1hi = w1[64 + lane], a0lo = w0[lane], a0hi = w0[64 + lane];
       int* run = L.run[wave];
       run[lane] = 0;                               // entries of sample `lane` placed so far
       const unsigned long long below = (1ull << lane) - 1ull;
@@ -334,15 +313,6 @@ __global__ __launch_bounds__(SBP_T) void sa2b_prep_kernel(SbPrepArgs A) {
         if (live && r == 0) run[s] = start + n;    // one lane per sample: the next round's entries follow
       }
       // gate words of the centre's hit rows: bit k of row (m, s) = bit s of word k
-      if (GEOA3_SB_STOP != 3) {   // lane = k holds bit s  ->  lane = s holds bit k: the row's 128-bit words, all hit rows at once
-        const unsigned long long g1a = sb_transpose64(a1lo, lane), g1b = sb_transpose64(a1hi, lane);
-        const unsigned long long g0a = sb_transpose64(a0lo, lane), g0b = sb_transpose64(a0hi, lane);
-        if (L.cnt[m][lane] > 0) {
-          const int pos = L.rpos[m][lane];
-          rg1[pos] = make_uint4((unsigned)g1a, (unsigned)(g1a >> 32), (unsigned)g1b, (unsigned)(g1b >> 32));
-          rg0[pos] = make_uint4((unsigned)g0a, (unsigned)(g0a >> 32), (unsigned)g0b, (unsigned)(g0b >> 32));
-        }
-      }
     }
   }
 }
@@ -350,6 +320,8 @@ __global__ __launch_bounds__(SBP_T) void sa2b_prep_kernel(SbPrepArgs A) {
 // ------------------------------------------------------------------------------------------------------------------
 struct SbBwdArgs {
   const unsigned char* scratch;    // [B][SB_BYTES] (sa2b_prep_kernel)
+  const uint4* m1;                 // [B * 128][64]: a1 > 0 of the row, bit k (the forward's gate words)
+  const uint4* m0;                 // a0 > 0, bit i
   const float* W2;                 // [256][128]
   const _Float16* w1img;           // W1^T as a fragment image (frag_image_kernel)
   const float* w1un;               // [1]: 1 / the image's power-of-two scale
@@ -373,8 +345,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int b = blockIdx.x / SB_P, part = blockIdx.x % SB_P;
   const unsigned char* sc = a.scratch + (size_t)b * SB_BYTES;
   const int32_t* rkey = reinterpret_cast<const int32_t*>(sc + SB_OFF_KEY);
-  const uint4* rg1 = reinterpret_cast<const uint4*>(sc + SB_OFF_G1);
-  const uint4* rg0 = reinterpret_cast<const uint4*>(sc + SB_OFF_G0);
+  const uint4* rg1 = a.m1 + (size_t)b * SB_ROWS;   // indexed by centre * 64 + sample
+  const uint4* rg0 = a.m0 + (size_t)b * SB_ROWS;
   const int32_t* ec = reinterpret_cast<const int32_t*>(sc + SB_OFF_EC);
   const float* eg = reinterpret_cast<const float*>(sc + SB_OFF_EG);
   const int4* tdesc = reinterpret_cast<const int4*>(sc + SB_OFF_TD);
@@ -439,8 +411,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int4 d = tile_desc(t);
     const bool ok = lane < d.y;
     r.key = ok ? rkey[d.x + lane] : 0;
-    r.g1 = ok ? rg1[d.x + lane] : make_uint4(0u, 0u, 0u, 0u);
-    r.g0 = ok ? reinterpret_cast<const uint2*>(rg0 + d.x + lane)[hf] : make_uint2(0u, 0u);
+    const int ms = (r.key >> 9) & (SB_ROWS - 1);             // centre * 64 + sample (bits 9-14 | 15-21 of the key)
+    r.g1 = ok ? rg1[ms] : make_uint4(0u, 0u, 0u, 0u);
+    r.g0 = ok ? reinterpret_cast<const uint2*>(rg0 + ms)[hf] : make_uint2(0u, 0u);
   };
 
   constexpr int PF = 16;   // W2 rows in flight per wave (512 bytes each)
@@ -630,7 +603,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (cc < (half == 0 ? rowsA : rowsB)) {
           const float4 ya = s_y[(half * 2 + 0) * 64 + cc], yb = s_y[(half * 2 + 1) * 64 + cc];
           const int key = s_key[half * 64 + cc];
-          float* yp = yrow + (size_t)(((key >> 9) & 127) * SB_S + ((key >> 16) & 63)) * 3;
+          float* yp = yrow + (size_t)((key >> 9) & (SB_ROWS - 1)) * 3;
           yp[0] = ya.x + yb.x;
           yp[1] = ya.y + yb.y;
           yp[2] = ya.z + yb.z;
@@ -690,12 +663,12 @@ __global__ __launch_bounds__(256) void affine3_grad_pm_kernel(const float* __res
 
 size_t sa2b_scratch_bytes(int B) { return (size_t)B * SB_BYTES; }
 
-// dout / outp / arg [B][256][128] channel-major, gidx [B][128][64], m1 / m0 [B * 128][128] gate words of the forward;
+// dout / outp / arg [B][256][128] channel-major, gidx [B][128][64], m1 / m0 [B * 128][64][4] the forward's gate words per row;
 // dr [B][512][128] (point-major), dnx1 [B][512][3] = W_x^T dr, dnx2 [B][128][3] -= the centres' share.  M1 = 512 points,
 // M2 = 128 centres, 64 samples (PointNetPP_ssg.py:68-76).
-int launch_sa2b_prep(const float* dout, const float* outp, const int32_t* arg, const int32_t* gidx, const unsigned long long* m1,
-                     const unsigned long long* m0, void* scratch, float* dr, int B, hipStream_t s) {
-  SbPrepArgs a{dout, outp, arg, gidx, m1, m0, static_cast<unsigned char*>(scratch), dr};
+int launch_sa2b_prep(const float* dout, const float* outp, const int32_t* arg, const int32_t* gidx, void* scratch, float* dr, int B,
+                     hipStream_t s) {
+  SbPrepArgs a{dout, outp, arg, gidx, static_cast<unsigned char*>(scratch), dr};
   const int lds = (int)sizeof(SbPrepLds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2b_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(sa2b_prep_kernel, dim3(B), dim3(SBP_T), lds, s, a);
@@ -703,9 +676,10 @@ int launch_sa2b_prep(const float* dout, const float* outp, const int32_t* arg, c
   return GEOA3_OK;
 }
 
-int launch_sa2b_bwd(const void* scratch, const float* W2, const void* w1t_img, const float* w1t_un, const float* Wx, float* dr,
-                    int B, hipStream_t s) {
-  SbBwdArgs a{static_cast<const unsigned char*>(scratch), W2, static_cast<const _Float16*>(w1t_img), w1t_un, Wx, dr,
+int launch_sa2b_bwd(const void* scratch, const unsigned* m1, const unsigned* m0, const float* W2, const void* w1t_img,
+                    const float* w1t_un, const float* Wx, float* dr, int B, hipStream_t s) {
+  SbBwdArgs a{static_cast<const unsigned char*>(scratch), reinterpret_cast<const uint4*>(m1), reinterpret_cast<const uint4*>(m0), W2,
+              static_cast<const _Float16*>(w1t_img), w1t_un, Wx, dr,
               const_cast<unsigned char*>(static_cast<const unsigned char*>(scratch))};
   const int lds = sa2b_bwd_lds();
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2b_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -188,15 +188,11 @@ int launch_reduce_dT(const float* part, int nparts, float* dT, int B, hipStream_
 // [hi / lo][lane][8 halves], un[0] = 1 / the image's power-of-two scale (R * K * 4 bytes; one workgroup, run once per
 // set of weights)
 int launch_frag_image(const float* W, int R, int K, void* img, float* un, hipStream_t s);
-// backward of both hidden layers in one kernel: entries sorted by arg-max sample, then
-// d a0 = gate0 . W1^T (gate1 . sparse(W2, g, arg))
-int launch_sa2_sort(const float* gz, const int32_t* argt, float* ent_g, int32_t* ent_c, long centres, hipStream_t s);
-int launch_sa2_bwd(const float* ent_g, const int32_t* ent_c, const float* W2, const void* w1t_img, const float* w1t_un,
-                   const unsigned long long* m1, const unsigned long long* m0, float* da0, int B, int M, hipStream_t s);
 // the level's forward in one kernel: out = relu(max_s W2 relu(W1 relu(rT[gidx] + shift) + b1) + b2), arg, gate bits m0 / m1
+// per ROW: [B * M][64 samples][4 words of 32 channels]
 int launch_sa2_fwd(const float* rT, const int32_t* gidx, const float* shift, const void* w1_img, const float* w1_un,
                    const float* b1, const void* w2_img, const float* w2_un, const float* b2, float* out, int32_t* arg,
-                   unsigned long long* m0, unsigned long long* m1, int B, int N1, int M, hipStream_t s);
+                   unsigned* m0, unsigned* m1, int B, int N1, int M, hipStream_t s);
 
 // PointNet++ level 1 in centroid ranges (pointnet2_net.hip pipelines the sampler's rounds against the MLP of the centroids
 // it has already chosen): the sampler's rounds j0 .. j1 - 1 (resuming from `temp`), ball query and forward MLP of centroids
@@ -211,16 +207,13 @@ int launch_sa1_forward_range(const float* xyz, const float* new_xyz, const int32
 // X point-major [P][128], or channel-major [P / Np][128][Np] (the backward's d f = W_f^T d r with W = the image of W_f^T)
 int launch_sa2_pre(const float* X, bool x_channel_major, int Np, const float* xyz, const void* wf_img, const float* wf_un,
                    const float* Wx, float* Y, long P, hipStream_t s);
-// sa2_bwd_kernel's sorted (value, channel) lists straight from d out2 / out2 (relu gate) / arg2, all channel-major [B][256][M]
-int launch_sa2_sort_cm(const float* dout, const float* outp, const int32_t* arg, float* ent_g, int32_t* ent_c, int B, int M,
-                       hipStream_t s);
 // level 2's backward with the rows in destination order (pointnet2_sa2b.hip): prep (rows, entries, gate words per cloud) ->
 // the pass (d r [B][512][128] point-major, the rows' coordinate terms) -> d c of the centres; W_x^T of a point-major tensor
 size_t sa2b_scratch_bytes(int B);
-int launch_sa2b_prep(const float* dout, const float* outp, const int32_t* arg, const int32_t* gidx, const unsigned long long* m1,
-                     const unsigned long long* m0, void* scratch, float* dr, int B, hipStream_t s);
-int launch_sa2b_bwd(const void* scratch, const float* W2, const void* w1t_img, const float* w1t_un, const float* Wx, float* dr,
-                    int B, hipStream_t s);
+int launch_sa2b_prep(const float* dout, const float* outp, const int32_t* arg, const int32_t* gidx, void* scratch, float* dr, int B,
+                     hipStream_t s);
+int launch_sa2b_bwd(const void* scratch, const unsigned* m1, const unsigned* m0, const float* W2, const void* w1t_img,
+                    const float* w1t_un, const float* Wx, float* dr, int B, hipStream_t s);
 int launch_sa2b_centre(const void* scratch, float* dnx2, int B, hipStream_t s);
 int launch_affine3_grad_pm(const float* dY, const float* Wx, float* dp, long points, hipStream_t s);
 // geoa3_pn2_sa1_backward with an event recorded between its two kernels (grad_new_xyz complete, grad_xyz not yet)

@@ -10,8 +10,8 @@
 #define GEOA3_PROF_FC 6       // fully connected chains (all launches of one forward or backward chain)
 #define GEOA3_PROF_GEO 7      // geo_loss_grad_kernel
 #define GEOA3_PROF_SA2_FWD 8  // sa2_fwd8_kernel: PointNet++ level 2, gather + MLP + max
-#define GEOA3_PROF_SA2_BWD 9  // sa2_bwd_kernel: level 2, pooled gradient -> grouped input gradient
-#define GEOA3_PROF_SA2_GRAD 10 // level 2, grouped gradient -> per-point sums (group_points_grad)
+#define GEOA3_PROF_SA2_BWD 9  // sa2b_bwd_kernel: level 2, pooled gradient -> per-point input gradient (rows in destination order)
+#define GEOA3_PROF_SA2_GRAD 10 // sa2b_prep_kernel: the rows / entries / tiles of that pass
 bool geoa3_prof_on();
 bool geoa3_prof_tag_on(int tag);   // this tag is being sampled (bench.py's per-kernel figures)
 void geoa3_prof_begin(int tag, hipStream_t s);

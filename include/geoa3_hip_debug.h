@@ -21,7 +21,7 @@ extern "C" {
  * tag: 0 = conv5+max (wide_max_kernel<3>), 1 = geoa3_nn1_pair ("CD kernel"), 2 = geoa3_knn,
  *      3 = T-Net conv3+max (wide_max_kernel<1>), 4 / 5 = PointNet++ level 1 backward / forward (sa1_*_kernel),
  *      6 = the fully connected chains, 7 = geo_loss_grad_kernel, 8 / 9 = PointNet++ level 2 forward / backward
- *      (sa2_fwd8_kernel, sa2_bwd_kernel), 10 = level 2's grouped gradient -> per-point sums.
+ *      (sa2_fwd8_kernel, sa2b_bwd_kernel), 10 = the backward's preparation pass (sa2b_prep_kernel).
  * ------------------------------------------------------------------------------------------ */
 int geoa3_profile_enable(int capacity);                 /* events for `capacity` launches per tag; 0 = off */
 int geoa3_profile_select(unsigned mask);                /* bit t set = tag t is recorded (default: all); an event

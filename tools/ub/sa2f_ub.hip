@@ -1,24 +1,9 @@
-// micro-benchmark of sa2_fwd_kernel (which phase bounds it?): hipcc --offload-arch=gfx950 -O3 -o sa2f_ub sa2f_ub.hip
+// micro-benchmark of sa2_fwd8_kernel (which phase bounds it?): hipcc --offload-arch=gfx950 -O3 -o sa2f_ub sa2f_ub.hip
 #include "../../geoa3_amd/csrc/pointnet2_sa2.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
-template <int MODE, int RING = 4>
-float run(const Sa2FwdArgs& a, int iters) {
-  const int lds = sa2_fwd_lds();
-  auto k = sa2_fwd_kernel<MODE, RING>;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k, dim3(512), dim3(256), lds, 0, a);
-  hipEventRecord(e0, 0);
-  for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k, dim3(512), dim3(256), lds, 0, a);
-  hipEventRecord(e1, 0);
-  hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
-  return ms * 1000.f / iters;
-}
 template <int MODE>
 float run8(const Sa2FwdArgs& a, int iters) {
   const int lds = sa2_fwd8_lds();
@@ -55,7 +40,7 @@ int main() {
   for (auto& v : w2) v = 0.1f * rnd();
   for (auto& v : b1) v = 0.1f * rnd();
   for (auto& v : b2) v = 0.1f * rnd();
-  float *drT, *dsh, *dw1, *dw2, *db1, *db2, *out; int *didx, *arg; unsigned long long *m0, *m1; char* scr;
+  float *drT, *dsh, *dw1, *dw2, *db1, *db2, *out; int *didx, *arg; unsigned *m0, *m1; char* scr;
   hipMalloc(&drT, rT.size() * 4); hipMalloc(&dsh, shift.size() * 4); hipMalloc(&dw1, w1.size() * 4); hipMalloc(&dw2, w2.size() * 4);
   hipMalloc(&db1, 512); hipMalloc(&db2, 1024); hipMalloc(&out, centres * 256 * 4); hipMalloc(&arg, centres * 256 * 4);
   hipMalloc(&didx, idx.size() * 4); hipMalloc(&m0, centres * 128 * 8); hipMalloc(&m1, centres * 128 * 8); hipMalloc(&scr, 196608 + 512);
@@ -76,16 +61,5 @@ int main() {
   printf("fwd8 no pooled stores  %.1f us\n", run8<3>(a, 5));
   printf("fwd8 no gather         %.1f us\n", run8<4>(a, 5));
   printf("fwd8 all               %.1f us\n", run8<0>(a, 5));
-  printf("mode0 (all)            %.1f us\n", run<0>(a, 5));
-  printf("mode1 (no gather)      %.1f us\n", run<1>(a, 5));
-  printf("mode2 (no W1 MFMAs)    %.1f us\n", run<2>(a, 5));
-  printf("mode3 (no W2 MFMAs)    %.1f us\n", run<3>(a, 5));
-  printf("mode4 (no pool stores) %.1f us\n", run<4>(a, 5));
-  printf("mode5 (no gate stores) %.1f us\n", run<5>(a, 5));
-  printf("mode6 (frag loads hoisted) %.1f us\n", run<6>(a, 5));
-  printf("mode0 ring 2           %.1f us\n", (run<0, 2>(a, 5)));
-  printf("mode0 ring 3           %.1f us\n", (run<0, 3>(a, 5)));
-  printf("mode0 ring 5           %.1f us\n", (run<0, 5>(a, 5)));
-  printf("mode0 (all)            %.1f us\n", run<0>(a, 5));
   return 0;
 }
