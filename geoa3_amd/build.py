@@ -31,7 +31,7 @@ def _hipcc() -> str:
 
 # per-file flags.  pointnet_conv_chain.hip: no SLP vectorisation = no packed-FP32 instructions (v_pk_mul_f32 / v_pk_fma_f32 with
 # SGPR-pair operands) in conv_bwd_chain_kernel, which with two wavefronts per SIMD computed wrong values in lanes 48-63
-# (found with tools/ub/dtpart_pair.hip; the same source with the packed instructions: ~1e-4 of the workgroups).
+# (NOTEBOOK 5a: found with tools/ub/dtpart_pair.hip; the same source with the packed instructions: ~1e-4 of the workgroups).
 # pointnet_conv_split.hip: the one-layer-per-launch kernels the chains are held to BIT FOR BIT (tests/test_gpu_pointnet.py)
 # must contract their multiply-adds the same way (no cost: configs[1] does not run them, configs[3] +0.2 %).
 # (pointnet_gemm.hip -- the FC heads -- loses 4 % of the iteration without SLP and is left alone.)
@@ -39,7 +39,7 @@ def _hipcc() -> str:
 # of every one of them (a sixth of the level-1 kernels' vector instructions); NaNs still propagate through the products.
 # -fno-slp-vectorize there: the operand split stays at two instructions per element (sa_split2).
 # -fno-slp-vectorize: the SLP vectoriser's packed-FP32 instructions (v_pk_add / mul / fma_f32) are behind three sightings of
-# wrong values on gfx950 (conv_bwd_chain_kernel at two waves per SIMD; the sampler beside sa1_fwd_kernel;
+# wrong values on gfx950 (NOTEBOOK 5a: conv_bwd_chain_kernel at two waves per SIMD; the sampler beside sa1_fwd_kernel;
 # geo_fused_kernel's long-row path at four waves per SIMD) -- every file compiles without them except the ONE where the
 # packing pays (pointnet_gemm.hip: conv_cm64_kernel and the FC kernels, +4.6 % on configs[1] without it; every other file 0:
 # tools/gpu_ab_noslp.sh), whose kernels stay under the replay soak's seven shapes.
@@ -83,7 +83,7 @@ def _digest(path: str, flags=None) -> str:
 def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
     flags_in = tuple(flags or ())
     flags = list(flags or FLAGS)
-    if "--no-file-flags" in flags:     # (tools: the build WITHOUT the per-file flags, e.g. the faulty one of DESIGN 5a)
+    if "--no-file-flags" in flags:     # (tools: the build WITHOUT the per-file flags, e.g. the faulty one of NOTEBOOK 5a)
         flags.remove("--no-file-flags")
     elif os.path.basename(src) in os.environ.get("GEOA3_NO_FILE_FLAGS_FOR", "").split(",") and objdir != OBJDIR:
         pass                           # (tools: a variant build without SOME files' flags)
@@ -115,7 +115,7 @@ def _compile(src: str, force: bool, objdir: str = OBJDIR, flags=None) -> str:
     return obj
 
 
-# kernels that must not hold packed-FP32 instructions: checked on the ISA the build's own flags produce, so that a
+# kernels that must not hold packed-FP32 instructions (NOTEBOOK 5a): checked on the ISA the build's own flags produce, so that a
 # lost per-file flag -- or a compiler that forms v_pk_*_f32 in another pass -- fails the BUILD instead of shipping a kernel
 # that is silently wrong in ~1e-4 of its workgroups
 # (round 5: and the farthest-point sampler, whose SLP-packed distance update is exact alone and wrong in 1.4e-3 of its rounds
@@ -129,7 +129,7 @@ ISA_GUARDS = {"pointnet_conv_chain.hip": ("conv_bwd_chain_kernel", r"v_pk_(mul|f
 # reads the HIGH half of a source register pair.  That is the form the stand-alone reproducer pins the fault on
 # (tools/ub/pk_neg_mfma_min.hip: v_pk_add / mul / fma_f32 with op_sel on src1 return src1 = 0 in lanes 48-63, ~1e-8 .. 5e-7 of
 # the executions, when the neighbouring wavefronts mix vector and f16 matrix instructions; op_sel_hi, neg and v_pk_mov_b32 are
-# clean: DESIGN 5a).  Only the SLP vectoriser forms it; every kernel that ever failed held one to eight of them.
+# clean: NOTEBOOK 5a).  Only the SLP vectoriser forms it; every kernel that ever failed held one to eight of them.
 # The pattern is deliberately wider than today's spelling (`op_sel:[0,1,0]`): any packed-FP32 arithmetic mnemonic (mul / fma /
 # add, with or without an encoding suffix) whose operand-select list -- `op_sel`, NOT `op_sel_hi` -- names a high half for
 # any source, whatever the separator a future disassembler prints.  tests/test_abi.py compiles a source that MUST be refused
@@ -184,7 +184,7 @@ def _isa_guard(src: str, flags) -> None:
         asm = open(out).read()
     hit = re.search(ISA_GUARD_ALL, asm)
     if hit:
-        raise RuntimeError("ISA guard: %s holds '%s' (DESIGN 5a: packed FP32 with op_sel reads a zero operand in lanes 48-63 "
+        raise RuntimeError("ISA guard: %s holds '%s' (NOTEBOOK 5a: packed FP32 with op_sel reads a zero operand in lanes 48-63 "
                            "beside matrix-core wavefronts); keep the two values apart (an opaque asm barrier) or compile the "
                            "file with %s" % (os.path.basename(src), hit.group(0).strip(), " ".join(_NOSLP)))
     if kernel is None:
@@ -197,7 +197,7 @@ def _isa_guard(src: str, flags) -> None:
         body = body[:body.index("s_endpgm")]
         hit = re.search(pattern, body)
         if hit:
-            raise RuntimeError("ISA guard: %s holds %s (DESIGN 5a: wrong values beside other wavefronts on its SIMDs); compile "
+            raise RuntimeError("ISA guard: %s holds %s (NOTEBOOK 5a: wrong values beside other wavefronts on its SIMDs); compile "
                                "%s with %s" % (m.group(1), hit.group(0), os.path.basename(src),
                                                FILE_FLAGS.get(os.path.basename(src))))
 

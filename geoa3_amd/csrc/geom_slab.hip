@@ -23,7 +23,7 @@ constexpr int SK_CHUNK = 1024;
 constexpr float S_INF = __builtin_inff();
 
 // (per-instance records and rows written by one workgroup each and read by the next kernel: a 128-byte line of their own,
-//  no two workgroups -- XCDs -- write into one cache line)
+//  no two workgroups -- XCDs -- write into one cache line; NOTEBOOK 5a)
 struct alignas(128) SlabGeo {
   float lo, inv_w;
   int axis, pad;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(SB_T) void slab_bin_kernel(const float* __restrict_
 typedef float slab_f2 __attribute__((ext_vector_type(2)));
 // Two candidates' squared distances to the query per packed instruction.  The query arrives NEGATED (slab_negq, once per
 // query): the differences are x + (-q) -- plain v_pk_add_f32 without a source modifier.  (x - q)^2 and (q - x)^2 are the same
-// bits.  (Written while `neg` modifiers were suspected of the wrong values of DESIGN 5a; the form that matters turned out to be
+// bits.  (Written while `neg` modifiers were suspected of the wrong values of NOTEBOOK 5a; the form that matters turned out to be
 // op_sel, which these hand-built pairs never carried.  Kept: it costs nothing and the build refuses op_sel either way.)
 __device__ __forceinline__ void slab_sqdist2(float nqx, float nqy, float nqz, float x0, float x1, float y0, float y1,
                                              float z0, float z1, float& d0, float& d1) {
@@ -700,7 +700,7 @@ constexpr int KG_T = 1024, KG_PPT = 8;       // cell sort: up to 8192 points
 constexpr int KG_CAP = 256;                  // entries of a wave's candidate list
 constexpr int KG_QPW = 8;                    // queries per wave (sequential)
 
-constexpr int KG_PITCH = ((16 * 16 * 16 + 1 + 31) / 32) * 32;   // ints per row of cell starts: whole lines
+constexpr int KG_PITCH = ((16 * 16 * 16 + 1 + 31) / 32) * 32;   // ints per row of cell starts: whole lines (NOTEBOOK 5a)
 struct alignas(128) GridGeo {
   float lox, loy, loz, inv_h;
 };

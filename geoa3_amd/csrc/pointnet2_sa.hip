@@ -217,7 +217,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void sa_split2(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
   const float2v x = {x0, x1};
   // (the scale as a VECTOR register operand of the packed multiply: packed-FP32 instructions with SGPR-pair operands at
-  // two waves per SIMD are what computed wrong values in conv_bwd_chain_kernel -- DESIGN 5a; none are formed here)
+  // two waves per SIMD are what computed wrong values in conv_bwd_chain_kernel -- NOTEBOOK 5a; none are formed here)
   float sv = s;
   asm volatile("" : "+v"(sv));
   const half2v h = __builtin_convertvector(x * sv, half2v);

@@ -10,7 +10,7 @@
 // couples two rows (row = (centre, sample)), so the rows may be taken in any order: here in the order of the point they
 // gather FROM.  Then the grouping's scatter-add is a sum over CONSECUTIVE rows, finished on chip, and each point's 512-byte
 // gradient row is written once.  Only rows some pooled channel points at are formed at all (a ball holds 25-64 distinct
-// points, its 256 channels pick 22-40 of them: tests/...): the matrix-core work of the level's backward halves.
+// points, its 256 channels pick 22-40 of them: NOTEBOOK 10): the matrix-core work of the level's backward halves.
 //   sa2b_prep_kernel   one workgroup per cloud: the hit rows (centre, sample) counted, ranked by (destination, centre) through
 //                      per-destination centre bit sets (deterministic: no arrival order anywhere), cut into P parts at
 //                      destination boundaries and into tiles of 64 rows; the pooled gradient's live entries (channel, value)

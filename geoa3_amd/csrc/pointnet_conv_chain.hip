@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   dh2 = gate_h2( W3eff^T Ga + Wc1^T Gb )          Ga = d/d(pre-activation of h3), Gb = that of the T-Net's c1
 //   g1  = gate_first( W2^T dh2 ),  q = w1^T g1,  dx = T q,  dTpart = per-workgroup sums of x q^T
 // dh2 and g1 never leave the registers.
-// Two waves per SIMD -- and NO packed-FP32 instructions.  Compiled with SLP vectorisation (604 v_pk_mul_f32 /
+// Two waves per SIMD -- and NO packed-FP32 instructions (NOTEBOOK 5a).  Compiled with SLP vectorisation (604 v_pk_mul_f32 /
 // v_pk_fma_f32 / v_pk_add_f32, among them the 3x3 transform with SGPR-pair operands) this kernel computed wrong values in
 // lanes 48-63 of ~1e-4 of its workgroups whenever two of its wavefronts shared a SIMD: p = T3^T x came out wrong at the start,
 // d = T q and the dx stores at the end (stage checksums of tools/ub/conv_bwd_chain_probe.patch in tools/ub/dtpart_pair.hip);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
     if (a.T3) {   // bmm(pc^T, T)^T : x'[c] = sum_d x[d] T[d][c]   (Model/PointNet.py:138)
       const float* t = a.T3 + (size_t)b * 9;
       // (one scalar chain per coordinate, each behind an opaque barrier: the SLP vectoriser otherwise pairs them into
-      //  v_pk_fma_f32 with op_sel -- a LOW result reading the HIGH half of a register pair, the form DESIGN 5a's stand-alone
+      //  v_pk_fma_f32 with op_sel -- a LOW result reading the HIGH half of a register pair, the form NOTEBOOK 5a's stand-alone
       //  reproducer shows going wrong beside matrix-core wavefronts; same multiply-adds, same order, same bits)
       p0 = __builtin_fmaf(x2, t[6], __builtin_fmaf(x1, t[3], x0 * t[0]));
       asm volatile("" : "+v"(p0), "+v"(x0), "+v"(x1), "+v"(x2));

@@ -78,7 +78,10 @@ def wide_shape(layer: str = "conv5") -> int:
     """MFMA shape of a split 1024-wide layer: 16 = v_mfma_f32_16x16x32_f16 (pointnet_wide16.hip), 32 =
     v_mfma_f32_32x32x16_f16 (pointnet_wide_split.hip).  Measured on MI355X: conv5 (K = 384 per group) 0.495 -> 0.444 ms on
     the 16x16x32 shape, the T-Nets' conv3 (K = 128 per group: a third of the MFMAs between two epilogues) 0.182 -> 0.292 ms
-    -- so conv5 takes 16, the T-Nets 32."""
+    -- so conv5 takes 16, the T-Nets 32.  (GEOA3_WIDE_SHAPE_TNET / GEOA3_WIDE_SHAPE_CONV5 = 16 | 32: A/B runs of tools/.)"""
+    env = os.environ.get("GEOA3_WIDE_SHAPE_CONV5" if layer == "conv5" else "GEOA3_WIDE_SHAPE_TNET")
+    if env in ("16", "32"):
+        return int(env)
     return 16 if layer == "conv5" else 32
 
 

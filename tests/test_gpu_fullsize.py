@@ -118,7 +118,7 @@ def test_pointnet_full_size_is_run_to_run_deterministic(clouds):
 def test_attack_loop_full_size_is_run_to_run_deterministic(clouds):
     """Five runs of 30 inner iterations of the full objective at B = 250 (deterministic gradient sums, both streams), a
     fresh runner each and nothing between the steps: iterate, Adam state and loss history equal bit for bit.  (This is the
-    test that found the cross-XCD visibility bug of DESIGN 5a: one run in 10-25 deviated in one of the last instances.)"""
+    test that found the cross-XCD visibility bug of NOTEBOOK 5a: one run in 10-25 deviated in one of the last instances.)"""
     import bench
     from geoa3_amd.attack import AttackRunner
     from geoa3_amd.data import synthetic_state_dict

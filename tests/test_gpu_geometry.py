@@ -396,7 +396,7 @@ def _oracle_objective(adv, ori, nrm, k):
 
 @pytest.mark.parametrize("N,k,ncoin", [(512, 8, 40), (700, 16, 40), (1024, 16, 120)])
 def test_pair_parallel_objective_long_rows_are_bit_stable_on_a_full_chip(ops, N, k, ncoin):
-    """DESIGN 5a, third sighting: with the packed-FP32 instructions the SLP vectoriser formed in geo_fused_kernel, the
+    """NOTEBOOK 5a, third sighting: with the packed-FP32 instructions the SLP vectoriser formed in geo_fused_kernel, the
     gradient of the points that own 40-source rows differed from launch to launch -- in half of the launches at 40
     instances (one workgroup per CU on 40 CUs, four wavefronts per SIMD), almost never at the 3 instances the test above
     uses.  geom_loss.hip is compiled without them (geoa3_amd/build.py FILE_FLAGS / ISA_GUARDS); 200 launches, every bit."""

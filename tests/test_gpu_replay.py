@@ -1,4 +1,4 @@
-"""Every cross-kernel hand-over of the loop, soaked: ONE attack iteration replayed thousands of times from the
+"""Every cross-kernel hand-over of the loop, soaked (NOTEBOOK 5a): ONE attack iteration replayed thousands of times from the
 same device state (tools/iteration_replay_soak.py); after every replay every tensor the iteration writes -- logits,
 losses, 1-NN / K-NN tables, both gradient parts, Adam moments, the iterate, and every buffer of the victim's workspace
 (activations, gate masks, arg-max keys, FC k-split partials, Gram partials, the dT3 partial sums, ...) -- is compared bit

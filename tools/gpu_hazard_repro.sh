@@ -1,5 +1,5 @@
 #!/bin/bash
-# DESIGN 5a, everything in one GPU call:  tools/gpu_hazard_repro.sh [launch pairs, default 100000]
+# NOTEBOOK 5a, everything in one GPU call:  tools/gpu_hazard_repro.sh [launch pairs, default 100000]
 #   1. tools/ub/xcd_visibility: the store -> kernel boundary -> load pattern on its own (expected: 0 wrong values);
 #   2. tools/ub/dtpart_pair: conv_bwd_chain_kernel + reduce_dT_kernel alone, against the two-wave build
 #      (tools/ub/lib_two_wave: `python -m geoa3_amd.build --variant tools/ub/lib_two_wave --no-file-flags` = the chain kernels

@@ -5,7 +5,7 @@
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/prof}; mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --single-mode"
+B="python3 bench.py --no-cpu-baseline --single-mode --no-other-configs"
 # configs[1]
 GEOA3_PN2_SIDE=0 GEOA3_GEO_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2/trace -o t -- $B --steps 60 --warmup 10 > $O/c2_trace.log 2>&1
 GEOA3_PN2_SIDE=0 GEOA3_GEO_STREAM=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c2/fetch -o t -- $B --steps 30 --warmup 5 --presteps 100 > $O/c2_fetch.log 2>&1

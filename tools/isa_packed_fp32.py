@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which kernels of the library hold packed-FP32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) with an SGPR
-operand, and at how many waves per SIMD (in conv_bwd_chain_kernel such instructions computed wrong values in
+operand, and at how many waves per SIMD (NOTEBOOK 5a: in conv_bwd_chain_kernel such instructions computed wrong values in
 lanes 48-63 with two waves per SIMD; that file is compiled without the SLP vectoriser).  Compiles every csrc/*.hip to ISA
 with the build's own flags (CPU only).    python tools/isa_packed_fp32.py > profiles/roundN_packed_fp32_kernels.txt"""
 import os
@@ -30,7 +30,7 @@ def main():
                 kern, body = m.group(1), m.group(2)
                 pk = re.findall(r"v_pk_(?:mul|fma|add)_f32 [^\n]*", body)
                 pk_s = [l for l in pk if re.search(r"\bs\[\d+:\d+\]", l)]
-                pk_n = [l for l in pk if re.search(r"op_sel:\[[^\]]*1", l)]   # (the form the fault is pinned on: DESIGN 5a)
+                pk_n = [l for l in pk if re.search(r"op_sel:\[[^\]]*1", l)]   # (the form the fault is pinned on: NOTEBOOK 5a)
                 if not pk:
                     continue
                 nv = int(vg.get(kern, 0))

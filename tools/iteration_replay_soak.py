@@ -1,7 +1,7 @@
 """One attack iteration replayed N times from the SAME device state; after every replay every tensor the iteration
 writes (logits, losses, neighbour tables, both gradient parts, Adam state, the iterate, and every buffer of the victim's
 workspace) is compared bit for bit with the first replay.  A kernel whose result depends on timing shows up by the name
-of the buffer it writes.  Used by tests/test_gpu_replay.py; stand-alone:
+of the buffer it writes (NOTEBOOK 5a).  Used by tests/test_gpu_replay.py; stand-alone:
 
     python tools/iteration_replay_soak.py [--iters 3000] [--b 250] [--n 1024] [--k 16] [--arch PointNet|PointNetPP]
                                           [--presteps 20] [--mode f16x2|f32]

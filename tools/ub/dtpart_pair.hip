@@ -1,4 +1,4 @@
-// DESIGN 5a, second reproducer: the loop's REAL producer / consumer pair, stand-alone (no torch, no Python):
+// NOTEBOOK 5a, second reproducer: the loop's REAL producer / consumer pair, stand-alone (no torch, no Python):
 // conv_bwd_chain_kernel (1000 workgroups at B = 250, N = 1024; its last instructions store 36 bytes of dT3 partial sums
 // per workgroup) followed by reduce_dT_kernel (9 workgroups; its first instructions read them), on random inputs, the two
 // input sets alternating so that a stale partial row shows as the OTHER set's value.

@@ -1,4 +1,4 @@
-// Reproducer (round 5): a kernel whose fp32 arithmetic the SLP vectoriser packed into v_pk_add_f32 / v_pk_mul_f32
+// Reproducer (round 5, NOTEBOOK 5a): a kernel whose fp32 arithmetic the SLP vectoriser packed into v_pk_add_f32 / v_pk_mul_f32
 // (VECTOR-register operands, op_sel / neg modifiers) is exact and deterministic ALONE -- one wavefront per SIMD -- and
 // computes wrong values at ~1e-4 per dependent round as soon as another kernel's wavefronts share its SIMDs.
 // The kernel is the library's farthest-point sampler (geoa3_amd/csrc/pointnet2_ops.hip, fps_kernel<256, 4>: 511 dependent

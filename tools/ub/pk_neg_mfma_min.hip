@@ -1,4 +1,4 @@
-// Minimal, self-contained reproducer of DESIGN 5a (no library, nothing but hipcc; gfx950 / MI355X, ROCm 7.2):
+// Minimal, self-contained reproducer of NOTEBOOK 5a (no library, nothing but hipcc; gfx950 / MI355X, ROCm 7.2):
 //     v_pk_add_f32 d, p, A op_sel:[0,1]          (d.lo = p.lo + A.HI, d.hi = p.hi + A.hi)
 // -- packed FP32 arithmetic whose src1 carries an op_sel bit, i.e. a LOW result that reads the HIGH half of a register pair --
 // is exact alone and returns, in lanes 48-63 of the wavefront, the result of an operand that reads as ZERO (add: p.lo

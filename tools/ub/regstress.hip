@@ -1,4 +1,4 @@
-// DESIGN 5a, hypothesis test: do two wavefronts of a 200+ VGPR kernel on one SIMD disturb each other's registers?
+// NOTEBOOK 5a, hypothesis test: do two wavefronts of a 200+ VGPR kernel on one SIMD disturb each other's registers?
 //   hipcc --offload-arch=gfx950 -O3 -o regstress regstress.hip ;  ./regstress [launches]
 // Every lane keeps R registers alive through a chain of integer updates (optionally with MFMAs and v_permlane32_swap between
 // the rounds, the instruction classes conv_bwd_chain_kernel mixes), then runs the inverse updates in place

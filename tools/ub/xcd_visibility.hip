@@ -1,4 +1,4 @@
-// Stand-alone reproducer for DESIGN 5a: is a small store made by the LAST instructions of a kernel's workgroups visible
+// Stand-alone reproducer for NOTEBOOK 5a: is a small store made by the LAST instructions of a kernel's workgroups visible
 // to the FIRST instructions of the next kernel of the same stream, when several workgroups (of different XCDs) write into
 // one cache line?
 //

@@ -1,4 +1,4 @@
-// What one cross-queue event dependency costs the MAIN queue: a chain of dependent kernels on one stream,
+// What one cross-queue event dependency costs the MAIN queue (NOTEBOOK 8, row 37): a chain of dependent kernels on one stream,
 // (a) as it is, (b) with a tiny kernel forked to a second stream behind every link and joined in front of the next one
 // (record main -> wait side -> side kernel -> record side -> wait main: the pattern of a side queue inside one call),
 // (c) with the tiny kernel in stream order instead.  (b) - (a) per link = two event records + two cross-queue waits as the main
