@@ -77,7 +77,8 @@ struct Sa2FwdArgs {
 //     loaded once per pair and CU (16 x 1 KB per wave), through a ring S8_RING k-steps deep;
 //   * layer 1 is split as (centre, 32-row tile) over the eight waves; the gather as (centre, 32-channel quarter).
 constexpr int S8_RING = 4;
-constexpr int sa2_fwd8_lds() { return S2_K * S2_K * 4 + 2 * 2 * 64 * S2_PH + (16 + S2_K + S2_C) * 4; }
+constexpr int S8_GRP = 4;       // consecutive pairs a workgroup takes in a row: their 8 centres' pooled outputs leave as one 32-byte run per channel
+constexpr int sa2_fwd8_lds() { return S2_K * S2_K * 4 + 2 * 2 * 64 * S2_PH + (16 + S2_K + S2_C) * 4 + 2 * S2_C * 2 * S8_GRP * 4; }
 
 template <int MODE>   // 0 = shipped; tools/ub/sa2f_ub.hip: 1 no W2 MFMAs, 2 no W1 MFMAs, 3 no pooled stores, 4 no gather, 5 no syncs C
 __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
@@ -87,6 +88,8 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
   float* s_red = reinterpret_cast<float*>(s_img + 2 * 2 * 64 * S2_PH);   // [0..7] a0 maxima, [8..15] a1 maxima (per wave)
   float* s_b1 = s_red + 16;
   float* s_b2 = s_b1 + S2_K;
+  float* s_out = s_b2 + S2_C;                                          // [256][8]: pooled outputs of a group's 8 centres
+  int* s_arg = reinterpret_cast<int*>(s_out + S2_C * 2 * S8_GRP);      // [256][8]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ci = wave >> 2, qt = wave & 3;       // phases A / B: this wave's centre and its channel quarter / row tile
@@ -117,10 +120,17 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) gv[q] = MODE == 4 ? make_float4(0.1f * q, 0.2f, -0.1f, 0.3f) : src[q];
   };
-  if ((int)blockIdx.x < pairs) request(blockIdx.x);
+  // A workgroup takes GROUPS of S8_GRP consecutive pairs (group g, g + gridDim.x, ...): the pooled outputs of a group's 8
+  // consecutive centres are collected in LDS and leave as one 32-byte run per channel.  (Written pair by pair -- 8 bytes
+  // per channel, 512 bytes apart -- every store was a quarter of a 32-byte sector: 328 MB of HBM writes per launch for
+  // 131 MB of results, profiles/round6_v1_c4_pmc.csv.)  M % 8 == 0 (the launcher checks): a group never straddles two clouds.
+  const int groups = pairs / S8_GRP;
+  if ((int)blockIdx.x < groups) request(blockIdx.x * S8_GRP);
   __syncthreads();
 
-  for (int p = blockIdx.x; p < pairs; p += gridDim.x) {
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x)
+  for (int pq = 0; pq < S8_GRP; ++pq) {
+    const int p = grp * S8_GRP + pq;
     const size_t centre = (size_t)(2 * p + ci);
     half8 ring[S8_RING][2];
 #pragma unroll
@@ -250,7 +260,10 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
     }
     __syncthreads();
     // the next pair's gather: in flight across phase C
-    if (p + gridDim.x < pairs) request(p + gridDim.x);
+    {
+      const int pn = pq + 1 < S8_GRP ? p + 1 : (grp + (int)gridDim.x) * S8_GRP;
+      if (pn < pairs) request(pn);
+    }
     // ---- C: pooled channels 32 wave .. + 31 for both centres, transposed (rows = samples)
     {
       f32x16 acc[4];     // [2 centre + column block]
@@ -309,15 +322,21 @@ __global__ __launch_bounds__(512) void sa2_fwd8_kernel(Sa2FwdArgs a) {
         v = take ? ov : v;
         smp = take ? os : smp;
         if (lane < 32 && (MODE != 3 || v == 123.f)) {
-          const int b = (2 * p) / a.M, m = 2 * p + cc - b * a.M;
           const int ch = 32 * wave + lane;
-          const size_t e = ((size_t)b * S2_C + ch) * a.M + m;
-          a.out[e] = fmaxf(v * un + s_b2[ch], 0.f);     // the (positive) scale commutes with the max
-          a.arg[e] = smp;
+          s_out[ch * (2 * S8_GRP) + 2 * pq + cc] = fmaxf(v * un + s_b2[ch], 0.f);     // the (positive) scale commutes with the max
+          s_arg[ch * (2 * S8_GRP) + 2 * pq + cc] = smp;
         }
       }
     }
     __syncthreads();   // the images and s_red are rewritten by the next pair
+    if (pq == S8_GRP - 1 && MODE != 3) {   // the group's 8 centres: thread (channel, half) writes 16 bytes of each table
+      const int c0 = 2 * S8_GRP * grp;                     // first centre of the group (global index)
+      const int b = c0 / a.M, m0 = c0 - b * a.M;
+      const int ch = tid >> 1, hh = tid & 1;
+      const size_t e = ((size_t)b * S2_C + ch) * a.M + m0 + 4 * hh;
+      *reinterpret_cast<float4*>(a.out + e) = *reinterpret_cast<const float4*>(s_out + ch * (2 * S8_GRP) + 4 * hh);
+      *reinterpret_cast<int4*>(a.arg + e) = *reinterpret_cast<const int4*>(s_arg + ch * (2 * S8_GRP) + 4 * hh);
+    }
   }
 }
 
@@ -472,13 +491,14 @@ int launch_frag_image(const float* W, int R, int K, void* img, float* un, hipStr
 int launch_sa2_fwd(const float* rT, const int32_t* gidx, const float* shift, const void* w1_img, const float* w1_un,
                    const float* b1, const void* w2_img, const float* w2_un, const float* b2, float* out, int32_t* arg,
                    unsigned* m0, unsigned* m1, int B, int N1, int M, hipStream_t s) {
-  if (M % 2 != 0 || (long)B * M > 0x3fffffffL) return GEOA3_ENOSUPPORT;
+  if (M % (2 * S8_GRP) != 0 || (long)B * M > 0x3fffffffL) return GEOA3_ENOSUPPORT;
   Sa2FwdArgs a{rT, gidx, shift, b1, b2, static_cast<const _Float16*>(w1_img), w1_un, static_cast<const _Float16*>(w2_img),
                w2_un, out, arg, m0, m1, B, N1, M};
   const long pairs = (long)B * M / 2;
   const int lds = sa2_fwd8_lds();
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_fwd8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  const unsigned grid = (unsigned)(pairs < 256 ? pairs : 256);   // one 8-wave workgroup per CU, persistent
+  const long groups = pairs / S8_GRP;
+  const unsigned grid = (unsigned)(groups < 256 ? groups : 256);   // one 8-wave workgroup per CU, persistent
   hipLaunchKernelGGL(sa2_fwd8_kernel<0>, dim3(grid), dim3(512), lds, s, a);
   GEOA3_CHECK_LAUNCH();
   return GEOA3_OK;
