@@ -45,13 +45,18 @@ BARS = {   # best: best constrain loss per instance; window: 50-step means of lo
     "n256_b8_tgt": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
     "n1024_b8_hard": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
     "n1024_b4_margin": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
-    "pn2_n1024_b4_tgt": dict(best=0.25, window=0.18, adv=0.15, last_margin=1.0, first=5e-3, first_steps=3),
+    # (round 6: the WHOLE run 13 times per mode, profiles/round6_longrun_noise_pn2.txt -- the float-atomics mode reached 20.4 %
+    #  in one of 13 runs, the perturbed deterministic loop 15.4 % / 0.125: the round-5 bars (0.18 / 0.15) sat INSIDE the loop's own
+    #  spread; bars = 1.25 x the largest of the 13 runs)
+    "pn2_n1024_b4_tgt": dict(best=0.25, window=0.26, adv=0.16, last_margin=1.0, first=5e-3, first_steps=3),
     # round 5: instances the reference never breaks (their success flag, the all-ones placeholder and the constants are held
     # exactly: they are "robust" by construction), and PointNet++ at b = 8 (twice the instances to average over)
     "n256_b8_fail": dict(best=0.10, window=0.025, adv=0.05, last_margin=0.05, first=5e-3),
     # (eight instances average the PointNet++ case's chaos down: windows seen at 5.7-8.6 % / adversarial fractions within 0.04
     #  in both summation modes, against 5-9 % / 0.06 at b = 4: two thirds of that case's bars)
-    "pn2_n1024_b8_tgt": dict(best=0.25, window=0.12, adv=0.10, last_margin=1.0, first=5e-3, first_steps=4),
+    #  round 6, measured at b = 8 itself: whole runs reach 12.1 % (perturbed deterministic) / 9.6 % (atomics), adversarial
+    #  fractions 0.07: bars = 1.25 x that)
+    "pn2_n1024_b8_tgt": dict(best=0.25, window=0.16, adv=0.10, last_margin=1.0, first=5e-3, first_steps=4),
 }
 ROBUST_STEPS = 3         # an instance counts as robustly (un)successful in a binary step with >= 3 / 0 adversarial steps
 
