@@ -33,7 +33,10 @@ constexpr int SB_S = 64;         // samples per ball
 constexpr int SB_N1 = 512;       // points the balls gather from (level 1's centroids)
 constexpr int SB_ROWS = SB_M * SB_S;      // 8192: most rows a cloud can have
 constexpr int SB_ENT = SB_M * S2_C;       // 32768: most entries
-constexpr int SB_P = 4;          // parts per cloud (fixed: the tiles, and with them the operand scales, depend on the cloud alone)
+#ifndef GEOA3_SB_P
+#define GEOA3_SB_P 4
+#endif
+constexpr int SB_P = GEOA3_SB_P; // parts per cloud (fixed: the tiles, and with them the operand scales, depend on the cloud alone)
 constexpr int SB_TILES = SB_ROWS / 64 + SB_P;   // most tiles
 #ifndef GEOA3_SB_STOP
 #define GEOA3_SB_STOP 0   // (tools: 1-3 end sa2b_prep_kernel early, 4 / 5 drop phase 3 / phase 1 of sa2b_bwd_kernel: timing only)
