@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/cad}; mkdir -p $O
 timeout 1800 python3 -m pytest tests/test_gpu_cad.py -x -q -m gpu 2>&1 | tail -5
-B="python3 bench.py --no-cpu-baseline --single-mode"
+B="python3 bench.py --no-cpu-baseline --single-mode --no-other-configs"
 for data in ellipsoid cad; do
   $B --data $data --steps 200 --warmup 10 2>/dev/null | tail -1 > $O/bench_c2_$data.json
   $B --data $data --arch PointNetPP --steps 40 --warmup 5 --presteps 20 2>/dev/null | tail -1 > $O/bench_c4_$data.json
