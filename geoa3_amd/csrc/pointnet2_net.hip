@@ -24,6 +24,8 @@ namespace {
 constexpr int M1 = 512, M2 = 128, S = 64;          // PointNetPP_ssg.py:58-76
 constexpr float R1 = 0.2f, R2 = 0.4f;
 constexpr int C1 = 128, C2 = 256, C3 = 1024;       // output widths of the three levels
+constexpr int MIN_N = 32;      // (the sampler picks 512 centroids of ANY cloud, repeating points of a small one: sampling_gpu.cu:69-173)
+constexpr int MAX_N = 8192;    // the sampler's register tiling (pointnet2_ops.hip); also keeps N * 3 <= C1 * M1 floats (gx2 in the backward)
 
 #define TRY(expr)               \
   do {                          \
@@ -123,7 +125,7 @@ Ws carve(void* base, int B, int N) {
   w.dh1 = (float*)take(b * 256 * M2 * f);
   w.dout2 = (float*)take(b * C2 * M2 * f);
   w.dnx2 = (float*)take(b * M2 * 3 * f);
-  w.d1 = (float*)take(b * 128 * M2 * S * f);
+  w.d1 = (float*)take(b * (size_t)(M1 * S * 3 > MAX_N ? M1 * S * 3 : MAX_N) * f);   // [B,N] sampler distances | [B,512,64,3] level-1 contributions
   w.df1 = (float*)take(b * C1 * M1 * f);
   w.dnx1 = (float*)take(b * M1 * 3 * f);
   w.g1 = (float*)take(b * M1 * C1 * f);
@@ -355,9 +357,6 @@ int fc(const float* X, int K, const float* W, const float* bias, float* Y, int N
 }
 
 }  // namespace
-
-constexpr int MIN_N = 32;      // (the sampler picks 512 centroids of ANY cloud, repeating points of a small one: sampling_gpu.cu:69-173)
-constexpr int MAX_N = 8192;    // the sampler's register tiling (pointnet2_ops.hip); also keeps N * 3 <= C1 * M1 floats (gx2 below)
 
 extern "C" int64_t geoa3_pn2ssg_workspace_bytes(int B, int N) {
   if (B <= 0 || N < MIN_N || N > MAX_N) return -1;
