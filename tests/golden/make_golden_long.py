@@ -21,7 +21,7 @@ moves the constants both ways, and some instances fail.  What makes a case hard 
   * `margin`:  the victim's last layer scaled x3 (clean logit gap to the target >= 8, top-2 margin x3), targeted, the
                harness' default constant 10 and lr 0.01;
   * `pn2`:     the PointNet++ SSG victim (Model/PointNetPP_ssg.py:106-124), last layer calibrated as PointNet's, targeted.
-Round 5 adds `n256_b8_fail` (targeted at the least likely class of a x3-margin victim under constant 3000 and lr 0.003: the
+Round 5 adds `n256_b8_fail` (targeted at the least likely class of a x3-margin victim under constant 2600 and lr 0.005 (LONG_CASES below): the
 reference leaves several of the eight instances un-attacked after 3 x 100 steps) and `pn2_n1024_b8_tgt` (PointNet++,
 eight instances, targeted at the least likely class -- an UNTARGETED run on this victim is adversarial from step 1 at any
 constant and a run targeted at the 10th-ranked class from step 2: both measured (best step 1-2 for all eight), no test of
