@@ -134,6 +134,7 @@ SIGNATURES = {
     "geoa3_conv1x1": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_debug_pointnet_workspace_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
                                                         C.POINTER(C.c_int64), C.c_int]),
+    "geoa3_debug_grid_nn1_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, vp]),
     "geoa3_debug_fc": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_debug_conv_cm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "geoa3_profile_enable": (C.c_int, [C.c_int]),

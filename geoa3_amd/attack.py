@@ -107,9 +107,9 @@ class AttackRunner:
         # nothing (measured), so it is taken for b <= 96 (cfg.late_join overrides).  Same results.
         lj = _cfg(cfg, "late_join", None)           # (tests: cfg.late_join = True / False)
         self.late_join = (b <= 96) if lj is None else bool(lj)
-        # the 1-NN tables through the uniform-grid search (geom_grid.hip; same bits as the all-pairs kernel, which
-        # stays the path for clouds beyond 4096 points or when cfg.brute_force_nn1 is set)
-        self.grid_nn1 = max(n, self.ne) <= 4096 and not _cfg(cfg, "brute_force_nn1", False)
+        # the 1-NN tables through the pruned searches (geom_grid.hip / geom_filter.hip; same bits as the all-pairs kernel,
+        # which stays the path for clouds of fewer than 32 points or when cfg.brute_force_nn1 is set)
+        self.grid_nn1 = min(n, self.ne) >= 32 and not _cfg(cfg, "brute_force_nn1", False)
         ne = self.ne
         f32 = dict(device=device, dtype=torch.float32)
         i32 = dict(device=device, dtype=torch.int32)

@@ -46,7 +46,7 @@ def _hipcc() -> str:
 _NOSLP = ["-fno-slp-vectorize", "-fno-vectorize"]   # (the loop vectoriser pairs fp32 work the same way: sa1_stage, attack_state)
 SLP_FILES = ("pointnet_gemm.hip",)
 FILE_FLAGS = {f: list(_NOSLP) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and f not in SLP_FILES}
-for _f in ("pointnet2_sa.hip", "pointnet2_sa2.hip", "pointnet2_sa2b.hip"):
+for _f in ("pointnet2_sa.hip", "pointnet2_sa2.hip", "pointnet2_sa2b.hip", "geom_filter.hip", "geom_grid.hip"):
     FILE_FLAGS[_f] = ["-fno-honor-nans"] + _NOSLP
 
 

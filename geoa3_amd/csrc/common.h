@@ -25,6 +25,15 @@ __device__ __forceinline__ float geoa3_sqdist(float ax, float ay, float az, floa
   return s + zz;
 }
 
+// The bits of a float, opaque to the optimiser: files compiled with -fno-honor-nans fold `(bits & 0x7fffffff) >= 0x7f800000`
+// into `|x| == inf` (the NaN half of the class test dropped) -- what must SEE a NaN tests these bits.
+__device__ __forceinline__ unsigned geoa3_opaque_bits(float x) {
+  unsigned u = __float_as_uint(x);
+  asm("" : "+v"(u));
+  return u;
+}
+__device__ __forceinline__ bool geoa3_nonfinite(float x) { return (geoa3_opaque_bits(x) & 0x7fffffffu) >= 0x7f800000u; }
+
 // wave-wide (64 lanes) reductions with DPP row operations (quad_perm, row_half_mirror, row_mirror, row_bcast15/31):
 // ~10 cycles per step where __shfl_xor compiles to a ds_bpermute round trip through the LDS crossbar.  The result is
 // read from lane 63 and returned uniformly.

@@ -9,8 +9,9 @@
 // else, and the cell range carries a margin far above float rounding, so the result is BIT-IDENTICAL to the
 // all-pairs search (tests/test_gpu_geometry.py) for any input: a query far from every point simply scans more
 // cells (in the limit: all of them, i.e. the all-pairs work).
-#include "geom_internal.h"
+#include "geom_filter.h"
 #include "profile.h"
+#include <cstdlib>
 
 namespace {
 
@@ -151,6 +152,11 @@ __device__ __forceinline__ void grid_ball(const int* __restrict__ s_start, float
   }
 }
 
+// NaN / inf among three coordinates, by their bits (this file is compiled with -fno-honor-nans for geom_filter.h)
+__device__ __forceinline__ bool grid_nonfinite3(float x, float y, float z) {
+  return geoa3_nonfinite(x) | geoa3_nonfinite(y) | geoa3_nonfinite(z);
+}
+
 // One candidate against a query's running (distance, index) minimum -- lexicographic, the un-fused distance of every search.
 __device__ __forceinline__ void nn1_take(float& best, int& bi, float qx, float qy, float qz, const float4 c) {
   const float d = geoa3_sqdist(qx, qy, qz, c.x, c.y, c.z);
@@ -183,7 +189,11 @@ constexpr int NN1_WIDE = 16;   // a query whose ball touches more grid columns i
 #ifndef GEOA3_NN1_CHUNK
 #define GEOA3_NN1_CHUNK 16
 #endif
-constexpr float GRID_BRUTE = GEOA3_GRID_BRUTE;   // fraction of the searched cloud inside the queries' boxes beyond which a batch is searched by brute force
+constexpr float GRID_BRUTE = GEOA3_GRID_BRUTE;   // fraction of the searched cloud inside the queries' boxes beyond which a batch is searched by brute force (in-kernel sweep)
+#ifndef GEOA3_GRID_FILTER
+#define GEOA3_GRID_FILTER 0.03f
+#endif
+constexpr float GRID_FILTER = GEOA3_GRID_FILTER; // ... the same with the matrix-core filter behind the kernel (geom_filter.hip): GEOA3_NN1_FILTER=0 switches it off
 constexpr int NN1_DIRECT = GEOA3_NN1_DIRECT;     // candidates of a column run scanned by the (query, column) pair's own lane
 #ifndef GEOA3_NN1_LONG
 #define GEOA3_NN1_LONG 24
@@ -191,11 +201,21 @@ constexpr int NN1_DIRECT = GEOA3_NN1_DIRECT;     // candidates of a column run s
 constexpr int NN1_LONG = GEOA3_NN1_LONG;         // a trip with a run longer than this is dealt a second time (below)
 constexpr int NN1_CHUNK = GEOA3_NN1_CHUNK;       // the rest of a run is dealt over the wavefront's lanes in chunks of this size
 
+// (a call, not inlined: the search's registers are allocated apart from the walk's -- inlined, grid_nn1_kernel<4> spilled 41)
+__device__ __attribute__((noinline)) void grid_filter_search(const float* P, const float* Q, int M, int Nq, int q0,
+                                                             const int32_t* prior, float* dout, int32_t* iout,
+                                                             unsigned char* smem) {
+  nf::search<GT>(P, Q, M, Nq, q0, prior, dout, iout, smem);
+}
+
 template <int PPT, int MODE = 0>   // MODE (tools/ub/nn1_ub.hip): 1 = build only, 2 = seeds only (no ball walk)
 // (two workgroups per CU while the cloud's LDS allows it -- up to 1024 points: at most 64 registers there)
 __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const float* __restrict__ A, const float* __restrict__ R, int Na,
                                                       int Nr, const int32_t* prior_ar, const int32_t* prior_ra,
-                                                      float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, int wide_thr) {
+                                                      float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, int wide_thr,
+                                                      float brute_frac, int filter) {
+  // brute_frac: the fraction of the searched cloud inside the queries' boxes beyond which the workgroup's queries are
+  // searched all-pairs; filter != 0 (clouds of more than 1024 points): through the matrix core (geom_filter.h), in place
   // prior_* (optional, may alias i_*): a searched-cloud index per query -- last iteration's answer -- used as the seed
   extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
   const int b = blockIdx.x;
@@ -274,8 +294,13 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
       qz[p] = Q[2 * Nq + q];
       int si = prior ? prior[(size_t)b * Nq + q] : q;
       si = si < 0 ? 0 : (si >= M ? M - 1 : si);
-      best[p] = geoa3_sqdist(qx[p], qy[p], qz[p], P[si], P[M + si], P[2 * M + si]);
+      const float sx = P[si], sy = P[M + si], sz = P[2 * M + si];
+      best[p] = geoa3_sqdist(qx[p], qy[p], qz[p], sx, sy, sz);
       bi[p] = si;
+      if (grid_nonfinite3(qx[p], qy[p], qz[p]) | grid_nonfinite3(sx, sy, sz)) {   // no radius: (inf, 0), where the all-pairs kernel starts
+        best[p] = G_INF;
+        bi[p] = 0;
+      }
       const float rho = sqrtf(best[p]) * g.inv_h * 1.00001f + 1e-4f;
       if (valid) est += (float)in_box((qx[p] - g.ox) * g.inv_h, (qy[p] - g.oy) * g.inv_h, (qz[p] - g.oz) * g.inv_h, rho);
     }
@@ -286,7 +311,16 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
 #pragma unroll
     for (int w = 0; w < GW; ++w) all += s_red[w];
     __syncthreads();
-    if (all > GRID_BRUTE * (float)Nq * (float)M) {
+    if (all > brute_frac * (float)Nq * (float)M) {
+      if (filter) {
+        // (the grid is not needed any more: the filter's chunks, queries, keys and lists take its place in LDS.  prior may
+        // alias iout: a pass reads its own slice's seeds before it writes that slice's results)
+        for (int q0 = 0; q0 < Nq; q0 += nf::Cfg<GT>::SLICE) {
+          __syncthreads();
+          grid_filter_search(P, Q, M, Nq, q0, prior ? prior + (size_t)b * Nq : nullptr, dout, iout, g_smem);
+        }
+        return;
+      }
       // every point against every query: the searched cloud is staged again in INDEX order, so that the running minimum
       // needs the strict comparison only (ascending indices: the first of equal distances wins, as in nn1_pair_kernel) --
       // 11 instead of 14 instructions per pair, and the seeds are not needed
@@ -329,8 +363,13 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
     // otherwise the point with the query's own index (adv_i = ori_i + offset_i in the attack loop)
     int si = prior ? prior[(size_t)b * Nq + q] : q;
     si = si < 0 ? 0 : (si >= M ? M - 1 : si);
-    float best = geoa3_sqdist(qx, qy, qz, P[si], P[M + si], P[2 * M + si]);
+    const float sx = P[si], sy = P[M + si], sz = P[2 * M + si];
+    float best = geoa3_sqdist(qx, qy, qz, sx, sy, sz);
     int bi = si;
+    if (grid_nonfinite3(qx, qy, qz) | grid_nonfinite3(sx, sy, sz)) {   // no radius: (inf, 0), where the all-pairs kernel starts
+      best = G_INF;
+      bi = 0;
+    }
     if (MODE == 3) {   // statistics: columns iterated per query, by bucket
       const float rho = sqrtf(best) * g.inv_h * 1.00001f + 1e-4f;
       const int nx = grid_coord(fx + rho) - grid_coord(fx - rho) + 1, ny = grid_coord(fy + rho) - grid_coord(fy - rho) + 1;
@@ -358,7 +397,7 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
 #pragma unroll
       for (int w = 0; w < GW; ++w) all += s_est[w];
       const int nq = Nq - t0 < GT ? Nq - t0 : GT;
-      brute = PPT == 1 && all > GRID_BRUTE * (float)nq * (float)M;    // (PPT > 1: decided for all batches above)
+      brute = PPT == 1 && all > brute_frac * (float)nq * (float)M;    // (PPT > 1: decided for all batches above)
     }
     if (brute) {
       // (workgroup-uniform: the cloud once more in INDEX order, strict comparison, no seed -- as above)
@@ -525,19 +564,35 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
   }
 }
 
-size_t grid_nn1_lds(int M) { return ((size_t)(GC + 4) + GC + GW * 8 + 4 * (size_t)M + 2 + 2 * GT + 2 * GW * 64) * 4; }
+size_t grid_nn1_lds(int M) {
+  const size_t g = ((size_t)(GC + 4) + GC + GW * 8 + 4 * (size_t)M + 2 + 2 * GT + 2 * GW * 64) * 4;
+  return M > GT && g < nf::Cfg<GT>::LDS ? nf::Cfg<GT>::LDS : g;      // (beyond 1024 points a workgroup may turn to nf::search)
+}
 
 }  // namespace
 
 // Same contract as geoa3_launch_nn1 without `only`; returns GEOA3_ENOSUPPORT when a cloud does not fit the
 // workgroup (callers then use the all-pairs kernel).
-int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
-                          const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra,
-                          hipStream_t s) {
+// brute_frac < 0 / filter < 0: the shipped policy (environment: GEOA3_GRID_BRUTE, GEOA3_NN1_FILTER=0)
+int geoa3_launch_grid_nn1_policy(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                                 const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra,
+                                 float brute_frac, int filter, hipStream_t s) {
   const int M = Na > Nr ? Na : Nr;
-  if (M > 4 * GT || (d_ra == nullptr) != (i_ra == nullptr)) return GEOA3_ENOSUPPORT;
+  if ((d_ra == nullptr) != (i_ra == nullptr)) return GEOA3_EINVAL;
   const size_t lds = grid_nn1_lds(M);
   const int wide_thr = NN1_WIDE;
+  static const int use_filter = []() { const char* e = getenv("GEOA3_NN1_FILTER"); return e ? atoi(e) : 1; }();
+  static const float env_frac = []() { const char* e = getenv("GEOA3_GRID_BRUTE"); return e ? (float)atof(e) : -1.f; }();
+  if (filter < 0) filter = use_filter;
+  filter = filter && Na >= 32 && Nr >= 32;
+  if (brute_frac < 0.f) brute_frac = env_frac >= 0.f ? env_frac : (filter ? GRID_FILTER : GRID_BRUTE);
+  // Up to 1024 points the filter kernel alone beats the walk wherever the iterates have left the surface, and costs the same
+  // on every kind of cloud (tools/nn1_filter_check.py --time, 250 instances, us per launch: walk 34 at offsets of 0.02 of the
+  // radius, 57 at 0.2, 50-170 on rods / clusters; filter ~45 everywhere): no grid at all
+  // ... and beyond 4096 points (no grid fits the workgroup's LDS; the filter works in chunks of 1024 candidates)
+  if (filter && (M <= GT || M > 4 * GT) && brute_frac < 1e8f)
+    return geoa3_launch_nn1_filter(a, r, B, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, s);
+  if (M > 4 * GT) return GEOA3_ENOSUPPORT;
   dim3 grid(B, d_ra ? 2 : 1);
 #define GEOA3_GRID_CASE(PPT)                                                                                    \
   if (M <= PPT * GT) {                                                                                          \
@@ -545,7 +600,8 @@ int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr,
     if (lds > 64 * 1024)                                                                                        \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(GT), lds, s, a, r, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, wide_thr);                     \
+    hipLaunchKernelGGL(kern, grid, dim3(GT), lds, s, a, r, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, wide_thr,     \
+                       brute_frac, filter);                                                                     \
     GEOA3_CHECK_LAUNCH();                                                                                       \
     return GEOA3_OK;                                                                                            \
   }
@@ -554,6 +610,25 @@ int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr,
   GEOA3_GRID_CASE(4)
 #undef GEOA3_GRID_CASE
   return GEOA3_ENOSUPPORT;
+}
+
+// Same contract as geoa3_launch_nn1 without `only`; returns GEOA3_ENOSUPPORT when a cloud does not fit the
+// workgroup (callers then use the all-pairs kernel).
+int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                          const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra,
+                          hipStream_t s) {
+  return geoa3_launch_grid_nn1_policy(a, r, B, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, -1.f, -1, s);
+}
+
+// geoa3_grid_nn1_pair with the search policy given (tests, tools/nn1_state_probe.py): brute_frac = the fraction of the
+// searched cloud inside the queries' boxes beyond which a workgroup's queries are searched all-pairs (0: always), filter =
+// by the matrix-core filter kernel (1) or the in-kernel sweep (0); negative = the shipped choice.  Same results all ways.
+extern "C" int geoa3_debug_grid_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                                         const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra,
+                                         float brute_frac, int filter, void* stream) {
+  if (!a || !r || !d_ar || !i_ar || B <= 0 || Na <= 0 || Nr <= 0) return GEOA3_EINVAL;
+  return geoa3_launch_grid_nn1_policy(a, r, B, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra, brute_frac, filter,
+                                      geoa3_stream(stream));
 }
 
 extern "C" int geoa3_grid_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,

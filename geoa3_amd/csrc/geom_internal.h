@@ -10,3 +10,7 @@ int geoa3_launch_knn(const float* q, const float* r, int B, int Nq, int Nr, int 
 // Grid-accelerated exact K=1 search (geom_grid.hip); GEOA3_ENOSUPPORT when a cloud exceeds 4096 points.
 int geoa3_launch_grid_nn1(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
                           const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, hipStream_t s);
+// The matrix-core filter + exact refinement as a kernel of its own (geom_filter.hip; the search itself: geom_filter.h):
+// every query of every instance, clouds of any size.
+int geoa3_launch_nn1_filter(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                            const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, hipStream_t s);

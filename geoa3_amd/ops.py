@@ -32,10 +32,10 @@ def _p(t: Optional[Tensor], dtype=None) -> Optional[int]:
     return t.data_ptr()
 
 
-def nn1_pair(a: Tensor, r: Tensor, both: bool = True, method: str = "brute", prior=None):
+def nn1_pair(a: Tensor, r: Tensor, both: bool = True, method: str = "brute", prior=None, policy=None):
     """a [B,3,Na], r [B,3,Nr] -> (d_ar [B,Na], i_ar int32 [B,Na], d_ra [B,Nr] | None, i_ra | None).
     method: "brute" (all pairs) or "grid" (uniform-grid search, same bits; prior = (i_ar, i_ra) of a previous call
-    seeds its radii)."""
+    seeds its radii; policy = (brute_frac, filter) of geoa3_debug_grid_nn1_pair for tests / tools)."""
     B, _, Na = a.shape
     Nr = r.shape[2]
     d_ar = torch.empty(B, Na, device=a.device, dtype=torch.float32)
@@ -46,6 +46,13 @@ def nn1_pair(a: Tensor, r: Tensor, both: bool = True, method: str = "brute", pri
         i_ra = torch.empty(B, Nr, device=a.device, dtype=torch.int32)
     if method == "grid":
         p_ar, p_ra = prior if prior is not None else (None, None)
+        if policy is not None:
+            check(_lib.load().geoa3_debug_grid_nn1_pair(_p(a, torch.float32), _p(r, torch.float32), B, Na, Nr,
+                                                        _p(p_ar, torch.int32) if p_ar is not None else None,
+                                                        _p(p_ra, torch.int32) if p_ra is not None and both else None,
+                                                        _p(d_ar), _p(i_ar), _p(d_ra), _p(i_ra), float(policy[0]),
+                                                        int(policy[1]), _stream()), "geoa3_debug_grid_nn1_pair")
+            return d_ar, i_ar, d_ra, i_ra
         check(_lib.load().geoa3_grid_nn1_pair(_p(a, torch.float32), _p(r, torch.float32), B, Na, Nr,
                                               _p(p_ar, torch.int32) if p_ar is not None else None,
                                               _p(p_ra, torch.int32) if p_ra is not None and both else None,

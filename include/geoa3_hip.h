@@ -56,10 +56,12 @@ const char* geoa3_strerror(int code);
 int geoa3_nn1_pair(const float* a, const float* r, int B, int Na, int Nr,
                    float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra, void* stream);
 
-/* geoa3_nn1_pair through a uniform grid over the searched cloud (16^3 cells, rebuilt per call in LDS): every query
- * scans the cells around it, shell by shell, until nothing outside can compete.  Bit-identical results for any input;
- * O(N) instead of O(N^2) work per instance for surface-like clouds.  Clouds of at most 4096 points
- * (GEOA3_ENOSUPPORT beyond).  prior_ar [B,Na] / prior_ra [B,Nr] (optional, MAY ALIAS i_ar / i_ra): an index into the
+/* geoa3_nn1_pair, pruned -- bit-identical results for any input.  Clouds of 1025..4096 points: a uniform grid over the
+ * searched cloud (16^3 cells, rebuilt per call in LDS), every query scans the cells its seed's ball touches: O(N) instead
+ * of O(N^2) work per instance for surface-like clouds; where the balls hold a large part of the cloud (dense clusters,
+ * thin parts, iterates far from the surface), and for every other cloud size (with fewer than 32 points: all pairs), the
+ * matrix core forms approximate distances of all pairs and only the pairs under the seed's radius (plus a bound on the
+ * approximation's error) are evaluated exactly (csrc/geom_filter.hip).  prior_ar [B,Na] / prior_ra [B,Nr] (optional, MAY ALIAS i_ar / i_ra): an index into the
  * searched cloud per query, e.g. last iteration's answer; it only seeds the search radius (default: the point with
  * the query's own index), any value gives the exact result. */
 int geoa3_grid_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,

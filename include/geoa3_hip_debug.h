@@ -47,6 +47,13 @@ int geoa3_debug_fc(const float* X, const float* W, const float* bias, float* Y, 
 int geoa3_debug_conv_cm(const float* X, const float* W, const float* bias, const float* Z, float* Y, int B, int N, int K,
                         int Co, int relu, int split /* 1: split-fp16 operands */, void* stream);
 
+/* geoa3_grid_nn1_pair (geoa3_hip.h) with its search policy given: brute_frac = the fraction of the searched cloud inside
+ * the queries' boxes beyond which a workgroup searches all pairs (0 = always), filter = through the matrix-core filter
+ * kernel (1) or the in-kernel sweep (0); negative values = the shipped choice.  Every policy returns the same bits. */
+int geoa3_debug_grid_nn1_pair(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
+                              const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra,
+                              float brute_frac, int filter, void* stream);
+
 /* Names and byte offsets (address order) of the buffers geoa3_pointnet_forward / _backward keep in their workspace:
  * tools/iteration_replay_soak.py attributes a run-to-run difference to the kernel that wrote it.  Returns the number
  * of buffers (names[i] are static strings). */
