@@ -262,12 +262,21 @@ def cd_kernel_line(ms, B, npoint):
     if not ms:
         return None
     cd_bytes = 40.0 * B * npoint
-    return {"kernel": "grid_nn1_kernel (exact 1-NN both directions, pruned grid search; all-pairs nn1_pair_kernel beyond "
-                      "4096 points)", "avg_launch_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": cd_bytes,
-            "hbm_GBps_algorithmic": round(cd_bytes / (ms * 1e-3) / 1e9, 2),
-            "hbm_frac": round(cd_bytes / (ms * 1e-3) / PEAK_HBM, 5),
-            "note": "not HBM-bound by construction (SURVEY 8d: 10 MB for up to 8*B*N^2 flops of search); the search prunes "
-                    "most pairs, so no all-pairs flop rate is quoted for it"}
+    filt = npoint <= 1024 or npoint > 4096
+    pairs = 2.0 * B * npoint * npoint
+    out = {"kernel": ("nn1_filter_kernel (exact 1-NN both directions: approximate distances of ALL pairs on the matrix core, "
+                      "exact evaluation of the pairs under the seed's radius; csrc/geom_filter.h)" if filt else
+                      "grid_nn1_kernel (exact 1-NN both directions: grid walk, workgroups with crowded boxes through the "
+                      "matrix-core filter search of csrc/geom_filter.h)"),
+           "avg_launch_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": cd_bytes,
+           "hbm_GBps_algorithmic": round(cd_bytes / (ms * 1e-3) / 1e9, 2),
+           "hbm_frac": round(cd_bytes / (ms * 1e-3) / PEAK_HBM, 5),
+           "note": "not HBM-bound by construction (SURVEY 8d: 10 MB per launch for 2*B*N^2 pairs of search)"}
+    if filt:   # every pair goes through the filter: its rate against the vector-issue floor
+        out["pairs_per_launch"] = pairs
+        out["pairs_per_cycle_per_simd"] = round(pairs / (ms * 1e-3) / (1024 * 2.4e9), 2)
+        out["issue_floor_pairs_per_cycle_per_simd"] = 19.7   # 1024 pairs per (8 v_min3 + compare + 2) * 4 + 8 MFMA issue cycles
+    return out
 
 
 class Bench:

@@ -110,6 +110,10 @@ class AttackRunner:
         # the 1-NN tables through the pruned searches (geom_grid.hip / geom_filter.hip; same bits as the all-pairs kernel,
         # which stays the path for clouds of fewer than 32 points or when cfg.brute_force_nn1 is set)
         self.grid_nn1 = min(n, self.ne) >= 32 and not _cfg(cfg, "brute_force_nn1", False)
+        # (tools: GEOA3_NN1_POLICY="brute_frac,filter" runs the loop's searches through geoa3_debug_grid_nn1_pair -- same
+        # bits, another split between grid walk, in-kernel sweep and filter search: include/geoa3_hip_debug.h)
+        pol = os.environ.get("GEOA3_NN1_POLICY")
+        self.nn1_policy = (float(pol.split(",")[0]), int(pol.split(",")[1])) if pol else None
         ne = self.ne
         f32 = dict(device=device, dtype=torch.float32)
         i32 = dict(device=device, dtype=torch.int32)
@@ -352,10 +356,14 @@ class AttackRunner:
                 if self.grid_nn1:   # seeded with the tables of the previous iteration (in place)
                     pa = t["i_ao"].data_ptr() if self.nn1_seeded else None
                     pr = t["i_oa"].data_ptr() if self.nn1_seeded and both else None
-                    check(lib.geoa3_grid_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n, pa, pr,
-                                                  t["d_ao"].data_ptr(), t["i_ao"].data_ptr(),
-                                                  t["d_oa"].data_ptr() if both else None,
-                                                  t["i_oa"].data_ptr() if both else None, sg), "grid_nn1_pair")
+                    out = (t["d_ao"].data_ptr(), t["i_ao"].data_ptr(), t["d_oa"].data_ptr() if both else None,
+                           t["i_oa"].data_ptr() if both else None)
+                    if self.nn1_policy is None:
+                        check(lib.geoa3_grid_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n, pa, pr, *out,
+                                                      sg), "grid_nn1_pair")
+                    else:
+                        check(lib.geoa3_debug_grid_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n, pa, pr,
+                                                            *out, *self.nn1_policy, sg), "grid_nn1_pair")
                     self.nn1_seeded = not self.sub
                 else:
                     check(lib.geoa3_nn1_pair(xe.data_ptr(), self.ori.data_ptr(), self.b, ne, self.n,

@@ -11,7 +11,6 @@
 // cells (in the limit: all of them, i.e. the all-pairs work).
 #include "geom_filter.h"
 #include "profile.h"
-#include <cstdlib>
 
 namespace {
 
@@ -193,7 +192,7 @@ constexpr float GRID_BRUTE = GEOA3_GRID_BRUTE;   // fraction of the searched clo
 #ifndef GEOA3_GRID_FILTER
 #define GEOA3_GRID_FILTER 0.03f
 #endif
-constexpr float GRID_FILTER = GEOA3_GRID_FILTER; // ... the same with the matrix-core filter behind the kernel (geom_filter.hip): GEOA3_NN1_FILTER=0 switches it off
+constexpr float GRID_FILTER = GEOA3_GRID_FILTER; // ... the same when the workgroup then runs the matrix-core filter search (geom_filter.h), the shipped form
 constexpr int NN1_DIRECT = GEOA3_NN1_DIRECT;     // candidates of a column run scanned by the (query, column) pair's own lane
 #ifndef GEOA3_NN1_LONG
 #define GEOA3_NN1_LONG 24
@@ -573,7 +572,7 @@ size_t grid_nn1_lds(int M) {
 
 // Same contract as geoa3_launch_nn1 without `only`; returns GEOA3_ENOSUPPORT when a cloud does not fit the
 // workgroup (callers then use the all-pairs kernel).
-// brute_frac < 0 / filter < 0: the shipped policy (environment: GEOA3_GRID_BRUTE, GEOA3_NN1_FILTER=0)
+// brute_frac < 0 / filter < 0: the shipped policy
 int geoa3_launch_grid_nn1_policy(const float* a, const float* r, int B, int Na, int Nr, const int32_t* prior_ar,
                                  const int32_t* prior_ra, float* d_ar, int32_t* i_ar, float* d_ra, int32_t* i_ra,
                                  float brute_frac, int filter, hipStream_t s) {
@@ -581,11 +580,9 @@ int geoa3_launch_grid_nn1_policy(const float* a, const float* r, int B, int Na, 
   if ((d_ra == nullptr) != (i_ra == nullptr)) return GEOA3_EINVAL;
   const size_t lds = grid_nn1_lds(M);
   const int wide_thr = NN1_WIDE;
-  static const int use_filter = []() { const char* e = getenv("GEOA3_NN1_FILTER"); return e ? atoi(e) : 1; }();
-  static const float env_frac = []() { const char* e = getenv("GEOA3_GRID_BRUTE"); return e ? (float)atof(e) : -1.f; }();
-  if (filter < 0) filter = use_filter;
+  if (filter < 0) filter = 1;
   filter = filter && Na >= 32 && Nr >= 32;
-  if (brute_frac < 0.f) brute_frac = env_frac >= 0.f ? env_frac : (filter ? GRID_FILTER : GRID_BRUTE);
+  if (brute_frac < 0.f) brute_frac = filter ? GRID_FILTER : GRID_BRUTE;
   // Up to 1024 points the filter kernel alone beats the walk wherever the iterates have left the surface, and costs the same
   // on every kind of cloud (tools/nn1_filter_check.py --time, 250 instances, us per launch: walk 34 at offsets of 0.02 of the
   // radius, 57 at 0.2, 50-170 on rods / clusters; filter ~45 everywhere): no grid at all
