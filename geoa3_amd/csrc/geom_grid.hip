@@ -207,6 +207,201 @@ __device__ __attribute__((noinline)) void grid_filter_search(const float* P, con
   nf::search<GT>(P, Q, M, Nq, q0, prior, dout, iout, smem);
 }
 
+// ---- The filter search on the grid's SORTED cloud (clouds of 1025..4096 points, the heavy workgroups): the records stay
+// where the counting sort left them (cell order = x-major), so the candidates a block of 32 queries can need -- those whose
+// cell x lies within the block's x-range +- its largest seed radius -- are ONE contiguous range of the sorted order, and a
+// wave multiplies a tile only for the blocks whose range holds it (same margin as grid_ball: a candidate outside is
+// farther than the seed along x alone).  The blocks of a wave are spread over the sorted order (block ids wave + 16 k), so
+// every wave finds about the same share of every chunk.  Candidates' images are built from LDS (no second trip to memory),
+// exact evaluation reads the same records; ties by the ORIGINAL index, as everywhere.
+constexpr int GS_PASS = 2 * GT;                       // queries per pass: four blocks of 32 per wave
+constexpr int GS_LIST = 224;                          // items per wave between exact evaluations
+constexpr size_t GS_OFF_P4 = ((size_t)(GC + 4) + GC + GW * 8) * 4;
+constexpr size_t GS_TAIL = (size_t)GS_PASS * 8 + 4 * (size_t)GS_PASS * 4 + (size_t)GW * GS_LIST * 4 + (GS_PASS / 32) * 2 * 4 + 32 * 4;
+struct GsTail {
+  unsigned long long* key;   // [GS_PASS] (distance bits : original index) of the pass's queries, by position
+  float *qx, *qy, *qz;       // [GS_PASS]
+  int* qidx;                 // [GS_PASS] query index (-1: none)
+  unsigned* list;            // [GW][GS_LIST]
+  int* blk;                  // [GS_PASS / 32][2] candidate range of a block of 32 positions
+  int* slab;                 // [17] first sorted position of every cell x
+};
+__device__ __forceinline__ GsTail gs_tail(unsigned char* smem, int M) {
+  GsTail t;
+  t.key = reinterpret_cast<unsigned long long*>(smem + GS_OFF_P4 + (size_t)M * 16);
+  t.qx = reinterpret_cast<float*>(t.key + GS_PASS);
+  t.qy = t.qx + GS_PASS;
+  t.qz = t.qy + GS_PASS;
+  t.qidx = reinterpret_cast<int*>(t.qz + GS_PASS);
+  t.list = reinterpret_cast<unsigned*>(t.qidx + GS_PASS);
+  t.blk = reinterpret_cast<int*>(t.list + GW * GS_LIST);
+  t.slab = t.blk + (GS_PASS / 32) * 2;
+  return t;
+}
+
+__device__ __attribute__((noinline)) void grid_filter_sorted(unsigned char* smem, int M, int nq, float cx, float cy, float cz,
+                                                             float inv_s, float* dout, int32_t* iout) {
+  using namespace nf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, kh = lane >> 5;
+  half8* s_img = reinterpret_cast<half8*>(smem);                                   // [32 tiles][2 k halves][32 rows]
+  const float4* s_p4 = reinterpret_cast<const float4*>(smem + GS_OFF_P4);          // the sorted cloud
+  const GsTail T0 = gs_tail(smem, M);
+  const float us = inv_s * 128.f, inv_s2 = inv_s * inv_s;
+  // ---- this lane's queries: block k of the wave = block wave + 16 k of the pass (positions 32 block + lane % 32)
+  half8 Bq[NF_B];
+  float T[NF_B];
+  int lo[NF_B], hi[NF_B], pos[NF_B], qid[NF_B];
+  int wlo = 0x7fffffff, whi = 0;
+#pragma unroll
+  for (int k = 0; k < NF_B; ++k) {
+    const int blk = wave + GW * k;
+    pos[k] = blk * 32 + n;
+    qid[k] = pos[k] < nq ? T0.qidx[pos[k]] : -1;
+    const bool valid = qid[k] >= 0;
+    const float qx = T0.qx[pos[k]], qy = T0.qy[pos[k]], qz = T0.qz[pos[k]];
+    const float seed_d = __uint_as_float((unsigned)(T0.key[pos[k]] >> 32));
+    const float ux = (qx - cx) * us, uy = (qy - cy) * us, uz = (qz - cz) * us;
+    _Float16 xh, xl, yh, yl, zh, zl;
+    nf_split(ux, xh, xl);
+    nf_split(uy, yh, yl);
+    nf_split(uz, zh, zl);
+    const _Float16 one = (_Float16)1.f, zero = (_Float16)0.f;
+    if (kh == 0) {
+      Bq[k][0] = xh; Bq[k][1] = xl; Bq[k][2] = xh; Bq[k][3] = yh; Bq[k][4] = yl; Bq[k][5] = yh; Bq[k][6] = zh; Bq[k][7] = zl;
+    } else {
+      Bq[k][0] = zh; Bq[k][1] = one; Bq[k][2] = one; Bq[k][3] = one; Bq[k][4] = zero; Bq[k][5] = zero; Bq[k][6] = zero; Bq[k][7] = zero;
+    }
+    const float Qn = ux * ux + uy * uy + uz * uz;
+    T[k] = valid ? (seed_d * inv_s2 + NF_EPS) * NF_UNIT - Qn : -NF_INF;
+#ifdef GEOA3_GS_DEBUG
+    if (GEOA3_GS_DEBUG & 2) T[k] = valid ? NF_INF : -NF_INF;
+#endif
+    lo[k] = __builtin_amdgcn_readfirstlane(T0.blk[2 * blk]);
+    hi[k] = __builtin_amdgcn_readfirstlane(T0.blk[2 * blk + 1]);
+#ifdef GEOA3_GS_DEBUG
+    if (GEOA3_GS_DEBUG & 1) { lo[k] = 0; hi[k] = M; }
+#endif
+    wlo = lo[k] < hi[k] && lo[k] < wlo ? lo[k] : wlo;
+    whi = lo[k] < hi[k] && hi[k] > whi ? hi[k] : whi;
+  }
+  unsigned* mylist = T0.list + wave * GS_LIST;
+  int cnt = 0;
+  // the exact evaluation of the collected (query, half tile) items: a lane per item, its 16 candidates' records from LDS
+  auto flush = [&]() {
+    for (int i0 = 0; i0 < cnt; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < cnt) {
+        const unsigned item = mylist[i];
+        const int ql = (int)(item & 127u), h = (int)((item >> 7) & 1u), t = (int)(item >> 8);
+        const int qp = (wave + GW * (ql >> 5)) * 32 + (ql & 31);
+        const float x = T0.qx[qp], y = T0.qy[qp], z = T0.qz[qp];
+        float best = NF_INF;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          float4 c[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int j = t * 32 + 16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3);
+            c[e] = s_p4[j < M ? j : M - 1];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int j = t * 32 + 16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3);
+            const float d = geoa3_sqdist(x, y, z, c[e].x, c[e].y, c[e].z);
+            const int ci = __float_as_int(c[e].w);
+            const bool take = (j < M) & ((d < best) | ((d == best) & (ci < bi)));
+            best = take ? d : best;
+            bi = take ? ci : bi;
+          }
+        }
+        if (bi != 0x7fffffff) atomicMin(&T0.key[qp], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi);
+      }
+    }
+    cnt = 0;
+  };
+  for (int c0 = 0; c0 < M; c0 += NF_CH) {
+    __syncthreads();            // (every wave is done with the previous chunk's images)
+    {
+      const int j = c0 + tid;   // GT == NF_CH: one candidate per thread
+      half8 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v0[e] = (_Float16)0.f;
+        v1[e] = (_Float16)0.f;
+      }
+      if (j < M) {
+        const float4 r = s_p4[j];
+        const float ux = (r.x - cx) * us, uy = (r.y - cy) * us, uz = (r.z - cz) * us;
+        _Float16 xh, xl, yh, yl, zh, zl;
+        nf_split(ux, xh, xl);
+        nf_split(uy, yh, yl);
+        nf_split(uz, zh, zl);
+        const _Float16 m2 = (_Float16)-2.f;
+        v0[0] = m2 * xh; v0[1] = m2 * xh; v0[2] = m2 * xl;
+        v0[3] = m2 * yh; v0[4] = m2 * yh; v0[5] = m2 * yl;
+        v0[6] = m2 * zh; v0[7] = m2 * zh;
+        const float Pn = ux * ux + uy * uy + uz * uz;
+        const _Float16 p0 = (_Float16)Pn;
+        const float r1 = Pn - (float)p0;
+        const _Float16 p1 = (_Float16)r1;
+        v1[0] = m2 * zl; v1[1] = p0; v1[2] = p1; v1[3] = (_Float16)(r1 - (float)p1);
+      } else {
+        v1[1] = (_Float16)60000.f;   // rows beyond the cloud: never under a threshold
+      }
+      s_img[(tid >> 5) * 64 + (tid & 31)] = v0;
+      s_img[(tid >> 5) * 64 + 32 + (tid & 31)] = v1;
+    }
+    __syncthreads();
+    const int left = M - c0;
+    const int ntile = left >= NF_CH ? NF_CH / 32 : (left + 31) >> 5;
+    int t0 = (wlo - c0) >> 5, t1 = (whi - c0 + 31) >> 5;      // the wave's tiles of this chunk
+    t0 = t0 < 0 ? 0 : t0;
+    t1 = t1 > ntile ? ntile : t1;
+#ifdef GEOA3_GS_DEBUG
+    if (GEOA3_GS_DEBUG & 4) t1 = t0;
+#endif
+    for (int t = t0; t < t1; ++t) {
+      const half8 a = s_img[t * 64 + lane];
+      const int j0 = c0 + t * 32;
+#pragma unroll
+      for (int k = 0; k < NF_B; ++k) {
+        if (j0 + 31 >= lo[k] && j0 < hi[k]) {     // (wave-uniform)
+          nf_f32x16 z;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) z[e] = 0.f;
+          const nf_f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bq[k], z, 0, 0, 0);
+          const bool hit = nf_min16(acc) <= T[k];
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {
+            const int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (hit) mylist[p] = ((unsigned)(j0 >> 5) << 8) | ((unsigned)kh << 7) | (unsigned)(32 * k + n);
+            cnt += __builtin_popcountll(mask);
+            if (cnt > GS_LIST - 64) flush();
+          }
+        }
+      }
+    }
+  }
+  flush();
+  if (kh == 0) {
+#pragma unroll
+    for (int k = 0; k < NF_B; ++k)
+      if (qid[k] >= 0) {
+        const unsigned long long key = T0.key[pos[k]];
+#ifdef GEOA3_GS_DEBUG
+        if ((GEOA3_GS_DEBUG & 8) && T0.qidx[pos[k]] != qid[k]) {
+          dout[qid[k]] = -7.f;
+          iout[qid[k]] = T0.qidx[pos[k]];
+          continue;
+        }
+#endif
+        dout[qid[k]] = __uint_as_float((unsigned)(key >> 32));
+        iout[qid[k]] = (int)(unsigned)key;
+      }
+  }
+}
+
 template <int PPT, int MODE = 0>   // MODE (tools/ub/nn1_ub.hip): 1 = build only, 2 = seeds only (no ball walk)
 // (two workgroups per CU while the cloud's LDS allows it -- up to 1024 points: at most 64 registers there)
 __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const float* __restrict__ A, const float* __restrict__ R, int Na,
@@ -312,11 +507,83 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
     __syncthreads();
     if (all > brute_frac * (float)Nq * (float)M) {
       if (filter) {
-        // (the grid is not needed any more: the filter's chunks, queries, keys and lists take its place in LDS.  prior may
-        // alias iout: a pass reads its own slice's seeds before it writes that slice's results)
-        for (int q0 = 0; q0 < Nq; q0 += nf::Cfg<GT>::SLICE) {
+        // ---- through the matrix core (geom_filter.h).  Scale: the cloud's cube (every point within 8 h of its centre) and
+        // this workgroup's queries
+        const float ccx = g.ox + 8.f * g.h, ccy = g.oy + 8.f * g.h, ccz = g.oz + 8.f * g.h;
+        float m = 8.f * g.h * 1.0001f;
+        // (branch-free on purpose, here and below: with `if (qi[p] >= 0)` around this line hipcc 7.2 placed a register spill of
+        // qi[1] INSIDE the divergent region -- lanes without a fourth query reloaded garbage: NOTEBOOK 10)
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+          const float dev = fmaxf(fmaxf(nf::nf_abs_or_inf(qx[p] - ccx), nf::nf_abs_or_inf(qy[p] - ccy)), nf::nf_abs_or_inf(qz[p] - ccz));
+          m = fmaxf(m, qi[p] >= 0 ? dev : 0.f);
+        }
+        m = geoa3_nonfinite(g.h) ? G_INF : m;
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < GW; ++w) m = fmaxf(m, s_red[w]);
+        const unsigned Em = (geoa3_opaque_bits(m) >> 23) & 0xffu;
+        if (!(Em <= 127u + 60u && Em >= 127u - 60u)) {
+          // not finite / absurd extents: the search on the unsorted cloud (its own exact sweep).  prior may alias iout: a
+          // pass reads its own slice's seeds before it writes that slice's results
+          for (int q0 = 0; q0 < Nq; q0 += nf::Cfg<GT>::SLICE) {
+            __syncthreads();
+            grid_filter_search(P, Q, M, Nq, q0, prior ? prior + (size_t)b * Nq : nullptr, dout, iout, g_smem);
+          }
+          return;
+        }
+        const float inv_s = 1.0f / (m * 1.000001f);
+        const GsTail tl = gs_tail(g_smem, M);
+        if (threadIdx.x <= GG) tl.slab[threadIdx.x] = s_start[threadIdx.x * GG * GG];
+#pragma unroll
+        for (int pass = 0; pass < (PPT + 1) / 2; ++pass) {
+          if (pass * GS_PASS >= Nq) break;        // (workgroup-uniform)
+          __syncthreads();                        // (the previous pass is done with the tail; the slab table is written)
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const int p = 2 * pass + pp;
+            if (p < PPT) {
+              const int ps = pp * GT + threadIdx.x;
+              const bool valid = qi[p] >= 0;
+              tl.qx[ps] = qx[p];
+              tl.qy[ps] = qy[p];
+              tl.qz[ps] = qz[p];
+              tl.qidx[ps] = qi[p];
+              tl.key[ps] = ((unsigned long long)__float_as_uint(best[p]) << 32) | (unsigned)bi[p];
+              // the block's x-range and its largest seed radius -> its candidates' range of the sorted order
+              float xmin = valid ? qx[p] : G_INF, xmax = valid ? qx[p] : -G_INF, bmax = valid ? best[p] : 0.f;
+#pragma unroll
+              for (int o = 16; o > 0; o >>= 1) {
+                xmin = fminf(xmin, __shfl_xor(xmin, o, 64));
+                xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+                bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
+              }
+              {
+                const bool any = xmin <= xmax;
+                const float rho = sqrtf(any ? bmax : 0.f) * g.inv_h * 1.00001f + 1e-4f;
+                const int l0 = tl.slab[grid_coord(((any ? xmin : g.ox) - g.ox) * g.inv_h - rho)];
+                const int l1 = tl.slab[grid_coord(((any ? xmax : g.ox) - g.ox) * g.inv_h + rho) + 1];
+                if ((threadIdx.x & 31) == 0) {
+                  tl.blk[2 * (ps >> 5)] = any ? l0 : 0;
+                  tl.blk[2 * (ps >> 5) + 1] = any ? l1 : 0;
+                }
+              }
+            } else {
+              const int ps = pp * GT + threadIdx.x;
+              tl.qidx[ps] = -1;
+              tl.qx[ps] = 0.f; tl.qy[ps] = 0.f; tl.qz[ps] = 0.f;
+              tl.key[ps] = 0ull;
+              if ((threadIdx.x & 31) == 0) {
+                tl.blk[2 * (ps >> 5)] = 0;
+                tl.blk[2 * (ps >> 5) + 1] = 0;
+              }
+            }
+          }
           __syncthreads();
-          grid_filter_search(P, Q, M, Nq, q0, prior ? prior + (size_t)b * Nq : nullptr, dout, iout, g_smem);
+          const int left = Nq - pass * GS_PASS;
+          grid_filter_sorted(g_smem, M, left < GS_PASS ? left : GS_PASS, ccx, ccy, ccz, inv_s, dout, iout);
         }
         return;
       }
@@ -565,7 +832,11 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
 
 size_t grid_nn1_lds(int M) {
   const size_t g = ((size_t)(GC + 4) + GC + GW * 8 + 4 * (size_t)M + 2 + 2 * GT + 2 * GW * 64) * 4;
-  return M > GT && g < nf::Cfg<GT>::LDS ? nf::Cfg<GT>::LDS : g;      // (beyond 1024 points a workgroup may turn to nf::search)
+  if (M <= GT) return g;
+  // (beyond 1024 points a workgroup may turn to the filter search: on the sorted cloud with its tail, or nf::search)
+  const size_t f = GS_OFF_P4 + (size_t)M * 16 + GS_TAIL;
+  const size_t h = f > nf::Cfg<GT>::LDS ? f : nf::Cfg<GT>::LDS;
+  return g > h ? g : h;
 }
 
 }  // namespace

@@ -26,6 +26,8 @@ def cases():
     yield "ellipsoid 4096 vs 1024", ori + 0.05 * torch.randn(4, 3, 4096, generator=g), ori[:, :, :1024].contiguous()
     big, _ = synthetic_clouds(2, 6000, seed=3)
     yield "6000 vs 5000 (beyond the grid's 4096)", big + 0.05 * torch.randn(2, 3, 6000, generator=g), big[:, :, :5000].contiguous()
+    for nq, m in ((2000, 3000), (1025, 3000), (4000, 4000), (3000, 2000)):   # fewer than 4096: lanes without a 4th query
+        yield "ellipsoid %d vs %d" % (nq, m), ori[:1, :, :nq] + 0.05 * torch.randn(1, 3, nq, generator=g), ori[:1, :, :m].contiguous()
     yield "ellipsoid 2500 vs 2049", ori[:, :, :2500] + 0.05 * torch.randn(4, 3, 2500, generator=g), ori[:, :, :2049].contiguous()
     a = ori[:, :, :1024] + 0.03 * torch.randn(4, 3, 1024, generator=g)
     a[:, :, :512] += torch.tensor([3.0, -2.0, 0.5]).view(1, 3, 1)
