@@ -216,6 +216,7 @@ __device__ __attribute__((noinline)) void grid_filter_search(const float* P, con
 // exact evaluation reads the same records; ties by the ORIGINAL index, as everywhere.
 constexpr int GS_PASS = 2 * GT;                       // queries per pass: four blocks of 32 per wave
 constexpr int GS_LIST = 224;                          // items per wave between exact evaluations
+static_assert(GT == nf::NF_CH, "grid_filter_sorted builds one candidate image per thread and chunk");
 constexpr size_t GS_OFF_P4 = ((size_t)(GC + 4) + GC + GW * 8) * 4;
 constexpr size_t GS_TAIL = (size_t)GS_PASS * 8 + 4 * (size_t)GS_PASS * 4 + (size_t)GW * GS_LIST * 4 + (GS_PASS / 32) * 2 * 4 + 32 * 4;
 struct GsTail {
@@ -273,14 +274,8 @@ __device__ __attribute__((noinline)) void grid_filter_sorted(unsigned char* smem
     }
     const float Qn = ux * ux + uy * uy + uz * uz;
     T[k] = valid ? (seed_d * inv_s2 + NF_EPS) * NF_UNIT - Qn : -NF_INF;
-#ifdef GEOA3_GS_DEBUG
-    if (GEOA3_GS_DEBUG & 2) T[k] = valid ? NF_INF : -NF_INF;
-#endif
     lo[k] = __builtin_amdgcn_readfirstlane(T0.blk[2 * blk]);
     hi[k] = __builtin_amdgcn_readfirstlane(T0.blk[2 * blk + 1]);
-#ifdef GEOA3_GS_DEBUG
-    if (GEOA3_GS_DEBUG & 1) { lo[k] = 0; hi[k] = M; }
-#endif
     wlo = lo[k] < hi[k] && lo[k] < wlo ? lo[k] : wlo;
     whi = lo[k] < hi[k] && hi[k] > whi ? hi[k] : whi;
   }
@@ -358,9 +353,6 @@ __device__ __attribute__((noinline)) void grid_filter_sorted(unsigned char* smem
     int t0 = (wlo - c0) >> 5, t1 = (whi - c0 + 31) >> 5;      // the wave's tiles of this chunk
     t0 = t0 < 0 ? 0 : t0;
     t1 = t1 > ntile ? ntile : t1;
-#ifdef GEOA3_GS_DEBUG
-    if (GEOA3_GS_DEBUG & 4) t1 = t0;
-#endif
     for (int t = t0; t < t1; ++t) {
       const half8 a = s_img[t * 64 + lane];
       const int j0 = c0 + t * 32;
@@ -389,13 +381,6 @@ __device__ __attribute__((noinline)) void grid_filter_sorted(unsigned char* smem
     for (int k = 0; k < NF_B; ++k)
       if (qid[k] >= 0) {
         const unsigned long long key = T0.key[pos[k]];
-#ifdef GEOA3_GS_DEBUG
-        if ((GEOA3_GS_DEBUG & 8) && T0.qidx[pos[k]] != qid[k]) {
-          dout[qid[k]] = -7.f;
-          iout[qid[k]] = T0.qidx[pos[k]];
-          continue;
-        }
-#endif
         dout[qid[k]] = __uint_as_float((unsigned)(key >> 32));
         iout[qid[k]] = (int)(unsigned)key;
       }
