@@ -30,11 +30,14 @@ int geoa3_launch_nn1_filter(const float* a, const float* r, int B, int Na, int N
   constexpr size_t lds = nf::Cfg<NF_T>::LDS;
   constexpr int slice = nf::Cfg<NF_T>::SLICE;
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  static const bool attr = []() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(nn1_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds) == hipSuccess;
-  }();
-  (void)attr;
+  // (once per device: the call costs host time in a loop that is enqueue-bound at small batches; nothing a result depends on)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nn1_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
   dim3 grid(B, d_ra ? 2 : 1, (M + slice - 1) / slice);
   hipLaunchKernelGGL(nn1_filter_kernel, grid, dim3(NF_T), lds, s, a, r, Na, Nr, prior_ar, prior_ra, d_ar, i_ar, d_ra, i_ra);
   GEOA3_CHECK_LAUNCH();
