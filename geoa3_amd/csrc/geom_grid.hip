@@ -476,7 +476,7 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
       const float sx = P[si], sy = P[M + si], sz = P[2 * M + si];
       best[p] = geoa3_sqdist(qx[p], qy[p], qz[p], sx, sy, sz);
       bi[p] = si;
-      if (grid_nonfinite3(qx[p], qy[p], qz[p]) | grid_nonfinite3(sx, sy, sz)) {   // no radius: (inf, 0), where the all-pairs kernel starts
+      if ((int)grid_nonfinite3(qx[p], qy[p], qz[p]) | (int)grid_nonfinite3(sx, sy, sz)) {   // no radius: (inf, 0), where the all-pairs kernel starts
         best[p] = G_INF;
         bi[p] = 0;
       }
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(GT, PPT == 1 ? 8 : 4) void grid_nn1_kernel(const fl
     const float sx = P[si], sy = P[M + si], sz = P[2 * M + si];
     float best = geoa3_sqdist(qx, qy, qz, sx, sy, sz);
     int bi = si;
-    if (grid_nonfinite3(qx, qy, qz) | grid_nonfinite3(sx, sy, sz)) {   // no radius: (inf, 0), where the all-pairs kernel starts
+    if ((int)grid_nonfinite3(qx, qy, qz) | (int)grid_nonfinite3(sx, sy, sz)) {   // no radius: (inf, 0), where the all-pairs kernel starts
       best = G_INF;
       bi = 0;
     }
