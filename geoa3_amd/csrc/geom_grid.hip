@@ -153,7 +153,7 @@ __device__ __forceinline__ void grid_ball(const int* __restrict__ s_start, float
 
 // NaN / inf among three coordinates, by their bits (this file is compiled with -fno-honor-nans for geom_filter.h)
 __device__ __forceinline__ bool grid_nonfinite3(float x, float y, float z) {
-  return geoa3_nonfinite(x) | geoa3_nonfinite(y) | geoa3_nonfinite(z);
+  return ((int)geoa3_nonfinite(x) | (int)geoa3_nonfinite(y) | (int)geoa3_nonfinite(z)) != 0;
 }
 
 // One candidate against a query's running (distance, index) minimum -- lexicographic, the un-fused distance of every search.
