@@ -333,7 +333,6 @@ struct SbBwdArgs {
   unsigned char* scratch_w;        // (the same scratch: the rows' coordinate terms are written into it)
 };
 
-constexpr int SB_TD_CAP = 40;   // tiles of one part held in LDS (a part has at most ceil(8192 / 64) = 128 ... see launch: rows / P + 1)
 constexpr int sa2b_bwd_lds() { return 2 * 64 * S2_PT * 4 + 16 * 4 + 2 * 64 * 4 + 2 * 2 * 64 * 4 * 4 + SB_TILES * 16; }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sa2b_bwd_kernel(SbBwdArgs a) {
