@@ -38,7 +38,7 @@ def _planar(x: Tensor) -> Tensor:
 @custom_op("geoa3::nn1_pair", mutates_args=(), device_types="cuda")
 def nn1_pair(a: Tensor, r: Tensor, both: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """a [B,3,Na], r [B,3,Nr] planar -> d_ar [B,Na], i_ar int32, d_ra [B,Nr], i_ra (empty [B,0] when not both)."""
-    d_ar, i_ar, d_ra, i_ra = ops.nn1_pair(_planar(a), _planar(r), both=both)
+    d_ar, i_ar, d_ra, i_ra = ops.nn1_pair(_planar(a), _planar(r), both=both, method="auto")
     if not both:
         d_ra, i_ra = a.new_empty(a.shape[0], 0, dtype=_f32), a.new_empty(a.shape[0], 0, dtype=_i32)
     return d_ar, i_ar, d_ra, i_ra
@@ -104,7 +104,7 @@ def knn_points_op(p1: Tensor, p2: Tensor, K: int) -> Tuple[Tensor, Tensor]:
     q = p1.detach().permute(0, 2, 1).contiguous().float()
     r = p2.detach().permute(0, 2, 1).contiguous().float()
     if K == 1:
-        d, i, _, _ = ops.nn1_pair(q, r, both=False)
+        d, i, _, _ = ops.nn1_pair(q, r, both=False, method="auto")
         d, i = d.unsqueeze(-1), i.unsqueeze(-1)
     else:
         d, i = ops.knn_planar(q, r, K)
@@ -145,7 +145,7 @@ def point_loss(adv_pc: Tensor, ori_pc: Tensor, kind: int) -> Tuple[Tensor, Tenso
     adv, ori = _planar(adv_pc), _planar(ori_pc)
     kw = dict(dis_type=0, w_dis=0.0, w_hd=0.0)
     if kind in (0, 1, 2):
-        d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(adv, ori, both=(kind == 0))
+        d_ao, i_ao, d_oa, i_oa = ops.nn1_pair(adv, ori, both=(kind == 0), method="auto")
         kw.update(d_ao=d_ao, i_ao=i_ao, d_oa=d_oa, i_oa=i_oa)
     if kind == 0:
         kw.update(dis_type=1, w_dis=1.0)
@@ -180,7 +180,7 @@ point_loss.register_autograd(_point_loss_backward, setup_context=_point_loss_set
 def kappa_adv(adv_pc: Tensor, ori_pc: Tensor, ori_normal: Tensor, k: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """_get_kappa_adv: -> (kappa_adv [b,n], normal [b,3,n], i_ao int32 [b,n], knn_adv int32 [b,n,k+1])."""
     adv, ori, nrm = _planar(adv_pc), _planar(ori_pc), _planar(ori_normal)
-    _, i_ao, _, _ = ops.nn1_pair(adv, ori, both=False)
+    _, i_ao, _, _ = ops.nn1_pair(adv, ori, both=False, method="auto")
     _, knn_adv = ops.knn_planar(adv, adv, k + 1)
     kap = ops.kappa(adv, nrm, knn_adv, i_ao)
     b, _, n = adv.shape

@@ -34,8 +34,9 @@ def _p(t: Optional[Tensor], dtype=None) -> Optional[int]:
 
 def nn1_pair(a: Tensor, r: Tensor, both: bool = True, method: str = "brute", prior=None, policy=None):
     """a [B,3,Na], r [B,3,Nr] -> (d_ar [B,Na], i_ar int32 [B,Na], d_ra [B,Nr] | None, i_ra | None).
-    method: "brute" (all pairs) or "grid" (uniform-grid search, same bits; prior = (i_ar, i_ra) of a previous call
-    seeds its radii; policy = (brute_frac, filter) of geoa3_debug_grid_nn1_pair for tests / tools)."""
+    method: "brute" (all pairs, geoa3_nn1_pair), "grid" (geoa3_grid_nn1_pair: the pruned searches -- matrix-core filter /
+    grid walk -- same bits; prior = (i_ar, i_ra) of a previous call seeds its radii; policy = (brute_frac, filter) of
+    geoa3_debug_grid_nn1_pair for tests / tools) or "auto" (the pruned search whenever both clouds hold >= 32 points)."""
     B, _, Na = a.shape
     Nr = r.shape[2]
     d_ar = torch.empty(B, Na, device=a.device, dtype=torch.float32)
@@ -44,6 +45,8 @@ def nn1_pair(a: Tensor, r: Tensor, both: bool = True, method: str = "brute", pri
     if both:
         d_ra = torch.empty(B, Nr, device=a.device, dtype=torch.float32)
         i_ra = torch.empty(B, Nr, device=a.device, dtype=torch.int32)
+    if method == "auto":
+        method = "grid" if min(Na, Nr) >= 32 else "brute"
     if method == "grid":
         p_ar, p_ra = prior if prior is not None else (None, None)
         if policy is not None:
