@@ -168,7 +168,7 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
     const float us = inv_s * 128.f, inv_s2 = inv_s * inv_s;
     // ---- query operands and thresholds
     half8 Bq[NF_B];
-    float T[NF_B];
+    float T[NF_B], Tb[NF_B];      // threshold = (distance bound / s^2) * UNIT + Tb
 #pragma unroll
     for (int k = 0; k < NF_B; ++k) {
       const float ux = (qx[k] - cx) * us, uy = (qy[k] - cy) * us, uz = (qz[k] - cz) * us;
@@ -183,7 +183,8 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
         Bq[k][0] = zh; Bq[k][1] = one; Bq[k][2] = one; Bq[k][3] = one; Bq[k][4] = zero; Bq[k][5] = zero; Bq[k][6] = zero; Bq[k][7] = zero;
       }
       const float Qn = ux * ux + uy * uy + uz * uz;
-      T[k] = qt[k] < Nq ? (seed_d[k] * inv_s2 + NF_EPS) * NF_UNIT - Qn : -NF_INF;
+      Tb[k] = qt[k] < Nq ? NF_EPS * NF_UNIT - Qn : -NF_INF;
+      T[k] = seed_d[k] * inv_s2 * NF_UNIT + Tb[k];
     }
     unsigned* mylist = s_list + wave * NF_LIST;
     unsigned long long* mykey = s_key + wave * NF_QW;
@@ -309,6 +310,13 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
         if (GEOA3_NF_STOP == 2) cnt += (int)(mask_any & 1ull);
         if (cnt > NF_LIST - 4 * 64) {
           if (GEOA3_NF_STOP >= 2) cnt = 0; else flush();
+          // the thresholds follow the best distances found so far (a seed far from the answer -- no prior, a junk prior --
+          // admits most of the cloud; after the first evaluations only what can still win or tie is admitted)
+#ifndef GEOA3_NF_NO_TIGHTEN
+#pragma unroll
+          for (int k = 0; k < NF_B; ++k)
+            T[k] = fminf(T[k], __uint_as_float((unsigned)(mykey[32 * k + n] >> 32)) * inv_s2 * NF_UNIT + Tb[k]);
+#endif
         }
         a = an;
       }

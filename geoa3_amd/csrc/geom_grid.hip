@@ -250,7 +250,7 @@ __device__ __attribute__((noinline)) void grid_filter_sorted(unsigned char* smem
   const float us = inv_s * 128.f, inv_s2 = inv_s * inv_s;
   // ---- this lane's queries: block k of the wave = block wave + 16 k of the pass (positions 32 block + lane % 32)
   half8 Bq[NF_B];
-  float T[NF_B];
+  float T[NF_B], Tb[NF_B];      // threshold = (distance bound / s^2) * UNIT + Tb
   int lo[NF_B], hi[NF_B], pos[NF_B], qid[NF_B];
   int wlo = 0x7fffffff, whi = 0;
 #pragma unroll
@@ -273,7 +273,8 @@ __device__ __attribute__((noinline)) void grid_filter_sorted(unsigned char* smem
       Bq[k][0] = zh; Bq[k][1] = one; Bq[k][2] = one; Bq[k][3] = one; Bq[k][4] = zero; Bq[k][5] = zero; Bq[k][6] = zero; Bq[k][7] = zero;
     }
     const float Qn = ux * ux + uy * uy + uz * uz;
-    T[k] = valid ? (seed_d * inv_s2 + NF_EPS) * NF_UNIT - Qn : -NF_INF;
+    Tb[k] = valid ? NF_EPS * NF_UNIT - Qn : -NF_INF;
+    T[k] = seed_d * inv_s2 * NF_UNIT + Tb[k];
     lo[k] = __builtin_amdgcn_readfirstlane(T0.blk[2 * blk]);
     hi[k] = __builtin_amdgcn_readfirstlane(T0.blk[2 * blk + 1]);
     wlo = lo[k] < hi[k] && lo[k] < wlo ? lo[k] : wlo;
@@ -369,7 +370,15 @@ __device__ __attribute__((noinline)) void grid_filter_sorted(unsigned char* smem
             const int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
             if (hit) mylist[p] = ((unsigned)(j0 >> 5) << 8) | ((unsigned)kh << 7) | (unsigned)(32 * k + n);
             cnt += __builtin_popcountll(mask);
-            if (cnt > GS_LIST - 64) flush();
+            if (cnt > GS_LIST - 64) {
+              flush();
+              // (the thresholds follow the best distances found so far: geom_filter.h)
+#ifndef GEOA3_NF_NO_TIGHTEN
+#pragma unroll
+              for (int kk = 0; kk < NF_B; ++kk)
+                T[kk] = fminf(T[kk], __uint_as_float((unsigned)(T0.key[pos[kk]] >> 32)) * inv_s2 * NF_UNIT + Tb[kk]);
+#endif
+            }
           }
         }
       }

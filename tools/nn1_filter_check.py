@@ -136,6 +136,9 @@ def bench(B=250):
                 for label, policy in (("grid", (1e9, 0)), ("sweep", (0.0, 0)), ("filter", (0.0, 1)), ("r5 policy", (0.12, 0)),
                                       ("f.12", (0.12, 1)), ("f.06", (0.06, 1)), ("f.03", (0.03, 1))):
                     row.append("%s %7.1f" % (label, timeit(lambda: ops.nn1_pair(A, R, method="grid", prior=pr, policy=policy))))
+                row.append("filter, no prior %7.1f" % timeit(lambda: ops.nn1_pair(A, R, method="grid", policy=(0.0, 1))))
+                junk = (torch.randint(0, N, (B, N), generator=g).int().cuda(), torch.randint(0, N, (B, N), generator=g).int().cuda())
+                row.append("filter, random prior %7.1f" % timeit(lambda: ops.nn1_pair(A, R, method="grid", prior=junk, policy=(0.0, 1))))
                 print("N=%d %-10s offsets %.2f  us/launch: %s" % (N, kind, scale, "  ".join(row)), flush=True)
 
 
