@@ -257,7 +257,7 @@ def knn_kernel_line(ms, B, npoint, knn):
             "algorithmic_bytes_per_launch": bytes_, "traffic": None}
 
 
-def cd_kernel_line(ms, B, npoint):
+def cd_kernel_line(ms, B, npoint, vector_only_us=None):
     """The "CD kernel" (BASELINE.json: CD-kernel HBM GB/s): algorithmic bytes 40 * B * N per launch."""
     if not ms:
         return None
@@ -272,6 +272,11 @@ def cd_kernel_line(ms, B, npoint):
            "hbm_GBps_algorithmic": round(cd_bytes / (ms * 1e-3) / 1e9, 2),
            "hbm_frac": round(cd_bytes / (ms * 1e-3) / PEAK_HBM, 5),
            "note": "not HBM-bound by construction (SURVEY 8d: 10 MB per launch for 2*B*N^2 pairs of search)"}
+    if vector_only_us is not None:
+        out["vector_only_form_us"] = round(vector_only_us, 2)
+        out["vector_only_form"] = ("the same search by grid walk + LDS-broadcast sweep on the vector unit alone (north_star's form, "
+                                   "geoa3_debug_grid_nn1_pair(..., 0.12, 0)) on the loop's state after the run, alone on the queue; "
+                                   "bit-identical results (checked in this run)")
     if filt:   # every pair goes through the filter: its rate against the vector-issue floor
         out["pairs_per_launch"] = pairs
         out["pairs_per_cycle_per_simd"] = round(pairs / (ms * 1e-3) / (1024 * 2.4e9), 2)
@@ -426,10 +431,38 @@ class Bench:
             runner.step(s, 0)
             host += time.perf_counter() - h0
         torch.cuda.synchronize()
+        # the same 1-NN search in north_star's form (grid walk + LDS-broadcast sweep, the vector unit only: round 5's policy)
+        # on the loop's state at this point, alone on the queue -- beside the shipped search's `nn1_pair` figure
+        vec_us = None
+        t = runner.t
+        if runner.need_nn and runner.grid_nn1 and runner.ne <= 4096 and runner.n <= 4096:
+            both = runner.dis_type == 1 and not getattr(runner.cfg, "is_cd_single_side", False)
+            xe = t["x"]
+            if xe.shape[2] == runner.ne:
+                tmp = [torch.empty_like(t[k]) for k in ("d_ao", "i_ao", "d_oa", "i_oa")]
+                ref = [torch.empty_like(t[k]) for k in ("d_ao", "i_ao", "d_oa", "i_oa")]
+                stream = torch.cuda.current_stream().cuda_stream
+                head = (xe.data_ptr(), runner.ori.data_ptr(), runner.b, runner.ne, runner.n, t["i_ao"].data_ptr(),
+                        t["i_oa"].data_ptr() if both else None)
+
+                def outs(bufs):
+                    return (bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr() if both else None,
+                            bufs[3].data_ptr() if both else None)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if (lib.geoa3_grid_nn1_pair(*head, *outs(ref), stream) == 0 and
+                        lib.geoa3_debug_grid_nn1_pair(*head, *outs(tmp), 0.12, 0, stream) == 0):
+                    e0.record()
+                    for _ in range(5):
+                        lib.geoa3_debug_grid_nn1_pair(*head, *outs(tmp), 0.12, 0, stream)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    vec_us = e0.elapsed_time(e1) / 5 * 1e3
+                    if not (torch.equal(tmp[1], ref[1]) and torch.equal(tmp[0].view(torch.int32), ref[0].view(torch.int32))):
+                        raise RuntimeError("the vector-only 1-NN search and the shipped one disagree")
         runner.end_search_step()
         del runner
         return {"dt": dt, "dt_local": dt_local, "kms": kms, "extra": n_extra, "host_enqueue_ms": host / n_host * 1e3,
-                "host_loop_ms": host_loop / steps * 1e3}
+                "host_loop_ms": host_loop / steps * 1e3, "nn1_vector_only_us": vec_us}
 
 
 def kernels_ms_dict(kms, extra, timed_tags):
@@ -475,7 +508,7 @@ def gpu_leg(bench, name, arch, npoint, knn, data, instances, steps, warmup, pres
                                                          TAG_SA2_BWD: "sa2b_bwd_kernel"}.get(big, ""), "c4",
                                          instances == BATCH and data == "ellipsoid")
         out["other_large_kernels"] = [roofs[t] for t in roofs if t != big]
-    out["cd_kernel"] = cd_kernel_line(kms.get(TAG_NN1), instances, npoint)
+    out["cd_kernel"] = cd_kernel_line(kms.get(TAG_NN1), instances, npoint, m.get("nn1_vector_only_us"))
     out["kernels_ms"] = kernels_ms_dict(kms, m["extra"], timed)
     if full_compare:
         # the full 250-instance batch on this GPU in the same process: what linear scaling is measured against
@@ -687,7 +720,7 @@ def main():
         if proxy is not None:
             fsteps, fdt = proxy
             out["strong_scaling_proxy"] = proxy_dict(fdt / fsteps * 1e3, ms_per_step, B, global_batch)
-        out["cd_kernel"] = cd_kernel_line(kms.get(TAG_NN1), B, npoint)
+        out["cd_kernel"] = cd_kernel_line(kms.get(TAG_NN1), B, npoint, m.get("nn1_vector_only_us"))
         out["kernels_ms"] = kernels_ms_dict(kms, extra, timed_tags)
         if multi is not None:
             out["multi_gpu"] = multi
