@@ -91,7 +91,11 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
     sy[k] = P[M + si[k]];
     sz[k] = P[2 * M + si[k]];
   }
-  // ---- the searched cloud's box -> centre; scale from the box and this workgroup's queries
+  // ---- centre and scale: the box of the searched cloud AND this workgroup's queries, in one reduction.  The candidates of
+  // the first chunk stay in registers for its images (a cloud of up to 1024 points is read once)
+  constexpr int CPT = NF_CH / NF_T;      // candidates per thread and chunk
+  static_assert(CPT * NF_T == NF_CH && CPT <= 4, "a chunk is a whole number of candidates per thread");
+  float kx[CPT], ky[CPT], kz[CPT];
   float lox = NF_INF, loy = NF_INF, loz = NF_INF, hix = -NF_INF, hiy = -NF_INF, hiz = -NF_INF, pbad = 0.f;
   for (int i0 = 0; i0 < M; i0 += 4 * NF_T) {
     float x[4], y[4], z[4];
@@ -102,6 +106,14 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
       y[u] = P[M + ii];
       z[u] = P[2 * M + ii];
     }
+    if (i0 == 0) {
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        kx[u] = x[u];
+        ky[u] = y[u];
+        kz[u] = z[u];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       lox = fminf(lox, x[u]); hix = fmaxf(hix, x[u]);
@@ -109,13 +121,6 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
       loz = fminf(loz, z[u]); hiz = fmaxf(hiz, z[u]);
       pbad = fmaxf(pbad, fmaxf(fmaxf(nf_abs_or_inf(x[u]), nf_abs_or_inf(y[u])), nf_abs_or_inf(z[u])));
     }
-  }
-  lox = -wave_max(-lox); loy = -wave_max(-loy); loz = -wave_max(-loz);
-  hix = wave_max(hix); hiy = wave_max(hiy); hiz = wave_max(hiz);
-  pbad = wave_max(pbad);
-  if (lane == 0) {
-    float* r = s_red + wave * 8;
-    r[0] = lox; r[1] = loy; r[2] = loz; r[3] = hix; r[4] = hiy; r[5] = hiz; r[6] = pbad;
   }
   float qx[NF_B], qy[NF_B], qz[NF_B];
 #pragma unroll
@@ -129,6 +134,17 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
       s_qy[wave * NF_QW + 32 * k + n] = qy[k];
       s_qz[wave * NF_QW + 32 * k + n] = qz[k];
     }
+    lox = fminf(lox, qx[k]); hix = fmaxf(hix, qx[k]);
+    loy = fminf(loy, qy[k]); hiy = fmaxf(hiy, qy[k]);
+    loz = fminf(loz, qz[k]); hiz = fmaxf(hiz, qz[k]);
+    pbad = fmaxf(pbad, fmaxf(fmaxf(nf_abs_or_inf(qx[k]), nf_abs_or_inf(qy[k])), nf_abs_or_inf(qz[k])));
+  }
+  lox = -wave_max(-lox); loy = -wave_max(-loy); loz = -wave_max(-loz);
+  hix = wave_max(hix); hiy = wave_max(hiy); hiz = wave_max(hiz);
+  pbad = wave_max(pbad);
+  if (lane == 0) {
+    float* r = s_red + wave * 8;
+    r[0] = lox; r[1] = loy; r[2] = loz; r[3] = hix; r[4] = hiy; r[5] = hiz; r[6] = pbad;
   }
   __syncthreads();
 #pragma unroll
@@ -139,16 +155,9 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
     pbad = fmaxf(pbad, r[6]);
   }
   const float cx = 0.5f * lox + 0.5f * hix, cy = 0.5f * loy + 0.5f * hiy, cz = 0.5f * loz + 0.5f * hiz;
-  float m = fmaxf(fmaxf(fmaxf(hix - cx, cx - lox), fmaxf(hiy - cy, cy - loy)), fmaxf(hiz - cz, cz - loz));
+  // (every point and query within m of the centre in every coordinate; 1.0001: the centre's own rounding)
+  float m = fmaxf(fmaxf(fmaxf(hix - cx, cx - lox), fmaxf(hiy - cy, cy - loy)), fmaxf(hiz - cz, cz - loz)) * 1.0001f;
   m = geoa3_opaque_bits(pbad) >= 0x7f800000u ? NF_INF : m;
-#pragma unroll
-  for (int k = 0; k < NF_B; ++k)
-    m = fmaxf(m, fmaxf(fmaxf(nf_abs_or_inf(qx[k] - cx), nf_abs_or_inf(qy[k] - cy)), nf_abs_or_inf(qz[k] - cz)));
-  m = wave_max(m);
-  if (lane == 0) s_red[wave * 8 + 7] = m;
-  __syncthreads();
-#pragma unroll
-  for (int w = 0; w < NF_W; ++w) m = fmaxf(m, s_red[w * 8 + 7]);
   const unsigned Em = (geoa3_opaque_bits(m) >> 23) & 0xffu;
   const bool ok = Em <= 127u + 60u && Em >= 127u - 60u;   // (workgroup-uniform; inf: 255; all points equal: 0)
 
@@ -194,15 +203,19 @@ __device__ __forceinline__ void search(const float* __restrict__ P, const float*
       // ---- the chunk: exact coordinates + images: row j of a tile, k half 0 = -2 (xh, xh, xl, yh, yh, yl, zh, zh),
       // k half 1 = (-2 zl, P0, P1, P2, 0, 0, 0, 0)
       {
-        constexpr int CPT = NF_CH / NF_T;      // candidates per thread
-        static_assert(CPT * NF_T == NF_CH, "a chunk is a whole number of candidates per thread");
         float x[CPT], y[CPT], z[CPT];
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
-          const int j = c0 + u * NF_T + tid, jj = j < M ? j : M - 1;
-          x[u] = P[jj];
-          y[u] = P[M + jj];
-          z[u] = P[2 * M + jj];
+          if (c0 == 0) {       // (workgroup-uniform: in registers since the pass over the cloud)
+            x[u] = kx[u];
+            y[u] = ky[u];
+            z[u] = kz[u];
+          } else {
+            const int j = c0 + u * NF_T + tid, jj = j < M ? j : M - 1;
+            x[u] = P[jj];
+            y[u] = P[M + jj];
+            z[u] = P[2 * M + jj];
+          }
         }
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
